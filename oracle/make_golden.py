@@ -1,0 +1,162 @@
+"""Generate golden vectors by running the UNMODIFIED reference on CPU (build container only).
+
+TEST INFRASTRUCTURE.  Usage (from the repo root):
+
+    python oracle/make_golden.py            # regenerates every case (one subprocess per case,
+                                            # because the reference's cfg is an import-time global)
+    python oracle/make_golden.py --case tiny_s3
+
+Writes ``tests/golden/weights_seed0.npz`` (the reference state_dict: seeded default init with
+randomised BN statistics/affine and MLP biases) and ``tests/golden/<case>.npz``
+(reference outputs + stage-boundary intermediates).  Inputs are NOT stored: they are regenerated
+from ``enerf_amd.synth.make_batch`` with the seed recorded in CASES (numpy PCG64, platform-stable).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# case -> dict(H, W, S, planes, render_if, seed, textured, human, full_intermediates)
+CASES = {
+    "tiny_s3": dict(H=32, W=64, S=3, planes=(8, 8), render_if=(True, True), seed=1, textured=False,
+                    human=False, inter="all"),
+    "tiny_s2": dict(H=32, W=64, S=2, planes=(8, 8), render_if=(True, True), seed=2, textured=True,
+                    human=False, inter="none"),
+    "tiny_s4_mask": dict(H=32, W=64, S=4, planes=(8, 8), render_if=(False, True), seed=3, textured=True,
+                         human=True, inter="none"),
+    "small_s3_eval": dict(H=64, W=96, S=3, planes=(16, 8), render_if=(False, True), seed=4, textured=True,
+                          human=False, inter="maps"),
+}
+
+
+def seeded_state_dict(net) -> dict:
+    """Default init under seed 0 is done by the caller; here: non-trivial BN + biases (seed 1)."""
+    g = torch.Generator().manual_seed(1)
+    sd = net.state_dict()
+    for k, v in sd.items():
+        if k.endswith("running_mean"):
+            v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+        elif k.endswith("running_var"):
+            v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+        elif (".bn." in k or k.split(".")[-2] == "1") and k.endswith("weight") and v.dim() == 1:
+            v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+        elif k.endswith("bias") and v.dim() == 1 and ("nerf_" in k or ".bn." in k or k.split(".")[-2] == "1"):
+            v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+    return sd
+
+
+def run_case(name: str) -> None:
+    from oracle.ref_loader import load_reference
+    from enerf_amd.config import EnerfConfig
+    from enerf_amd.synth import make_batch
+
+    c = CASES[name]
+    opts = ["enerf.cas_config.volume_planes", ",".join(map(str, c["planes"])),
+            "enerf.cas_config.render_if", ",".join(map(str, c["render_if"]))]
+    cfg, ref_network = load_reference("configs/enerf/dtu_pretrain.yaml", opts)
+    if c["human"]:
+        from lib.networks.enerf import network_human as ref_network  # noqa: F811
+    from lib.networks.enerf import utils as ref_utils
+
+    torch.manual_seed(0)
+    torch.set_num_threads(1)                       # fixed summation order
+    net = ref_network.Network().eval()
+    sd = seeded_state_dict(net)
+    net.load_state_dict(sd)
+    wpath = os.path.join(GOLDEN, "weights_seed0.npz")
+    wnp = {k: v.numpy() for k, v in sd.items() if not k.endswith("num_batches_tracked")}
+    if os.path.exists(wpath):
+        old = np.load(wpath)
+        assert all(np.array_equal(old[k], wnp[k]) for k in wnp), "weights changed between cases"
+    else:
+        np.savez_compressed(wpath, **wnp)
+
+    ecfg = EnerfConfig.from_yacs(cfg)
+    batch_np = make_batch(c["H"], c["W"], c["S"], ecfg, seed=c["seed"], textured=c["textured"],
+                          mask_box=c["human"])
+    batch = {k: torch.from_numpy(v) for k, v in batch_np.items()}
+
+    # record stage boundaries by wrapping the reference's own functions (no reference code is edited)
+    rec = {}
+    level = {"i": -1}
+
+    def tap(fn_name, handler):
+        orig = getattr(ref_utils, fn_name)
+
+        def wrapped(*a, **k):
+            out = orig(*a, **k)
+            handler(out, a, k)
+            return out
+        setattr(ref_utils, fn_name, wrapped)
+
+    def on_volume(out, a, k):
+        level["i"] = k["level"]
+        i = level["i"]
+        rec[f"vol_{i}"], rec[f"dv_{i}"], rec[f"nf_{i}"] = out
+
+    def on_reg(out, a, k):
+        i = level["i"]
+        rec[f"depth_{i}"], rec[f"std_{i}"] = out
+        rec[f"prob_{i}"] = a[0]
+
+    tap("build_feature_volume", on_volume)
+    tap("depth_regression", on_reg)
+    tap("build_rays", lambda out, a, k: rec.__setitem__(f"rays12_{level['i']}", out))
+    tap("get_vox_feat", lambda out, a, k: (rec.__setitem__(f"vox_{level['i']}", out),
+                                           rec.__setitem__(f"feat3d_{level['i']}", a[1])))
+    tap("get_img_feat", lambda out, a, k: rec.__setitem__(f"img_{level['i']}", out))
+    tap("get_proj_mats", lambda out, a, k: rec.__setitem__(f"proj_{level['i'] + 1}", out))
+    for i in range(2):
+        m = getattr(net, f"nerf_{i}")
+        m.register_forward_hook(lambda mod, inp, out, i=i: rec.__setitem__(f"raw_{i}", out))
+        r = getattr(net, f"cost_reg_{i}")
+        r.register_forward_hook(lambda mod, inp, out, i=i: rec.__setitem__(f"feat3d_{i}", out[0]))
+    feats = {}
+    net.feature_net.register_forward_hook(
+        lambda mod, inp, out: feats.update(feat_l0=out[0], feat_l1=out[1], feat_l2=out[2]))
+
+    with torch.no_grad():
+        out = net(batch)
+
+    save = {f"out/{k}": v.numpy() for k, v in out.items()}
+    inter = c["inter"]
+    if inter == "all":
+        save.update({f"mid/{k}": v.detach().numpy() for k, v in rec.items()})
+        save.update({f"mid/{k}": v.detach().numpy() for k, v in feats.items()})
+    elif inter == "maps":
+        for k, v in rec.items():
+            if k.split("_")[0] in ("depth", "std", "nf", "proj", "rays12"):
+                save[f"mid/{k}"] = v.detach().numpy()
+    save["meta/torch_version"] = np.array(torch.__version__)
+    np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **save)
+    rgb = out[[k for k in out if k.startswith("rgb")][-1]]
+    print(f"[golden] {name}: {len(save)} arrays; rgb mean {rgb.mean():.4f} min {rgb.min():.4f} "
+          f"max {rgb.max():.4f}; keys {sorted(out)}")
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", default=None)
+    a = ap.parse_args()
+    os.makedirs(GOLDEN, exist_ok=True)
+    if a.case:
+        run_case(a.case)
+        return
+    wpath = os.path.join(GOLDEN, "weights_seed0.npz")
+    if os.path.exists(wpath):
+        os.remove(wpath)
+    for name in CASES:
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--case", name], check=True, cwd=ROOT)
+
+
+if __name__ == "__main__":
+    main()

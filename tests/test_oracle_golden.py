@@ -1,0 +1,71 @@
+"""Pin the oracle restatement to vectors produced by the unmodified reference (oracle/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import enerf_oracle as O
+from golden_cases import CASES, case_batch, case_config, load_golden, load_weights
+
+# same torch build + same primitive order => bit-identical on the generating machine; allow fp32
+# re-association noise (SURVEY.md §8c measured 5.8e-5 between thread counts) elsewhere.
+ATOL, RTOL = 2e-4, 2e-4
+
+
+@pytest.fixture(scope="module")
+def weights():
+    return load_weights()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_matches_reference_outputs(name, weights):
+    cfg, batch, gold = case_config(name), case_batch(name), load_golden(name)
+    mids = {}
+    with torch.no_grad():
+        out = O.forward(cfg, weights, batch, intermediates=mids)
+    ref_keys = sorted(k[4:] for k in gold if k.startswith("out/"))
+    assert sorted(out) == ref_keys
+    for k in ref_keys:
+        np.testing.assert_allclose(out[k].numpy(), gold["out/" + k], atol=ATOL, rtol=RTOL, err_msg=k)
+    for k in [k[4:] for k in gold if k.startswith("mid/")]:
+        if k in mids:
+            np.testing.assert_allclose(mids[k].numpy(), gold["mid/" + k], atol=ATOL, rtol=RTOL, err_msg=k)
+
+
+def test_oracle_stagewise_tiny(weights):
+    """Each stage fed with the REFERENCE's own upstream tensors (no error accumulation)."""
+    name = "tiny_s3"
+    cfg, batch, g = case_config(name), case_batch(name), load_golden(name)
+    T = lambda k: torch.from_numpy(g["mid/" + k])
+    with torch.no_grad():
+        f2, f1, f0 = O.feature_net(weights, batch["src_inps"].reshape(-1, 3, 32, 64))
+        for a, k in ((f2, "feat_l0"), (f1, "feat_l1"), (f0, "feat_l2")):
+            np.testing.assert_allclose(a.numpy(), g["mid/" + k], atol=1e-5, rtol=1e-5)
+        feats = {"level_0": T("feat_l0").reshape(1, 3, 32, 8, 16), "level_1": T("feat_l1").reshape(1, 3, 16, 16, 32),
+                 "level_2": T("feat_l2").reshape(1, 3, 8, 32, 64)}
+        for i in range(2):
+            P = O.proj_mats(batch, cfg.cas.im_feat_scale[i], cfg.cas.volume_scale[i])
+            np.testing.assert_allclose(P.numpy(), g[f"mid/proj_{i}"], atol=1e-5, rtol=1e-5)
+        prev = (None, None, None)
+        for i in range(2):
+            vol, dv, nf = O.feature_volume(cfg, feats[f"level_{i}"], batch, cfg.cas.volume_planes[i], *prev, i)
+            np.testing.assert_allclose(dv.numpy(), g[f"mid/dv_{i}"], atol=1e-4, rtol=1e-6)
+            np.testing.assert_allclose(nf.numpy(), g[f"mid/nf_{i}"], atol=1e-4, rtol=1e-6)
+            np.testing.assert_allclose(vol.numpy(), g[f"mid/vol_{i}"], atol=1e-5, rtol=1e-5)
+            feat, prob = O.cost_reg(weights, f"cost_reg_{i}", T(f"vol_{i}"))
+            np.testing.assert_allclose(feat.numpy(), g[f"mid/feat3d_{i}"], atol=1e-4, rtol=1e-5)
+            np.testing.assert_allclose(prob.numpy(), g[f"mid/prob_{i}"], atol=1e-4, rtol=1e-5)
+            d, s = O.depth_regression(cfg, T(f"prob_{i}"), T(f"dv_{i}"), i)
+            np.testing.assert_allclose(d.numpy(), g[f"mid/depth_{i}"], atol=1e-5, rtol=1e-5)
+            np.testing.assert_allclose(s.numpy(), g[f"mid/std_{i}"], atol=1e-5, rtol=1e-5)
+            rays = O.build_rays(cfg, T(f"depth_{i}"), T(f"std_{i}"), batch, T(f"nf_{i}"), i)
+            np.testing.assert_allclose(rays.numpy(), g[f"mid/rays12_{i}"], atol=1e-4, rtol=1e-6)
+            r = O.render_rays(cfg, weights, T(f"rays12_{i}"), i, batch,
+                              feats[f"level_{cfg.cas.render_im_feat_level[i]}"], T(f"feat3d_{i}"), True)
+            np.testing.assert_allclose(r["_vox"].numpy(), g[f"mid/vox_{i}"], atol=1e-5, rtol=1e-5)
+            np.testing.assert_allclose(r["_img"].numpy(), g[f"mid/img_{i}"], atol=1e-5, rtol=1e-4)
+            np.testing.assert_allclose(r["_raw"].reshape(g[f"mid/raw_{i}"].shape).numpy(), g[f"mid/raw_{i}"],
+                                       atol=1e-5, rtol=1e-4)
+            np.testing.assert_allclose(r["rgb"].numpy(), g[f"out/rgb_level{i}"], atol=1e-5, rtol=1e-4)
+            np.testing.assert_allclose(r["depth"].numpy(), g[f"out/depth_level{i}"], atol=1e-4, rtol=1e-5)
+            np.testing.assert_allclose(r["weights"].numpy(), g[f"out/weights_level{i}"], atol=1e-5, rtol=1e-4)
+            prev = (T(f"depth_{i}"), T(f"std_{i}"), T(f"nf_{i}"))
