@@ -1,0 +1,216 @@
+// capi.hip — the extern "C" boundary (include/enerf_hip.h): argument validation, the cost-regularisation
+// network driver, error reporting.  No torch types; raw device pointers + sizes + a hipStream_t.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "kernels.h"
+
+using namespace enerf;
+
+namespace {
+thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ENERF_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return ENERF_OK;
+}
+#define REQUIRE(cond, ...) \
+    do { if (!(cond)) return fail(ENERF_EINVAL, __VA_ARGS__); } while (0)
+
+// ---- cost-reg layer table ------------------------------------------------------------------------
+struct LayerSpec { int idx, cin, cout, kind, relu, bn; };
+// returns number of layers; the fused heads (8 -> 8+1) are appended last with idx = -1
+int costreg_layers(int cin0, int full, LayerSpec* L) {
+    int n = 0;
+    L[n++] = {0, cin0, 8, kConvS1, 1, 1};
+    L[n++] = {1, 8, 16, kConvS2, 1, 1};
+    L[n++] = {2, 16, 16, kConvS1, 1, 1};
+    L[n++] = {3, 16, 32, kConvS2, 1, 1};
+    L[n++] = {4, 32, 32, kConvS1, 1, 1};
+    if (full) {
+        L[n++] = {5, 32, 64, kConvS2, 1, 1};
+        L[n++] = {6, 64, 64, kConvS1, 1, 1};
+        L[n++] = {7, 64, 32, kConvT2, 0, 1};
+    }
+    L[n++] = {9, 32, 16, kConvT2, 0, 1};
+    L[n++] = {11, 16, 8, kConvT2, 0, 1};
+    L[n++] = {-1, 8, 9, kConvS1, 0, 0};
+    return n;
+}
+long long layer_floats(const LayerSpec& s) { return conv3d_packed_floats(s.cin, s.cout, s.kind) + 2 * cdiv(s.cout, 16) * 16; }
+}  // namespace
+
+extern "C" {
+
+int enerf_abi_version(void) { return ENERF_ABI_VERSION; }
+const char* enerf_last_error(void) { return g_err; }
+
+int enerf_channels_last(const float* src, float* dst, int n, int C, long long P, int Cpad, enerf_stream_t stream) {
+    REQUIRE(src && dst && n > 0 && C > 0 && P > 0 && Cpad >= C, "channels_last: bad arguments");
+    launch_channels_last(src, dst, n, C, P, Cpad, (hipStream_t)stream);
+    return check_launch("channels_last");
+}
+int enerf_channels_first(const float* src, float* dst, int n, int C, long long P, int Cpad, enerf_stream_t stream) {
+    REQUIRE(src && dst && n > 0 && C > 0 && P > 0 && Cpad >= C, "channels_first: bad arguments");
+    launch_channels_first(src, dst, n, C, P, Cpad, (hipStream_t)stream);
+    return check_launch("channels_first");
+}
+int enerf_pack_img_feat_rgb(const float* im_feat, int C, int Hf, int Wf, const float* src_inps, int H, int W, int Hr,
+                            int Wr, int tex, int n_img, float* out, enerf_stream_t stream) {
+    REQUIRE(im_feat && src_inps && out, "pack_img_feat_rgb: null pointer");
+    REQUIRE(C > 0 && tex >= C + 3 && tex % 4 == 0 && n_img > 0 && Hr > 0 && Wr > 0, "pack_img_feat_rgb: bad shape");
+    launch_pack_img_feat_rgb(im_feat, C, Hf, Wf, src_inps, H, W, Hr, Wr, tex, n_img, out, (hipStream_t)stream);
+    return check_launch("pack_img_feat_rgb");
+}
+int enerf_get_proj_mats(const float* src_ixts, const float* src_exts, const float* tar_ixt, const float* tar_ext, int B,
+                        int S, float src_scale, float tar_scale, float* proj, enerf_stream_t stream) {
+    REQUIRE(src_ixts && src_exts && tar_ixt && tar_ext && proj && B > 0 && S > 0, "get_proj_mats: bad arguments");
+    launch_proj_mats(src_ixts, src_exts, tar_ixt, tar_ext, B, S, src_scale, tar_scale, proj, (hipStream_t)stream);
+    return check_launch("get_proj_mats");
+}
+int enerf_get_depth_values(const float* near_far, const float* prev_depth, const float* prev_std,
+                           const float* prev_near_far, int B, int D, int h, int w, int hp, int wp, int depth_inv,
+                           float* depth_values, float* near_far_out, enerf_stream_t stream) {
+    REQUIRE(depth_values && near_far_out && B > 0 && D > 0 && h > 0 && w > 0, "get_depth_values: bad arguments");
+    if (prev_depth) REQUIRE(prev_std && prev_near_far && hp > 0 && wp > 0, "get_depth_values: incomplete previous level");
+    else REQUIRE(near_far, "get_depth_values: near_far required at level 0");
+    launch_depth_values(near_far, prev_depth, prev_std, prev_near_far, B, D, h, w, hp, wp, depth_inv, depth_values,
+                        near_far_out, (hipStream_t)stream);
+    return check_launch("get_depth_values");
+}
+int enerf_build_feature_volume(const float* feat, const float* proj, const float* depth_values, int B, int S, int C,
+                               int Hs, int Ws, int D, int h, int w, float* vol, enerf_stream_t stream) {
+    REQUIRE(feat && proj && depth_values && vol, "build_feature_volume: null pointer");
+    REQUIRE(C == 8 || C == 16 || C == 32, "build_feature_volume: C=%d unsupported (8/16/32)", C);
+    REQUIRE(B > 0 && S > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0, "build_feature_volume: bad shape");
+    launch_feature_volume(feat, proj, depth_values, B, S, C, Hs, Ws, D, h, w, vol, (hipStream_t)stream);
+    return check_launch("build_feature_volume");
+}
+
+long long enerf_cost_reg_packed_floats(int in_channels, int full) {
+    LayerSpec L[12];
+    int n = costreg_layers(in_channels, full, L);
+    long long t = 0;
+    for (int i = 0; i < n; ++i) t += layer_floats(L[i]);
+    return t;
+}
+int enerf_cost_reg_pack(const enerf_costreg_raw_t* raw, float* packed, enerf_stream_t stream) {
+    REQUIRE(raw && packed, "cost_reg_pack: null pointer");
+    REQUIRE(raw->in_channels == 8 || raw->in_channels == 16 || raw->in_channels == 32, "cost_reg_pack: in_channels");
+    LayerSpec L[12];
+    int n = costreg_layers(raw->in_channels, raw->full, L);
+    float* p = packed;
+    for (int i = 0; i < n; ++i) {
+        const LayerSpec& s = L[i];
+        long long wf = conv3d_packed_floats(s.cin, s.cout, s.kind);
+        int cp = cdiv(s.cout, 16) * 16;
+        if (s.idx >= 0) {
+            const enerf_conv_bn_t& c = raw->conv[s.idx];
+            REQUIRE(c.w && c.bn_weight && c.bn_bias && c.bn_mean && c.bn_var, "cost_reg_pack: conv%d missing", s.idx);
+            launch_conv3d_pack(c.w, nullptr, s.cout, c.bn_weight, c.bn_bias, c.bn_mean, c.bn_var, 1e-5f, s.cin, s.cout,
+                               s.kind, p, p + wf, p + wf + cp, (hipStream_t)stream);
+        } else {
+            REQUIRE(raw->feat_conv_w && raw->depth_conv_w, "cost_reg_pack: heads missing");
+            launch_conv3d_pack(raw->feat_conv_w, raw->depth_conv_w, 8, nullptr, nullptr, nullptr, nullptr, 1e-5f, s.cin,
+                               s.cout, s.kind, p, p + wf, p + wf + cp, (hipStream_t)stream);
+        }
+        p += layer_floats(s);
+    }
+    return check_launch("cost_reg_pack");
+}
+size_t enerf_cost_reg_workspace_bytes(int full, int B, int D, int h, int w) {
+    long long n0 = (long long)B * D * h * w, n1 = n0 / 8, n2 = n1 / 8, n3 = n2 / 8;
+    long long f = n0 * 8 /*c0*/ + n1 * 16 * 2 /*c1,c2*/ + n2 * 32 * 2 /*c3,c4*/ + n1 * 16 /*y9*/ + n0 * 8 /*y11*/;
+    if (full) f += n3 * 64 * 2 + n2 * 32;
+    return (size_t)f * sizeof(float);
+}
+int enerf_cost_reg(const float* packed, int in_channels, int full, const float* vol, int B, int D, int h, int w,
+                   float* feat, float* prob, void* workspace, size_t workspace_bytes, enerf_stream_t stream) {
+    REQUIRE(packed && vol && feat && prob && workspace, "cost_reg: null pointer");
+    int div = full ? 8 : 4;
+    REQUIRE(D % div == 0 && h % div == 0 && w % div == 0, "cost_reg: D,h,w (%d,%d,%d) must be divisible by %d", D, h, w, div);
+    if (workspace_bytes < enerf_cost_reg_workspace_bytes(full, B, D, h, w))
+        return fail(ENERF_EWORKSPACE, "cost_reg: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    LayerSpec L[12];
+    int n = costreg_layers(in_channels, full, L);
+    Conv3dDesc desc[12];
+    const float* p = packed;
+    for (int i = 0; i < n; ++i) {
+        long long wf = conv3d_packed_floats(L[i].cin, L[i].cout, L[i].kind);
+        int cp = cdiv(L[i].cout, 16) * 16;
+        desc[i] = {p, L[i].bn ? p + wf : nullptr, L[i].bn ? p + wf + cp : nullptr, L[i].cin, L[i].cout, L[i].kind, L[i].relu};
+        p += layer_floats(L[i]);
+    }
+    long long n0 = (long long)B * D * h * w, n1 = n0 / 8, n2 = n1 / 8, n3 = n2 / 8;
+    float* ws = (float*)workspace;
+    auto take = [&](long long nf) { float* r = ws; ws += nf; return r; };
+    float *c0 = take(n0 * 8), *c1 = take(n1 * 16), *c2 = take(n1 * 16), *c3 = take(n2 * 32), *c4 = take(n2 * 32);
+    float *y9 = take(n1 * 16), *y11 = take(n0 * 8);
+    int i = 0;
+    launch_conv3d(desc[i++], vol, nullptr, c0, nullptr, B, D, h, w, st);                    // conv0
+    launch_conv3d(desc[i++], c0, nullptr, c1, nullptr, B, D, h, w, st);                     // conv1 (s2)
+    launch_conv3d(desc[i++], c1, nullptr, c2, nullptr, B, D / 2, h / 2, w / 2, st);         // conv2
+    launch_conv3d(desc[i++], c2, nullptr, c3, nullptr, B, D / 2, h / 2, w / 2, st);         // conv3 (s2)
+    launch_conv3d(desc[i++], c3, nullptr, c4, nullptr, B, D / 4, h / 4, w / 4, st);         // conv4
+    const float* x = c4;
+    if (full) {
+        float *c5 = take(n3 * 64), *c6 = take(n3 * 64), *y7 = take(n2 * 32);
+        launch_conv3d(desc[i++], c4, nullptr, c5, nullptr, B, D / 4, h / 4, w / 4, st);     // conv5 (s2)
+        launch_conv3d(desc[i++], c5, nullptr, c6, nullptr, B, D / 8, h / 8, w / 8, st);     // conv6
+        launch_conv3d(desc[i++], c6, c4, y7, nullptr, B, D / 8, h / 8, w / 8, st);          // conv4 + conv7
+        x = y7;
+    }
+    launch_conv3d(desc[i++], x, c2, y9, nullptr, B, D / 4, h / 4, w / 4, st);               // conv2 + conv9
+    launch_conv3d(desc[i++], y9, c0, y11, nullptr, B, D / 2, h / 2, w / 2, st);             // conv0 + conv11
+    launch_conv3d(desc[i++], y11, nullptr, feat, prob, B, D, h, w, st);                     // feat_conv ++ depth_conv
+    return check_launch("cost_reg");
+}
+
+int enerf_depth_regression(const float* prob, const float* depth_values, int B, int D, int h, int w, int depth_inv,
+                           float* depth, float* std, enerf_stream_t stream) {
+    REQUIRE(prob && depth_values && depth && std && B > 0 && D > 0 && h > 0 && w > 0, "depth_regression: bad arguments");
+    launch_depth_regression(prob, depth_values, B, D, h, w, depth_inv, depth, std, (hipStream_t)stream);
+    return check_launch("depth_regression");
+}
+int enerf_build_rays(const float* rays8, const float* depth, const float* std, const float* near_far, int B, int N,
+                     int h, int w, int Hr, int Wr, int depth_inv, float* rays12, enerf_stream_t stream) {
+    REQUIRE(rays8 && depth && std && near_far && rays12, "build_rays: null pointer");
+    REQUIRE(B > 0 && N >= 0 && h > 0 && w > 0 && Hr >= h && Wr >= w, "build_rays: bad shape");
+    if (N == 0) return ENERF_OK;
+    launch_build_rays(rays8, depth, std, near_far, B, N, h, w, Hr, Wr, depth_inv, rays12, (hipStream_t)stream);
+    return check_launch("build_rays");
+}
+
+long long enerf_nerf_packed_floats(int F) { return nerf_packed_floats(F); }
+int enerf_nerf_pack(const enerf_nerf_raw_t* raw, int F, int viewdir_agg, float* packed, enerf_stream_t stream) {
+    REQUIRE(raw && packed, "nerf_pack: null pointer");
+    REQUIRE(F == 11 || F == 35, "nerf_pack: F=%d unsupported (feat_ch+3 must be 11 or 35)", F);
+    REQUIRE(raw->glob_w && raw->glob_b && raw->aggw_w && raw->aggw_b && raw->fc_w && raw->fc_b && raw->lr0_w &&
+                raw->lr0_b && raw->sigma_w && raw->sigma_b && raw->col0_w && raw->col0_b && raw->col2_w && raw->col2_b,
+            "nerf_pack: missing parameter");
+    if (viewdir_agg) REQUIRE(raw->view_w && raw->view_b, "nerf_pack: view_fc missing");
+    launch_nerf_pack(*raw, F, viewdir_agg, packed, (hipStream_t)stream);
+    return check_launch("nerf_pack");
+}
+int enerf_render_rays(const enerf_render_args_t* a, enerf_stream_t stream) {
+    REQUIRE(a, "render_rays: null args");
+    REQUIRE(a->rays12 && a->tex && a->vol && a->src_exts && a->src_ixts && a->tar_ext && a->packed && a->rgb &&
+                a->depth && a->weights, "render_rays: null pointer");
+    REQUIRE(a->B > 0 && a->N >= 0 && a->Hr > 1 && a->Wr > 1 && a->D > 0 && a->h > 0 && a->w > 0, "render_rays: bad shape");
+    if (a->N == 0) return ENERF_OK;
+    int rc = launch_render_rays(*a, (hipStream_t)stream);
+    if (rc != 0)
+        return fail(ENERF_EINVAL, "render_rays: unsupported configuration (code %d: F=%d S=%d n_samples=%d B=%d)", rc,
+                    a->F, a->S, a->n_samples, a->B);
+    return check_launch("render_rays");
+}
+
+}  // extern "C"

@@ -1,0 +1,134 @@
+// common.h — shared device helpers for the ENeRF gfx950 kernels.
+//
+// Every kernel in this directory is written for CDNA4 (wave64, MFMA f32 16x16x4, 160 KiB LDS).  The
+// same sources are also compiled by tests/ with -DENERF_EMU against tests/emu/hip_emu.h (a CPU
+// emulation of lanes/waves used only to check kernel logic without a GPU); that build is never
+// loaded by the product.
+#pragma once
+
+#ifdef ENERF_EMU
+#include "hip_emu.h"
+typedef emu_f32x4 f32x4;
+#else
+#include <hip/hip_runtime.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define ENERF_LAUNCH(kern, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), (shmem), (stream), __VA_ARGS__)
+#define ENERF_LAUNCH_SIMPLE ENERF_LAUNCH
+#define ENERF_DYN_SMEM(type, name) \
+    extern __shared__ __attribute__((aligned(16))) char enerf_dyn_smem_[]; \
+    type* name = reinterpret_cast<type*>(enerf_dyn_smem_)
+#endif
+
+#include <stdint.h>
+
+namespace enerf {
+
+constexpr int kWave = 64;
+
+__host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ __forceinline__ long long cdivl(long long a, long long b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// torch.nn.functional.interpolate(mode='bilinear', align_corners=True) source coordinate.
+// ATen computes scale = (in-1)/(out-1) in float, src = scale*dst, i0 = int(src), l1 = src - i0,
+// i1 = i0 + (i0 < in-1).  (reference call sites: utils.py:115-117, 394-396, 611; network.py:32)
+// ---------------------------------------------------------------------------------------------
+struct Lerp1 {
+    int i0, i1;
+    float l0, l1;
+};
+__host__ __device__ __forceinline__ float ac_scale(int in, int out) {
+    return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+}
+__host__ __device__ __forceinline__ Lerp1 ac_lerp(int dst, float scale, int in) {
+    Lerp1 r;
+    float src = scale * (float)dst;
+    r.i0 = (int)src;
+    if (r.i0 > in - 1) r.i0 = in - 1;
+    r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+    r.l1 = src - (float)r.i0;
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+// value = h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)   (ATen upsample_bilinear2d order)
+__host__ __device__ __forceinline__ float ac_blend(const Lerp1& y, const Lerp1& x, float v00, float v01, float v10,
+                                                   float v11) {
+    return y.l0 * (x.l0 * v00 + x.l1 * v01) + y.l1 * (x.l0 * v10 + x.l1 * v11);
+}
+
+// ---------------------------------------------------------------------------------------------
+// F.grid_sample(align_corners=True) pixel coordinate from a normalised coordinate:
+// ((g + 1) / 2) * (size - 1)      (ATen grid_sampler_unnormalize)
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ float gs_unnorm(float g, int size) { return ((g + 1.f) * 0.5f) * (float)(size - 1); }
+
+// Bilinear taps with ZEROS padding (homo_warp, utils.py:87-89) or BORDER padding (get_img_feat,
+// utils.py:706).  Returns corner indices (clamped for addressing) and weights (0 for invalid taps).
+struct Taps2 {
+    int x0, x1, y0, y1;
+    float w00, w01, w10, w11;  // (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+};
+template <bool BORDER>
+__host__ __device__ __forceinline__ Taps2 gs_taps2(float ix, float iy, int W, int H) {
+    Taps2 t;
+    if (BORDER) {  // clip_coordinates: min(size-1, max(ix, 0))
+        ix = fminf((float)(W - 1), fmaxf(ix, 0.f));
+        iy = fminf((float)(H - 1), fmaxf(iy, 0.f));
+    }
+    // guard against NaN / huge values before the float->int conversion (result is then all-zero taps)
+    bool finite = (ix > -1e8f) && (ix < 1e8f) && (iy > -1e8f) && (iy < 1e8f);
+    if (!finite) { ix = -10.f; iy = -10.f; }
+    float fx = floorf(ix), fy = floorf(iy);
+    int x0 = (int)fx, y0 = (int)fy;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    float tx1 = ix - fx, ty1 = iy - fy;      // weight of the +1 corner
+    float tx0 = (float)x1 - ix, ty0 = (float)y1 - iy;
+    bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
+    bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    t.w00 = (vx0 && vy0) ? tx0 * ty0 : 0.f;
+    t.w01 = (vx1 && vy0) ? tx1 * ty0 : 0.f;
+    t.w10 = (vx0 && vy1) ? tx0 * ty1 : 0.f;
+    t.w11 = (vx1 && vy1) ? tx1 * ty1 : 0.f;
+    t.x0 = x0 < 0 ? 0 : (x0 > W - 1 ? W - 1 : x0);
+    t.x1 = x1 < 0 ? 0 : (x1 > W - 1 ? W - 1 : x1);
+    t.y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0);
+    t.y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
+    return t;
+}
+
+__device__ __forceinline__ float clamp_min(float v, float lo) { return v < lo ? lo : v; }  // torch.clamp_min
+
+// torch.linspace(0,1,D)[k]: step = 1/(D-1); k < D/2 ? step*k : 1 - step*(D-1-k)   (ATen RangeFactories)
+__host__ __device__ __forceinline__ float linspace01(int k, int D) {
+    if (D == 1) return 0.f;
+    float step = 1.f / (float)(D - 1);
+    return k < D / 2 ? step * (float)k : 1.f - step * (float)(D - 1 - k);
+}
+
+// 4x4 inverse by cofactors in fp64 (camera matrices; a handful of threads per frame)
+__host__ __device__ __forceinline__ bool inv4x4(const double* m, double* inv) {
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    if (det == 0.0) return false;
+    double r = 1.0 / det;
+    for (int i = 0; i < 16; ++i) inv[i] *= r;
+    return true;
+}
+
+}  // namespace enerf

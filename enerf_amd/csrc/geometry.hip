@@ -1,0 +1,284 @@
+// geometry.hip — layout packers and the small per-pixel / per-ray stages of the ENeRF hot path.
+// HBM-bound elementwise kernels: one thread per output element, coalesced along the fastest axis.
+#include "kernels.h"
+
+namespace enerf {
+
+// -------------------------------------------------------------------------------------------------
+// (n, C, P) -> (n, P, Cpad): FeatureNet / cost-volume tensors to channels-last (pad channels = 0).
+// Reads are coalesced across threads for every channel; each thread writes Cpad contiguous floats.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_channels_last(const float* __restrict__ src, float* __restrict__ dst, int n,
+                                                       int C, long long P, int Cpad) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n * P) return;
+    long long img = i / P, p = i - img * P;
+    const float* s = src + img * C * P + p;
+    float* d = dst + i * Cpad;
+    for (int c = 0; c < Cpad; ++c) d[c] = c < C ? s[(long long)c * P] : 0.f;
+}
+__global__ __launch_bounds__(256) void k_channels_first(const float* __restrict__ src, float* __restrict__ dst, int n,
+                                                        int C, long long P, int Cpad) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n * P) return;
+    long long img = i / P, p = i - img * P;
+    const float* s = src + i * Cpad;
+    float* d = dst + img * C * P + p;
+    for (int c = 0; c < C; ++c) d[(long long)c * P] = s[c];
+}
+void launch_channels_last(const float* src, float* dst, int n, int C, long long P, int Cpad, hipStream_t st) {
+    long long tot = (long long)n * P;
+    ENERF_LAUNCH_SIMPLE(k_channels_last, (unsigned)cdivl(tot, 256), 256, 0, st, src, dst, n, C, P, Cpad);
+}
+void launch_channels_first(const float* src, float* dst, int n, int C, long long P, int Cpad, hipStream_t st) {
+    long long tot = (long long)n * P;
+    ENERF_LAUNCH_SIMPLE(k_channels_first, (unsigned)cdivl(tot, 256), 256, 0, st, src, dst, n, C, P, Cpad);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Source-view texture for the render stage: tex[img][y][x] = [im_feat(C) | rgb(3) | 0-pad] at the render
+// resolution.  rgb = bilinear_ac(src*0.5+0.5, render_scale)  (unpreprocess, utils.py:605-612);
+// im_feat is resized with the same align_corners rule when its resolution differs (network.py:29-32).
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_img_feat_rgb(const float* __restrict__ im_feat, int C, int Hf, int Wf,
+                                                           const float* __restrict__ src, int H, int W, int Hr, int Wr,
+                                                           int tex, int n_img, float* __restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long npix = (long long)Hr * Wr;
+    if (i >= npix * n_img) return;
+    int img = (int)(i / npix);
+    int p = (int)(i - (long long)img * npix);
+    int y = p / Wr, x = p - y * Wr;
+    float* o = out + i * tex;
+    {   // image features
+        Lerp1 ly = ac_lerp(y, ac_scale(Hf, Hr), Hf), lx = ac_lerp(x, ac_scale(Wf, Wr), Wf);
+        const float* f = im_feat + (long long)img * C * Hf * Wf;
+        bool same = (Hf == Hr) && (Wf == Wr);
+        for (int c = 0; c < C; ++c) {
+            const float* fc = f + (long long)c * Hf * Wf;
+            o[c] = same ? fc[y * Wf + x]
+                        : ac_blend(ly, lx, fc[ly.i0 * Wf + lx.i0], fc[ly.i0 * Wf + lx.i1], fc[ly.i1 * Wf + lx.i0],
+                                   fc[ly.i1 * Wf + lx.i1]);
+        }
+    }
+    {   // colours
+        Lerp1 ly = ac_lerp(y, ac_scale(H, Hr), H), lx = ac_lerp(x, ac_scale(W, Wr), W);
+        const float* s = src + (long long)img * 3 * H * W;
+        for (int c = 0; c < 3; ++c) {
+            const float* sc = s + (long long)c * H * W;
+            float v00 = sc[ly.i0 * W + lx.i0] * 0.5f + 0.5f, v01 = sc[ly.i0 * W + lx.i1] * 0.5f + 0.5f;
+            float v10 = sc[ly.i1 * W + lx.i0] * 0.5f + 0.5f, v11 = sc[ly.i1 * W + lx.i1] * 0.5f + 0.5f;
+            o[C + c] = ac_blend(ly, lx, v00, v01, v10, v11);
+        }
+    }
+    for (int c = C + 3; c < tex; ++c) o[c] = 0.f;
+}
+void launch_pack_img_feat_rgb(const float* im_feat, int C, int Hf, int Wf, const float* src_inps, int H, int W, int Hr,
+                              int Wr, int tex, int n_img, float* out, hipStream_t st) {
+    long long tot = (long long)Hr * Wr * n_img;
+    ENERF_LAUNCH_SIMPLE(k_pack_img_feat_rgb, (unsigned)cdivl(tot, 256), 256, 0, st, im_feat, C, Hf, Wf, src_inps, H, W,
+                        Hr, Wr, tex, n_img, out);
+}
+
+// -------------------------------------------------------------------------------------------------
+// get_proj_mats (utils.py:35-55):  P[b,s] = (K_s' E_s[:3]) · inv([K_t' E_t[:3]; 0 0 0 1]),
+// K' = K with rows 0,1 scaled.  One thread per (b,s); fp64 internally (a 4x4 inverse per frame),
+// rounded to fp32 on store.
+// -------------------------------------------------------------------------------------------------
+// proj3x4 = K'(3x3, rows 0,1 scaled) * E[:3] (3x4)
+__device__ __forceinline__ void k_times_e(const float* K, const float* E, float scale, double* out34) {
+    for (int r = 0; r < 3; ++r) {
+        double sc = r < 2 ? (double)scale : 1.0;
+        for (int c = 0; c < 4; ++c) {
+            double a = 0;
+            for (int k = 0; k < 3; ++k) a += ((double)K[r * 3 + k] * sc) * (double)E[k * 4 + c];
+            out34[r * 4 + c] = a;
+        }
+    }
+}
+__global__ void k_proj_mats(const float* __restrict__ src_ixts, const float* __restrict__ src_exts,
+                            const float* __restrict__ tar_ixt, const float* __restrict__ tar_ext, int B, int S,
+                            float src_scale, float tar_scale, float* __restrict__ proj) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * S) return;
+    int b = i / S;
+    double t44[16], tinv[16], s34[12];
+    k_times_e(tar_ixt + b * 9, tar_ext + b * 16, tar_scale, t44);
+    t44[12] = t44[13] = t44[14] = 0.0;
+    t44[15] = 1.0;
+    if (!inv4x4(t44, tinv)) {
+        for (int k = 0; k < 16; ++k) tinv[k] = NAN;
+    }
+    k_times_e(src_ixts + i * 9, src_exts + i * 16, src_scale, s34);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) {
+            double a = 0;
+            for (int k = 0; k < 4; ++k) a += s34[r * 4 + k] * tinv[k * 4 + c];
+            proj[i * 12 + r * 4 + c] = (float)a;
+        }
+}
+void launch_proj_mats(const float* src_ixts, const float* src_exts, const float* tar_ixt, const float* tar_ext, int B,
+                      int S, float src_scale, float tar_scale, float* proj, hipStream_t st) {
+    ENERF_LAUNCH_SIMPLE(k_proj_mats, cdiv(B * S, 64), 64, 0, st, src_ixts, src_exts, tar_ixt, tar_ext, B, S, src_scale,
+                        tar_scale, proj);
+}
+
+// -------------------------------------------------------------------------------------------------
+// get_depth_values (utils.py:98-151).  One thread per (b, y, x); loops the D planes.
+// Level 0 (pdepth == nullptr): planes uniform in disparity (depth_inv) or depth between batch near/far.
+// Level >0: x(h/hp) align-corners upsample of the previous level's {depth, std, near_far} (all in
+// disparity: only the depth_inv[level-1]==True branch is live, utils.py:122-130), then
+// [1/min(d+s, nf0), 1/max(d-s, nf1)] and D planes in between.
+// torch.linspace(0,1,D): step=1/(D-1); t_k = k<D/2 ? step*k : 1 - step*(D-1-k).
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_depth_values(const float* __restrict__ near_far,
+                                                      const float* __restrict__ pdepth, const float* __restrict__ pstd,
+                                                      const float* __restrict__ pnf, int B, int D, int h, int w, int hp,
+                                                      int wp, int depth_inv, float* __restrict__ dv,
+                                                      float* __restrict__ nf_out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int hw = h * w;
+    if (i >= B * hw) return;
+    int b = i / hw, p = i - b * hw;
+    float nn, ff;
+    if (pdepth == nullptr) {
+        nn = near_far[b * 2 + 0];
+        ff = near_far[b * 2 + 1];
+    } else {
+        int y = p / w, x = p - y * w;
+        Lerp1 ly = ac_lerp(y, ac_scale(hp, h), hp), lx = ac_lerp(x, ac_scale(wp, w), wp);
+        int o00 = ly.i0 * wp + lx.i0, o01 = ly.i0 * wp + lx.i1, o10 = ly.i1 * wp + lx.i0, o11 = ly.i1 * wp + lx.i1;
+        const float* pd = pdepth + (long long)b * hp * wp;
+        const float* ps = pstd + (long long)b * hp * wp;
+        const float* n0 = pnf + (long long)b * 2 * hp * wp;
+        const float* n1 = n0 + hp * wp;
+        float d = ac_blend(ly, lx, pd[o00], pd[o01], pd[o10], pd[o11]);
+        float s = ac_blend(ly, lx, ps[o00], ps[o01], ps[o10], ps[o11]);
+        float a0 = ac_blend(ly, lx, n0[o00], n0[o01], n0[o10], n0[o11]);
+        float a1 = ac_blend(ly, lx, n1[o00], n1[o01], n1[o10], n1[o11]);
+        float lo = d + s, hi = d - s;
+        if (lo > a0) lo = a0;     // utils.py:123-125
+        if (hi < a1) hi = a1;     // utils.py:126-127
+        nn = 1.f / lo;            // utils.py:128
+        ff = 1.f / hi;
+    }
+    float first = 0.f, last = 0.f;
+    float inn = 1.f / nn, iff = 1.f / ff;
+    for (int k = 0; k < D; ++k) {
+        float t = linspace01(k, D);
+        float v = depth_inv ? 1.f / (inn + t * (iff - inn)) : nn + t * (ff - nn);
+        dv[((long long)b * D + k) * hw + p] = v;
+        if (k == 0) first = v;
+        if (k == D - 1) last = v;
+    }
+    if (depth_inv) {             // utils.py:149-150
+        first = 1.f / clamp_min(first, 1e-6f);
+        last = 1.f / clamp_min(last, 1e-6f);
+    }
+    nf_out[((long long)b * 2 + 0) * hw + p] = first;
+    nf_out[((long long)b * 2 + 1) * hw + p] = last;
+}
+void launch_depth_values(const float* near_far, const float* pdepth, const float* pstd, const float* pnf, int B, int D,
+                         int h, int w, int hp, int wp, int depth_inv, float* dv, float* nf_out, hipStream_t st) {
+    ENERF_LAUNCH_SIMPLE(k_depth_values, cdiv(B * h * w, 256), 256, 0, st, near_far, pdepth, pstd, pnf, B, D, h, w, hp,
+                        wp, depth_inv, dv, nf_out);
+}
+
+// -------------------------------------------------------------------------------------------------
+// depth_regression (utils.py:658-667): softmax over D, E[v], sqrt(max(Var,1e-10)); v = 1/max(dv,1e-6)
+// for disparity-space levels.  One thread per pixel; prob/dv are (B,D,h,w) so every plane read is
+// coalesced across the wave.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_depth_regression(const float* __restrict__ prob, const float* __restrict__ dv,
+                                                          int B, int D, int h, int w, int depth_inv,
+                                                          float* __restrict__ depth, float* __restrict__ std) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int hw = h * w;
+    if (i >= B * hw) return;
+    int b = i / hw, p = i - b * hw;
+    const float* pr = prob + (long long)b * D * hw + p;
+    const float* dp = dv + (long long)b * D * hw + p;
+    float m = -INFINITY;
+    for (int k = 0; k < D; ++k) m = fmaxf(m, pr[(long long)k * hw]);
+    float se = 0.f;
+    for (int k = 0; k < D; ++k) se += expf(pr[(long long)k * hw] - m);
+    float mu = 0.f;
+    for (int k = 0; k < D; ++k) {
+        float pk = expf(pr[(long long)k * hw] - m) / se;
+        float v = dp[(long long)k * hw];
+        if (depth_inv) v = 1.f / clamp_min(v, 1e-6f);
+        mu += pk * v;
+    }
+    float var = 0.f;
+    for (int k = 0; k < D; ++k) {
+        float pk = expf(pr[(long long)k * hw] - m) / se;
+        float v = dp[(long long)k * hw];
+        if (depth_inv) v = 1.f / clamp_min(v, 1e-6f);
+        float dd = v - mu;
+        var += pk * (dd * dd);
+    }
+    depth[i] = mu;
+    std[i] = sqrtf(clamp_min(var, 1e-10f));
+}
+void launch_depth_regression(const float* prob, const float* dv, int B, int D, int h, int w, int depth_inv,
+                             float* depth, float* std, hipStream_t st) {
+    ENERF_LAUNCH_SIMPLE(k_depth_regression, cdiv(B * h * w, 256), 256, 0, st, prob, dv, B, D, h, w, depth_inv, depth,
+                        std);
+}
+
+// -------------------------------------------------------------------------------------------------
+// build_rays (utils.py:390-420): x(Hr/h) align-corners upsample of {depth, std, near_far}, per-ray
+// [near, far] clamped into the volume bounds, gathered at the ray's integer (u, v); appended to the
+// 8-float ray -> 12 floats [o(3), d(3), u, v, ray_near, ray_far, vol_near, vol_far].
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_rays(const float* __restrict__ rays8, const float* __restrict__ depth,
+                                                    const float* __restrict__ std, const float* __restrict__ nf, int B,
+                                                    int N, int h, int w, int Hr, int Wr, int depth_inv,
+                                                    float* __restrict__ rays12) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * N) return;
+    int b = (int)(i / N);
+    const float* r = rays8 + i * 8;
+    float rv[8];
+    for (int k = 0; k < 8; ++k) rv[k] = r[k];
+    int u = (int)rv[6], v = (int)rv[7];                     // .long(): truncation
+    u = u < 0 ? u + Wr : u;                                  // python negative indexing
+    v = v < 0 ? v + Hr : v;
+    u = u < 0 ? 0 : (u > Wr - 1 ? Wr - 1 : u);
+    v = v < 0 ? 0 : (v > Hr - 1 ? Hr - 1 : v);
+    Lerp1 ly = ac_lerp(v, ac_scale(h, Hr), h), lx = ac_lerp(u, ac_scale(w, Wr), w);
+    int o00 = ly.i0 * w + lx.i0, o01 = ly.i0 * w + lx.i1, o10 = ly.i1 * w + lx.i0, o11 = ly.i1 * w + lx.i1;
+    const float* pd = depth + (long long)b * h * w;
+    const float* ps = std + (long long)b * h * w;
+    const float* n0 = nf + (long long)b * 2 * h * w;
+    const float* n1 = n0 + h * w;
+    bool same = (h == Hr) && (w == Wr);
+    float d, s, a0, a1;
+    if (same) {
+        d = pd[o00]; s = ps[o00]; a0 = n0[o00]; a1 = n1[o00];
+    } else {
+        d = ac_blend(ly, lx, pd[o00], pd[o01], pd[o10], pd[o11]);
+        s = ac_blend(ly, lx, ps[o00], ps[o01], ps[o10], ps[o11]);
+        a0 = ac_blend(ly, lx, n0[o00], n0[o01], n0[o10], n0[o11]);
+        a1 = ac_blend(ly, lx, n1[o00], n1[o01], n1[o10], n1[o11]);
+    }
+    float rn, rf;
+    if (depth_inv) {              // utils.py:402-407
+        rn = d + s; if (rn > a0) rn = a0;
+        rf = d - s; if (rf < a1) rf = a1;
+    } else {                      // utils.py:409-413
+        rn = d - s; if (rn < a0) rn = a0;
+        rf = d + s; if (rf > a1) rf = a1;
+    }
+    float* o = rays12 + i * 12;
+    for (int k = 0; k < 8; ++k) o[k] = rv[k];
+    o[8] = rn; o[9] = rf; o[10] = a0; o[11] = a1;
+}
+void launch_build_rays(const float* rays8, const float* depth, const float* std, const float* nf, int B, int N, int h,
+                       int w, int Hr, int Wr, int depth_inv, float* rays12, hipStream_t st) {
+    long long tot = (long long)B * N;
+    ENERF_LAUNCH_SIMPLE(k_build_rays, (unsigned)cdivl(tot, 256), 256, 0, st, rays8, depth, std, nf, B, N, h, w, Hr, Wr,
+                        depth_inv, rays12);
+}
+
+}  // namespace enerf

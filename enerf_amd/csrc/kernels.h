@@ -1,0 +1,56 @@
+// kernels.h — host-side launchers implemented by the .hip files in this directory.
+// All pointers are device pointers; nothing here allocates or synchronises.
+#pragma once
+#include "common.h"
+#include "../../include/enerf_hip.h"
+
+namespace enerf {
+
+// ---- geometry.hip -------------------------------------------------------------------------------
+void launch_channels_last(const float* src, float* dst, int n, int C, long long P, int Cpad, hipStream_t st);
+void launch_channels_first(const float* src, float* dst, int n, int C, long long P, int Cpad, hipStream_t st);
+void launch_pack_img_feat_rgb(const float* im_feat, int C, int Hf, int Wf, const float* src_inps, int H, int W,
+                              int Hr, int Wr, int tex, int n_img, float* out, hipStream_t st);
+void launch_proj_mats(const float* src_ixts, const float* src_exts, const float* tar_ixt, const float* tar_ext, int B,
+                      int S, float src_scale, float tar_scale, float* proj, hipStream_t st);
+void launch_depth_values(const float* near_far, const float* pdepth, const float* pstd, const float* pnf, int B, int D,
+                         int h, int w, int hp, int wp, int depth_inv, float* dv, float* nf_out, hipStream_t st);
+void launch_depth_regression(const float* prob, const float* dv, int B, int D, int h, int w, int depth_inv,
+                             float* depth, float* std, hipStream_t st);
+void launch_build_rays(const float* rays8, const float* depth, const float* std, const float* nf, int B, int N, int h,
+                       int w, int Hr, int Wr, int depth_inv, float* rays12, hipStream_t st);
+
+// ---- volume.hip ---------------------------------------------------------------------------------
+void launch_feature_volume(const float* feat_nhwc, const float* proj, const float* dv, int B, int S, int C, int Hs,
+                           int Ws, int D, int h, int w, float* vol, hipStream_t st);
+
+// ---- conv3d.hip ---------------------------------------------------------------------------------
+enum ConvKind { kConvS1 = 0, kConvS2 = 1, kConvT2 = 2 };
+struct Conv3dDesc {
+    const float* w;         // packed A operands (see conv3d.hip)
+    const float* scale;     // per-cout epilogue scale (BN folded) or nullptr (=1)
+    const float* shift;     // per-cout epilogue shift or nullptr (=0)
+    int cin, cout, kind, relu;
+};
+// number of floats of the packed weight image for a layer
+long long conv3d_packed_floats(int cin, int cout, int kind);
+// pack torch-layout weights (Conv3d: (cout,cin,3,3,3); ConvTranspose3d: (cin,cout,3,3,3)) + BN into
+// {packed A operands, scale[coutpad], shift[coutpad]}
+// rows [0,cout1) of the GEMM come from w, rows [cout1,cout) from w2 (used to fuse feat_conv ++ depth_conv)
+void launch_conv3d_pack(const float* w, const float* w2, int cout1, const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var,
+                        float eps, int cin, int cout, int kind, float* packed, float* scale, float* shift,
+                        hipStream_t st);
+// in: (B, Di, Hi, Wi, cin) channels-last; out: (B, Do, Ho, Wo, cout_store); residual (same shape as out) optional.
+// cout_store lets the fused heads write feat (8 ch) and prob (1 ch) to two tensors: if out2 != nullptr,
+// channels [0,8) go to out (stride 8) and channel 8 goes to out2 (stride 1).
+void launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, float* out, float* out2, int B, int Di,
+                   int Hi, int Wi, hipStream_t st);
+
+// ---- render.hip ---------------------------------------------------------------------------------
+using NerfRaw = enerf_nerf_raw_t;     // torch-layout parameter pointers of one NeRF (nerf.py:6-89)
+long long nerf_packed_floats(int feat_ch_plus3);
+void launch_nerf_pack(const NerfRaw& raw, int F, int viewdir_agg, float* packed, hipStream_t st);
+using RenderArgs = enerf_render_args_t;
+int launch_render_rays(const RenderArgs& a, hipStream_t st);  // returns 0, or <0 for unsupported shapes
+
+}  // namespace enerf

@@ -1,0 +1,497 @@
+// render.hip — fused per-ray rendering: sample_along_depth (utils.py:422-441) + get_vox_feat
+// (utils.py:456-458) + get_img_feat (utils.py:689-722) + Agg/NeRF MLP (nerf.py:29-89) + raw2outputs
+// (utils.py:571-603), i.e. Network.render_rays (network.py:24-43) in ONE kernel.  Nothing between the
+// 12-float rays and {rgb, depth, weights} ever touches HBM (the reference materialises ~118 MB of
+// gathered features plus every MLP activation).
+//
+// Mapping.  A wave owns 16 rays; lane l = (g = l>>4, j = l&15) works on ray j.  For every sample the
+// MLP runs on v_mfma_f32_16x16x4_f32 with the *weights* as the A operand (rows = output units) and the
+// 16 points as the B/D columns:
+//     A: lane holds W[row = j][k = g]      B: lane holds X[k = g][col = j]
+//     D: lane holds rows 4g+r (r = 0..3) of column j
+// A layer's D registers are therefore directly the next layer's B operands (k-step (tile,r) supplies
+// unit 16*tile+4g+r from lane group g); the packed weight image (nerf_pack) is permuted to that K
+// order, so activations never move between lanes.  Gathered per-view features use the same idea:
+// lane group g fetches channels [gR, gR+R) of the texel (R = ceil((C+3)/4)), register r is k-step r.
+// Width-1 heads (agg weight, sigma, colour logit) are in-lane dot products + a 2-step xor reduction over
+// the four lane groups.  Softmaxes over views and the compositing scan over samples are in-lane.
+//
+// Algebra (fp re-association only): global_fc = W_a·a_s + W_vm·[var,mean] and
+// color.0 = W_p·[h,vox,agg] + W_v·[x_s,dir_s] — the view-independent halves are evaluated once per
+// point instead of once per view (201 instead of 369 MFMAs per 16 points at S=3, C=8).
+//
+// Roofline: MFMA-bound (fp32 157.3 TF).  Algorithmic FLOPs/point: SURVEY.md §8a (50,952 at level 1).
+#include "kernels.h"
+
+namespace enerf {
+
+// ---- packed weight image ---------------------------------------------------------------------------
+struct NerfLayout {
+    int F, R, TR;
+    int view, viewb, glob, globb, aggw, fc, fcb, lr0, lr0b, sigma, c0p, c0b, c0v, col2, total;  // float offsets
+};
+__host__ __device__ __forceinline__ NerfLayout nerf_layout(int F) {
+    NerfLayout L;
+    L.F = F; L.R = (F + 3) / 4; L.TR = (L.R + 3) / 4;
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += (n + 63) / 64 * 64; return r; };
+    L.view = take(L.TR * 64);
+    L.viewb = take(L.TR * 16);
+    L.glob = take(3 * L.R * 2 * 64);
+    L.globb = take(32);
+    L.aggw = take(33);
+    L.fc = take(8 * 64);
+    L.fcb = take(16);
+    L.lr0 = take(6 * 4 * 64);
+    L.lr0b = take(64);
+    L.sigma = take(65);
+    L.c0p = take(22 * 4 * 64);
+    L.c0b = take(64);
+    L.c0v = take((L.R + 1) * 4 * 64);
+    L.col2 = take(65);
+    L.total = o;
+    return L;
+}
+long long nerf_packed_floats(int F) { return nerf_layout(F).total; }
+
+// slot (g, r) of the channel layout -> channel index (or -1)
+__host__ __device__ __forceinline__ int slot_channel(int g, int r, int R, int F) {
+    int c = g * R + r;
+    return (r < R && c < F) ? c : -1;
+}
+
+__global__ __launch_bounds__(256) void k_nerf_pack(NerfRaw w, int F, int viewdir_agg, float* __restrict__ out) {
+    const NerfLayout L = nerf_layout(F);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.total) return;
+    const int R = L.R;
+    const int CI = 88 + F + 4;    // color.0 fan-in
+    float v = 0.f;
+    auto mfma_lane = [&](int rel, int& e, int& g, int& row) { e = rel >> 6; g = (rel & 63) >> 4; row = rel & 15; };
+    int e, g, row;
+    if (i >= L.col2) {
+        int k = i - L.col2;
+        if (k < 64) v = w.col2_w[k]; else if (k == 64) v = w.col2_b[0];
+    } else if (i >= L.c0v) {
+        mfma_lane(i - L.c0v, e, g, row);
+        int ks = e >> 2, vt = e & 3, unit = 16 * vt + row;
+        if (ks < R) { int c = slot_channel(g, ks, R, F); if (c >= 0) v = w.col0_w[unit * CI + 88 + c]; }
+        else if (ks == R) v = w.col0_w[unit * CI + 88 + F + g];
+    } else if (i >= L.c0b) {
+        int k = i - L.c0b; if (k < 64) v = w.col0_b[k];
+    } else if (i >= L.c0p) {
+        mfma_lane(i - L.c0p, e, g, row);
+        int ks = e >> 2, vt = e & 3, unit = 16 * vt + row;
+        if (ks < 16) v = w.col0_w[unit * CI + 16 * (ks >> 2) + 4 * g + (ks & 3)];         // h
+        else if (ks < 18) v = w.col0_w[unit * CI + 64 + 2 * g + (ks - 16)];                // vox
+        else if (ks < 22) v = w.col0_w[unit * CI + 72 + 4 * g + (ks - 18)];                // agg
+    } else if (i >= L.sigma) {
+        int k = i - L.sigma;
+        if (k < 64) v = w.sigma_w[k]; else if (k == 64) v = w.sigma_b[0];
+    } else if (i >= L.lr0b) {
+        int k = i - L.lr0b; if (k < 64) v = w.lr0_b[k];
+    } else if (i >= L.lr0) {
+        mfma_lane(i - L.lr0, e, g, row);
+        int ks = e >> 2, vt = e & 3, unit = 16 * vt + row;
+        if (ks < 2) v = w.lr0_w[unit * 24 + 2 * g + ks];                                   // vox
+        else if (ks < 6) v = w.lr0_w[unit * 24 + 8 + 4 * g + (ks - 2)];                    // agg
+    } else if (i >= L.fcb) {
+        int k = i - L.fcb; if (k < 16) v = w.fc_b[k];
+    } else if (i >= L.fc) {
+        mfma_lane(i - L.fc, e, g, row);                       // e = u*4 + r'
+        if (e < 8) v = w.fc_w[row * 32 + 16 * (e >> 2) + 4 * g + (e & 3)];
+    } else if (i >= L.aggw) {
+        int k = i - L.aggw;
+        if (k < 32) v = w.aggw_w[k]; else if (k == 32) v = w.aggw_b[0];
+    } else if (i >= L.globb) {
+        int k = i - L.globb; if (k < 32) v = w.glob_b[k];
+    } else if (i >= L.glob) {
+        mfma_lane(i - L.glob, e, g, row);                     // e = (part*R + r)*2 + u
+        int u = e & 1, pr = e >> 1, part = pr / R, r = pr - part * R;
+        int c = slot_channel(g, r, R, F);
+        if (part < 3 && c >= 0) v = w.glob_w[(16 * u + row) * 3 * F + part * F + c];
+    } else if (i >= L.viewb) {
+        int k = i - L.viewb;                                   // [t][16]: row 4g'+r' of tile t
+        int t = k >> 4, rr = k & 15;
+        int c = slot_channel(rr >> 2, 4 * t + (rr & 3), R, F);
+        if (t < L.TR && c >= 0 && viewdir_agg) v = w.view_b[c];
+    } else {
+        mfma_lane(i - L.view, e, g, row);                      // e = t
+        int c = slot_channel(row >> 2, 4 * e + (row & 3), R, F);
+        if (e < L.TR && c >= 0 && viewdir_agg) v = w.view_w[c * 4 + g];
+    }
+    out[i] = v;
+}
+void launch_nerf_pack(const NerfRaw& raw, int F, int viewdir_agg, float* packed, hipStream_t st) {
+    int total = nerf_layout(F).total;
+    ENERF_LAUNCH_SIMPLE(k_nerf_pack, cdiv(total, 256), 256, 0, st, raw, F, viewdir_agg, packed);
+}
+
+// ---- device helpers ----------------------------------------------------------------------------------
+__device__ __forceinline__ float group_sum(float v) {      // sum over the 4 lane groups (lanes j, j+16, j+32, j+48)
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ f32x4 lds4(const float* p) {     // 16-byte aligned LDS/global read
+    float4 t = *reinterpret_cast<const float4*>(p);
+    return f32x4{t.x, t.y, t.z, t.w};
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 a) {
+    return f32x4{fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f)};
+}
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b, float acc) {
+    acc += a[0] * b[0]; acc += a[1] * b[1]; acc += a[2] * b[2]; acc += a[3] * b[3];
+    return acc;
+}
+#define ENERF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// camera table in LDS, per (b,s): E[:3] (12) | K' (9) | centre (3) ; per b: target centre (3)
+constexpr int kCamStride = 24;
+
+template <int R, int S>
+__global__ __launch_bounds__(256) void k_render_rays(RenderArgs a) {
+    constexpr int TR = (R + 3) / 4;
+    const NerfLayout L = nerf_layout(a.F);
+    ENERF_DYN_SMEM(float, smem);
+    float* wl = smem;                                    // packed weights
+    float* cam = smem + L.total;                         // B*S*24
+    float* tcen = cam + a.B * S * kCamStride;            // B*3
+
+    // ---- prologue: stage weights + camera table ----
+    for (int i = threadIdx.x * 4; i < L.total; i += blockDim.x * 4)
+        *reinterpret_cast<float4*>(wl + i) = *reinterpret_cast<const float4*>(a.packed + i);
+    for (int i = threadIdx.x; i < a.B * (S + 1); i += blockDim.x) {
+        int b = i / (S + 1), s = i - b * (S + 1);
+        const float* E = (s < S) ? a.src_exts + ((long long)b * S + s) * 16 : a.tar_ext + (long long)b * 16;
+        double m[16], inv[16];
+        for (int k = 0; k < 16; ++k) m[k] = (double)E[k];
+        bool ok = inv4x4(m, inv);
+        float c0 = ok ? (float)inv[3] : NAN, c1 = ok ? (float)inv[7] : NAN, c2 = ok ? (float)inv[11] : NAN;
+        if (s < S) {
+            float* c = cam + ((long long)b * S + s) * kCamStride;
+            for (int k = 0; k < 12; ++k) c[k] = E[k];
+            const float* K = a.src_ixts + ((long long)b * S + s) * 9;
+            for (int k = 0; k < 9; ++k) c[12 + k] = (k < 6) ? K[k] * a.render_scale : K[k];     // utils.py:700-701
+            c[21] = c0; c[22] = c1; c[23] = c2;
+        } else {
+            tcen[b * 3 + 0] = c0; tcen[b * 3 + 1] = c1; tcen[b * 3 + 2] = c2;
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const int wave_in_block = threadIdx.x >> 6, waves_per_block = blockDim.x >> 6;
+    const long long nrays = (long long)a.B * a.N;
+    const long long ntiles = cdivl(nrays, 16);
+    const int Ns = a.n_samples;
+    const int TEX = 4 * R;
+    const float* wlane = wl + lane;
+
+    for (long long tile = (long long)blockIdx.x * waves_per_block + wave_in_block; tile < ntiles;
+         tile += (long long)gridDim.x * waves_per_block) {
+        long long ray = tile * 16 + j;
+        const bool rok = ray < nrays;
+        const long long rr = rok ? ray : nrays - 1;
+        const int b = (int)(rr / a.N);
+        const float* rp = a.rays12 + rr * 12;
+        const float4 q0 = *reinterpret_cast<const float4*>(rp), q1 = *reinterpret_cast<const float4*>(rp + 4),
+                     q2 = *reinterpret_cast<const float4*>(rp + 8);
+        const float ox = q0.x, oy = q0.y, oz = q0.z, dx = q0.w, dy = q1.x, dz = q1.y, ru = q1.z, rv = q1.w;
+        const float rn = q2.x, rf = q2.y, vn = q2.z, vf = q2.w;
+        // normalised (x,y) of the ray inside the feature volume: network.py:37 then utils.py:457
+        const float gxv = (ru / (float)(a.Wr - 1)) * 2.f - 1.f, gyv = (rv / (float)(a.Hr - 1)) * 2.f - 1.f;
+        const float* volb = a.vol + (long long)b * a.D * a.h * a.w * 8 + 2 * g;
+        const float* texb = a.tex + (long long)b * S * a.Hr * a.Wr * TEX + g * R;
+        const float* camb = cam + (long long)b * S * kCamStride;
+        const float tcx = tcen[b * 3], tcy = tcen[b * 3 + 1], tcz = tcen[b * 3 + 2];
+
+        float Tacc = 1.f;                 // transmittance, raw2outputs utils.py:588-589
+        float wk[8];                      // per-sample weights (Ns <= 8)
+        float rgbacc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) rgbacc[r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wk[k] = 0.f;
+
+#pragma unroll 1
+        for (int k = 0; k < Ns; ++k) {
+            // ---------- sample placement (utils.py:425-436) ----------
+            float tk = (Ns == 1) ? 0.5f : linspace01(k, Ns);
+            float z = rn + (rf - rn) * tk;
+            float zz = a.depth_inv ? 1.f / clamp_min(z, 1e-6f) : z;
+            float X = ox + dx * zz, Y = oy + dy * zz, Z = oz + dz * zz;
+            float dn = a.depth_inv ? (vn - z) / clamp_min(vn - vf, 1e-6f) : (z - vn) / clamp_min(vf - vn, 1e-6f);
+
+            // ---------- voxel feature: trilinear, zeros padding (utils.py:457) ----------
+            float vox[2] = {0.f, 0.f};
+            {
+                float ix = gs_unnorm(gxv, a.w), iy = gs_unnorm(gyv, a.h), iz = gs_unnorm(dn * 2.f - 1.f, a.D);
+                bool fin = (ix > -1e8f) && (ix < 1e8f) && (iy > -1e8f) && (iy < 1e8f) && (iz > -1e8f) && (iz < 1e8f);
+                if (!fin) { ix = iy = iz = -10.f; }
+                float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+                int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+                float wx1 = ix - fx, wy1 = iy - fy, wz1 = iz - fz;
+                float wx0 = (float)(x0 + 1) - ix, wy0 = (float)(y0 + 1) - iy, wz0 = (float)(z0 + 1) - iz;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {           // order tnw,tne,tsw,tse,bnw,bne,bsw,bse
+                    int xx = x0 + (c & 1), yy = y0 + ((c >> 1) & 1), zc = z0 + (c >> 2);
+                    float wgt = ((c & 1) ? wx1 : wx0) * (((c >> 1) & 1) ? wy1 : wy0) * ((c >> 2) ? wz1 : wz0);
+                    bool ok = xx >= 0 && xx < a.w && yy >= 0 && yy < a.h && zc >= 0 && zc < a.D;
+                    float2 t = ok ? *reinterpret_cast<const float2*>(volb + (((long long)zc * a.h + yy) * a.w + xx) * 8)
+                                  : make_float2(0.f, 0.f);
+                    vox[0] += t.x * wgt;
+                    vox[1] += t.y * wgt;
+                }
+            }
+
+            // ---------- per-view image features + direction code (utils.py:698-720) ----------
+            float x[S][R], dsel[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float* c = camb + s * kCamStride;
+                float cx = X * c[0] + Y * c[1] + Z * c[2] + c[3];
+                float cy = X * c[4] + Y * c[5] + Z * c[6] + c[7];
+                float cz = X * c[8] + Y * c[9] + Z * c[10] + c[11];
+                float px = cx * c[12] + cy * c[13] + cz * c[14];
+                float py = cx * c[15] + cy * c[16] + cz * c[17];
+                float pz = cx * c[18] + cy * c[19] + cz * c[20];
+                float zc = clamp_min(pz, 1e-6f);
+                float gx = ((px / zc) / (float)(a.Wr - 1)) * 2.f - 1.f, gy = ((py / zc) / (float)(a.Hr - 1)) * 2.f - 1.f;
+                Taps2 t = gs_taps2<true>(gs_unnorm(gx, a.Wr), gs_unnorm(gy, a.Hr), a.Wr, a.Hr);
+                const float* tb = texb + (long long)s * a.Hr * a.Wr * TEX;
+                const float* p00 = tb + ((long long)t.y0 * a.Wr + t.x0) * TEX;
+                const float* p01 = tb + ((long long)t.y0 * a.Wr + t.x1) * TEX;
+                const float* p10 = tb + ((long long)t.y1 * a.Wr + t.x0) * TEX;
+                const float* p11 = tb + ((long long)t.y1 * a.Wr + t.x1) * TEX;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float acc = p00[r] * t.w00;
+                    acc += p01[r] * t.w01;
+                    acc += p10[r] * t.w10;
+                    acc += p11[r] * t.w11;
+                    x[s][r] = acc;
+                }
+                // direction code
+                float tx = X - tcx, ty = Y - tcy, tz = Z - tcz;
+                float sx = X - c[21], sy = Y - c[22], sz = Z - c[23];
+                float tnr = sqrtf(tx * tx + ty * ty + tz * tz) + 1e-6f, snr = sqrtf(sx * sx + sy * sy + sz * sz) + 1e-6f;
+                tx /= tnr; ty /= tnr; tz /= tnr;
+                sx /= snr; sy /= snr; sz /= snr;
+                float ex = tx - sx, ey = ty - sy, ez = tz - sz;
+                float en = fmaxf(sqrtf(ex * ex + ey * ey + ez * ez), 1e-6f);
+                float dot = tx * sx + ty * sy + tz * sz;
+                dsel[s] = g == 0 ? ex / en : (g == 1 ? ey / en : (g == 2 ? ez / en : dot));
+            }
+
+            // ---------- Agg (nerf.py:74-89) ----------
+            float av[S][R];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                f32x4 va[TR];
+#pragma unroll
+                for (int t = 0; t < TR; ++t) {
+                    va[t] = lds4(wl + L.viewb + t * 16 + 4 * g);
+                    va[t] = ENERF_MFMA(wlane[L.view + t * 64], dsel[s], va[t]);
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) av[s][r] = x[s][r] + fmaxf(va[r >> 2][r & 3], 0.f);
+            }
+            float var[R], mean[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float m = 0.f;
+#pragma unroll
+                for (int s = 0; s < S; ++s) m += av[s][r];
+                m /= (float)S;
+                float q = 0.f;
+#pragma unroll
+                for (int s = 0; s < S; ++s) { float d = av[s][r] - m; q += d * d; }
+                mean[r] = m;
+                var[r] = q / (float)(S - 1);                      // unbiased, nerf.py:82
+            }
+            f32x4 P[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) P[u] = lds4(wl + L.globb + u * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    P[u] = ENERF_MFMA(wlane[L.glob + (((1 * R + r) * 2 + u) << 6)], var[r], P[u]);
+                    P[u] = ENERF_MFMA(wlane[L.glob + (((2 * R + r) * 2 + u) << 6)], mean[r], P[u]);
+                }
+            f32x4 gf[S][2];
+            float aw[S];
+            const f32x4 aggw0 = lds4(wl + L.aggw + 4 * g), aggw1 = lds4(wl + L.aggw + 16 + 4 * g);
+            const float aggb = wl[L.aggw + 32];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                gf[s][0] = P[0]; gf[s][1] = P[1];
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        gf[s][u] = ENERF_MFMA(wlane[L.glob + (((0 * R + r) * 2 + u) << 6)], av[s][r], gf[s][u]);
+                gf[s][0] = relu4(gf[s][0]); gf[s][1] = relu4(gf[s][1]);
+                float part = dot4(gf[s][1], aggw1, dot4(gf[s][0], aggw0, 0.f));
+                aw[s] = fmaxf(group_sum(part) + aggb, 0.f);
+            }
+            {   // softmax over views
+                float m = aw[0];
+#pragma unroll
+                for (int s = 1; s < S; ++s) m = fmaxf(m, aw[s]);
+                float se = 0.f;
+#pragma unroll
+                for (int s = 0; s < S; ++s) { aw[s] = expf(aw[s] - m); se += aw[s]; }
+#pragma unroll
+                for (int s = 0; s < S; ++s) aw[s] /= se;
+            }
+            f32x4 G[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                G[u] = gf[0][u] * aw[0];
+#pragma unroll
+                for (int s = 1; s < S; ++s) G[u] += gf[s][u] * aw[s];
+            }
+            f32x4 agg = lds4(wl + L.fcb + 4 * g);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) agg = ENERF_MFMA(wlane[L.fc + ((u * 4 + r) << 6)], G[u][r], agg);
+            agg = relu4(agg);
+
+            // ---------- NeRF trunk (nerf.py:33-37) ----------
+            f32x4 hid[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) hid[v] = lds4(wl + L.lr0b + v * 16 + 4 * g);
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                float bop = ks < 2 ? vox[ks] : agg[ks - 2];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) hid[v] = ENERF_MFMA(wlane[L.lr0 + ((ks * 4 + v) << 6)], bop, hid[v]);
+            }
+            float sig = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                hid[v] = relu4(hid[v]);
+                sig = dot4(hid[v], lds4(wl + L.sigma + v * 16 + 4 * g), sig);
+            }
+            sig = group_sum(sig) + wl[L.sigma + 64];
+            sig = sig > 20.f ? sig : log1pf(expf(sig));            // nn.Softplus(beta=1, threshold=20)
+
+            // ---------- colour head (nerf.py:38-42) ----------
+            f32x4 P2[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) P2[v] = lds4(wl + L.c0b + v * 16 + 4 * g);
+#pragma unroll
+            for (int ks = 0; ks < 22; ++ks) {
+                float bop = ks < 16 ? hid[ks >> 2][ks & 3] : (ks < 18 ? vox[ks - 16] : agg[ks - 18]);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) P2[v] = ENERF_MFMA(wlane[L.c0p + ((ks * 4 + v) << 6)], bop, P2[v]);
+            }
+            float cl[S];
+            const float c2b = wl[L.col2 + 64];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                f32x4 cc[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) cc[v] = P2[v];
+#pragma unroll
+                for (int ks = 0; ks <= R; ++ks) {
+                    float bop = ks < R ? x[s][ks < R ? ks : 0] : dsel[s];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) cc[v] = ENERF_MFMA(wlane[L.c0v + ((ks * 4 + v) << 6)], bop, cc[v]);
+                }
+                float part = 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) part = dot4(relu4(cc[v]), lds4(wl + L.col2 + v * 16 + 4 * g), part);
+                cl[s] = fmaxf(group_sum(part) + c2b, 0.f);
+            }
+            {   // softmax over views (nerf.py:41)
+                float m = cl[0];
+#pragma unroll
+                for (int s = 1; s < S; ++s) m = fmaxf(m, cl[s]);
+                float se = 0.f;
+#pragma unroll
+                for (int s = 0; s < S; ++s) { cl[s] = expf(cl[s] - m); se += cl[s]; }
+#pragma unroll
+                for (int s = 0; s < S; ++s) cl[s] /= se;
+            }
+
+            // ---------- compositing step (utils.py:584-592) ----------
+            float alpha = 1.f - expf(-sig);
+            float wgt = alpha * Tacc;
+            Tacc *= (1.f - alpha + 1e-10f);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float col = x[0][r] * cl[0];
+#pragma unroll
+                for (int s = 1; s < S; ++s) col += x[s][r] * cl[s];
+                rgbacc[r] += wgt * col;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                if (kk == k) wk[kk] = wgt;
+        }
+
+        // ---------- depth from softmaxed weights (utils.py:593-595) + stores ----------
+        float m = wk[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) if (k < Ns) m = fmaxf(m, wk[k]);
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (k < Ns) { wk[k] = expf(wk[k] - m); se += wk[k]; }
+        float depth = 0.f, accw = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < Ns) {
+                wk[k] /= se;
+                float tk = (Ns == 1) ? 0.5f : linspace01(k, Ns);
+                depth += wk[k] * (rn + (rf - rn) * tk);
+                accw += wk[k];
+            }
+        if (rok) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                int c = g * R + r - (a.F - 3);
+                if (c >= 0 && c < 3) {
+                    float v = rgbacc[r];
+                    if (a.white_bkgd) v += 1.f - accw;              // utils.py:599-601
+                    a.rgb[ray * 3 + c] = v;
+                }
+            }
+            if (g == 0) {
+                a.depth[ray] = depth;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (k < Ns) a.weights[ray * Ns + k] = wk[k];
+            }
+        }
+    }
+}
+
+template <int R>
+static int dispatch_s(const RenderArgs& a, unsigned grid, size_t shmem, hipStream_t st) {
+    switch (a.S) {
+        case 2: ENERF_LAUNCH((k_render_rays<R, 2>), grid, 256, shmem, st, a); return 0;
+        case 3: ENERF_LAUNCH((k_render_rays<R, 3>), grid, 256, shmem, st, a); return 0;
+        case 4: ENERF_LAUNCH((k_render_rays<R, 4>), grid, 256, shmem, st, a); return 0;
+        default: return -3;
+    }
+}
+int launch_render_rays(const RenderArgs& a, hipStream_t st) {
+    if (a.n_samples < 1 || a.n_samples > 8) return -1;
+    const int R = (a.F + 3) / 4;
+    size_t shmem = ((size_t)nerf_layout(a.F).total + (size_t)a.B * a.S * kCamStride + (size_t)a.B * 3) * sizeof(float);
+    if (shmem > 64 * 1024) return -2;
+    long long ntiles = cdivl((long long)a.B * a.N, 16);
+    long long blocks = cdivl(ntiles, 4);
+    unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);     // persistent waves stride over ray tiles
+    if (grid == 0) return 0;
+    switch (R) {
+        case 3: return dispatch_s<3>(a, grid, shmem, st);          // C = 8  (level 1)
+        case 9: return dispatch_s<9>(a, grid, shmem, st);          // C = 32 (level 0)
+        default: return -4;
+    }
+}
+
+}  // namespace enerf

@@ -1,0 +1,78 @@
+// volume.hip — homography warp + variance aggregation (homo_warp utils.py:57-95,
+// build_feature_volume utils.py:322-349) fused into one gather kernel.
+//
+// Layout: source features channels-last (B,S,Hs,Ws,C); output cost volume channels-last
+// (B,D,h,w,C).  C/4 consecutive lanes own one voxel (one float4 of channels each), so every bilinear
+// tap of a voxel is a single contiguous C*4-byte segment and the store of 64/(C/4) neighbouring
+// voxels is one contiguous run.  The per-view warped features are never materialised: Σx and Σx² stay in
+// registers (the reference writes 2 + S volumes).
+//
+// Algorithmic HBM bytes per launch: read S*Hs*Ws*C*4 (features, once) + D*h*w*4 (depth planes),
+// write D*h*w*C*4.  The 4-tap gathers re-read features from L2/MALL, not HBM.
+#include "kernels.h"
+
+namespace enerf {
+
+template <int CQ>  // CQ = C/4 lanes per voxel
+__global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict__ feat, const float* __restrict__ proj,
+                                                        const float* __restrict__ dv, int B, int S, int Hs, int Ws,
+                                                        int D, int h, int w, float* __restrict__ vol) {
+    constexpr int C = CQ * 4;
+    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long nvox = (long long)B * D * h * w;
+    long long vox = gid / CQ;
+    int cq = (int)(gid - vox * CQ);
+    if (vox >= nvox) return;
+    int hw = h * w;
+    int b = (int)(vox / ((long long)D * hw));
+    int rem = (int)(vox - (long long)b * D * hw);
+    int p = rem % hw;
+    int y = p / w, x = p - y * w;
+    float depth = dv[vox];                      // (B,D,h,w) has the same linear index as the voxel
+    float fx = (float)x, fy = (float)y;
+    float half_w = (float)((Ws - 1) / 2.0), half_h = (float)((Hs - 1) / 2.0);   // utils.py:82-83
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < S; ++s) {
+        const float* P = proj + ((long long)b * S + s) * 12;
+        float px = P[0] * fx + P[1] * fy + P[2] + P[3] / depth;       // utils.py:72
+        float py = P[4] * fx + P[5] * fy + P[6] + P[7] / depth;
+        float pz = P[8] * fx + P[9] * fy + P[10] + P[11] / depth;
+        float z = clamp_min(pz, 1e-6f);                                // utils.py:80
+        float gx = (px / z) / half_w - 1.f, gy = (py / z) / half_h - 1.f;
+        Taps2 t = gs_taps2<false>(gs_unnorm(gx, Ws), gs_unnorm(gy, Hs), Ws, Hs);
+        const float* f = feat + ((long long)b * S + s) * Hs * Ws * C + cq * 4;
+        const float4 v00 = *reinterpret_cast<const float4*>(f + ((long long)t.y0 * Ws + t.x0) * C);
+        const float4 v01 = *reinterpret_cast<const float4*>(f + ((long long)t.y0 * Ws + t.x1) * C);
+        const float4 v10 = *reinterpret_cast<const float4*>(f + ((long long)t.y1 * Ws + t.x0) * C);
+        const float4 v11 = *reinterpret_cast<const float4*>(f + ((long long)t.y1 * Ws + t.x1) * C);
+        float4 r;
+        r.x = v00.x * t.w00; r.x += v01.x * t.w01; r.x += v10.x * t.w10; r.x += v11.x * t.w11;
+        r.y = v00.y * t.w00; r.y += v01.y * t.w01; r.y += v10.y * t.w10; r.y += v11.y * t.w11;
+        r.z = v00.z * t.w00; r.z += v01.z * t.w01; r.z += v10.z * t.w10; r.z += v11.z * t.w11;
+        r.w = v00.w * t.w00; r.w += v01.w * t.w01; r.w += v10.w * t.w10; r.w += v11.w * t.w11;
+        s1.x += r.x; s1.y += r.y; s1.z += r.z; s1.w += r.w;
+        s2.x += r.x * r.x; s2.y += r.y * r.y; s2.z += r.z * r.z; s2.w += r.w * r.w;
+    }
+    float fs = (float)S;                                               // utils.py:345
+    float4 o;
+    float m;
+    m = s1.x / fs; o.x = s2.x / fs - m * m;
+    m = s1.y / fs; o.y = s2.y / fs - m * m;
+    m = s1.z / fs; o.z = s2.z / fs - m * m;
+    m = s1.w / fs; o.w = s2.w / fs - m * m;
+    *reinterpret_cast<float4*>(vol + vox * C + cq * 4) = o;
+}
+
+void launch_feature_volume(const float* feat_nhwc, const float* proj, const float* dv, int B, int S, int C, int Hs,
+                           int Ws, int D, int h, int w, float* vol, hipStream_t st) {
+    long long threads = (long long)B * D * h * w * (C / 4);
+    unsigned grid = (unsigned)cdivl(threads, 256);
+    switch (C) {
+        case 32: ENERF_LAUNCH_SIMPLE(k_feature_volume<8>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, vol); break;
+        case 16: ENERF_LAUNCH_SIMPLE(k_feature_volume<4>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, vol); break;
+        case 8: ENERF_LAUNCH_SIMPLE(k_feature_volume<2>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, vol); break;
+        default: break;   // validated by the C-ABI layer
+    }
+}
+
+}  // namespace enerf

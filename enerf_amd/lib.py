@@ -1,0 +1,226 @@
+"""ctypes binding of the C ABI in include/enerf_hip.h (libenerf_hip.so).
+
+PyTorch is used only as the owner of device memory and streams: every call passes raw
+``tensor.data_ptr()`` addresses, sizes and the current HIP stream handle.  There is NO CPU or eager
+fallback: if the shared library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libenerf_hip.so")
+ABI_VERSION = 1
+
+_f = C.c_void_p     # device float*
+_i = C.c_int
+_ll = C.c_longlong
+_fl = C.c_float
+
+
+class ConvBn(C.Structure):
+    _fields_ = [("w", _f), ("bn_weight", _f), ("bn_bias", _f), ("bn_mean", _f), ("bn_var", _f)]
+
+
+class CostRegRaw(C.Structure):
+    _fields_ = [("conv", ConvBn * 12), ("feat_conv_w", _f), ("depth_conv_w", _f), ("in_channels", _i), ("full", _i)]
+
+
+class NerfRaw(C.Structure):
+    _fields_ = [(n, _f) for n in ("view_w", "view_b", "glob_w", "glob_b", "aggw_w", "aggw_b", "fc_w", "fc_b",
+                                  "lr0_w", "lr0_b", "sigma_w", "sigma_b", "col0_w", "col0_b", "col2_w", "col2_b")]
+
+
+class RenderArgs(C.Structure):
+    _fields_ = ([(n, _f) for n in ("rays12", "tex", "vol", "src_exts", "src_ixts", "tar_ext", "packed", "rgb",
+                                   "depth", "weights")]
+                + [(n, _i) for n in ("B", "N", "S", "n_samples", "depth_inv", "Hr", "Wr", "F", "D", "h", "w",
+                                     "white_bkgd")]
+                + [("render_scale", _fl)])
+
+
+_SIGNATURES = {
+    "enerf_abi_version": (_i, []),
+    "enerf_last_error": (C.c_char_p, []),
+    "enerf_channels_last": (_i, [_f, _f, _i, _i, _ll, _i, _f]),
+    "enerf_channels_first": (_i, [_f, _f, _i, _i, _ll, _i, _f]),
+    "enerf_pack_img_feat_rgb": (_i, [_f, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _f, _f]),
+    "enerf_get_proj_mats": (_i, [_f, _f, _f, _f, _i, _i, _fl, _fl, _f, _f]),
+    "enerf_get_depth_values": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f]),
+    "enerf_build_feature_volume": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f]),
+    "enerf_cost_reg_packed_floats": (_ll, [_i, _i]),
+    "enerf_cost_reg_pack": (_i, [C.POINTER(CostRegRaw), _f, _f]),
+    "enerf_cost_reg_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
+    "enerf_cost_reg": (_i, [_f, _i, _i, _f, _i, _i, _i, _i, _f, _f, _f, C.c_size_t, _f]),
+    "enerf_depth_regression": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f]),
+    "enerf_build_rays": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f]),
+    "enerf_nerf_packed_floats": (_ll, [_i]),
+    "enerf_nerf_pack": (_i, [C.POINTER(NerfRaw), _i, _i, _f, _f]),
+    "enerf_render_rays": (_i, [C.POINTER(RenderArgs), _f]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class EnerfError(RuntimeError):
+    pass
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise EnerfError(f"expected contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+class EnerfLib:
+    """Thin typed wrapper over the shared library.  ``path`` is only overridden by tests (CPU-emulated
+    twin built from the same kernel sources); the product always loads :data:`LIB_PATH`."""
+
+    def __init__(self, path: str = LIB_PATH):
+        if not os.path.exists(path):
+            raise EnerfError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(hipcc --offload-arch=gfx950); there is no fallback path")
+        self.path = path
+        self.dll = C.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(self.dll, name)          # raises AttributeError if a symbol is missing
+            fn.restype, fn.argtypes = res, args
+        v = self.dll.enerf_abi_version()
+        if v != ABI_VERSION:
+            raise EnerfError(f"ABI version mismatch: library {v}, binding {ABI_VERSION}")
+
+    # -- plumbing --------------------------------------------------------------------------------
+    @staticmethod
+    def stream_of(t: torch.Tensor):
+        return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else None
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise EnerfError(f"{what} failed ({rc}): {self.dll.enerf_last_error().decode()}")
+
+    # -- entry points -----------------------------------------------------------------------------
+    def channels_last(self, src, n, C_, P, Cpad=None):
+        Cpad = Cpad or C_
+        dst = torch.empty((n, P, Cpad), dtype=torch.float32, device=src.device)
+        self._check(self.dll.enerf_channels_last(_ptr(src), _ptr(dst), n, C_, P, Cpad, self.stream_of(src)),
+                    "channels_last")
+        return dst
+
+    def channels_first(self, src, n, C_, P, Cpad=None):
+        Cpad = Cpad or C_
+        dst = torch.empty((n, C_, P), dtype=torch.float32, device=src.device)
+        self._check(self.dll.enerf_channels_first(_ptr(src), _ptr(dst), n, C_, P, Cpad, self.stream_of(src)),
+                    "channels_first")
+        return dst
+
+    def pack_img_feat_rgb(self, im_feat, src_inps, Hr, Wr):
+        n_img, Cf, Hf, Wf = im_feat.shape
+        H, W = src_inps.shape[-2:]
+        tex = 4 * ((Cf + 3 + 3) // 4)
+        out = torch.empty((n_img, Hr, Wr, tex), dtype=torch.float32, device=im_feat.device)
+        self._check(self.dll.enerf_pack_img_feat_rgb(_ptr(im_feat), Cf, Hf, Wf, _ptr(src_inps), H, W, Hr, Wr, tex,
+                                                     n_img, _ptr(out), self.stream_of(out)), "pack_img_feat_rgb")
+        return out
+
+    def get_proj_mats(self, src_ixts, src_exts, tar_ixt, tar_ext, src_scale, tar_scale):
+        B, S = src_ixts.shape[:2]
+        proj = torch.empty((B, S, 3, 4), dtype=torch.float32, device=src_ixts.device)
+        self._check(self.dll.enerf_get_proj_mats(_ptr(src_ixts), _ptr(src_exts), _ptr(tar_ixt), _ptr(tar_ext), B, S,
+                                                 float(src_scale), float(tar_scale), _ptr(proj),
+                                                 self.stream_of(proj)), "get_proj_mats")
+        return proj
+
+    def get_depth_values(self, near_far, prev, B, D, h, w, depth_inv):
+        dev = near_far.device
+        dv = torch.empty((B, D, h, w), dtype=torch.float32, device=dev)
+        nf = torch.empty((B, 2, h, w), dtype=torch.float32, device=dev)
+        if prev is None:
+            pd = ps = pn = None
+            hp = wp = 0
+        else:
+            pd, ps, pn = prev
+            hp, wp = pd.shape[-2:]
+        self._check(self.dll.enerf_get_depth_values(_ptr(near_far), _ptr(pd), _ptr(ps), _ptr(pn), B, D, h, w, hp, wp,
+                                                    int(depth_inv), _ptr(dv), _ptr(nf), self.stream_of(dv)),
+                    "get_depth_values")
+        return dv, nf
+
+    def build_feature_volume(self, feat_cl, proj, dv, Cc):
+        B, S, Hs, Ws = feat_cl.shape[:4]
+        _, D, h, w = dv.shape
+        vol = torch.empty((B, D, h, w, Cc), dtype=torch.float32, device=dv.device)
+        self._check(self.dll.enerf_build_feature_volume(_ptr(feat_cl), _ptr(proj), _ptr(dv), B, S, Cc, Hs, Ws, D, h, w,
+                                                        _ptr(vol), self.stream_of(vol)), "build_feature_volume")
+        return vol
+
+    def cost_reg_pack(self, raw: CostRegRaw, device):
+        n = self.dll.enerf_cost_reg_packed_floats(raw.in_channels, raw.full)
+        packed = torch.empty((n,), dtype=torch.float32, device=device)
+        self._check(self.dll.enerf_cost_reg_pack(C.byref(raw), _ptr(packed), self.stream_of(packed)), "cost_reg_pack")
+        return packed
+
+    def cost_reg(self, packed, in_channels, full, vol, workspace=None):
+        B, D, h, w, _ = vol.shape
+        need = self.dll.enerf_cost_reg_workspace_bytes(int(full), B, D, h, w)
+        if workspace is None or workspace.numel() * 4 < need:
+            workspace = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=vol.device)
+        feat = torch.empty((B, D, h, w, 8), dtype=torch.float32, device=vol.device)
+        prob = torch.empty((B, D, h, w), dtype=torch.float32, device=vol.device)
+        self._check(self.dll.enerf_cost_reg(_ptr(packed), in_channels, int(full), _ptr(vol), B, D, h, w, _ptr(feat),
+                                            _ptr(prob), _ptr(workspace), workspace.numel() * 4,
+                                            self.stream_of(vol)), "cost_reg")
+        return feat, prob
+
+    def depth_regression(self, prob, dv, depth_inv):
+        B, D, h, w = prob.shape
+        depth = torch.empty((B, h, w), dtype=torch.float32, device=prob.device)
+        std = torch.empty_like(depth)
+        self._check(self.dll.enerf_depth_regression(_ptr(prob), _ptr(dv), B, D, h, w, int(depth_inv), _ptr(depth),
+                                                    _ptr(std), self.stream_of(prob)), "depth_regression")
+        return depth, std
+
+    def build_rays(self, rays8, depth, std, near_far, Hr, Wr, depth_inv):
+        B, N = rays8.shape[:2]
+        h, w = depth.shape[-2:]
+        out = torch.empty((B, N, 12), dtype=torch.float32, device=rays8.device)
+        self._check(self.dll.enerf_build_rays(_ptr(rays8), _ptr(depth), _ptr(std), _ptr(near_far), B, N, h, w, Hr, Wr,
+                                              int(depth_inv), _ptr(out), self.stream_of(out)), "build_rays")
+        return out
+
+    def nerf_pack(self, raw: NerfRaw, F: int, viewdir_agg: bool, device):
+        n = self.dll.enerf_nerf_packed_floats(F)
+        packed = torch.empty((n,), dtype=torch.float32, device=device)
+        self._check(self.dll.enerf_nerf_pack(C.byref(raw), F, int(viewdir_agg), _ptr(packed),
+                                             self.stream_of(packed)), "nerf_pack")
+        return packed
+
+    def render_rays(self, rays12, tex, vol, src_exts, src_ixts, tar_ext, packed, *, n_samples, depth_inv, F,
+                    render_scale, white_bkgd=False):
+        B, N = rays12.shape[:2]
+        S, Hr, Wr = tex.shape[1:4]
+        _, D, h, w, _ = vol.shape
+        dev = rays12.device
+        rgb = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+        depth = torch.empty((B, N), dtype=torch.float32, device=dev)
+        weights = torch.empty((B, N, n_samples), dtype=torch.float32, device=dev)
+        a = RenderArgs(_ptr(rays12), _ptr(tex), _ptr(vol), _ptr(src_exts), _ptr(src_ixts), _ptr(tar_ext),
+                       _ptr(packed), _ptr(rgb), _ptr(depth), _ptr(weights), B, N, S, n_samples, int(depth_inv), Hr,
+                       Wr, F, D, h, w, int(white_bkgd), float(render_scale))
+        self._check(self.dll.enerf_render_rays(C.byref(a), self.stream_of(rays12)), "render_rays")
+        return rgb, depth, weights
+
+
+_LIB: Optional[EnerfLib] = None
+
+
+def get_lib() -> EnerfLib:
+    """The product library (HIP, gfx950).  Raises if it has not been built — never falls back."""
+    global _LIB
+    if _LIB is None:
+        _LIB = EnerfLib(LIB_PATH)
+    return _LIB

@@ -1,0 +1,128 @@
+/* enerf_hip.h — C ABI of the MI355X-native ENeRF rendering path (libenerf_hip.so).
+ *
+ * The reference (zju3dv/ENeRF) has no FFI: its hot path is a chain of torch ops inside
+ * lib/networks/enerf/{network,utils,nerf,cost_reg_net}.py.  Each entry point below replaces the
+ * reference function cited next to it, fused where the reference materialises intermediates.
+ * Conventions:
+ *   - every pointer is a DEVICE pointer to fp32 data unless stated; buffers are caller-owned
+ *     (PyTorch tensors in the Python binding); nothing is allocated or freed here;
+ *   - `stream` is a hipStream_t; calls only enqueue work (no host sync);
+ *   - return 0 on success, a negative ENERF_E* code otherwise; enerf_last_error() gives the text
+ *     (thread-local).
+ * Layouts (HBM):  2-D features channels-last (n_img,H,W,C); 3-D volumes channels-last (B,D,h,w,C);
+ *   depth hypotheses / probabilities (B,D,h,w); depth/std maps (B,h,w); near_far maps (B,2,h,w);
+ *   rays (B,N,8) -> (B,N,12); texels (B,S,Hr,Wr,TEX) with TEX = 4*ceil((C+3)/4) = [feat C | rgb 3 | 0].
+ */
+#ifndef ENERF_HIP_H_
+#define ENERF_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ENERF_ABI_VERSION 1
+#define ENERF_OK 0
+#define ENERF_EINVAL (-1)   /* bad argument / unsupported shape */
+#define ENERF_ELAUNCH (-2)  /* HIP launch error */
+#define ENERF_EWORKSPACE (-3)
+
+typedef void* enerf_stream_t; /* hipStream_t */
+
+int enerf_abi_version(void);
+const char* enerf_last_error(void);
+
+/* ---- layout adapters at the PyTorch boundary (FeatureNet output is NCHW, network.py:58-67) ---- */
+/* (n, C, P) -> (n, P, Cpad), pad channels zero-filled;  and back (drops the padding). */
+int enerf_channels_last(const float* src, float* dst, int n, int C, long long P, int Cpad, enerf_stream_t stream);
+int enerf_channels_first(const float* src, float* dst, int n, int C, long long P, int Cpad, enerf_stream_t stream);
+
+/* unpreprocess (utils.py:605-612) + im_feat resize (network.py:29-32) + cat (network.py:34), written
+ * as texels.  im_feat (n_img,C,Hf,Wf) NCHW, src_inps (n_img,3,H,W) in [-1,1]; out (n_img,Hr,Wr,tex). */
+int enerf_pack_img_feat_rgb(const float* im_feat, int C, int Hf, int Wf, const float* src_inps, int H, int W,
+                            int Hr, int Wr, int tex, int n_img, float* out, enerf_stream_t stream);
+
+/* ---- get_proj_mats (utils.py:35-55): proj (B,S,3,4) ---- */
+int enerf_get_proj_mats(const float* src_ixts, const float* src_exts, const float* tar_ixt, const float* tar_ext,
+                        int B, int S, float src_scale, float tar_scale, float* proj, enerf_stream_t stream);
+
+/* ---- get_depth_values (utils.py:98-151).  prev_* = NULL at level 0 (then near_far is (B,2));
+ * otherwise prev_depth/prev_std (B,hp,wp) and prev_near_far (B,2,hp,wp) from the previous level
+ * (disparity units).  Outputs depth_values (B,D,h,w), near_far_out (B,2,h,w). ---- */
+int enerf_get_depth_values(const float* near_far, const float* prev_depth, const float* prev_std,
+                           const float* prev_near_far, int B, int D, int h, int w, int hp, int wp, int depth_inv,
+                           float* depth_values, float* near_far_out, enerf_stream_t stream);
+
+/* ---- homo_warp + build_feature_volume (utils.py:57-95, 322-349), fused.
+ * feat (B,S,Hs,Ws,C) channels-last, C in {8,16,32}; vol (B,D,h,w,C). ---- */
+int enerf_build_feature_volume(const float* feat, const float* proj, const float* depth_values, int B, int S, int C,
+                               int Hs, int Ws, int D, int h, int w, float* vol, enerf_stream_t stream);
+
+/* ---- CostRegNet / MinCostRegNet (cost_reg_net.py:4-86) ---- */
+typedef struct {
+    const float* w;         /* Conv3d (cout,cin,3,3,3) or ConvTranspose3d (cin,cout,3,3,3) */
+    const float* bn_weight; /* BatchNorm3d affine + running statistics (eval mode, eps 1e-5) */
+    const float* bn_bias;
+    const float* bn_mean;
+    const float* bn_var;
+} enerf_conv_bn_t;
+typedef struct {
+    enerf_conv_bn_t conv[12]; /* conv0..conv6, conv7, conv9, conv11 at their own index; others unused */
+    const float* feat_conv_w; /* (8,8,3,3,3) */
+    const float* depth_conv_w; /* (1,8,3,3,3) */
+    int in_channels;          /* 32 (level 0) or 16 (level 1) */
+    int full;                 /* 1 = CostRegNet (3 down/3 up), 0 = MinCostRegNet (2/2) */
+} enerf_costreg_raw_t;
+long long enerf_cost_reg_packed_floats(int in_channels, int full);
+int enerf_cost_reg_pack(const enerf_costreg_raw_t* raw, float* packed, enerf_stream_t stream);
+size_t enerf_cost_reg_workspace_bytes(int full, int B, int D, int h, int w);
+/* vol (B,D,h,w,in_channels) -> feat (B,D,h,w,8), prob (B,D,h,w).  D,h,w divisible by 4 (8 if full). */
+int enerf_cost_reg(const float* packed, int in_channels, int full, const float* vol, int B, int D, int h, int w,
+                   float* feat, float* prob, void* workspace, size_t workspace_bytes, enerf_stream_t stream);
+
+/* ---- depth_regression (utils.py:658-667) ---- */
+int enerf_depth_regression(const float* prob, const float* depth_values, int B, int D, int h, int w, int depth_inv,
+                           float* depth, float* std, enerf_stream_t stream);
+
+/* ---- build_rays (utils.py:390-420): rays8 (B,N,8) + maps at (h,w) -> rays12 (B,N,12); (Hr,Wr) is the
+ * render resolution the maps are upsampled to. ---- */
+int enerf_build_rays(const float* rays8, const float* depth, const float* std, const float* near_far, int B, int N,
+                     int h, int w, int Hr, int Wr, int depth_inv, float* rays12, enerf_stream_t stream);
+
+/* ---- NeRF + Agg MLP weights (nerf.py:6-89), torch nn.Linear layouts (out,in) ---- */
+typedef struct {
+    const float *view_w, *view_b;   /* agg.view_fc.0    (F,4),(F)   — ignored when viewdir_agg == 0 */
+    const float *glob_w, *glob_b;   /* agg.global_fc.0  (32,3F),(32) */
+    const float *aggw_w, *aggw_b;   /* agg.agg_w_fc.0   (1,32),(1) */
+    const float *fc_w, *fc_b;       /* agg.fc.0         (16,32),(16) */
+    const float *lr0_w, *lr0_b;     /* lr0.0            (64,24),(64) */
+    const float *sigma_w, *sigma_b; /* sigma.0          (1,64),(1) */
+    const float *col0_w, *col0_b;   /* color.0          (64,88+F+4),(64) */
+    const float *col2_w, *col2_b;   /* color.2          (1,64),(1) */
+} enerf_nerf_raw_t;
+long long enerf_nerf_packed_floats(int F); /* F = feat_ch + 3 */
+int enerf_nerf_pack(const enerf_nerf_raw_t* raw, int F, int viewdir_agg, float* packed, enerf_stream_t stream);
+
+/* ---- render_rays (network.py:24-43) = sample_along_depth + get_vox_feat + get_img_feat + NeRF +
+ * raw2outputs, fused.  F in {11, 35}; S in {2,3,4}; n_samples in [1,8]. ---- */
+typedef struct {
+    const float* rays12;   /* (B,N,12) */
+    const float* tex;      /* (B,S,Hr,Wr,TEX) from enerf_pack_img_feat_rgb */
+    const float* vol;      /* (B,D,h,w,8) feature volume from enerf_cost_reg */
+    const float* src_exts; /* (B,S,4,4) */
+    const float* src_ixts; /* (B,S,3,3) */
+    const float* tar_ext;  /* (B,4,4) */
+    const float* packed;   /* enerf_nerf_pack output */
+    float* rgb;            /* (B,N,3) */
+    float* depth;          /* (B,N) */
+    float* weights;        /* (B,N,n_samples) */
+    int B, N, S, n_samples, depth_inv, Hr, Wr, F, D, h, w, white_bkgd;
+    float render_scale;
+} enerf_render_args_t;
+int enerf_render_rays(const enerf_render_args_t* args, enerf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENERF_HIP_H_ */
