@@ -1,0 +1,183 @@
+"""bench.py — rendered frames/sec of the ENeRF path at 512x640, 3 source views (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one ``Network.forward(batch)`` = one rendered frame (FeatureNet in PyTorch-ROCm + the HIP
+path), on the DTU eval configuration the reference quotes its 21.78 FPS on (README.md:113:
+``render_if False,True``, ``volume_planes 48,8``).  Inputs are synthetic, resident in
+HBM before the timed region; weights are random-init with randomised BN statistics.  Rendering is
+frame-parallel: every rank renders its own frames, no data-path collective (scaling = weak).
+Timing mirrors run.py:62-76 (sync both sides) with a barrier and max-over-ranks.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BASELINE_FPS_RTX3090 = 21.778975517304048      # BASELINE.md §1 / README.md:121
+PEAK_F32_MFMA_TFLOPS = 157.3                   # MI355X_MICROARCH.md
+FLOP_PER_SAMPLE_L1 = 50952                     # SURVEY.md §8a (a14+a15 derivation, S=3, F=11)
+
+
+class StageTimer:
+    """Records a HIP event after every stage of Network.forward (same stream the kernels run on)."""
+
+    def __init__(self):
+        self.frames = []
+        self.cur = None
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.cur = [("begin", e)]
+
+    def mark(self, name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.cur.append((name, e))
+
+    def end(self):
+        self.frames.append(self.cur)
+        self.cur = None
+
+    def summary(self):
+        acc = {}
+        for fr in self.frames:
+            for (_, e0), (n1, e1) in zip(fr[:-1], fr[1:]):
+                acc.setdefault(n1, []).append(e0.elapsed_time(e1))
+        return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stages", action="store_true")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--views", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL
+
+    from __graft_entry__ import _seeded_network
+    from enerf_amd.config import EnerfConfig
+    from enerf_amd.synth import make_batch
+
+    cfg = EnerfConfig.dtu_eval()
+    net = _seeded_network(cfg, dev)
+    H, W, S = args.height, args.width, args.views
+    batch_np = make_batch(H, W, S, cfg, seed=rank, textured=True)
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in batch_np.items()}
+
+    def step():
+        return net(batch)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(out["rgb_level1"]).all()), "non-finite render"
+
+    result = None
+    if rank == 0:
+        fps = world * args.steps / elapsed
+        result = {
+            "metric": "rendered frames/sec @512x640 3-src-view", "value": fps, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": fps / BASELINE_FPS_RTX3090, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"DTU generalizable eval (dtu_pretrain.yaml, render_if False,True, "
+                                   f"volume_planes 48,8), {H}x{W}, {S} src views, one target view per step",
+                       "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world} (no collectives)"},
+        }
+
+    # ---- per-stage HIP-event timings + roofline of the dominant kernel (rank 0, not in the timed region) ----
+    if rank == 0 and not args.no_stages:
+        timer = StageTimer()
+        net._timer = timer
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        net._timer = None
+        stages = timer.summary()
+        result["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
+        # dominant single kernel: the fused level-1 render launch (k_render_rays<3,3>): 2 samples x H*W rays
+        n_samples_total = H * W * cfg.cas.num_samples[1]
+        flops = FLOP_PER_SAMPLE_L1 * n_samples_total if (S == 3) else None
+        dur_ms = stages.get("render_1")
+        if flops and dur_ms:
+            ach = flops / (dur_ms * 1e-3) / 1e12
+            result["roofline"] = {"kernel": "k_render_rays<3,3> (level-1 fused render)", "bound": "mfma",
+                                  "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                                  "algorithmic_flops_per_launch": flops, "avg_launch_ms": dur_ms}
+
+    # ---- CPU baseline: the oracle (torch CPU restatement of the reference) on this box's host cores ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import enerf_oracle as O
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        cb = {k: torch.from_numpy(v) for k, v in batch_np.items()}
+        with torch.no_grad():
+            small = {k: torch.from_numpy(v) for k, v in make_batch(64, 96, S, cfg, seed=0).items()}
+            O.forward(cfg, sd, small)                      # page-in / thread-pool warm-up (untimed)
+            n_frames, t0 = 0, time.perf_counter()
+            while n_frames < 2 or (time.perf_counter() - t0 < 10.0 and n_frames < 8):
+                ref = O.forward(cfg, sd, cb)
+                n_frames += 1
+            cpu_s = (time.perf_counter() - t0) / n_frames
+        result["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": ncores, "kind": "port",
+                                  "sample": f"{n_frames} full {H}x{W} {S}-view frames through oracle/enerf_oracle.py "
+                                            f"(torch CPU, {ncores} threads), first small frame untimed"}
+        err = float((out["rgb_level1"].cpu() - ref["rgb_level1"]).abs().max())
+        result["parity_vs_oracle"] = {"rgb_level1_max_abs": err,
+                                      "psnr_db": O.psnr(out["rgb_level1"].cpu(), ref["rgb_level1"])}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -182,9 +182,9 @@ int enerf_depth_regression(const float* prob, const float* depth_values, int B, 
 }
 int enerf_build_rays(const float* rays8, const float* depth, const float* std, const float* near_far, int B, int N,
                      int h, int w, int Hr, int Wr, int depth_inv, float* rays12, enerf_stream_t stream) {
+    if (N == 0 && B > 0) return ENERF_OK;
     REQUIRE(rays8 && depth && std && near_far && rays12, "build_rays: null pointer");
     REQUIRE(B > 0 && N >= 0 && h > 0 && w > 0 && Hr >= h && Wr >= w, "build_rays: bad shape");
-    if (N == 0) return ENERF_OK;
     launch_build_rays(rays8, depth, std, near_far, B, N, h, w, Hr, Wr, depth_inv, rays12, (hipStream_t)stream);
     return check_launch("build_rays");
 }
@@ -202,6 +202,7 @@ int enerf_nerf_pack(const enerf_nerf_raw_t* raw, int F, int viewdir_agg, float* 
 }
 int enerf_render_rays(const enerf_render_args_t* a, enerf_stream_t stream) {
     REQUIRE(a, "render_rays: null args");
+    if (a->N == 0 && a->B > 0) return ENERF_OK;              // empty ray list (e.g. an all-false mask_at_box)
     REQUIRE(a->rays12 && a->tex && a->vol && a->src_exts && a->src_ixts && a->tar_ext && a->packed && a->rgb &&
                 a->depth && a->weights, "render_rays: null pointer");
     REQUIRE(a->B > 0 && a->N >= 0 && a->Hr > 1 && a->Wr > 1 && a->D > 0 && a->h > 0 && a->w > 0, "render_rays: bad shape");

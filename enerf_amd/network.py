@@ -212,6 +212,11 @@ class Network(nn.Module):
             setattr(self, f"nerf_{i}", NerfParams(cas.nerf_model_feat_ch[i] + 3, self.cfg.viewdir_agg))
         self._packed: Dict[str, torch.Tensor] = {}
         self._tex_cache = None
+        self._timer = None                  # optional stage timer (bench.py): .begin()/.mark(name)/.end()
+
+    def _mark(self, name):
+        if self._timer is not None:
+            self._timer.mark(name)
 
     # -- weight images ---------------------------------------------------------------------------
     @property
@@ -284,11 +289,13 @@ class Network(nn.Module):
         if nerf is not None and nerf is not getattr(self, name):
             raise RuntimeError("render_rays: nerf_model must be this network's nerf_{level}")
         tex = self._texels(level, batch, im_feat)
+        self._mark(f"texels_{level}")
         rgb, depth, weights = self.lib.render_rays(
             rays.contiguous(), tex, vol, batch["src_exts"].contiguous(), batch["src_ixts"].contiguous(),
             batch["tar_ext"].contiguous(), self._packed_weights(name), n_samples=cas.num_samples[level],
             depth_inv=cas.depth_inv[level], F=cas.nerf_model_feat_ch[level] + 3,
             render_scale=cas.render_scale[level], white_bkgd=self.cfg.white_bkgd)
+        self._mark(f"render_{level}")
         return {"rgb": rgb, "depth": depth, "weights": weights}
 
     def batchify_rays(self, rays, **kwargs):
@@ -308,8 +315,11 @@ class Network(nn.Module):
         self._tex_cache = None
         src = batch["src_inps"]
         B, S, _, H, W = src.shape
+        if self._timer is not None:
+            self._timer.begin()
         with torch.no_grad():
             feats = self.forward_feat(src)
+            self._mark("feature_net")
             ret = {}
             prev = None
             for i in range(cas.num):
@@ -326,17 +336,22 @@ class Network(nn.Module):
                                        "reference (utils.py:130)")
                 dv, near_far = lib.get_depth_values(batch["near_far"].contiguous(), prev, B, D, h, w,
                                                     cas.depth_inv[i])
+                self._mark(f"prep_{i}")
                 vol = lib.build_feature_volume(feat_cl, proj, dv, C)
+                self._mark(f"volume_{i}")
                 name = f"cost_reg_{i}"
                 m = getattr(self, name)
                 feat3d, prob = lib.cost_reg(self._packed_weights(name), m.in_channels, m.full, vol)
+                self._mark(f"cost_reg_{i}")
                 depth, std = lib.depth_regression(prob, dv, cas.depth_inv[i])
+                self._mark(f"depth_reg_{i}")
                 prev = (depth, std, near_far)
                 if not cas.render_if[i]:
                     continue
                 Hr, Wr = int(H * cas.render_scale[i]), int(W * cas.render_scale[i])
                 rays = lib.build_rays(batch[f"rays_{i}"].contiguous(), depth, std, near_far, Hr, Wr,
                                       cas.depth_inv[i])
+                self._mark(f"build_rays_{i}")
                 masked = self.human and "mask_at_box" in batch and i == cas.num - 1
                 if masked:
                     mask = batch["mask_at_box"].bool().reshape(1, -1)
@@ -354,6 +369,8 @@ class Network(nn.Module):
                 if self.check_nan and bool(ret_i["rgb"].isnan().any()):
                     raise RuntimeError(f"NaN in rgb_level{i}")
                 ret.update({f"{k}_level{i}": v for k, v in ret_i.items()})
+        if self._timer is not None:
+            self._timer.end()
         return ret
 
 

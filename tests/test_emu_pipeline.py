@@ -1,0 +1,144 @@
+"""CPU checks of the *actual kernel sources* (compiled against the lane emulator) and of the host
+logic (Network, ctypes binding, C-ABI argument checks) against reference goldens and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from enerf_amd.config import EnerfConfig
+from enerf_amd.lib import EnerfError
+from enerf_amd.network import Network, NetworkHuman
+from enerf_amd.synth import make_batch
+from oracle import enerf_oracle as O
+from emu_lib import emu_lib
+from golden_cases import CASES, case_batch, case_config, load_golden, load_weights
+
+
+def _net(cfg, human=False):
+    net = (NetworkHuman if human else Network)(cfg, lib=emu_lib()).eval()
+    net.load_state_dict(load_weights(), strict=False)
+    return net
+
+
+def _close(a, ref, tol, name=""):
+    a, ref = np.asarray(a), np.asarray(ref)
+    scale = max(np.abs(ref).max(), 1e-12)
+    err = np.abs(a - ref).max() / scale
+    assert err < tol, f"{name}: max err / max|ref| = {err:.3e} (tol {tol})"
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_emulated_kernels_match_reference_goldens(name):
+    cfg, batch, gold = case_config(name), case_batch(name), load_golden(name)
+    out = _net(cfg, CASES[name]["human"])(batch)
+    assert sorted(out) == sorted(k[4:] for k in gold if k.startswith("out/"))
+    for k, v in out.items():
+        assert v.shape == gold["out/" + k].shape, k
+        _close(v.numpy(), gold["out/" + k], 2e-5, k)
+
+
+def test_state_dict_names_match_reference():
+    sd = load_weights()
+    net = Network(EnerfConfig())
+    mine = {k for k in net.state_dict() if not k.endswith("num_batches_tracked")}
+    assert mine == set(sd), sorted(mine ^ set(sd))[:10]
+    for k, v in net.state_dict().items():
+        if k in sd:
+            assert tuple(v.shape) == tuple(sd[k].shape), k
+    net.load_state_dict(sd, strict=False)
+
+
+def test_training_mode_is_loud():
+    net = Network(EnerfConfig(), lib=emu_lib()).train()
+    with pytest.raises(NotImplementedError):
+        net(case_batch("tiny_s3"))
+
+
+def test_batch2_ragged_rays_and_white_bkgd():
+    """B=2, a ray list whose length is not a multiple of the 16-ray tile, white_bkgd quirk, vs oracle."""
+    cfg = EnerfConfig(white_bkgd=True).with_cas(volume_planes=(8, 8))
+    b = make_batch(32, 64, 3, cfg, seed=11, B=2, textured=True)
+    keep = np.random.default_rng(0).permutation(32 * 64)[:1003]
+    b["rays_1"] = np.ascontiguousarray(b["rays_1"][:, keep])
+    b["rays_0"] = np.ascontiguousarray(b["rays_0"][:, :77])
+    batch = {k: torch.from_numpy(v) for k, v in b.items()}
+    out = _net(cfg)(batch)
+    with torch.no_grad():
+        ref = O.forward(cfg, load_weights(), batch)
+    for k in ref:
+        _close(out[k].numpy(), ref[k].numpy(), 5e-5, k)
+
+
+def test_render_rays_surface_accepts_reference_volume_layout():
+    """render_rays(rays, level=, batch=, im_feat=, feature_volume=(B,8,D,h,w), nerf_model=) like network.py:24."""
+    name = "tiny_s3"
+    cfg, batch, g = case_config(name), case_batch(name), load_golden(name)
+    net = _net(cfg)
+    feats = {"level_2": torch.from_numpy(g["mid/feat_l2"]).reshape(1, 3, 8, 32, 64)}
+    out = net.render_rays(torch.from_numpy(g["mid/rays12_1"]), level=1, batch=batch, im_feat=feats["level_2"],
+                          feature_volume=torch.from_numpy(g["mid/feat3d_1"]), nerf_model=net.nerf_1)
+    _close(out["rgb"].numpy(), g["out/rgb_level1"], 1e-5, "rgb")
+    _close(out["depth"].numpy(), g["out/depth_level1"], 1e-5, "depth")
+    _close(out["weights"].numpy(), g["out/weights_level1"], 1e-5, "weights")
+    # chunked == unchunked (batchify_rays, network.py:45-55)
+    net.cfg = EnerfConfig(cas=cfg.cas, chunk_size=500)
+    out2 = net.batchify_rays(torch.from_numpy(g["mid/rays12_1"]), level=1, batch=batch, im_feat=feats["level_2"],
+                             feature_volume=torch.from_numpy(g["mid/feat3d_1"]), nerf_model=net.nerf_1)
+    assert torch.equal(out2["rgb"], out["rgb"])
+
+
+def test_stage_kernels_against_reference_intermediates():
+    """Every C-ABI stage fed with the reference's own upstream tensors."""
+    name = "tiny_s3"
+    cfg, batch, g = case_config(name), case_batch(name), load_golden(name)
+    lib, cas = emu_lib(), cfg.cas
+    T = lambda k: torch.from_numpy(g["mid/" + k]).contiguous()
+    net = _net(cfg)
+    prev = None
+    for i in range(2):
+        P = lib.get_proj_mats(batch["src_ixts"], batch["src_exts"], batch["tar_ixt"], batch["tar_ext"],
+                              cas.im_feat_scale[i], cas.volume_scale[i])
+        _close(P.numpy(), g[f"mid/proj_{i}"], 1e-6, f"proj_{i}")
+        D = cas.volume_planes[i]
+        h, w = g[f"mid/dv_{i}"].shape[-2:]
+        dv, nf = lib.get_depth_values(batch["near_far"], prev, 1, D, h, w, cas.depth_inv[i])
+        _close(dv.numpy(), g[f"mid/dv_{i}"], 1e-6, f"dv_{i}")
+        _close(nf.numpy(), g[f"mid/nf_{i}"], 1e-6, f"nf_{i}")
+        f = T(f"feat_l{i}")                                                # (S, C, Hs, Ws)
+        S, C, Hs, Ws = f.shape
+        fcl = lib.channels_last(f.reshape(S, C, Hs * Ws), S, C, Hs * Ws).view(1, S, Hs, Ws, C)
+        vol = lib.build_feature_volume(fcl, T(f"proj_{i}"), T(f"dv_{i}"), C)
+        ref_vol = T(f"vol_{i}")                                            # (1,C,D,h,w)
+        _close(vol.permute(0, 4, 1, 2, 3).numpy(), ref_vol.numpy(), 1e-5, f"vol_{i}")
+        vin = lib.channels_last(ref_vol.reshape(1, C, -1), 1, C, D * h * w).view(1, D, h, w, C)
+        m = getattr(net, f"cost_reg_{i}")
+        feat, prob = lib.cost_reg(net._packed_weights(f"cost_reg_{i}"), m.in_channels, m.full, vin)
+        _close(feat.permute(0, 4, 1, 2, 3).numpy(), g[f"mid/feat3d_{i}"], 1e-5, f"feat3d_{i}")
+        _close(prob.numpy(), g[f"mid/prob_{i}"], 1e-5, f"prob_{i}")
+        d, s = lib.depth_regression(T(f"prob_{i}"), T(f"dv_{i}"), cas.depth_inv[i])
+        _close(d.numpy(), g[f"mid/depth_{i}"], 1e-6, f"depth_{i}")
+        _close(s.numpy(), g[f"mid/std_{i}"], 1e-5, f"std_{i}")
+        Hr, Wr = int(32 * cas.render_scale[i]), int(64 * cas.render_scale[i])
+        r = lib.build_rays(batch[f"rays_{i}"], T(f"depth_{i}"), T(f"std_{i}"), T(f"nf_{i}"), Hr, Wr, cas.depth_inv[i])
+        _close(r.numpy(), g[f"mid/rays12_{i}"], 1e-6, f"rays12_{i}")
+        prev = (T(f"depth_{i}"), T(f"std_{i}"), T(f"nf_{i}"))
+
+
+def test_capi_rejects_bad_arguments():
+    lib = emu_lib()
+    with pytest.raises(EnerfError, match="unsupported"):
+        lib.build_feature_volume(torch.zeros(1, 3, 8, 8, 12), torch.zeros(1, 3, 3, 4), torch.ones(1, 4, 4, 4), 12)
+    with pytest.raises(EnerfError, match="divisible"):
+        net = _net(case_config("tiny_s3"))
+        lib.cost_reg(net._packed_weights("cost_reg_1"), 16, True, torch.zeros(1, 4, 8, 8, 16))
+    with pytest.raises(EnerfError, match="contiguous float32"):
+        lib.depth_regression(torch.zeros(1, 4, 4, 4, dtype=torch.float64), torch.ones(1, 4, 4, 4), True)
+
+
+def test_empty_ray_list():
+    name = "tiny_s3"
+    cfg, batch, g = case_config(name), case_batch(name), load_golden(name)
+    net = _net(cfg)
+    out = net.render_rays(torch.zeros(1, 0, 12), level=1, batch=batch,
+                          im_feat=torch.from_numpy(g["mid/feat_l2"]).reshape(1, 3, 8, 32, 64),
+                          feature_volume=torch.from_numpy(g["mid/feat3d_1"]), nerf_model=net.nerf_1)
+    assert out["rgb"].shape == (1, 0, 3) and out["weights"].shape == (1, 0, 2)

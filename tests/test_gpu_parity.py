@@ -1,0 +1,154 @@
+"""Parity of the HIP path on a real MI355X (through the C ABI) against reference goldens and the oracle.
+
+Tolerances: the reference's own fp32 result moves by 5.8e-5 max-abs in rgb between thread counts
+(SURVEY.md §8c); north_star asks for <= 1e-3 PSNR / depth deviation.  We require max|err|/max|ref| <= 1e-4
+on every output and PSNR(ours, reference) >= 70 dB.
+"""
+import numpy as np
+import pytest
+import torch
+
+from enerf_amd.config import EnerfConfig
+from enerf_amd.synth import make_batch
+from oracle import enerf_oracle as O
+from golden_cases import CASES, case_batch, case_config, load_golden, load_weights
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _net(cfg, human=False):
+    from enerf_amd.network import Network, NetworkHuman
+    net = (NetworkHuman if human else Network)(cfg)           # product library: enerf_amd/libenerf_hip.so
+    net.load_state_dict(load_weights(), strict=False)
+    return net.to(_dev()).eval()
+
+
+def _to(batch):
+    return {k: v.to(_dev()) for k, v in batch.items()}
+
+
+def _rel(a, ref):
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-12)
+
+
+def test_product_library_is_loaded_not_a_fallback():
+    from enerf_amd.lib import LIB_PATH, get_lib
+    assert get_lib().path == LIB_PATH
+    maps = open("/proc/self/maps").read()
+    assert "libenerf_hip.so" in maps
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_goldens(name):
+    cfg, gold = case_config(name), load_golden(name)
+    out = _net(cfg, CASES[name]["human"])(_to(case_batch(name)))
+    torch.cuda.synchronize()
+    assert sorted(out) == sorted(k[4:] for k in gold if k.startswith("out/"))
+    for k, v in out.items():
+        assert v.shape == gold["out/" + k].shape, k
+        assert _rel(v.cpu().numpy(), gold["out/" + k]) < REL_TOL, (k, _rel(v.cpu().numpy(), gold["out/" + k]))
+
+
+def test_stages_vs_reference_intermediates():
+    from enerf_amd.lib import get_lib
+    name = "tiny_s3"
+    cfg, batch, g = case_config(name), _to(case_batch(name)), load_golden(name)
+    lib, cas, dev = get_lib(), cfg.cas, _dev()
+    T = lambda k: torch.from_numpy(g["mid/" + k]).contiguous().to(dev)
+    net = _net(cfg)
+    prev = None
+    for i in range(2):
+        P = lib.get_proj_mats(batch["src_ixts"], batch["src_exts"], batch["tar_ixt"], batch["tar_ext"],
+                              cas.im_feat_scale[i], cas.volume_scale[i])
+        assert _rel(P.cpu(), g[f"mid/proj_{i}"]) < 1e-6
+        D = cas.volume_planes[i]
+        h, w = g[f"mid/dv_{i}"].shape[-2:]
+        dv, nf = lib.get_depth_values(batch["near_far"], prev, 1, D, h, w, cas.depth_inv[i])
+        assert _rel(dv.cpu(), g[f"mid/dv_{i}"]) < 1e-6 and _rel(nf.cpu(), g[f"mid/nf_{i}"]) < 1e-6
+        f = T(f"feat_l{i}")
+        S, C, Hs, Ws = f.shape
+        fcl = lib.channels_last(f.reshape(S, C, Hs * Ws), S, C, Hs * Ws).view(1, S, Hs, Ws, C)
+        vol = lib.build_feature_volume(fcl, T(f"proj_{i}"), T(f"dv_{i}"), C)
+        assert _rel(vol.permute(0, 4, 1, 2, 3).cpu(), g[f"mid/vol_{i}"]) < 2e-5
+        vin = lib.channels_last(T(f"vol_{i}").reshape(1, C, -1), 1, C, D * h * w).view(1, D, h, w, C)
+        m = getattr(net, f"cost_reg_{i}")
+        feat, prob = lib.cost_reg(net._packed_weights(f"cost_reg_{i}"), m.in_channels, m.full, vin)
+        assert _rel(feat.permute(0, 4, 1, 2, 3).cpu(), g[f"mid/feat3d_{i}"]) < 2e-5
+        assert _rel(prob.cpu(), g[f"mid/prob_{i}"]) < 2e-5
+        d, s = lib.depth_regression(T(f"prob_{i}"), T(f"dv_{i}"), cas.depth_inv[i])
+        assert _rel(d.cpu(), g[f"mid/depth_{i}"]) < 1e-5 and _rel(s.cpu(), g[f"mid/std_{i}"]) < 1e-4
+        Hr, Wr = int(32 * cas.render_scale[i]), int(64 * cas.render_scale[i])
+        r = lib.build_rays(batch[f"rays_{i}"], T(f"depth_{i}"), T(f"std_{i}"), T(f"nf_{i}"), Hr, Wr, cas.depth_inv[i])
+        assert _rel(r.cpu(), g[f"mid/rays12_{i}"]) < 1e-6
+        out = net.render_rays(T(f"rays12_{i}"), level=i, batch=batch,
+                              im_feat=T(f"feat_l{cas.render_im_feat_level[i]}")[None],
+                              feature_volume=T(f"feat3d_{i}"), nerf_model=getattr(net, f"nerf_{i}"))
+        assert _rel(out["rgb"].cpu(), g[f"out/rgb_level{i}"]) < 2e-5
+        assert _rel(out["depth"].cpu(), g[f"out/depth_level{i}"]) < 2e-5
+        assert _rel(out["weights"].cpu(), g[f"out/weights_level{i}"]) < 2e-5
+        prev = (T(f"depth_{i}"), T(f"std_{i}"), T(f"nf_{i}"))
+
+
+@pytest.mark.parametrize("S,B,hw", [(3, 1, (128, 160)), (4, 2, (64, 96)), (2, 1, (96, 128))])
+def test_against_oracle_medium(S, B, hw):
+    """Seeded medium-size frames, both levels rendered, ragged ray lists; oracle on CPU in seconds."""
+    cfg = EnerfConfig().with_cas(volume_planes=(16, 8))
+    b = make_batch(hw[0], hw[1], S, cfg, seed=100 + S, B=B, textured=True)
+    keep = np.random.default_rng(S).permutation(hw[0] * hw[1])[: hw[0] * hw[1] - 37]
+    b["rays_1"] = np.ascontiguousarray(b["rays_1"][:, keep])
+    batch = {k: torch.from_numpy(v) for k, v in b.items()}
+    out = _net(cfg)(_to(batch))
+    with torch.no_grad():
+        ref = O.forward(cfg, load_weights(), batch)
+    for k in ref:
+        assert _rel(out[k].cpu(), ref[k]) < REL_TOL, (k, _rel(out[k].cpu(), ref[k]))
+    assert O.psnr(out["rgb_level1"].cpu(), ref["rgb_level1"]) > 70.0
+
+
+def test_full_size_dtu_eval_vs_oracle_and_properties():
+    """BASELINE config 2 (512x640, 3 views, planes 48,8, render_if False,True)."""
+    cfg = EnerfConfig.dtu_eval()
+    b = make_batch(512, 640, 3, cfg, seed=0, textured=True)
+    batch = {k: torch.from_numpy(v) for k, v in b.items()}
+    net = _net(cfg)
+    out = net(_to(batch))
+    out2 = net(_to(batch))
+    torch.cuda.synchronize()
+    for k in out:                                      # run-to-run determinism
+        assert torch.equal(out[k], out2[k]), k
+    rgb, w, d = out["rgb_level1"].cpu(), out["weights_level1"].cpu(), out["depth_level1"].cpu()
+    assert torch.isfinite(rgb).all() and torch.isfinite(d).all()
+    assert torch.allclose(w.sum(-1), torch.ones_like(w.sum(-1)), atol=1e-5)          # softmaxed weights
+    src = torch.from_numpy(b["src_inps"]) * 0.5 + 0.5                                # rgb is a convex blend x alpha
+    assert rgb.min() >= -1e-5 and rgb.max() <= float(src.max()) + 1e-5
+    assert d.min() >= 425.0 - 1e-2 and d.max() <= 905.0 + 1e-2                       # inside [near, far]
+    with torch.no_grad():
+        ref = O.forward(cfg, load_weights(), batch)
+    for k in ref:
+        assert _rel(out[k].cpu(), ref[k]) < REL_TOL, (k, _rel(out[k].cpu(), ref[k]))
+    psnr = O.psnr(rgb, ref["rgb_level1"])
+    assert psnr > 70.0, psnr
+    # north_star tolerance: PSNR against a common pseudo ground truth moves by < 1e-3 dB
+    gt = torch.clamp(ref["rgb_level1"] + 0.05 * torch.randn_like(ref["rgb_level1"]), 0, 1)
+    assert abs(O.psnr(rgb, gt) - O.psnr(ref["rgb_level1"], gt)) < 1e-3
+
+
+def test_lego_shape_800x800_4views():
+    """BASELINE config 3 shapes (H=W=800, S=4, planes 64,8, both levels): runs, finite, deterministic."""
+    cfg = EnerfConfig()
+    b = make_batch(800, 800, 4, cfg, seed=5, textured=True, near_far=(2.5, 5.5))
+    # lego-like intrinsics/extrinsics are not needed for the shape check; reuse the DTU rig scaled to the range
+    b["near_far"][:] = np.array([425.0, 905.0], np.float32)
+    net = _net(cfg)
+    out = net(_to({k: torch.from_numpy(v) for k, v in b.items()}))
+    torch.cuda.synchronize()
+    assert out["rgb_level1"].shape == (1, 640000, 3) and out["rgb_level0"].shape == (1, 40000, 3)
+    for v in out.values():
+        assert torch.isfinite(v).all()
