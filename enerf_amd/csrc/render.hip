@@ -150,7 +150,7 @@ __device__ __forceinline__ float dot4(f32x4 a, f32x4 b, float acc) {
 constexpr int kCamStride = 24;
 
 template <int R, int S>
-__global__ __launch_bounds__(256) void k_render_rays(RenderArgs a) {
+__global__ __launch_bounds__(256, 2) void k_render_rays(RenderArgs a) {
     constexpr int TR = (R + 3) / 4;
     const NerfLayout L = nerf_layout(a.F);
     ENERF_DYN_SMEM(float, smem);
@@ -216,6 +216,9 @@ __global__ __launch_bounds__(256) void k_render_rays(RenderArgs a) {
 
 #pragma unroll 1
         for (int k = 0; k < Ns; ++k) {
+            // Keep the MFMA A operands (weights) in LDS: without this barrier LICM hoists all ~155 LDS reads
+            // out of the sample loop into registers and the kernel drops to 1 wave/SIMD with spills.
+            asm volatile("" ::: "memory");
             // ---------- sample placement (utils.py:425-436) ----------
             float tk = (Ns == 1) ? 0.5f : linspace01(k, Ns);
             float z = rn + (rf - rn) * tk;
