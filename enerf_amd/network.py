@@ -281,7 +281,9 @@ class Network(nn.Module):
         """network.py:24-43.  ``rays`` (B,N,12); kwargs: level, batch, im_feat, feature_volume, nerf_model."""
         level, batch, im_feat, vol = kwargs["level"], kwargs["batch"], kwargs["im_feat"], kwargs["feature_volume"]
         cas = self.cfg.cas
-        if vol.dim() == 5 and vol.shape[-1] != 8 and vol.shape[1] == 8:        # reference layout (B,8,D,h,w)
+        if not getattr(vol, "_enerf_channels_last", False):                     # reference layout (B,8,D,h,w)
+            if vol.dim() != 5 or vol.shape[1] != 8:
+                raise RuntimeError("feature_volume must be (B,8,D,h,w) or a channels-last volume from forward()")
             B, _, D, h, w = vol.shape
             vol = self.lib.channels_last(vol.contiguous(), B, 8, D * h * w).view(B, D, h, w, 8)
         nerf = kwargs.get("nerf_model", None)
@@ -342,6 +344,7 @@ class Network(nn.Module):
                 name = f"cost_reg_{i}"
                 m = getattr(self, name)
                 feat3d, prob = lib.cost_reg(self._packed_weights(name), m.in_channels, m.full, vol)
+                feat3d._enerf_channels_last = True      # (B,D,h,w,8); render_rays also accepts (B,8,D,h,w)
                 self._mark(f"cost_reg_{i}")
                 depth, std = lib.depth_regression(prob, dv, cas.depth_inv[i])
                 self._mark(f"depth_reg_{i}")
