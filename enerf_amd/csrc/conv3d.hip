@@ -17,6 +17,9 @@
 // fp32 MFMA is exact fp32 (a k-ordered fmaf chain), which keeps the 1e-3 PSNR parity bar.
 //
 // Roofline: MFMA-bound (fp32 157.3 TF peak).  Algorithmic FLOPs = 2*27*cin*cout per output voxel (s1).
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace enerf {
@@ -127,13 +130,18 @@ __global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, c
                                                 const float* __restrict__ shift, const float* __restrict__ in,
                                                 const float* __restrict__ residual, float* __restrict__ out,
                                                 float* __restrict__ out2, int cout, int relu, int B, int Di, int Hi,
-                                                int Wi, int Do, int Ho, int Wo) {
+                                                int Wi, int Do, int Ho, int Wo, int rt_total) {
     constexpr int CPL = (CIN >= 16) ? 4 : CIN / 4;
     constexpr int NB = CIN / (4 * CPL);
     constexpr int KS = CIN / 4;
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, j = lane & 15;
-    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // a wave owns RT of the layer's rt_total row tiles (output-channel tiles of 16): tiny deep layers are
+    // split over more waves this way (conv6 has only 80 voxel tiles but 4 row tiles)
+    const int rsplit = rt_total / RT;
+    const long long wave_all = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long wave = wave_all / rsplit;
+    const int rt_base = (int)(wave_all - wave * rsplit) * RT;
 
     // ---- which voxels does this wave own? ----
     // conv: n = B*Do*Ho*Wo output voxels in raster order.  convT: per parity class, n = B*Di*Hi*Wi
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, c
                         const int ks = cb * CPL + r;
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt) {
-                            float a = wl[(((long long)tap * KS + ks) * RT + rt) * 64];
+                            float a = wl[(((long long)tap * KS + ks) * rt_total + rt_base + rt) * 64];
 #pragma unroll
                             for (int ct = 0; ct < CT; ++ct)
                                 acc[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[ct][r], acc[ct][rt], 0, 0, 0);
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, c
             o = (((long long)vb[ct] * Do + vd[ct]) * Ho + vh[ct]) * Wo + vw[ct];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            int c0 = rt * 16 + 4 * g;
+            int c0 = (rt_base + rt) * 16 + 4 * g;
             if (c0 >= cout) continue;
             float y[4];
 #pragma unroll
@@ -261,18 +269,29 @@ static void launch_one(const Conv3dDesc& L, const float* in, const float* residu
     if (KIND == kConvS1) { Do = Di; Ho = Hi; Wo = Wi; }
     else if (KIND == kConvS2) { Do = (Di - 1) / 2 + 1; Ho = (Hi - 1) / 2 + 1; Wo = (Wi - 1) / 2 + 1; }
     else { Do = 2 * Di; Ho = 2 * Hi; Wo = 2 * Wi; }
+    const int rt_total = cdiv(L.cout, 16);
     long long n = (KIND == kConvT2) ? (long long)B * Di * Hi * Wi : (long long)B * Do * Ho * Wo;
     long long groups = cdivl(cdivl(n, 16), CT);
-    long long waves = (KIND == kConvT2) ? groups * 8 : groups;
+    long long waves = ((KIND == kConvT2) ? groups * 8 : groups) * (rt_total / RT);
     unsigned grid = (unsigned)cdivl(waves, 4);
     ENERF_LAUNCH((k_conv3d<CIN, RT, KIND, CT>), grid, 256, 0, st, L.w, L.scale, L.shift, in, residual, out, out2, L.cout,
-                 L.relu, B, Di, Hi, Wi, Do, Ho, Wo);
+                 L.relu, B, Di, Hi, Wi, Do, Ho, Wo, rt_total);
 }
 
+// Pick (row tiles per wave, column tiles per wave): favour operand reuse when the layer has plenty of
+// voxel tiles, favour wave count when it does not (the deep levels have 80..2000 tiles for 1024 SIMDs).
 template <int CIN, int KIND>
 static bool dispatch_rt(const Conv3dDesc& L, const float* in, const float* residual, float* out, float* out2, int B,
                         int Di, int Hi, int Wi, hipStream_t st) {
-    switch (cdiv(L.cout, 16)) {
+    const int rt_total = cdiv(L.cout, 16);
+    long long n = (KIND == kConvS1) ? (long long)B * Di * Hi * Wi
+                  : (KIND == kConvS2) ? (long long)B * ((Di - 1) / 2 + 1) * ((Hi - 1) / 2 + 1) * ((Wi - 1) / 2 + 1)
+                                      : 8LL * B * Di * Hi * Wi;
+    const long long tiles = cdivl(n, 16);
+    const int ct_default = rt_total == 1 ? 4 : (rt_total == 2 ? 2 : 1);
+    const bool small = cdivl(tiles, ct_default) < 1024;      // fewer waves than SIMDs: split finer
+    if (small) { launch_one<CIN, 1, KIND, 1>(L, in, residual, out, out2, B, Di, Hi, Wi, st); return true; }
+    switch (rt_total) {
         case 1: launch_one<CIN, 1, KIND, 4>(L, in, residual, out, out2, B, Di, Hi, Wi, st); return true;
         case 2: launch_one<CIN, 2, KIND, 2>(L, in, residual, out, out2, B, Di, Hi, Wi, st); return true;
         case 4: launch_one<CIN, 4, KIND, 1>(L, in, residual, out, out2, B, Di, Hi, Wi, st); return true;
@@ -290,8 +309,187 @@ static bool dispatch_cin(const Conv3dDesc& L, const float* in, const float* resi
         default: return false;
     }
 }
+
+// =====================================================================================================
+// V2: stride-1 convolution with the haloed input box staged in LDS.
+// A block (4 waves) owns a BD x 8 x 16 box of output voxels = BD*8 MFMA column tiles (16 consecutive x
+// each); the (BD+2) x 10 x 18 input box of one 16-channel block (8 for Cin=8) is copied once into LDS
+// (zero-filled outside the volume = the conv's zero padding) and every tap's B operand is a single
+// ds_read_b128 (ds_read_b64 for Cin=8) at a constant offset from the lane's voxel.  That removes the 27x
+// re-read of activations through the TA/L1 path that bounds V1; A operands (weights) still stream from
+// L1/L2 as 256-B coalesced loads, one per CTW MFMAs.
+// =====================================================================================================
+template <int CIN, int RT, int BD>
+__global__ __launch_bounds__(256) void k_conv3d_s1_lds(const float* __restrict__ wpk, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ in,
+                                                       float* __restrict__ out, float* __restrict__ out2, int cout,
+                                                       int relu, int B, int D, int H, int W, int nbd, int nbh, int nbw) {
+    constexpr int BH = 8, BW = 16;
+    constexpr int CB = CIN >= 16 ? 16 : CIN;          // channels staged per pass
+    constexpr int CPL = CB / 4;                         // channels per lane per LDS read
+    constexpr int NCB = CIN / CB;
+    constexpr int KS = CIN / 4;
+    constexpr int CTW = BD * BH / 4;                    // column tiles per wave
+    constexpr int HX = BW + 2, HY = BH + 2, HZ = BD + 2;
+    constexpr int NVOX = HZ * HY * HX;
+    constexpr int QV = CB / 4;
+    ENERF_DYN_SMEM(float, lds);
+
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
+    // XCD-aware block order: consecutive block ids land on different XCDs (private L2s), so give each
+    // XCD a contiguous run of boxes; neighbouring boxes (shared halos) then hit the same L2.
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, k = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    int t = bid;
+    const int bw = t % nbw; t /= nbw;
+    const int bh = t % nbh; t /= nbh;
+    const int bd = t % nbd;
+    const int b = t / nbd;
+    const int x0 = bw * BW, y0 = bh * BH, z0 = bd * BD;
+
+    f32x4 acc[CTW][RT];
+#pragma unroll
+    for (int c = 0; c < CTW; ++c)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[c][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float* inb = in + (long long)b * D * H * W * CIN;
+    const float* wl = wpk + lane;
+
+#pragma unroll 1
+    for (int cb = 0; cb < NCB; ++cb) {
+        if (cb > 0) __syncthreads();                   // previous pass finished reading LDS
+        for (int i = threadIdx.x; i < NVOX * QV; i += 256) {
+            const int v = i / QV, q = i - v * QV;
+            const int dx = v % HX, dy = (v / HX) % HY, dz = v / (HX * HY);
+            const int gx = x0 + dx - 1, gy = y0 + dy - 1, gz = z0 + dz - 1;
+            const bool ok = gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) val = *reinterpret_cast<const float4*>(inb + (((long long)gz * H + gy) * W + gx) * CIN + cb * CB + q * 4);
+            *reinterpret_cast<float4*>(lds + v * CB + q * 4) = val;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll 1
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int tap = (kd * 3 + kh) * 3 + kw;
+                    float bv[CTW][4];
+#pragma unroll
+                    for (int c = 0; c < CTW; ++c) {
+                        const int tile = wv * CTW + c, td = tile / BH, th = tile - td * BH;
+                        const float* p = lds + (((td + kd) * HY + (th + kh)) * HX + (j + kw)) * CB + g * CPL;
+                        if (CPL == 4) {
+                            float4 tq = *reinterpret_cast<const float4*>(p);
+                            bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
+                        } else {
+                            float2 tq = *reinterpret_cast<const float2*>(p);
+                            bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = 0.f; bv[c][3] = 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < CPL; ++r) {
+                        const int ks = cb * CPL + r;
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            const float a = wl[(((long long)tap * KS + ks) * RT + rt) * 64];
+#pragma unroll
+                            for (int c = 0; c < CTW; ++c)
+                                acc[c][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[c][r], acc[c][rt], 0, 0, 0);
+                        }
+                    }
+                }
+    }
+
+    // ---- epilogue (same as V1): BN scale/shift, ReLU, float4 store; fused heads go to out/out2 ----
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+        const int tile = wv * CTW + c, td = tile / BH, th = tile - td * BH;
+        const int z = z0 + td, y = y0 + th, x = x0 + j;
+        if (z >= D || y >= H || x >= W) continue;
+        const long long o = (((long long)b * D + z) * H + y) * W + x;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int c0 = rt * 16 + 4 * g;
+            if (c0 >= cout) continue;
+            float yv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = c0 + r;
+                const float sc = scale ? scale[ch] : 1.f, sh = shift ? shift[ch] : 0.f;
+                yv[r] = acc[c][rt][r] * sc + sh;
+            }
+            if (out2 != nullptr) {
+                if (c0 < 8) *reinterpret_cast<float4*>(out + o * 8 + c0) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+                else if (c0 == 8) out2[o] = yv[0];
+                continue;
+            }
+            if (relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yv[r] = fmaxf(yv[r], 0.f);
+            }
+            *reinterpret_cast<float4*>(out + o * cout + c0) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+        }
+    }
+}
+
+template <int CIN, int RT, int BD>
+static void launch_s1_lds(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,
+                          hipStream_t st) {
+    constexpr int CB = CIN >= 16 ? 16 : CIN;
+    const int nbd = cdiv(D, BD), nbh = cdiv(H, 8), nbw = cdiv(W, 16);
+    const size_t shmem = (size_t)(BD + 2) * 10 * 18 * CB * sizeof(float);
+    const unsigned grid = (unsigned)((long long)B * nbd * nbh * nbw);
+    ENERF_LAUNCH((k_conv3d_s1_lds<CIN, RT, BD>), grid, 256, shmem, st, L.w, L.scale, L.shift, in, out, out2, L.cout,
+                 L.relu, B, D, H, W, nbd, nbh, nbw);
+}
+template <int CIN>
+static bool dispatch_s1_lds(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,
+                            hipStream_t st) {
+    const int rt_total = cdiv(L.cout, 16);
+    if (rt_total == 1) {
+        if (D % 4 == 0) launch_s1_lds<CIN, 1, 4>(L, in, out, out2, B, D, H, W, st);
+        else launch_s1_lds<CIN, 1, 2>(L, in, out, out2, B, D, H, W, st);
+        return true;
+    }
+    if (rt_total == 2) { launch_s1_lds<CIN, 2, 2>(L, in, out, out2, B, D, H, W, st); return true; }
+    return false;
+}
+// Tuning/test switches (read per call; getenv is ~100 ns against a >10 us launch):
+//   ENERF_CONV_V1=1            force the global-load kernel everywhere (A/B runs)
+//   ENERF_CONV_V2_MIN_VOX=n    smallest layer (output voxels) routed to the LDS-staged kernel
+static int conv_v2_enabled() {
+    const char* e = getenv("ENERF_CONV_V1");
+    return (e && e[0] == '1') ? 0 : 1;
+}
+static long long conv_v2_min_vox() {
+    const char* e = getenv("ENERF_CONV_V2_MIN_VOX");
+    return e ? atoll(e) : 16384;
+}
+
 void launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, float* out, float* out2, int B, int Di,
                    int Hi, int Wi, hipStream_t st) {
+    // LDS-staged path: stride-1 layers with enough voxels to fill the chip and cout <= 32
+    if (L.kind == kConvS1 && residual == nullptr && conv_v2_enabled() && L.cout <= 32 &&
+        (long long)B * Di * Hi * Wi >= conv_v2_min_vox()) {
+        bool ok = false;
+        switch (L.cin) {
+            case 8: ok = dispatch_s1_lds<8>(L, in, out, out2, B, Di, Hi, Wi, st); break;
+            case 16: ok = dispatch_s1_lds<16>(L, in, out, out2, B, Di, Hi, Wi, st); break;
+            case 32: ok = dispatch_s1_lds<32>(L, in, out, out2, B, Di, Hi, Wi, st); break;
+            default: break;
+        }
+        if (getenv("ENERF_TRACE")) fprintf(stderr, "[enerf] conv3d %d->%d vox=%lld : %s\n", L.cin, L.cout,
+                                           (long long)B * Di * Hi * Wi, ok ? "V2 lds" : "V1");
+        if (ok) return;
+    }
+
     switch (L.kind) {
         case kConvS1: dispatch_cin<kConvS1>(L, in, residual, out, out2, B, Di, Hi, Wi, st); break;
         case kConvS2: dispatch_cin<kConvS2>(L, in, residual, out, out2, B, Di, Hi, Wi, st); break;

@@ -39,45 +39,62 @@ void launch_channels_first(const float* src, float* dst, int n, int C, long long
 // Source-view texture for the render stage: tex[img][y][x] = [im_feat(C) | rgb(3) | 0-pad] at the render
 // resolution.  rgb = bilinear_ac(src*0.5+0.5, render_scale)  (unpreprocess, utils.py:605-612);
 // im_feat is resized with the same align_corners rule when its resolution differs (network.py:29-32).
+// NCHW -> texel transpose through LDS: a block reads 256 consecutive pixels channel by channel
+// (coalesced), parks them as [pixel][tex+1] in LDS (odd stride: conflict-free) and streams the
+// 256*tex contiguous output floats with coalesced float4 stores.
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_img_feat_rgb(const float* __restrict__ im_feat, int C, int Hf, int Wf,
                                                            const float* __restrict__ src, int H, int W, int Hr, int Wr,
                                                            int tex, int n_img, float* __restrict__ out) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long npix = (long long)Hr * Wr;
-    if (i >= npix * n_img) return;
-    int img = (int)(i / npix);
-    int p = (int)(i - (long long)img * npix);
-    int y = p / Wr, x = p - y * Wr;
-    float* o = out + i * tex;
-    {   // image features
-        Lerp1 ly = ac_lerp(y, ac_scale(Hf, Hr), Hf), lx = ac_lerp(x, ac_scale(Wf, Wr), Wf);
-        const float* f = im_feat + (long long)img * C * Hf * Wf;
-        bool same = (Hf == Hr) && (Wf == Wr);
-        for (int c = 0; c < C; ++c) {
-            const float* fc = f + (long long)c * Hf * Wf;
-            o[c] = same ? fc[y * Wf + x]
-                        : ac_blend(ly, lx, fc[ly.i0 * Wf + lx.i0], fc[ly.i0 * Wf + lx.i1], fc[ly.i1 * Wf + lx.i0],
-                                   fc[ly.i1 * Wf + lx.i1]);
+    ENERF_DYN_SMEM(float, tile);                       // 256 * (tex + 1)
+    const int ts = tex + 1;
+    const long long npix = (long long)Hr * Wr, total = npix * n_img;
+    const long long base = (long long)blockIdx.x * 256;
+    const long long i = base + threadIdx.x;
+    if (i < total) {
+        int img = (int)(i / npix);
+        int p = (int)(i - (long long)img * npix);
+        int y = p / Wr, x = p - y * Wr;
+        float* o = tile + threadIdx.x * ts;
+        {   // image features
+            Lerp1 ly = ac_lerp(y, ac_scale(Hf, Hr), Hf), lx = ac_lerp(x, ac_scale(Wf, Wr), Wf);
+            const float* f = im_feat + (long long)img * C * Hf * Wf;
+            bool same = (Hf == Hr) && (Wf == Wr);
+            for (int c = 0; c < C; ++c) {
+                const float* fc = f + (long long)c * Hf * Wf;
+                o[c] = same ? fc[y * Wf + x]
+                            : ac_blend(ly, lx, fc[ly.i0 * Wf + lx.i0], fc[ly.i0 * Wf + lx.i1], fc[ly.i1 * Wf + lx.i0],
+                                       fc[ly.i1 * Wf + lx.i1]);
+            }
         }
-    }
-    {   // colours
-        Lerp1 ly = ac_lerp(y, ac_scale(H, Hr), H), lx = ac_lerp(x, ac_scale(W, Wr), W);
-        const float* s = src + (long long)img * 3 * H * W;
-        for (int c = 0; c < 3; ++c) {
-            const float* sc = s + (long long)c * H * W;
-            float v00 = sc[ly.i0 * W + lx.i0] * 0.5f + 0.5f, v01 = sc[ly.i0 * W + lx.i1] * 0.5f + 0.5f;
-            float v10 = sc[ly.i1 * W + lx.i0] * 0.5f + 0.5f, v11 = sc[ly.i1 * W + lx.i1] * 0.5f + 0.5f;
-            o[C + c] = ac_blend(ly, lx, v00, v01, v10, v11);
+        {   // colours
+            Lerp1 ly = ac_lerp(y, ac_scale(H, Hr), H), lx = ac_lerp(x, ac_scale(W, Wr), W);
+            const float* s = src + (long long)img * 3 * H * W;
+            for (int c = 0; c < 3; ++c) {
+                const float* sc = s + (long long)c * H * W;
+                float v00 = sc[ly.i0 * W + lx.i0] * 0.5f + 0.5f, v01 = sc[ly.i0 * W + lx.i1] * 0.5f + 0.5f;
+                float v10 = sc[ly.i1 * W + lx.i0] * 0.5f + 0.5f, v11 = sc[ly.i1 * W + lx.i1] * 0.5f + 0.5f;
+                o[C + c] = ac_blend(ly, lx, v00, v01, v10, v11);
+            }
         }
+        for (int c = C + 3; c < tex; ++c) o[c] = 0.f;
     }
-    for (int c = C + 3; c < tex; ++c) o[c] = 0.f;
+    __syncthreads();
+    const long long nvalid = total - base < 256 ? total - base : 256;      // pixels of this block
+    const int nq = (int)(nvalid * tex / 4);                                // tex % 4 == 0
+    float4* dst = reinterpret_cast<float4*>(out + base * tex);
+    for (int q = threadIdx.x; q < nq; q += 256) {
+        int e = q * 4, px = e / tex, c = e - px * tex;
+        const float* t = tile + px * ts + c;
+        dst[q] = make_float4(t[0], t[1], t[2], t[3]);
+    }
 }
 void launch_pack_img_feat_rgb(const float* im_feat, int C, int Hf, int Wf, const float* src_inps, int H, int W, int Hr,
                               int Wr, int tex, int n_img, float* out, hipStream_t st) {
     long long tot = (long long)Hr * Wr * n_img;
-    ENERF_LAUNCH_SIMPLE(k_pack_img_feat_rgb, (unsigned)cdivl(tot, 256), 256, 0, st, im_feat, C, Hf, Wf, src_inps, H, W,
-                        Hr, Wr, tex, n_img, out);
+    size_t shmem = (size_t)256 * (tex + 1) * sizeof(float);
+    ENERF_LAUNCH(k_pack_img_feat_rgb, (unsigned)cdivl(tot, 256), 256, shmem, st, im_feat, C, Hf, Wf, src_inps, H, W, Hr,
+                 Wr, tex, n_img, out);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -186,44 +203,61 @@ void launch_depth_values(const float* near_far, const float* pdepth, const float
 
 // -------------------------------------------------------------------------------------------------
 // depth_regression (utils.py:658-667): softmax over D, E[v], sqrt(max(Var,1e-10)); v = 1/max(dv,1e-6)
-// for disparity-space levels.  One thread per pixel; prob/dv are (B,D,h,w) so every plane read is
-// coalesced across the wave.
+// for disparity-space levels.  A wave handles 16 pixels x 4 depth slices (lane = slice*16 + pixel; slice s
+// takes planes k = s, s+4, ...): level 0 has only 64x80 pixels, so one thread per pixel would leave the
+// chip idle behind a 48-step serial loop.  Slices are combined with two xor-shuffles.  prob/dv are
+// (B,D,h,w): each plane read is a contiguous 64-B run per slice.
 // -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float slice_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
+__device__ __forceinline__ float slice_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
 __global__ __launch_bounds__(256) void k_depth_regression(const float* __restrict__ prob, const float* __restrict__ dv,
                                                           int B, int D, int h, int w, int depth_inv,
                                                           float* __restrict__ depth, float* __restrict__ std) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int hw = h * w;
-    if (i >= B * hw) return;
-    int b = i / hw, p = i - b * hw;
+    const int lane = threadIdx.x & 63, sl = lane >> 4;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int hw = h * w;
+    const long long i = wave * 16 + (lane & 15);
+    const bool ok = i < (long long)B * hw;
+    const long long ii = ok ? i : 0;
+    const int b = (int)(ii / hw), p = (int)(ii - (long long)b * hw);
     const float* pr = prob + (long long)b * D * hw + p;
     const float* dp = dv + (long long)b * D * hw + p;
     float m = -INFINITY;
-    for (int k = 0; k < D; ++k) m = fmaxf(m, pr[(long long)k * hw]);
+    for (int k = sl; k < D; k += 4) m = fmaxf(m, pr[(long long)k * hw]);
+    m = slice_max(m);
     float se = 0.f;
-    for (int k = 0; k < D; ++k) se += expf(pr[(long long)k * hw] - m);
+    for (int k = sl; k < D; k += 4) se += expf(pr[(long long)k * hw] - m);
+    se = slice_sum(se);
     float mu = 0.f;
-    for (int k = 0; k < D; ++k) {
+    for (int k = sl; k < D; k += 4) {
         float pk = expf(pr[(long long)k * hw] - m) / se;
         float v = dp[(long long)k * hw];
         if (depth_inv) v = 1.f / clamp_min(v, 1e-6f);
         mu += pk * v;
     }
+    mu = slice_sum(mu);
     float var = 0.f;
-    for (int k = 0; k < D; ++k) {
+    for (int k = sl; k < D; k += 4) {
         float pk = expf(pr[(long long)k * hw] - m) / se;
         float v = dp[(long long)k * hw];
         if (depth_inv) v = 1.f / clamp_min(v, 1e-6f);
         float dd = v - mu;
         var += pk * (dd * dd);
     }
-    depth[i] = mu;
-    std[i] = sqrtf(clamp_min(var, 1e-10f));
+    var = slice_sum(var);
+    if (ok && sl == 0) {
+        depth[i] = mu;
+        std[i] = sqrtf(clamp_min(var, 1e-10f));
+    }
 }
 void launch_depth_regression(const float* prob, const float* dv, int B, int D, int h, int w, int depth_inv,
                              float* depth, float* std, hipStream_t st) {
-    ENERF_LAUNCH_SIMPLE(k_depth_regression, cdiv(B * h * w, 256), 256, 0, st, prob, dv, B, D, h, w, depth_inv, depth,
-                        std);
+    long long waves = cdivl((long long)B * h * w, 16);
+    ENERF_LAUNCH(k_depth_regression, (unsigned)cdivl(waves, 4), 256, 0, st, prob, dv, B, D, h, w, depth_inv, depth, std);
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -142,3 +142,24 @@ def test_empty_ray_list():
                           im_feat=torch.from_numpy(g["mid/feat_l2"]).reshape(1, 3, 8, 32, 64),
                           feature_volume=torch.from_numpy(g["mid/feat3d_1"]), nerf_model=net.nerf_1)
     assert out["rgb"].shape == (1, 0, 3) and out["weights"].shape == (1, 0, 2)
+
+
+@pytest.mark.parametrize("force", ["v1", "v2"])
+def test_conv3d_variants_agree_with_reference(force, monkeypatch):
+    """Both conv3d code paths (global-load V1 incl. the row-split small-layer form, LDS-staged V2) on a
+    case whose volumes are not multiples of the 8x16 LDS box (h,w = 16,24 / 8,12 / 4,6)."""
+    if force == "v1":
+        monkeypatch.setenv("ENERF_CONV_V1", "1")
+    else:
+        monkeypatch.setenv("ENERF_CONV_V2_MIN_VOX", "0")
+    name = "small_s3_eval"
+    cfg, batch, gold = case_config(name), case_batch(name), load_golden(name)
+    out = _net(cfg)(batch)
+    for k, v in out.items():
+        _close(v.numpy(), gold["out/" + k], 2e-5, k)
+    # and the level-0 network (MinCostRegNet, Cin=32: two LDS channel passes)
+    name = "tiny_s3"
+    cfg, batch, gold = case_config(name), case_batch(name), load_golden(name)
+    out = _net(cfg)(batch)
+    for k, v in out.items():
+        _close(v.numpy(), gold["out/" + k], 2e-5, k)
