@@ -146,7 +146,7 @@ int enerf_cost_reg(const float* packed, int in_channels, int full, const float* 
     for (int i = 0; i < n; ++i) {
         long long wf = conv3d_packed_floats(L[i].cin, L[i].cout, L[i].kind);
         int cp = cdiv(L[i].cout, 16) * 16;
-        desc[i] = {p, L[i].bn ? p + wf : nullptr, L[i].bn ? p + wf + cp : nullptr, L[i].cin, L[i].cout, L[i].kind, L[i].relu};
+        desc[i] = {p, p + wf, p + wf + cp, L[i].cin, L[i].cout, L[i].kind, L[i].relu};   // scale/shift = 1/0 without BN
         p += layer_floats(L[i]);
     }
     long long n0 = (long long)B * D * h * w, n1 = n0 / 8, n2 = n1 / 8, n3 = n2 / 8;

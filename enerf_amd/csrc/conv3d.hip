@@ -113,17 +113,6 @@ void launch_conv3d_pack(const float* w, const float* w2, int cout1, const float*
 }
 
 // ---- the implicit-GEMM kernel ---------------------------------------------------------------------
-template <int CPL>
-__device__ __forceinline__ void load_b(const float* __restrict__ p, bool ok, float (&v)[4]) {
-    if (CPL == 4) {
-        float4 t = ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
-        float2 t = ok ? *reinterpret_cast<const float2*>(p) : make_float2(0.f, 0.f);
-        v[0] = t.x; v[1] = t.y; v[2] = 0.f; v[3] = 0.f;
-    }
-}
-
 // CIN: input channels (8,16,32,64); RT: cout row tiles of 16; KIND; CT: 16-voxel column tiles per wave.
 template <int CIN, int RT, int KIND, int CT>
 __global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, const float* __restrict__ scale,
@@ -182,47 +171,88 @@ __global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, c
 
     const int ntd = (KIND == kConvT2) ? 1 + pd : 3, nth = (KIND == kConvT2) ? 1 + ph : 3,
               ntw = (KIND == kConvT2) ? 1 + pw : 3;
-    int tap = (KIND == kConvT2) ? convt_class_offset(cls) : 0;
-    const float* wl = wpk + lane;
-    for (int td = 0; td < ntd; ++td)
-        for (int th = 0; th < nth; ++th)
-            for (int tw = 0; tw < ntw; ++tw, ++tap) {
-                const float* pin[CT];
-                bool ok[CT];
+    const int ntaps = ntd * nth * ntw;
+    const int tap0 = (KIND == kConvT2) ? convt_class_offset(cls) : 0;
+    const float* wl = wpk + lane + (long long)rt_base * 64;
+    constexpr int NA = KS * RT;                       // A operands (weights) per tap
+
+    // One tap's operands: all loads are UNCONDITIONAL (out-of-range voxels read voxel 0 and are zeroed
+    // afterwards with a select) and issued back to back, and taps are double-buffered, so a tap's ~10
+    // L2 round trips overlap the previous tap's MFMAs instead of serialising behind exec-mask branches
+    // and per-load s_waitcnt vmcnt(0) (which is what hipcc emits for `ok ? *p : 0`).
+    auto issue = [&](int t, float4 (&bq)[CT][NB], bool (&bok)[CT], float (&aq)[NA]) {
+        int td, th, tw;
+        if (KIND == kConvT2) {
+            tw = (ntw == 2) ? (t & 1) : 0;
+            const int t2 = (ntw == 2) ? (t >> 1) : t;
+            th = (nth == 2) ? (t2 & 1) : 0;
+            td = (nth == 2) ? (t2 >> 1) : t2;
+        } else {
+            tw = t % 3; th = (t / 3) % 3; td = t / 9;
+        }
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    int id, ih, iw;
-                    if (KIND == kConvT2) {
-                        int k, dq;
-                        convt_axis(pd, td, k, dq); id = vd[ct] + dq;
-                        convt_axis(ph, th, k, dq); ih = vh[ct] + dq;
-                        convt_axis(pw, tw, k, dq); iw = vw[ct] + dq;
-                    } else {
-                        constexpr int s = (KIND == kConvS2) ? 2 : 1;
-                        id = vd[ct] * s - 1 + td; ih = vh[ct] * s - 1 + th; iw = vw[ct] * s - 1 + tw;
-                    }
-                    ok[ct] = vok[ct] && id >= 0 && id < Di && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi;
-                    long long off = ok[ct] ? ((((long long)vb[ct] * Di + id) * Hi + ih) * Wi + iw) : 0;
-                    pin[ct] = in + off * CIN + g * CPL;
-                }
+        for (int ct = 0; ct < CT; ++ct) {
+            int id, ih, iw;
+            if (KIND == kConvT2) {
+                int k, dq;
+                convt_axis(pd, td, k, dq); id = vd[ct] + dq;
+                convt_axis(ph, th, k, dq); ih = vh[ct] + dq;
+                convt_axis(pw, tw, k, dq); iw = vw[ct] + dq;
+            } else {
+                constexpr int s = (KIND == kConvS2) ? 2 : 1;
+                id = vd[ct] * s - 1 + td; ih = vh[ct] * s - 1 + th; iw = vw[ct] * s - 1 + tw;
+            }
+            bok[ct] = vok[ct] && id >= 0 && id < Di && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi;
+            const long long off = bok[ct] ? ((((long long)vb[ct] * Di + id) * Hi + ih) * Wi + iw) : 0;
+            const float* p = in + off * CIN + g * CPL;
 #pragma unroll
-                for (int cb = 0; cb < NB; ++cb) {
-                    float bv[CT][4];
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) load_b<CPL>(pin[ct] + cb * 4 * CPL, ok[ct], bv[ct]);
-#pragma unroll
-                    for (int r = 0; r < CPL; ++r) {
-                        const int ks = cb * CPL + r;
-#pragma unroll
-                        for (int rt = 0; rt < RT; ++rt) {
-                            float a = wl[(((long long)tap * KS + ks) * rt_total + rt_base + rt) * 64];
-#pragma unroll
-                            for (int ct = 0; ct < CT; ++ct)
-                                acc[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[ct][r], acc[ct][rt], 0, 0, 0);
-                        }
-                    }
+            for (int cb = 0; cb < NB; ++cb) {
+                if (CPL == 4) {
+                    bq[ct][cb] = *reinterpret_cast<const float4*>(p + cb * 16);
+                } else {
+                    const float2 t2 = *reinterpret_cast<const float2*>(p + cb * 8);
+                    bq[ct][cb] = make_float4(t2.x, t2.y, 0.f, 0.f);
                 }
             }
+        }
+        const float* wt = wl + (long long)(tap0 + t) * KS * rt_total * 64;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) aq[ks * RT + rt] = wt[(ks * rt_total + rt) * 64];
+    };
+    auto compute = [&](const float4 (&bq)[CT][NB], const bool (&bok)[CT], const float (&aq)[NA]) {
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            float bv[CT][4];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                bv[ct][0] = bok[ct] ? bq[ct][cb].x : 0.f; bv[ct][1] = bok[ct] ? bq[ct][cb].y : 0.f;
+                bv[ct][2] = bok[ct] ? bq[ct][cb].z : 0.f; bv[ct][3] = bok[ct] ? bq[ct][cb].w : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < CPL; ++r)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[(cb * CPL + r) * RT + rt], bv[ct][r],
+                                                                           acc[ct][rt], 0, 0, 0);
+        }
+    };
+    {
+        float4 b0[CT][NB], b1[CT][NB];
+        bool k0[CT], k1[CT];
+        float a0[NA], a1[NA];
+        issue(0, b0, k0, a0);
+#pragma unroll 1
+        for (int t = 0; t < ntaps; t += 2) {
+            issue(t + 1 < ntaps ? t + 1 : ntaps - 1, b1, k1, a1);   // clamped: always loads, never branches
+            compute(b0, k0, a0);
+            issue(t + 2 < ntaps ? t + 2 : ntaps - 1, b0, k0, a0);
+            if (t + 1 < ntaps) compute(b1, k1, a1);
+        }
+    }
 
     // ---- epilogue: BN scale/shift, skip add, ReLU; lane owns channels rt*16+4g..+3 of voxel j ----
 #pragma unroll
@@ -241,7 +271,7 @@ __global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, c
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int c = c0 + r;
-                float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+                float sc = scale[c], sh = shift[c];      // always valid (pack writes 1/0 without BN)
                 y[r] = acc[ct][rt][r] * sc + sh;
             }
             if (out2 != nullptr) {          // fused heads: channels 0..7 -> out (8 ch), channel 8 -> out2
@@ -360,51 +390,81 @@ __global__ __launch_bounds__(256) void k_conv3d_s1_lds(const float* __restrict__
     const float* inb = in + (long long)b * D * H * W * CIN;
     const float* wl = wpk + lane;
 
+    constexpr int NIT = (NVOX * QV + 255) / 256;     // float4 staging loads per thread
+    constexpr int NAQ = 3 * CPL * RT;                 // A operands of one (kd,kh) row of taps
 #pragma unroll 1
     for (int cb = 0; cb < NCB; ++cb) {
         if (cb > 0) __syncthreads();                   // previous pass finished reading LDS
-        for (int i = threadIdx.x; i < NVOX * QV; i += 256) {
-            const int v = i / QV, q = i - v * QV;
-            const int dx = v % HX, dy = (v / HX) % HY, dz = v / (HX * HY);
-            const int gx = x0 + dx - 1, gy = y0 + dy - 1, gz = z0 + dz - 1;
-            const bool ok = gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) val = *reinterpret_cast<const float4*>(inb + (((long long)gz * H + gy) * W + gx) * CIN + cb * CB + q * 4);
-            *reinterpret_cast<float4*>(lds + v * CB + q * 4) = val;
+        {   // stage the haloed box: all loads issued back to back and unconditionally (clamped address,
+            // zero-select afterwards) so they overlap instead of serialising behind exec-mask branches
+            float4 sv[NIT];
+            bool sk[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = threadIdx.x + it * 256;
+                const int ic = i < NVOX * QV ? i : NVOX * QV - 1;
+                const int v = ic / QV, q = ic - v * QV;
+                const int dx = v % HX, dy = (v / HX) % HY, dz = v / (HX * HY);
+                const int gx = x0 + dx - 1, gy = y0 + dy - 1, gz = z0 + dz - 1;
+                sk[it] = gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
+                const long long off = sk[it] ? (((long long)gz * H + gy) * W + gx) : 0;
+                sv[it] = *reinterpret_cast<const float4*>(inb + off * CIN + cb * CB + q * 4);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = threadIdx.x + it * 256;
+                if (i < NVOX * QV)
+                    *reinterpret_cast<float4*>(lds + i * 4) = sk[it] ? sv[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         __syncthreads();
-#pragma unroll 1
-        for (int kd = 0; kd < 3; ++kd)
-#pragma unroll 1
-            for (int kh = 0; kh < 3; ++kh)
+
+        auto issue_a = [&](int u, float (&aq)[NAQ]) {           // weights of taps (kd,kh,0..2), u = kd*3+kh
+            const float* wt = wl + ((long long)(u * 3) * KS + cb * CPL) * RT * 64;
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int tap = (kd * 3 + kh) * 3 + kw;
-                    float bv[CTW][4];
+            for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-                    for (int c = 0; c < CTW; ++c) {
-                        const int tile = wv * CTW + c, td = tile / BH, th = tile - td * BH;
-                        const float* p = lds + (((td + kd) * HY + (th + kh)) * HX + (j + kw)) * CB + g * CPL;
-                        if (CPL == 4) {
-                            float4 tq = *reinterpret_cast<const float4*>(p);
-                            bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
-                        } else {
-                            float2 tq = *reinterpret_cast<const float2*>(p);
-                            bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = 0.f; bv[c][3] = 0.f;
-                        }
-                    }
+                for (int r = 0; r < CPL; ++r)
 #pragma unroll
-                    for (int r = 0; r < CPL; ++r) {
-                        const int ks = cb * CPL + r;
+                    for (int rt = 0; rt < RT; ++rt)
+                        aq[(kw * CPL + r) * RT + rt] = wt[((long long)(kw * KS + r) * RT + rt) * 64];
+        };
+        auto compute = [&](int u, const float (&aq)[NAQ]) {
+            const int kd = u / 3, kh = u - kd * 3;
 #pragma unroll
-                        for (int rt = 0; rt < RT; ++rt) {
-                            const float a = wl[(((long long)tap * KS + ks) * RT + rt) * 64];
+            for (int kw = 0; kw < 3; ++kw) {
+                float bv[CTW][4];
 #pragma unroll
-                            for (int c = 0; c < CTW; ++c)
-                                acc[c][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[c][r], acc[c][rt], 0, 0, 0);
-                        }
+                for (int c = 0; c < CTW; ++c) {
+                    const int tile = wv * CTW + c, td = tile / BH, th = tile - td * BH;
+                    const float* p = lds + (((td + kd) * HY + (th + kh)) * HX + (j + kw)) * CB + g * CPL;
+                    if (CPL == 4) {
+                        float4 tq = *reinterpret_cast<const float4*>(p);
+                        bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
+                    } else {
+                        float2 tq = *reinterpret_cast<const float2*>(p);
+                        bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = 0.f; bv[c][3] = 0.f;
                     }
                 }
+#pragma unroll
+                for (int r = 0; r < CPL; ++r)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int c = 0; c < CTW; ++c)
+                            acc[c][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[(kw * CPL + r) * RT + rt], bv[c][r],
+                                                                              acc[c][rt], 0, 0, 0);
+            }
+        };
+        float a0[NAQ], a1[NAQ];
+        issue_a(0, a0);
+#pragma unroll 1
+        for (int u = 0; u < 9; u += 2) {
+            issue_a(u + 1 < 9 ? u + 1 : 8, a1);
+            compute(u, a0);
+            issue_a(u + 2 < 9 ? u + 2 : 8, a0);
+            if (u + 1 < 9) compute(u + 1, a1);
+        }
     }
 
     // ---- epilogue (same as V1): BN scale/shift, ReLU, float4 store; fused heads go to out/out2 ----
@@ -422,7 +482,7 @@ __global__ __launch_bounds__(256) void k_conv3d_s1_lds(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ch = c0 + r;
-                const float sc = scale ? scale[ch] : 1.f, sh = shift ? shift[ch] : 0.f;
+                const float sc = scale[ch], sh = shift[ch];
                 yv[r] = acc[c][rt][r] * sc + sh;
             }
             if (out2 != nullptr) {

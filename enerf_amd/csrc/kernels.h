@@ -28,8 +28,8 @@ void launch_feature_volume(const float* feat_nhwc, const float* proj, const floa
 enum ConvKind { kConvS1 = 0, kConvS2 = 1, kConvT2 = 2 };
 struct Conv3dDesc {
     const float* w;         // packed A operands (see conv3d.hip)
-    const float* scale;     // per-cout epilogue scale (BN folded) or nullptr (=1)
-    const float* shift;     // per-cout epilogue shift or nullptr (=0)
+    const float* scale;     // per-cout epilogue scale (BN folded; 1 without BN), padded to 16*row tiles
+    const float* shift;     // per-cout epilogue shift (0 without BN)
     int cin, cout, kind, relu;
 };
 // number of floats of the packed weight image for a layer
