@@ -99,6 +99,20 @@ __host__ __device__ __forceinline__ Taps2 gs_taps2(float ix, float iy, int W, in
 
 __device__ __forceinline__ float clamp_min(float v, float lo) { return v < lo ? lo : v; }  // torch.clamp_min
 
+// Hardware transcendental forms (v_rcp_f32 / v_sqrt_f32 / v_exp_f32, ~1 ulp) for the render kernel's
+// per-sample geometry and softmaxes: an IEEE-correct fp32 divide or sqrt expands to ~10 VALU
+// instructions and the sample loop had ~50 of them per 201 MFMAs.  The induced error (<=1e-6 relative)
+// is two orders of magnitude inside the parity budget.  The CPU emulator uses libm.
+#ifdef ENERF_EMU
+__device__ __forceinline__ float fast_rcp(float x) { return 1.f / x; }
+__device__ __forceinline__ float fast_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ float fast_exp(float x) { return expf(x); }
+#else
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+#endif
+
 // torch.linspace(0,1,D)[k]: step = 1/(D-1); k < D/2 ? step*k : 1 - step*(D-1-k)   (ATen RangeFactories)
 __host__ __device__ __forceinline__ float linspace01(int k, int D) {
     if (D == 1) return 0.f;

@@ -21,6 +21,8 @@
 // point instead of once per view (201 instead of 369 MFMAs per 16 points at S=3, C=8).
 //
 // Roofline: MFMA-bound (fp32 157.3 TF).  Algorithmic FLOPs/point: SURVEY.md §8a (50,952 at level 1).
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace enerf {
@@ -149,8 +151,8 @@ __device__ __forceinline__ float dot4(f32x4 a, f32x4 b, float acc) {
 // camera table in LDS, per (b,s): E[:3] (12) | K' (9) | centre (3) ; per b: target centre (3)
 constexpr int kCamStride = 24;
 
-template <int R, int S>
-__global__ __launch_bounds__(256, 2) void k_render_rays(RenderArgs a) {
+template <int R, int S, int OCC>   // OCC = resident 256-thread blocks per CU the register budget is sized for
+__global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
     constexpr int TR = (R + 3) / 4;
     const NerfLayout L = nerf_layout(a.F);
     ENERF_DYN_SMEM(float, smem);
@@ -203,6 +205,8 @@ __global__ __launch_bounds__(256, 2) void k_render_rays(RenderArgs a) {
         const float gxv = (ru / (float)(a.Wr - 1)) * 2.f - 1.f, gyv = (rv / (float)(a.Hr - 1)) * 2.f - 1.f;
         const float* volb = a.vol + (long long)b * a.D * a.h * a.w * 8 + 2 * g;
         const float* texb = a.tex + (long long)b * S * a.Hr * a.Wr * TEX + g * R;
+        const float rcpW = fast_rcp((float)(a.Wr - 1)), rcpH = fast_rcp((float)(a.Hr - 1));
+        const int view_stride = a.Hr * a.Wr * TEX;     // < 2^31 floats (checked by the launcher)
         const float* camb = cam + (long long)b * S * kCamStride;
         const float tcx = tcen[b * 3], tcy = tcen[b * 3 + 1], tcz = tcen[b * 3 + 2];
 
@@ -222,9 +226,10 @@ __global__ __launch_bounds__(256, 2) void k_render_rays(RenderArgs a) {
             // ---------- sample placement (utils.py:425-436) ----------
             float tk = (Ns == 1) ? 0.5f : linspace01(k, Ns);
             float z = rn + (rf - rn) * tk;
-            float zz = a.depth_inv ? 1.f / clamp_min(z, 1e-6f) : z;
+            float zz = a.depth_inv ? fast_rcp(clamp_min(z, 1e-6f)) : z;
             float X = ox + dx * zz, Y = oy + dy * zz, Z = oz + dz * zz;
-            float dn = a.depth_inv ? (vn - z) / clamp_min(vn - vf, 1e-6f) : (z - vn) / clamp_min(vf - vn, 1e-6f);
+            float dn = a.depth_inv ? (vn - z) * fast_rcp(clamp_min(vn - vf, 1e-6f))
+                                   : (z - vn) * fast_rcp(clamp_min(vf - vn, 1e-6f));
 
             // ---------- voxel feature: trilinear, zeros padding (utils.py:457) ----------
             float vox[2] = {0.f, 0.f};
@@ -241,8 +246,10 @@ __global__ __launch_bounds__(256, 2) void k_render_rays(RenderArgs a) {
                     int xx = x0 + (c & 1), yy = y0 + ((c >> 1) & 1), zc = z0 + (c >> 2);
                     float wgt = ((c & 1) ? wx1 : wx0) * (((c >> 1) & 1) ? wy1 : wy0) * ((c >> 2) ? wz1 : wz0);
                     bool ok = xx >= 0 && xx < a.w && yy >= 0 && yy < a.h && zc >= 0 && zc < a.D;
-                    float2 t = ok ? *reinterpret_cast<const float2*>(volb + (((long long)zc * a.h + yy) * a.w + xx) * 8)
-                                  : make_float2(0.f, 0.f);
+                    // unconditional load from the clamped voxel, zero weight when outside (zeros padding)
+                    int xc = min(max(xx, 0), a.w - 1), yc = min(max(yy, 0), a.h - 1), zk = min(max(zc, 0), a.D - 1);
+                    float2 t = *reinterpret_cast<const float2*>(volb + ((zk * a.h + yc) * a.w + xc) * 8);
+                    wgt = ok ? wgt : 0.f;
                     vox[0] += t.x * wgt;
                     vox[1] += t.y * wgt;
                 }
@@ -259,14 +266,14 @@ __global__ __launch_bounds__(256, 2) void k_render_rays(RenderArgs a) {
                 float px = cx * c[12] + cy * c[13] + cz * c[14];
                 float py = cx * c[15] + cy * c[16] + cz * c[17];
                 float pz = cx * c[18] + cy * c[19] + cz * c[20];
-                float zc = clamp_min(pz, 1e-6f);
-                float gx = ((px / zc) / (float)(a.Wr - 1)) * 2.f - 1.f, gy = ((py / zc) / (float)(a.Hr - 1)) * 2.f - 1.f;
+                float rz = fast_rcp(clamp_min(pz, 1e-6f));
+                float gx = ((px * rz) * rcpW) * 2.f - 1.f, gy = ((py * rz) * rcpH) * 2.f - 1.f;
                 Taps2 t = gs_taps2<true>(gs_unnorm(gx, a.Wr), gs_unnorm(gy, a.Hr), a.Wr, a.Hr);
-                const float* tb = texb + (long long)s * a.Hr * a.Wr * TEX;
-                const float* p00 = tb + ((long long)t.y0 * a.Wr + t.x0) * TEX;
-                const float* p01 = tb + ((long long)t.y0 * a.Wr + t.x1) * TEX;
-                const float* p10 = tb + ((long long)t.y1 * a.Wr + t.x0) * TEX;
-                const float* p11 = tb + ((long long)t.y1 * a.Wr + t.x1) * TEX;
+                const float* tb = texb + s * view_stride;
+                const float* p00 = tb + (t.y0 * a.Wr + t.x0) * TEX;
+                const float* p01 = tb + (t.y0 * a.Wr + t.x1) * TEX;
+                const float* p10 = tb + (t.y1 * a.Wr + t.x0) * TEX;
+                const float* p11 = tb + (t.y1 * a.Wr + t.x1) * TEX;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     float acc = p00[r] * t.w00;
@@ -278,13 +285,14 @@ __global__ __launch_bounds__(256, 2) void k_render_rays(RenderArgs a) {
                 // direction code
                 float tx = X - tcx, ty = Y - tcy, tz = Z - tcz;
                 float sx = X - c[21], sy = Y - c[22], sz = Z - c[23];
-                float tnr = sqrtf(tx * tx + ty * ty + tz * tz) + 1e-6f, snr = sqrtf(sx * sx + sy * sy + sz * sz) + 1e-6f;
-                tx /= tnr; ty /= tnr; tz /= tnr;
-                sx /= snr; sy /= snr; sz /= snr;
+                float tir = fast_rcp(fast_sqrt(tx * tx + ty * ty + tz * tz) + 1e-6f);
+                float sir = fast_rcp(fast_sqrt(sx * sx + sy * sy + sz * sz) + 1e-6f);
+                tx *= tir; ty *= tir; tz *= tir;
+                sx *= sir; sy *= sir; sz *= sir;
                 float ex = tx - sx, ey = ty - sy, ez = tz - sz;
-                float en = fmaxf(sqrtf(ex * ex + ey * ey + ez * ez), 1e-6f);
+                float eir = fast_rcp(fmaxf(fast_sqrt(ex * ex + ey * ey + ez * ez), 1e-6f));
                 float dot = tx * sx + ty * sy + tz * sz;
-                dsel[s] = g == 0 ? ex / en : (g == 1 ? ey / en : (g == 2 ? ez / en : dot));
+                dsel[s] = g == 0 ? ex * eir : (g == 1 ? ey * eir : (g == 2 ? ez * eir : dot));
             }
 
             // ---------- Agg (nerf.py:74-89) ----------
@@ -306,12 +314,12 @@ __global__ __launch_bounds__(256, 2) void k_render_rays(RenderArgs a) {
                 float m = 0.f;
 #pragma unroll
                 for (int s = 0; s < S; ++s) m += av[s][r];
-                m /= (float)S;
+                m *= (1.f / (float)S);
                 float q = 0.f;
 #pragma unroll
                 for (int s = 0; s < S; ++s) { float d = av[s][r] - m; q += d * d; }
                 mean[r] = m;
-                var[r] = q / (float)(S - 1);                      // unbiased, nerf.py:82
+                var[r] = q * (1.f / (float)(S - 1));              // unbiased, nerf.py:82
             }
             f32x4 P[2];
 #pragma unroll
@@ -345,9 +353,10 @@ __global__ __launch_bounds__(256, 2) void k_render_rays(RenderArgs a) {
                 for (int s = 1; s < S; ++s) m = fmaxf(m, aw[s]);
                 float se = 0.f;
 #pragma unroll
-                for (int s = 0; s < S; ++s) { aw[s] = expf(aw[s] - m); se += aw[s]; }
+                for (int s = 0; s < S; ++s) { aw[s] = fast_exp(aw[s] - m); se += aw[s]; }
+                se = fast_rcp(se);
 #pragma unroll
-                for (int s = 0; s < S; ++s) aw[s] /= se;
+                for (int s = 0; s < S; ++s) aw[s] *= se;
             }
             f32x4 G[2];
 #pragma unroll
@@ -416,13 +425,14 @@ __global__ __launch_bounds__(256, 2) void k_render_rays(RenderArgs a) {
                 for (int s = 1; s < S; ++s) m = fmaxf(m, cl[s]);
                 float se = 0.f;
 #pragma unroll
-                for (int s = 0; s < S; ++s) { cl[s] = expf(cl[s] - m); se += cl[s]; }
+                for (int s = 0; s < S; ++s) { cl[s] = fast_exp(cl[s] - m); se += cl[s]; }
+                se = fast_rcp(se);
 #pragma unroll
-                for (int s = 0; s < S; ++s) cl[s] /= se;
+                for (int s = 0; s < S; ++s) cl[s] *= se;
             }
 
             // ---------- compositing step (utils.py:584-592) ----------
-            float alpha = 1.f - expf(-sig);
+            float alpha = 1.f - fast_exp(-sig);
             float wgt = alpha * Tacc;
             Tacc *= (1.f - alpha + 1e-10f);
 #pragma unroll
@@ -443,12 +453,13 @@ __global__ __launch_bounds__(256, 2) void k_render_rays(RenderArgs a) {
         for (int k = 1; k < 8; ++k) if (k < Ns) m = fmaxf(m, wk[k]);
         float se = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) if (k < Ns) { wk[k] = expf(wk[k] - m); se += wk[k]; }
+        for (int k = 0; k < 8; ++k) if (k < Ns) { wk[k] = fast_exp(wk[k] - m); se += wk[k]; }
+        se = fast_rcp(se);
         float depth = 0.f, accw = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
             if (k < Ns) {
-                wk[k] /= se;
+                wk[k] *= se;
                 float tk = (Ns == 1) ? 0.5f : linspace01(k, Ns);
                 depth += wk[k] * (rn + (rf - rn) * tk);
                 accw += wk[k];
@@ -472,12 +483,16 @@ __global__ __launch_bounds__(256, 2) void k_render_rays(RenderArgs a) {
     }
 }
 
-template <int R>
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+template <int R, int OCC>
 static int dispatch_s(const RenderArgs& a, unsigned grid, size_t shmem, hipStream_t st) {
     switch (a.S) {
-        case 2: ENERF_LAUNCH((k_render_rays<R, 2>), grid, 256, shmem, st, a); return 0;
-        case 3: ENERF_LAUNCH((k_render_rays<R, 3>), grid, 256, shmem, st, a); return 0;
-        case 4: ENERF_LAUNCH((k_render_rays<R, 4>), grid, 256, shmem, st, a); return 0;
+        case 2: ENERF_LAUNCH((k_render_rays<R, 2, OCC>), grid, 256, shmem, st, a); return 0;
+        case 3: ENERF_LAUNCH((k_render_rays<R, 3, OCC>), grid, 256, shmem, st, a); return 0;
+        case 4: ENERF_LAUNCH((k_render_rays<R, 4, OCC>), grid, 256, shmem, st, a); return 0;
         default: return -3;
     }
 }
@@ -486,15 +501,19 @@ int launch_render_rays(const RenderArgs& a, hipStream_t st) {
     const int R = (a.F + 3) / 4;
     size_t shmem = ((size_t)nerf_layout(a.F).total + (size_t)a.B * a.S * kCamStride + (size_t)a.B * 3) * sizeof(float);
     if (shmem > 64 * 1024) return -2;
+    if ((long long)a.S * a.Hr * a.Wr * 4 * R >= (1LL << 31) || (long long)a.D * a.h * a.w * 8 >= (1LL << 31)) return -5;
     long long ntiles = cdivl((long long)a.B * a.N, 16);
     long long blocks = cdivl(ntiles, 4);
-    unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);     // persistent waves stride over ray tiles
+    // Persistent waves: the weight image (40-56 KB) is staged into LDS once per block, so launch only as
+    // many blocks as are co-resident (OCC per CU x 256 CUs) and let each wave stride over ray tiles.
+    // Tuning knobs (A/B runs): ENERF_RENDER_OCC (2|3), ENERF_RENDER_WAVES_PER_CU_X (grid multiplier).
+    const int occ = env_int("ENERF_RENDER_OCC", 2);
+    const long long resident = 256LL * occ * env_int("ENERF_RENDER_GRID_X", 1);
+    unsigned grid = (unsigned)(blocks < resident ? blocks : resident);
     if (grid == 0) return 0;
-    switch (R) {
-        case 3: return dispatch_s<3>(a, grid, shmem, st);          // C = 8  (level 1)
-        case 9: return dispatch_s<9>(a, grid, shmem, st);          // C = 32 (level 0)
-        default: return -4;
-    }
+    if (R == 3) return occ == 3 ? dispatch_s<3, 3>(a, grid, shmem, st) : dispatch_s<3, 2>(a, grid, shmem, st);   // C = 8
+    if (R == 9) return dispatch_s<9, 2>(a, grid, shmem, st);                                                   // C = 32
+    return -4;
 }
 
 }  // namespace enerf

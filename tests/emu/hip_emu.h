@@ -53,6 +53,8 @@ inline float2 make_float2(float x, float y) { return {x, y}; }
 inline float3 make_float3(float x, float y, float z) { return {x, y, z}; }
 inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 typedef float emu_f32x4 __attribute__((vector_size(16)));
+inline int min(int a, int b) { return a < b ? a : b; }
+inline int max(int a, int b) { return a > b ? a : b; }
 
 namespace emu {
 
