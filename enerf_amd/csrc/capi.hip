@@ -215,3 +215,98 @@ int enerf_render_rays(const enerf_render_args_t* a, enerf_stream_t stream) {
 }
 
 }  // extern "C"
+
+// ---- FeatureNet driver ------------------------------------------------------------------------------
+namespace {
+struct FLayer { int cin, cout, k, stride, relu; };
+// order: conv0.0 conv0.1 conv1.0 conv1.1 conv2.0 conv2.1 toplayer lat1 lat0 smooth1 smooth0
+const FLayer kFeat[11] = {{3, 8, 3, 1, 1},  {8, 8, 3, 1, 1},   {8, 16, 5, 2, 1},  {16, 16, 3, 1, 1}, {16, 32, 5, 2, 1},
+                          {32, 32, 3, 1, 1}, {32, 32, 1, 1, 0}, {16, 32, 1, 1, 0}, {8, 32, 1, 1, 0},  {32, 16, 3, 1, 0},
+                          {32, 8, 3, 1, 0}};
+long long flayer_floats(const FLayer& f) { return conv2d_packed_floats(f.cin, f.cout, f.k) + 2 * cdiv(f.cout, 16) * 16; }
+}  // namespace
+
+extern "C" {
+long long enerf_feature_net_packed_floats(void) {
+    long long t = 0;
+    for (int i = 0; i < 11; ++i) t += flayer_floats(kFeat[i]);
+    return t;
+}
+int enerf_feature_net_pack(const enerf_featnet_raw_t* raw, float* packed, enerf_stream_t stream) {
+    REQUIRE(raw && packed, "feature_net_pack: null pointer");
+    const float* pw[5] = {raw->toplayer_w, raw->lat1_w, raw->lat0_w, raw->smooth1_w, raw->smooth0_w};
+    const float* pb[5] = {raw->toplayer_b, raw->lat1_b, raw->lat0_b, raw->smooth1_b, raw->smooth0_b};
+    float* p = packed;
+    for (int i = 0; i < 11; ++i) {
+        const FLayer& f = kFeat[i];
+        long long wf = conv2d_packed_floats(f.cin, f.cout, f.k);
+        int cp = cdiv(f.cout, 16) * 16;
+        if (i < 6) {
+            const enerf_conv_bn_t& c = raw->conv[i];
+            REQUIRE(c.w && c.bn_weight && c.bn_bias && c.bn_mean && c.bn_var, "feature_net_pack: conv %d missing", i);
+            launch_conv2d_pack(c.w, nullptr, c.bn_weight, c.bn_bias, c.bn_mean, c.bn_var, 1e-5f, f.cin, f.cout, f.k, p,
+                               p + wf, p + wf + cp, (hipStream_t)stream);
+        } else {
+            REQUIRE(pw[i - 6] && pb[i - 6], "feature_net_pack: FPN conv %d missing", i);
+            launch_conv2d_pack(pw[i - 6], pb[i - 6], nullptr, nullptr, nullptr, nullptr, 1e-5f, f.cin, f.cout, f.k, p,
+                               p + wf, p + wf + cp, (hipStream_t)stream);
+        }
+        p += flayer_floats(f);
+    }
+    return check_launch("feature_net_pack");
+}
+size_t enerf_feature_net_workspace_bytes(int n_img, int H, int W) {
+    long long p0 = (long long)n_img * H * W, p1 = p0 / 4, p2 = p1 / 4;
+    // c0a(8) c0(8) f0pre(32) @full ; c1a(16) c1(16) f1pre(32) @half ; c2a(32) c2(32) @quarter
+    return (size_t)(p0 * (8 + 8 + 32) + p1 * (16 + 16 + 32) + p2 * (32 + 32)) * sizeof(float);
+}
+int enerf_feature_net(const float* packed, const float* src_inps, int n_img, int H, int W, float* feat_l0,
+                      float* feat_l1, float* feat_l2, int l2_stride, void* workspace, size_t workspace_bytes,
+                      enerf_stream_t stream) {
+    REQUIRE(packed && src_inps && feat_l0 && feat_l1 && feat_l2 && workspace, "feature_net: null pointer");
+    REQUIRE(n_img > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "feature_net: H,W (%d,%d) must be divisible by 4", H, W);
+    REQUIRE(l2_stride == 8 || l2_stride == 12, "feature_net: l2_stride must be 8 (features) or 12 (texels)");
+    if (workspace_bytes < enerf_feature_net_workspace_bytes(n_img, H, W))
+        return fail(ENERF_EWORKSPACE, "feature_net: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    Conv2dDesc d[11];
+    const float* p = packed;
+    for (int i = 0; i < 11; ++i) {
+        const FLayer& f = kFeat[i];
+        long long wf = conv2d_packed_floats(f.cin, f.cout, f.k);
+        int cp = cdiv(f.cout, 16) * 16;
+        d[i] = {p, p + wf, p + wf + cp, f.cin, f.cout, f.k, f.stride, f.relu, 0, nullptr};
+        p += flayer_floats(f);
+    }
+    const long long p0 = (long long)n_img * H * W, p1 = p0 / 4, p2 = p1 / 4;
+    const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4;
+    float* ws = (float*)workspace;
+    auto take = [&](long long nf) { float* r = ws; ws += nf; return r; };
+    float *c0a = take(p0 * 8), *c0 = take(p0 * 8), *f0pre = take(p0 * 32);
+    float *c1a = take(p1 * 16), *c1 = take(p1 * 16), *f1pre = take(p1 * 32);
+    float *c2a = take(p2 * 32), *c2 = take(p2 * 32);
+    int rc = 0;
+    rc |= launch_conv2d(d[0], src_inps, c0a, nullptr, n_img, H, W, 0, 0, st);          // conv0.0 (NCHW image in)
+    rc |= launch_conv2d(d[1], c0a, c0, nullptr, n_img, H, W, 0, 0, st);                // conv0.1
+    rc |= launch_conv2d(d[2], c0, c1a, nullptr, n_img, H, W, 0, 0, st);                // conv1.0 (s2)
+    rc |= launch_conv2d(d[3], c1a, c1, nullptr, n_img, H1, W1, 0, 0, st);              // conv1.1
+    rc |= launch_conv2d(d[4], c1, c2a, nullptr, n_img, H1, W1, 0, 0, st);              // conv2.0 (s2)
+    rc |= launch_conv2d(d[5], c2a, c2, nullptr, n_img, H2, W2, 0, 0, st);              // conv2.1
+    rc |= launch_conv2d(d[6], c2, feat_l0, nullptr, n_img, H2, W2, 0, 0, st);          // toplayer  -> level_0
+    rc |= launch_conv2d(d[7], c1, f1pre, feat_l0, n_img, H1, W1, H2, W2, st);          // up2(feat2) + lat1(conv1)
+    rc |= launch_conv2d(d[8], c0, f0pre, f1pre, n_img, H, W, H1, W1, st);              // up2(feat1) + lat0(conv0)
+    rc |= launch_conv2d(d[9], f1pre, feat_l1, nullptr, n_img, H1, W1, 0, 0, st);       // smooth1   -> level_1
+    d[10].out_stride = l2_stride;
+    d[10].rgb_src = (l2_stride == 12) ? src_inps : nullptr;
+    rc |= launch_conv2d(d[10], f0pre, feat_l2, nullptr, n_img, H, W, 0, 0, st);        // smooth0   -> level_2 / texels
+    if (rc != 0) return fail(ENERF_EINVAL, "feature_net: unsupported layer shape");
+    return check_launch("feature_net");
+}
+int enerf_pack_texels_cl(const float* feat_cl, int C, const float* src_inps, int H, int W, int Hr, int Wr, int tex,
+                         int n_img, float* out, enerf_stream_t stream) {
+    REQUIRE(feat_cl && src_inps && out, "pack_texels_cl: null pointer");
+    REQUIRE(C > 0 && C % 4 == 0 && tex >= C + 3 && tex % 4 == 0 && n_img > 0 && Hr > 0 && Wr > 0, "pack_texels_cl: bad shape");
+    launch_pack_texels_cl(feat_cl, C, src_inps, H, W, Hr, Wr, tex, n_img, out, (hipStream_t)stream);
+    return check_launch("pack_texels_cl");
+}
+}  // extern "C"

@@ -1,0 +1,283 @@
+// conv2d.hip — the 2-D FPN feature extractor (FeatureNet, feature_net.py:4-36; ConvBnReLU utils.py:10-20)
+// as fp32-MFMA implicit GEMMs with LDS-staged input tiles, channels-last activations.
+//
+// Same scheme as conv3d.hip's V2 kernel, specialised to 2-D and generalised to k in {1,3,5}, stride in
+// {1,2}:  D[cout][pixel] += W[cout][k]·X[k][pixel] on v_mfma_f32_16x16x4_f32, weights = A operand (packed
+// once, streamed from L1/L2 with one-row-of-taps-ahead prefetch), pixels = B/D columns (16 consecutive x
+// per column tile), the haloed input tile of one 16-channel block staged once per block in LDS so every
+// tap is one ds_read_b128.  Epilogue fuses BN (scale/shift) or bias, ReLU, and — for the FPN lateral
+// convs — the bilinear x2 (align_corners) upsample-add of the coarser map (feature_net.py:24-25).
+// Outputs are channels-last, i.e. exactly the layout the warp/variance and render kernels gather from,
+// so the NCHW->NHWC adapter kernels disappear when this path is used.
+//
+// First layer (Cin=3): input is the NCHW image batch; it is staged as [pixel][4] (4th channel 0) so a
+// tap is one k-step with lane group g supplying channel g.
+#include <stdlib.h>
+
+#include "kernels.h"
+
+namespace enerf {
+
+__host__ __device__ __forceinline__ int c2_cinp(int cin) { return cin <= 4 ? 4 : cin; }             // padded Cin
+__host__ __device__ __forceinline__ int c2_cb(int cinp) { return cinp >= 16 ? 16 : cinp; }         // channels / LDS pass
+long long conv2d_packed_floats(int cin, int cout, int k) {
+    return (long long)k * k * (c2_cinp(cin) / 4) * cdiv(cout, 16) * 64;
+}
+
+// packed[((tap*KS + ks)*RT + rt)*64 + lane], lane=(g,i): W[cout = rt*16+i][cin = chan(ks,g)][kh][kw]
+__global__ __launch_bounds__(256) void k_conv2d_pack(const float* __restrict__ w, const float* __restrict__ bias,
+                                                     const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+                                                     const float* __restrict__ bn_mean, const float* __restrict__ bn_var,
+                                                     float eps, int cin, int cout, int k, float* __restrict__ packed,
+                                                     float* __restrict__ scale, float* __restrict__ shift) {
+    const int cinp = c2_cinp(cin), CB = c2_cb(cinp), CPL = CB / 4, KS = cinp / 4, RT = cdiv(cout, 16);
+    const long long total = (long long)k * k * KS * RT * 64;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < RT * 16) {
+        int co = (int)i;
+        float sc = 1.f, sh = 0.f;
+        if (co < cout) {
+            if (bn_w != nullptr) {
+                sc = bn_w[co] / sqrtf(bn_var[co] + eps);
+                sh = bn_b[co] - bn_mean[co] * sc;
+            } else if (bias != nullptr) {
+                sh = bias[co];
+            }
+        }
+        scale[co] = sc;
+        shift[co] = sh;
+    }
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    long long q = i >> 6;
+    const int rt = (int)(q % RT); q /= RT;
+    const int ks = (int)(q % KS);
+    const int tap = (int)(q / KS);
+    const int g = lane >> 4, co = rt * 16 + (lane & 15);
+    const int cb = ks / CPL, r = ks - cb * CPL;
+    const int ci = cb * CB + g * CPL + r;
+    float v = 0.f;
+    if (co < cout && ci < cin) v = w[((long long)co * cin + ci) * k * k + tap];
+    packed[i] = v;
+}
+void launch_conv2d_pack(const float* w, const float* bias, const float* bn_w, const float* bn_b, const float* bn_mean,
+                        const float* bn_var, float eps, int cin, int cout, int k, float* packed, float* scale,
+                        float* shift, hipStream_t st) {
+    long long total = conv2d_packed_floats(cin, cout, k);
+    ENERF_LAUNCH_SIMPLE(k_conv2d_pack, (unsigned)cdivl(total, 256), 256, 0, st, w, bias, bn_w, bn_b, bn_mean, bn_var, eps,
+                        cin, cout, k, packed, scale, shift);
+}
+
+// CINP: padded input channels (4,8,16,32); RT: cout tiles of 16; K: 1/3/5; STR: 1/2; TH: output rows per block
+// (x TW=32 columns = 2 column tiles per row); NCHW3: input is the (n,3,H,W) image batch.
+template <int CINP, int RT, int K, int STR, int TH, bool NCHW3>
+__global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, const float* __restrict__ scale,
+                                                const float* __restrict__ shift, const float* __restrict__ in,
+                                                float* __restrict__ out, const float* __restrict__ up,
+                                                const float* __restrict__ rgb_src, int out_stride, int cout,
+                                                int relu, int N, int Hi, int Wi, int Ho, int Wo, int Hc, int Wc,
+                                                int tiles_y, int tiles_x) {
+    constexpr int TW = 32, P = (K - 1) / 2;
+    constexpr int CB = CINP >= 16 ? 16 : CINP, CPL = CB / 4, NCB = CINP / CB, KS = CINP / 4;
+    constexpr int IH = (TH - 1) * STR + K, IW = (TW - 1) * STR + K;
+    constexpr int NT = TH * (TW / 16), CTW = NT / 4;      // column tiles per block / per wave
+    constexpr int QV = CB / 4 > 0 ? CB / 4 : 1;
+    constexpr int NPX = IH * IW;
+    ENERF_DYN_SMEM(float, lds);
+
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
+    int bid = blockIdx.x;
+    {   // XCD-contiguous block order (bijective), see conv3d.hip
+        const int nblk = gridDim.x, q = nblk / 8, r = nblk % 8, xcd = bid % 8, kk = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
+    }
+    const int tx = bid % tiles_x;
+    const int ty = (bid / tiles_x) % tiles_y;
+    const int n = bid / (tiles_x * tiles_y);
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * STR - P, ix0 = ox0 * STR - P;
+
+    f32x4 acc[CTW][RT];
+#pragma unroll
+    for (int c = 0; c < CTW; ++c)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[c][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wl = wpk + lane;
+    constexpr int NAQ = K * CPL * RT;
+
+#pragma unroll 1
+    for (int cb = 0; cb < NCB; ++cb) {
+        if (cb > 0) __syncthreads();
+        if (NCHW3) {
+            // image batch (n,3,Hi,Wi): one thread per tile pixel, three coalesced plane reads
+            constexpr int NIT = (NPX + 255) / 256;
+            float v0[NIT], v1[NIT], v2[NIT];
+            bool sk[NIT];
+            const float* base = in + (long long)n * 3 * Hi * Wi;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = threadIdx.x + it * 256, ic = i < NPX ? i : NPX - 1;
+                const int ly = ic / IW, lx = ic - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
+                sk[it] = gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+                const int off = sk[it] ? gy * Wi + gx : 0;
+                v0[it] = base[off]; v1[it] = base[Hi * Wi + off]; v2[it] = base[2 * Hi * Wi + off];
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = threadIdx.x + it * 256;
+                if (i < NPX)
+                    *reinterpret_cast<float4*>(lds + i * 4) =
+                        sk[it] ? make_float4(v0[it], v1[it], v2[it], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            constexpr int NIT = (NPX * QV + 255) / 256;
+            float4 sv[NIT];
+            bool sk[NIT];
+            const float* base = in + (long long)n * Hi * Wi * CINP + cb * CB;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = threadIdx.x + it * 256, ic = i < NPX * QV ? i : NPX * QV - 1;
+                const int px = ic / QV, q = ic - px * QV;
+                const int ly = px / IW, lx = px - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
+                sk[it] = gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+                const int off = sk[it] ? gy * Wi + gx : 0;
+                sv[it] = *reinterpret_cast<const float4*>(base + (long long)off * CINP + q * 4);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = threadIdx.x + it * 256;
+                if (i < NPX * QV)
+                    *reinterpret_cast<float4*>(lds + i * 4) = sk[it] ? sv[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        __syncthreads();
+
+        auto issue_a = [&](int kh, float (&aq)[NAQ]) {         // weights of the taps (kh, 0..K-1) for this pass
+            const float* wt = wl + ((long long)(kh * K) * KS + cb * CPL) * RT * 64;
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                for (int r = 0; r < CPL; ++r)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        aq[(kw * CPL + r) * RT + rt] = wt[((long long)(kw * KS + r) * RT + rt) * 64];
+        };
+        auto compute = [&](int kh, const float (&aq)[NAQ]) {
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                float bv[CTW][4];
+#pragma unroll
+                for (int c = 0; c < CTW; ++c) {
+                    const int tile = wv * CTW + c, tr = tile / (TW / 16), tc = tile - tr * (TW / 16);
+                    const float* p = lds + ((tr * STR + kh) * IW + (tc * 16 + j) * STR + kw) * CB + g * CPL;
+                    if (CPL == 4) {
+                        const float4 tq = *reinterpret_cast<const float4*>(p);
+                        bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
+                    } else if (CPL == 2) {
+                        const float2 tq = *reinterpret_cast<const float2*>(p);
+                        bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = 0.f; bv[c][3] = 0.f;
+                    } else {
+                        bv[c][0] = p[0]; bv[c][1] = 0.f; bv[c][2] = 0.f; bv[c][3] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < CPL; ++r)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int c = 0; c < CTW; ++c)
+                            acc[c][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[(kw * CPL + r) * RT + rt], bv[c][r],
+                                                                              acc[c][rt], 0, 0, 0);
+            }
+        };
+        float a0[NAQ], a1[NAQ];
+        issue_a(0, a0);
+#pragma unroll 1
+        for (int kh = 0; kh < K; kh += 2) {
+            issue_a(kh + 1 < K ? kh + 1 : K - 1, a1);
+            compute(kh, a0);
+            issue_a(kh + 2 < K ? kh + 2 : K - 1, a0);
+            if (kh + 1 < K) compute(kh + 1, a1);
+        }
+    }
+
+    // ---- epilogue: BN/bias, optional x2 bilinear upsample-add of the coarser FPN map, ReLU ----
+    const float sy = ac_scale(Hc, Ho), sx = ac_scale(Wc, Wo);
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+        const int tile = wv * CTW + c, tr = tile / (TW / 16), tc = tile - tr * (TW / 16);
+        const int oy = oy0 + tr, ox = ox0 + tc * 16 + j;
+        if (oy >= Ho || ox >= Wo) continue;
+        const long long o = ((long long)n * Ho + oy) * Wo + ox;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int c0 = rt * 16 + 4 * g;
+            if (c0 == cout && rgb_src != nullptr) {
+                // texel mode (smooth0 -> render gather source): the first idle lane group appends
+                // [rgb*0.5+0.5 | 0] (unpreprocess utils.py:608 + cat network.py:34) behind the features
+                const float* sp = rgb_src + (long long)n * 3 * Ho * Wo + (long long)oy * Wo + ox;
+                *reinterpret_cast<float4*>(out + o * out_stride + c0) =
+                    make_float4(sp[0] * 0.5f + 0.5f, sp[(long long)Ho * Wo] * 0.5f + 0.5f,
+                                sp[2LL * Ho * Wo] * 0.5f + 0.5f, 0.f);
+            }
+            if (c0 >= cout) continue;
+            float y[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = acc[c][rt][r] * scale[c0 + r] + shift[c0 + r];
+            if (up != nullptr) {            // feature_net.py:24-25: F.interpolate(x, 2, bilinear, align_corners) + y
+                const Lerp1 ly = ac_lerp(oy, sy, Hc), lx = ac_lerp(ox, sx, Wc);
+                const float* ub = up + (long long)n * Hc * Wc * cout + c0;
+                const float4 u00 = *reinterpret_cast<const float4*>(ub + ((long long)ly.i0 * Wc + lx.i0) * cout);
+                const float4 u01 = *reinterpret_cast<const float4*>(ub + ((long long)ly.i0 * Wc + lx.i1) * cout);
+                const float4 u10 = *reinterpret_cast<const float4*>(ub + ((long long)ly.i1 * Wc + lx.i0) * cout);
+                const float4 u11 = *reinterpret_cast<const float4*>(ub + ((long long)ly.i1 * Wc + lx.i1) * cout);
+                y[0] = ac_blend(ly, lx, u00.x, u01.x, u10.x, u11.x) + y[0];
+                y[1] = ac_blend(ly, lx, u00.y, u01.y, u10.y, u11.y) + y[1];
+                y[2] = ac_blend(ly, lx, u00.z, u01.z, u10.z, u11.z) + y[2];
+                y[3] = ac_blend(ly, lx, u00.w, u01.w, u10.w, u11.w) + y[3];
+            }
+            if (relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.f);
+            }
+            *reinterpret_cast<float4*>(out + o * out_stride + c0) = make_float4(y[0], y[1], y[2], y[3]);
+        }
+    }
+}
+
+template <int CINP, int RT, int K, int STR, int TH, bool NCHW3>
+static void launch_c2(const Conv2dDesc& L, const float* in, float* out, const float* up, int N, int Hi, int Wi, int Hc,
+                      int Wc, hipStream_t st) {
+    const float* rgb_src = L.rgb_src;
+    const int out_stride = L.out_stride > 0 ? L.out_stride : L.cout;
+    constexpr int P = (K - 1) / 2, CB = CINP >= 16 ? 16 : CINP;
+    const int Ho = (Hi + 2 * P - K) / STR + 1, Wo = (Wi + 2 * P - K) / STR + 1;
+    const int tiles_y = cdiv(Ho, TH), tiles_x = cdiv(Wo, 32);
+    constexpr int IH = (TH - 1) * STR + K, IW = 31 * STR + K;
+    const size_t shmem = (size_t)IH * IW * CB * sizeof(float);
+    const unsigned grid = (unsigned)((long long)N * tiles_y * tiles_x);
+    ENERF_LAUNCH((k_conv2d<CINP, RT, K, STR, TH, NCHW3>), grid, 256, shmem, st, L.w, L.scale, L.shift, in, out, up, rgb_src,
+                 out_stride, L.cout, L.relu, N, Hi, Wi, Ho, Wo, Hc, Wc, tiles_y, tiles_x);
+}
+
+// The eleven FeatureNet layers use exactly these shapes (feature_net.py:7-22).
+int launch_conv2d(const Conv2dDesc& L, const float* in, float* out, const float* up, int N, int Hi, int Wi, int Hc,
+                  int Wc, hipStream_t st) {
+    const int key = L.cin * 10000 + L.cout * 100 + L.k * 10 + L.stride;
+    switch (key) {
+        case 3 * 10000 + 8 * 100 + 31: launch_c2<4, 1, 3, 1, 8, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;     // conv0.0
+        case 8 * 10000 + 8 * 100 + 31: launch_c2<8, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;    // conv0.1
+        case 8 * 10000 + 16 * 100 + 52: launch_c2<8, 1, 5, 2, 4, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;   // conv1.0
+        case 16 * 10000 + 16 * 100 + 31: launch_c2<16, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // conv1.1
+        case 16 * 10000 + 32 * 100 + 52: launch_c2<16, 2, 5, 2, 4, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // conv2.0
+        case 32 * 10000 + 32 * 100 + 31: launch_c2<32, 2, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // conv2.1
+        case 32 * 10000 + 32 * 100 + 11: launch_c2<32, 2, 1, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // toplayer
+        case 16 * 10000 + 32 * 100 + 11: launch_c2<16, 2, 1, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // lat1
+        case 8 * 10000 + 32 * 100 + 11: launch_c2<8, 2, 1, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;   // lat0
+        case 32 * 10000 + 16 * 100 + 31: launch_c2<32, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // smooth1
+        case 32 * 10000 + 8 * 100 + 31: launch_c2<32, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;  // smooth0
+        default: return -1;
+    }
+}
+
+}  // namespace enerf

@@ -98,6 +98,57 @@ void launch_pack_img_feat_rgb(const float* im_feat, int C, int Hf, int Wf, const
 }
 
 // -------------------------------------------------------------------------------------------------
+// Same texel image, from CHANNELS-LAST features (n,Hr,Wr,C) already at the render resolution (the HIP
+// FeatureNet's output): tex = [feat | bilinear_ac(src*0.5+0.5) | 0].  Used for level-0 rendering, where
+// the colours are a x0.25 resize; at level 1 the smooth0 conv writes texels directly (conv2d.hip).
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_texels_cl(const float* __restrict__ feat, int C,
+                                                        const float* __restrict__ src, int H, int W, int Hr, int Wr,
+                                                        int tex, int n_img, float* __restrict__ out) {
+    ENERF_DYN_SMEM(float, tile);                       // 256 * (tex + 1)
+    const int ts = tex + 1;
+    const long long npix = (long long)Hr * Wr, total = npix * n_img;
+    const long long base = (long long)blockIdx.x * 256;
+    const long long i = base + threadIdx.x;
+    if (i < total) {
+        int img = (int)(i / npix);
+        int p = (int)(i - (long long)img * npix);
+        int y = p / Wr, x = p - y * Wr;
+        float* o = tile + threadIdx.x * ts;
+        const float* f = feat + i * C;
+        for (int c = 0; c < C; c += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(f + c);
+            o[c] = v.x; o[c + 1] = v.y; o[c + 2] = v.z; o[c + 3] = v.w;
+        }
+        Lerp1 ly = ac_lerp(y, ac_scale(H, Hr), H), lx = ac_lerp(x, ac_scale(W, Wr), W);
+        const float* s = src + (long long)img * 3 * H * W;
+        for (int c = 0; c < 3; ++c) {
+            const float* sc = s + (long long)c * H * W;
+            float v00 = sc[ly.i0 * W + lx.i0] * 0.5f + 0.5f, v01 = sc[ly.i0 * W + lx.i1] * 0.5f + 0.5f;
+            float v10 = sc[ly.i1 * W + lx.i0] * 0.5f + 0.5f, v11 = sc[ly.i1 * W + lx.i1] * 0.5f + 0.5f;
+            o[C + c] = ac_blend(ly, lx, v00, v01, v10, v11);
+        }
+        for (int c = C + 3; c < tex; ++c) o[c] = 0.f;
+    }
+    __syncthreads();
+    const long long nvalid = total - base < 256 ? total - base : 256;
+    const int nq = (int)(nvalid * tex / 4);
+    float4* dst = reinterpret_cast<float4*>(out + base * tex);
+    for (int q = threadIdx.x; q < nq; q += 256) {
+        int e = q * 4, px = e / tex, c = e - px * tex;
+        const float* t = tile + px * ts + c;
+        dst[q] = make_float4(t[0], t[1], t[2], t[3]);
+    }
+}
+void launch_pack_texels_cl(const float* feat_cl, int C, const float* src_inps, int H, int W, int Hr, int Wr, int tex,
+                           int n_img, float* out, hipStream_t st) {
+    long long tot = (long long)Hr * Wr * n_img;
+    size_t shmem = (size_t)256 * (tex + 1) * sizeof(float);
+    ENERF_LAUNCH(k_pack_texels_cl, (unsigned)cdivl(tot, 256), 256, shmem, st, feat_cl, C, src_inps, H, W, Hr, Wr, tex,
+                 n_img, out);
+}
+
+// -------------------------------------------------------------------------------------------------
 // get_proj_mats (utils.py:35-55):  P[b,s] = (K_s' E_s[:3]) · inv([K_t' E_t[:3]; 0 0 0 1]),
 // K' = K with rows 0,1 scaled.  One thread per (b,s); fp64 internally (a 4x4 inverse per frame),
 // rounded to fp32 on store.

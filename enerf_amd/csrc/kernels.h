@@ -46,6 +46,27 @@ void launch_conv3d_pack(const float* w, const float* w2, int cout1, const float*
 void launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, float* out, float* out2, int B, int Di,
                    int Hi, int Wi, hipStream_t st);
 
+// ---- conv2d.hip (FeatureNet) ----------------------------------------------------------------------
+struct Conv2dDesc {
+    const float* w;        // packed A operands
+    const float* scale;    // per-cout scale (BN folded; 1 for plain convs)
+    const float* shift;    // per-cout shift (BN folded, or the conv bias)
+    int cin, cout, k, stride, relu;
+    int out_stride;        // floats between consecutive output pixels (0 = cout)
+    const float* rgb_src;  // texel mode: (n,3,Ho,Wo) images appended as [rgb*0.5+0.5 | 0] behind the features
+};
+long long conv2d_packed_floats(int cin, int cout, int k);
+void launch_conv2d_pack(const float* w, const float* bias, const float* bn_w, const float* bn_b, const float* bn_mean,
+                        const float* bn_var, float eps, int cin, int cout, int k, float* packed, float* scale,
+                        float* shift, hipStream_t st);
+// in: channels-last (N,Hi,Wi,cin) — or the NCHW image batch for the 3-channel first layer; out: channels-last.
+// up (optional): coarser channels-last map (N,Hc,Wc,cout) added after a x2 align-corners bilinear upsample.
+int launch_conv2d(const Conv2dDesc& L, const float* in, float* out, const float* up, int N, int Hi, int Wi, int Hc,
+                  int Wc, hipStream_t st);
+// texels from channels-last features at the render resolution + resized colours (general case)
+void launch_pack_texels_cl(const float* feat_cl, int C, const float* src_inps, int H, int W, int Hr, int Wr, int tex,
+                           int n_img, float* out, hipStream_t st);
+
 // ---- render.hip ---------------------------------------------------------------------------------
 using NerfRaw = enerf_nerf_raw_t;     // torch-layout parameter pointers of one NeRF (nerf.py:6-89)
 long long nerf_packed_floats(int feat_ch_plus3);

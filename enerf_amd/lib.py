@@ -30,6 +30,11 @@ class CostRegRaw(C.Structure):
     _fields_ = [("conv", ConvBn * 12), ("feat_conv_w", _f), ("depth_conv_w", _f), ("in_channels", _i), ("full", _i)]
 
 
+class FeatNetRaw(C.Structure):
+    _fields_ = [("conv", ConvBn * 6)] + [(n, _f) for n in ("toplayer_w", "toplayer_b", "lat1_w", "lat1_b", "lat0_w",
+                                                            "lat0_b", "smooth1_w", "smooth1_b", "smooth0_w", "smooth0_b")]
+
+
 class NerfRaw(C.Structure):
     _fields_ = [(n, _f) for n in ("view_w", "view_b", "glob_w", "glob_b", "aggw_w", "aggw_b", "fc_w", "fc_b",
                                   "lr0_w", "lr0_b", "sigma_w", "sigma_b", "col0_w", "col0_b", "col2_w", "col2_b")]
@@ -49,6 +54,11 @@ _SIGNATURES = {
     "enerf_channels_last": (_i, [_f, _f, _i, _i, _ll, _i, _f]),
     "enerf_channels_first": (_i, [_f, _f, _i, _i, _ll, _i, _f]),
     "enerf_pack_img_feat_rgb": (_i, [_f, _i, _i, _i, _f, _i, _i, _i, _i, _i, _i, _f, _f]),
+    "enerf_feature_net_packed_floats": (_ll, []),
+    "enerf_feature_net_pack": (_i, [C.POINTER(FeatNetRaw), _f, _f]),
+    "enerf_feature_net_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
+    "enerf_feature_net": (_i, [_f, _f, _i, _i, _i, _f, _f, _f, _i, _f, C.c_size_t, _f]),
+    "enerf_pack_texels_cl": (_i, [_f, _i, _f, _i, _i, _i, _i, _i, _i, _f, _f]),
     "enerf_get_proj_mats": (_i, [_f, _f, _f, _f, _i, _i, _fl, _fl, _f, _f]),
     "enerf_get_depth_values": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f]),
     "enerf_build_feature_volume": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f]),
@@ -125,6 +135,39 @@ class EnerfLib:
         out = torch.empty((n_img, Hr, Wr, tex), dtype=torch.float32, device=im_feat.device)
         self._check(self.dll.enerf_pack_img_feat_rgb(_ptr(im_feat), Cf, Hf, Wf, _ptr(src_inps), H, W, Hr, Wr, tex,
                                                      n_img, _ptr(out), self.stream_of(out)), "pack_img_feat_rgb")
+        return out
+
+    def feature_net_pack(self, raw: FeatNetRaw, device):
+        n = self.dll.enerf_feature_net_packed_floats()
+        packed = torch.empty((n,), dtype=torch.float32, device=device)
+        self._check(self.dll.enerf_feature_net_pack(C.byref(raw), _ptr(packed), self.stream_of(packed)),
+                    "feature_net_pack")
+        return packed
+
+    def feature_net(self, packed, src_inps, l2_stride=8, workspace=None):
+        """src_inps (n,3,H,W) -> channels-last (n,H/4,W/4,32), (n,H/2,W/2,16), (n,H,W,l2_stride)."""
+        n, _, H, W = src_inps.shape
+        dev = src_inps.device
+        need = self.dll.enerf_feature_net_workspace_bytes(n, H, W)
+        if workspace is None or workspace.numel() * 4 < need:
+            workspace = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=dev)
+        f0 = torch.empty((n, H // 4, W // 4, 32), dtype=torch.float32, device=dev)
+        f1 = torch.empty((n, H // 2, W // 2, 16), dtype=torch.float32, device=dev)
+        f2 = torch.empty((n, H, W, l2_stride), dtype=torch.float32, device=dev)
+        self._check(self.dll.enerf_feature_net(_ptr(packed), _ptr(src_inps), n, H, W, _ptr(f0), _ptr(f1), _ptr(f2),
+                                               l2_stride, _ptr(workspace), workspace.numel() * 4,
+                                               self.stream_of(src_inps)), "feature_net")
+        return f0, f1, f2, workspace
+
+    def pack_texels_cl(self, feat_cl, src_inps, Hr, Wr):
+        n_img, hf, wf, Cf = feat_cl.shape
+        if (hf, wf) != (Hr, Wr):
+            raise EnerfError("pack_texels_cl: features must already be at the render resolution")
+        H, W = src_inps.shape[-2:]
+        tex = 4 * ((Cf + 3 + 3) // 4)
+        out = torch.empty((n_img, Hr, Wr, tex), dtype=torch.float32, device=feat_cl.device)
+        self._check(self.dll.enerf_pack_texels_cl(_ptr(feat_cl), Cf, _ptr(src_inps), H, W, Hr, Wr, tex, n_img, _ptr(out),
+                                                  self.stream_of(out)), "pack_texels_cl")
         return out
 
     def get_proj_mats(self, src_ixts, src_exts, tar_ixt, tar_ext, src_scale, tar_scale):

@@ -24,7 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .config import EnerfConfig
-from .lib import ConvBn, CostRegRaw, EnerfLib, NerfRaw, get_lib
+from .lib import ConvBn, CostRegRaw, EnerfLib, FeatNetRaw, NerfRaw, get_lib
 
 
 # --------------------------------------------------------------------------------------------------
@@ -61,6 +61,22 @@ class FeatureNet(nn.Module):
     @staticmethod
     def _up2(x):
         return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+
+    def raw(self) -> FeatNetRaw:
+        """Parameter pointers for the HIP FeatureNet (enerf_feature_net_pack)."""
+        r = FeatNetRaw()
+        blocks = [self.conv0[0], self.conv0[1], self.conv1[0], self.conv1[1], self.conv2[0], self.conv2[1]]
+        for i, m in enumerate(blocks):
+            for t in (m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var):
+                _require_f32c(t)
+            r.conv[i] = ConvBn(m.conv.weight.data_ptr(), m.bn.weight.data_ptr(), m.bn.bias.data_ptr(),
+                               m.bn.running_mean.data_ptr(), m.bn.running_var.data_ptr())
+        for name in ("toplayer", "lat1", "lat0", "smooth1", "smooth0"):
+            m = getattr(self, name)
+            _require_f32c(m.weight), _require_f32c(m.bias)
+            setattr(r, name + "_w", m.weight.data_ptr())
+            setattr(r, name + "_b", m.bias.data_ptr())
+        return r
 
     def forward(self, x):
         c0 = self.conv0(x)
@@ -198,8 +214,14 @@ class Network(nn.Module):
     """
 
     def __init__(self, cfg: Optional[EnerfConfig] = None, human: bool = False, lib: Optional[EnerfLib] = None,
-                 check_nan: bool = False):
+                 check_nan: bool = False, feature_backend: str = "hip"):
         super().__init__()
+        if feature_backend not in ("hip", "torch"):
+            raise ValueError("feature_backend must be 'hip' or 'torch'")
+        # "torch": FeatureNet in PyTorch-ROCm/MIOpen (north_star's split); "hip": enerf_feature_net on the
+        # matrix cores, channels-last outputs (SURVEY.md §8f row 2 — MIOpen was 49 % of the frame).
+        self.feature_backend = feature_backend
+        self._feat_ws = None
         self.cfg = cfg or EnerfConfig()
         self.cfg.cas.validate()
         self.human = human
@@ -246,6 +268,8 @@ class Network(nn.Module):
             dev = next(m.parameters()).device
             if isinstance(m, CostRegParams):
                 self._packed[name] = self.lib.cost_reg_pack(m.raw(), dev)
+            elif isinstance(m, FeatureNet):
+                self._packed[name] = self.lib.feature_net_pack(m.raw(), dev)
             else:
                 self._packed[name] = self.lib.nerf_pack(m.raw(), m.feat_ch, m.viewdir_agg, dev)
         return self._packed[name]
@@ -259,15 +283,39 @@ class Network(nn.Module):
                 "level_1": f1.reshape(B, S, f1.shape[1], H // 2, W // 2),
                 "level_0": f2.reshape(B, S, f2.shape[1], H // 4, W // 4)}
 
+    def _forward_feat_hip(self, x, texel_level2: bool):
+        """HIP FeatureNet: channels-last (B,S,h,w,C) maps tagged ``_enerf_cl``; level_2 optionally comes
+        out as ready render texels (tagged ``_enerf_tex``) when it is only used for the full-res render."""
+        B, S, C, H, W = x.shape
+        f0, f1, f2, self._feat_ws = self.lib.feature_net(self._packed_weights("feature_net"),
+                                                        x.reshape(B * S, C, H, W).contiguous(),
+                                                        12 if texel_level2 else 8, self._feat_ws)
+        feats = {"level_0": f0.view(B, S, H // 4, W // 4, 32), "level_1": f1.view(B, S, H // 2, W // 2, 16),
+                 "level_2": f2.view(B, S, H, W, f2.shape[-1])}
+        for k, v in feats.items():
+            v._enerf_cl = True
+        if texel_level2:
+            feats["level_2"]._enerf_tex = True
+        return feats
+
     def _texels(self, level, batch, im_feat):
         """unpreprocess + cat as the channels-last gather source (network.py:28-34); cached per frame."""
+        if getattr(im_feat, "_enerf_tex", False):
+            return im_feat
         key = (level, im_feat.data_ptr(), batch["src_inps"].data_ptr())
         if self._tex_cache is not None and self._tex_cache[0] == key:
             return self._tex_cache[1]
         cas = self.cfg.cas
-        B, S, Cf, Hf, Wf = im_feat.shape
         H, W = batch["src_inps"].shape[-2:]
         Hr, Wr = int(H * cas.render_scale[level]), int(W * cas.render_scale[level])
+        if getattr(im_feat, "_enerf_cl", False):
+            B, S, hf, wf, Cf = im_feat.shape
+            tex = self.lib.pack_texels_cl(im_feat.reshape(B * S, hf, wf, Cf),
+                                          batch["src_inps"].reshape(B * S, 3, H, W).contiguous(), Hr, Wr)
+            tex = tex.view(B, S, Hr, Wr, tex.shape[-1])
+            self._tex_cache = (key, tex)
+            return tex
+        B, S, Cf, Hf, Wf = im_feat.shape
         up = cas.render_scale[level] / cas.im_ibr_scale[level]
         if (int(Hf * up), int(Wf * up)) != (Hr, Wr):
             raise RuntimeError("im_feat resolution inconsistent with render_scale / im_ibr_scale")
@@ -320,7 +368,15 @@ class Network(nn.Module):
         if self._timer is not None:
             self._timer.begin()
         with torch.no_grad():
-            feats = self.forward_feat(src)
+            hip_feats = self.feature_backend == "hip"
+            if hip_feats:
+                # level_2 is only ever the im_feat of a full-resolution render: emit it as texels directly
+                uses = [i for i in range(cas.num) if cas.render_if[i] and cas.render_im_feat_level[i] == 2]
+                tex2 = bool(uses) and all(cas.render_scale[i] == 1.0 and cas.im_ibr_scale[i] == 1.0 for i in uses) \
+                    and all(cas.nerf_model_feat_ch[i] == 8 for i in uses)
+                feats = self._forward_feat_hip(src, tex2)
+            else:
+                feats = self.forward_feat(src)
             self._mark("feature_net")
             ret = {}
             prev = None
@@ -328,8 +384,14 @@ class Network(nn.Module):
                 D = cas.volume_planes[i]
                 h, w = int(H * cas.volume_scale[i]), int(W * cas.volume_scale[i])
                 f = feats[f"level_{i}"]
-                C, Hs, Ws = f.shape[2:]
-                feat_cl = lib.channels_last(f.reshape(B * S, C, Hs * Ws), B * S, C, Hs * Ws).view(B, S, Hs, Ws, C)
+                if hip_feats:
+                    feat_cl = f                                   # already (B,S,Hs,Ws,C)
+                    Hs, Ws, C = f.shape[2:]
+                    if i == 2 and C != 8:
+                        raise RuntimeError("level_2 texels cannot feed a cost volume")
+                else:
+                    C, Hs, Ws = f.shape[2:]
+                    feat_cl = lib.channels_last(f.reshape(B * S, C, Hs * Ws), B * S, C, Hs * Ws).view(B, S, Hs, Ws, C)
                 proj = lib.get_proj_mats(batch["src_ixts"].contiguous(), batch["src_exts"].contiguous(),
                                          batch["tar_ixt"].contiguous(), batch["tar_ext"].contiguous(),
                                          cas.im_feat_scale[i], cas.volume_scale[i])

@@ -43,6 +43,42 @@ int enerf_channels_first(const float* src, float* dst, int n, int C, long long P
 int enerf_pack_img_feat_rgb(const float* im_feat, int C, int Hf, int Wf, const float* src_inps, int H, int W,
                             int Hr, int Wr, int tex, int n_img, float* out, enerf_stream_t stream);
 
+/* A bias-free convolution followed by BatchNorm in eval mode (ConvBnReLU utils.py:10-33). */
+typedef struct {
+    const float* w;         /* Conv2d (cout,cin,k,k) / Conv3d (cout,cin,3,3,3) / ConvTranspose3d (cin,cout,3,3,3) */
+    const float* bn_weight; /* BatchNorm affine + running statistics (eps 1e-5) */
+    const float* bn_bias;
+    const float* bn_mean;
+    const float* bn_var;
+} enerf_conv_bn_t;
+
+/* ---- FeatureNet (feature_net.py:4-36) + forward_feat's reshapes (network.py:58-67), in HIP.
+ * BASELINE's north_star keeps the 2-D FPN in PyTorch-ROCm; it measured 49 % of the
+ * frame there, so this optional entry point computes the same three feature maps on the matrix cores and
+ * writes them CHANNELS-LAST (what the warp and render kernels read), removing the layout adapters.
+ * src_inps (n_img,3,H,W) in [-1,1], H and W divisible by 4.  Outputs:
+ *   feat_l0 (n_img,H/4,W/4,32) = reference feats['level_0'];  feat_l1 (n_img,H/2,W/2,16) = 'level_1';
+ *   feat_l2 (n_img,H,W,l2_stride): l2_stride 8 -> plain 'level_2'; l2_stride 12 -> render texels
+ *   [level_2 (8) | src*0.5+0.5 (3) | 0] (unpreprocess utils.py:605-612 at render_scale 1 + cat network.py:34). */
+typedef struct {
+    enerf_conv_bn_t conv[6];                      /* conv0.0, conv0.1, conv1.0, conv1.1, conv2.0, conv2.1 (Conv2d + BN2d) */
+    const float *toplayer_w, *toplayer_b;         /* (32,32,1,1),(32) */
+    const float *lat1_w, *lat1_b;                 /* (32,16,1,1) */
+    const float *lat0_w, *lat0_b;                 /* (32,8,1,1) */
+    const float *smooth1_w, *smooth1_b;           /* (16,32,3,3) */
+    const float *smooth0_w, *smooth0_b;           /* (8,32,3,3) */
+} enerf_featnet_raw_t;
+long long enerf_feature_net_packed_floats(void);
+int enerf_feature_net_pack(const enerf_featnet_raw_t* raw, float* packed, enerf_stream_t stream);
+size_t enerf_feature_net_workspace_bytes(int n_img, int H, int W);
+int enerf_feature_net(const float* packed, const float* src_inps, int n_img, int H, int W, float* feat_l0,
+                      float* feat_l1, float* feat_l2, int l2_stride, void* workspace, size_t workspace_bytes,
+                      enerf_stream_t stream);
+/* texels from channels-last features already at the render resolution (level-0 rendering with the HIP
+ * FeatureNet): out (n_img,Hr,Wr,tex) = [feat (C) | bilinear_ac(src*0.5+0.5) (3) | 0]. */
+int enerf_pack_texels_cl(const float* feat_cl, int C, const float* src_inps, int H, int W, int Hr, int Wr, int tex,
+                         int n_img, float* out, enerf_stream_t stream);
+
 /* ---- get_proj_mats (utils.py:35-55): proj (B,S,3,4) ---- */
 int enerf_get_proj_mats(const float* src_ixts, const float* src_exts, const float* tar_ixt, const float* tar_ext,
                         int B, int S, float src_scale, float tar_scale, float* proj, enerf_stream_t stream);
@@ -60,13 +96,6 @@ int enerf_build_feature_volume(const float* feat, const float* proj, const float
                                int Hs, int Ws, int D, int h, int w, float* vol, enerf_stream_t stream);
 
 /* ---- CostRegNet / MinCostRegNet (cost_reg_net.py:4-86) ---- */
-typedef struct {
-    const float* w;         /* Conv3d (cout,cin,3,3,3) or ConvTranspose3d (cin,cout,3,3,3) */
-    const float* bn_weight; /* BatchNorm3d affine + running statistics (eval mode, eps 1e-5) */
-    const float* bn_bias;
-    const float* bn_mean;
-    const float* bn_var;
-} enerf_conv_bn_t;
 typedef struct {
     enerf_conv_bn_t conv[12]; /* conv0..conv6, conv7, conv9, conv11 at their own index; others unused */
     const float* feat_conv_w; /* (8,8,3,3,3) */

@@ -163,3 +163,29 @@ def test_conv3d_variants_agree_with_reference(force, monkeypatch):
     out = _net(cfg)(batch)
     for k, v in out.items():
         _close(v.numpy(), gold["out/" + k], 2e-5, k)
+
+
+def test_hip_feature_net_matches_reference_feature_maps():
+    """enerf_feature_net (conv2d.hip) against the reference FeatureNet's three outputs, plain and texel mode."""
+    name = "tiny_s3"
+    cfg, batch, g = case_config(name), case_batch(name), load_golden(name)
+    net, lib = _net(cfg), emu_lib()
+    src = batch["src_inps"][0].contiguous()
+    f0, f1, f2, _ = lib.feature_net(net._packed_weights("feature_net"), src, 8)
+    for a, k in ((f0, "feat_l0"), (f1, "feat_l1"), (f2, "feat_l2")):
+        _close(a.permute(0, 3, 1, 2).numpy(), g["mid/" + k], 5e-6, k)
+    _, _, t2, _ = lib.feature_net(net._packed_weights("feature_net"), src, 12)
+    assert torch.equal(t2[..., :8], f2)
+    _close(t2[..., 8:11].permute(0, 3, 1, 2).numpy(), (src * 0.5 + 0.5).numpy(), 1e-7, "texel rgb")
+    assert float(t2[..., 11].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["tiny_s3", "small_s3_eval"])
+def test_torch_feature_backend_still_matches(name):
+    """feature_backend='torch' (north_star's split: FeatureNet in PyTorch, adapters + HIP path after it)."""
+    cfg, batch, gold = case_config(name), case_batch(name), load_golden(name)
+    net = Network(cfg, lib=emu_lib(), feature_backend="torch").eval()
+    net.load_state_dict(load_weights(), strict=False)
+    out = net(batch)
+    for k, v in out.items():
+        _close(v.numpy(), gold["out/" + k], 2e-5, k)

@@ -22,9 +22,9 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _net(cfg, human=False):
+def _net(cfg, human=False, feature_backend="hip"):
     from enerf_amd.network import Network, NetworkHuman
-    net = (NetworkHuman if human else Network)(cfg)           # product library: enerf_amd/libenerf_hip.so
+    net = (NetworkHuman if human else Network)(cfg, feature_backend=feature_backend)   # enerf_amd/libenerf_hip.so
     net.load_state_dict(load_weights(), strict=False)
     return net.to(_dev()).eval()
 
@@ -45,10 +45,11 @@ def test_product_library_is_loaded_not_a_fallback():
     assert "libenerf_hip.so" in maps
 
 
+@pytest.mark.parametrize("backend", ["hip", "torch"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_goldens(name):
+def test_goldens(name, backend):
     cfg, gold = case_config(name), load_golden(name)
-    out = _net(cfg, CASES[name]["human"])(_to(case_batch(name)))
+    out = _net(cfg, CASES[name]["human"], backend)(_to(case_batch(name)))
     torch.cuda.synchronize()
     assert sorted(out) == sorted(k[4:] for k in gold if k.startswith("out/"))
     for k, v in out.items():
@@ -94,6 +95,17 @@ def test_stages_vs_reference_intermediates():
         assert _rel(out["depth"].cpu(), g[f"out/depth_level{i}"]) < 2e-5
         assert _rel(out["weights"].cpu(), g[f"out/weights_level{i}"]) < 2e-5
         prev = (T(f"depth_{i}"), T(f"std_{i}"), T(f"nf_{i}"))
+
+
+@pytest.mark.parametrize("S,B,hw", [(3, 1, (128, 160)), (4, 2, (64, 96)), (2, 1, (96, 128))])
+def test_hip_feature_net_vs_reference_maps():
+    from enerf_amd.lib import get_lib
+    name = "tiny_s3"
+    cfg, batch, g = case_config(name), _to(case_batch(name)), load_golden(name)
+    net, lib = _net(cfg), get_lib()
+    f0, f1, f2, _ = lib.feature_net(net._packed_weights("feature_net"), batch["src_inps"][0].contiguous(), 8)
+    for a, k in ((f0, "feat_l0"), (f1, "feat_l1"), (f2, "feat_l2")):
+        assert _rel(a.permute(0, 3, 1, 2).cpu(), g["mid/" + k]) < 1e-5, k
 
 
 @pytest.mark.parametrize("S,B,hw", [(3, 1, (128, 160)), (4, 2, (64, 96)), (2, 1, (96, 128))])
