@@ -97,7 +97,6 @@ def test_stages_vs_reference_intermediates():
         prev = (T(f"depth_{i}"), T(f"std_{i}"), T(f"nf_{i}"))
 
 
-@pytest.mark.parametrize("S,B,hw", [(3, 1, (128, 160)), (4, 2, (64, 96)), (2, 1, (96, 128))])
 def test_hip_feature_net_vs_reference_maps():
     from enerf_amd.lib import get_lib
     name = "tiny_s3"
