@@ -107,6 +107,25 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
 
 #pragma unroll 1
     for (int cb = 0; cb < NCB; ++cb) {
+        auto issue_a = [&](int kh, float (&aq)[NAQ]) {         // weights of the taps (kh, 0..K-1) for this pass
+            const float* wt = wl + ((long long)(kh * K) * KS + cb * CPL) * RT * 64;
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                for (int r = 0; r < CPL; ++r)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        aq[(kw * CPL + r) * RT + rt] = wt[((long long)(kw * KS + r) * RT + rt) * 64];
+        };
+        // k<=3: the whole pass's weights are requested BEFORE the tile is staged, so their L2 latency hides
+        // behind the staging traffic; sched_barrier pins the loads here (hipcc otherwise sinks each load to
+        // just before its MFMA and waits vmcnt(0) on it).
+        float aq_all[K <= 3 ? K : 1][NAQ];
+        if (K <= 3) {
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh) issue_a(kh, aq_all[kh]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (cb > 0) __syncthreads();
         if (NCHW3) {
             // image batch (n,3,Hi,Wi): one thread per tile pixel, three coalesced plane reads
@@ -152,16 +171,6 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
         }
         __syncthreads();
 
-        auto issue_a = [&](int kh, float (&aq)[NAQ]) {         // weights of the taps (kh, 0..K-1) for this pass
-            const float* wt = wl + ((long long)(kh * K) * KS + cb * CPL) * RT * 64;
-#pragma unroll
-            for (int kw = 0; kw < K; ++kw)
-#pragma unroll
-                for (int r = 0; r < CPL; ++r)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-                        aq[(kw * CPL + r) * RT + rt] = wt[((long long)(kw * KS + r) * RT + rt) * 64];
-        };
         auto compute = [&](int kh, const float (&aq)[NAQ]) {
 #pragma unroll
             for (int kw = 0; kw < K; ++kw) {
@@ -190,14 +199,21 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
                                                                               acc[c][rt], 0, 0, 0);
             }
         };
-        float a0[NAQ], a1[NAQ];
-        issue_a(0, a0);
+        if (K <= 3) {
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh) compute(kh, aq_all[kh]);
+        } else {
+            float a0[NAQ], a1[NAQ];
+            issue_a(0, a0);
 #pragma unroll 1
-        for (int kh = 0; kh < K; kh += 2) {
-            issue_a(kh + 1 < K ? kh + 1 : K - 1, a1);
-            compute(kh, a0);
-            issue_a(kh + 2 < K ? kh + 2 : K - 1, a0);
-            if (kh + 1 < K) compute(kh + 1, a1);
+            for (int kh = 0; kh < K; kh += 2) {
+                issue_a(kh + 1 < K ? kh + 1 : K - 1, a1);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(kh, a0);
+                issue_a(kh + 2 < K ? kh + 2 : K - 1, a0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kh + 1 < K) compute(kh + 1, a1);
+            }
         }
     }
 

@@ -350,7 +350,8 @@ static bool dispatch_cin(const Conv3dDesc& L, const float* in, const float* resi
 // L1/L2 as 256-B coalesced loads, one per CTW MFMAs.
 // =====================================================================================================
 template <int CIN, int RT, int BD>
-__global__ __launch_bounds__(256) void k_conv3d_s1_lds(const float* __restrict__ wpk, const float* __restrict__ scale,
+__global__ __launch_bounds__(256, (BD == 4 ? 2 : 3)) void k_conv3d_s1_lds(   // = co-resident blocks/CU the LDS box allows
+const float* __restrict__ wpk, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ in,
                                                        float* __restrict__ out, float* __restrict__ out2, int cout,
                                                        int relu, int B, int D, int H, int W, int nbd, int nbh, int nbw) {
@@ -391,11 +392,28 @@ __global__ __launch_bounds__(256) void k_conv3d_s1_lds(const float* __restrict__
     const float* wl = wpk + lane;
 
     constexpr int NIT = (NVOX * QV + 255) / 256;     // float4 staging loads per thread
-    constexpr int NAQ = 3 * CPL * RT;                 // A operands of one (kd,kh) row of taps
+    constexpr int NAT = CPL * RT;                     // A operands (weights) of one tap
 #pragma unroll 1
     for (int cb = 0; cb < NCB; ++cb) {
+        // Operand pipeline (all 27 taps unrolled, order pinned with sched_barrier):
+        //   weights (A): 3-deep register ring, tap t+2 requested from L1/L2 while tap t runs on the matrix core
+        //                (one tap = CTW*CPL*RT MFMAs >= 512 cycles, two taps cover the L2 latency);
+        //   activations (B): 2-deep ring of LDS reads, tap t+1 read while tap t runs.
+        // Left to itself hipcc sinks every weight load to just before its MFMA (s_waitcnt vmcnt(0) per load)
+        // or, fully unrolled without fences, hoists ~250 VGPRs of LDS reads and spills.
+        auto issue_a = [&](int tap, float (&aq)[NAT]) {
+            const float* wt = wl + ((long long)tap * KS + cb * CPL) * RT * 64;
+#pragma unroll
+            for (int r = 0; r < CPL; ++r)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) aq[r * RT + rt] = wt[(r * RT + rt) * 64];
+        };
+        float aq[3][NAT];
+        issue_a(0, aq[0]);
+        issue_a(1, aq[1]);
+        __builtin_amdgcn_sched_barrier(0);
         if (cb > 0) __syncthreads();                   // previous pass finished reading LDS
-        {   // stage the haloed box: all loads issued back to back and unconditionally (clamped address,
+        {   // stage the haloed box: loads issued back to back and unconditionally (clamped address,
             // zero-select afterwards) so they overlap instead of serialising behind exec-mask branches
             float4 sv[NIT];
             bool sk[NIT];
@@ -419,51 +437,42 @@ __global__ __launch_bounds__(256) void k_conv3d_s1_lds(const float* __restrict__
         }
         __syncthreads();
 
-        auto issue_a = [&](int u, float (&aq)[NAQ]) {           // weights of taps (kd,kh,0..2), u = kd*3+kh
-            const float* wt = wl + ((long long)(u * 3) * KS + cb * CPL) * RT * 64;
+        const float* lbase[CTW];                        // this lane's voxel (tap 0,0,0) in each of its column tiles
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
+        for (int c = 0; c < CTW; ++c) {
+            const int tile = wv * CTW + c, td = tile / BH, th = tile - td * BH;
+            lbase[c] = lds + ((td * HY + th) * HX + j) * CB + g * CPL;
+        }
+        auto read_b = [&](int tap, float (&bv)[CTW][4]) {
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            const int off = ((kd * HY + kh) * HX + kw) * CB;
 #pragma unroll
-                for (int r = 0; r < CPL; ++r)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-                        aq[(kw * CPL + r) * RT + rt] = wt[((long long)(kw * KS + r) * RT + rt) * 64];
-        };
-        auto compute = [&](int u, const float (&aq)[NAQ]) {
-            const int kd = u / 3, kh = u - kd * 3;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                float bv[CTW][4];
-#pragma unroll
-                for (int c = 0; c < CTW; ++c) {
-                    const int tile = wv * CTW + c, td = tile / BH, th = tile - td * BH;
-                    const float* p = lds + (((td + kd) * HY + (th + kh)) * HX + (j + kw)) * CB + g * CPL;
-                    if (CPL == 4) {
-                        float4 tq = *reinterpret_cast<const float4*>(p);
-                        bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
-                    } else {
-                        float2 tq = *reinterpret_cast<const float2*>(p);
-                        bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = 0.f; bv[c][3] = 0.f;
-                    }
+            for (int c = 0; c < CTW; ++c) {
+                if (CPL == 4) {
+                    const float4 tq = *reinterpret_cast<const float4*>(lbase[c] + off);
+                    bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
+                } else {
+                    const float2 tq = *reinterpret_cast<const float2*>(lbase[c] + off);
+                    bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = 0.f; bv[c][3] = 0.f;
                 }
-#pragma unroll
-                for (int r = 0; r < CPL; ++r)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                        for (int c = 0; c < CTW; ++c)
-                            acc[c][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[(kw * CPL + r) * RT + rt], bv[c][r],
-                                                                              acc[c][rt], 0, 0, 0);
             }
         };
-        float a0[NAQ], a1[NAQ];
-        issue_a(0, a0);
-#pragma unroll 1
-        for (int u = 0; u < 9; u += 2) {
-            issue_a(u + 1 < 9 ? u + 1 : 8, a1);
-            compute(u, a0);
-            issue_a(u + 2 < 9 ? u + 2 : 8, a0);
-            if (u + 1 < 9) compute(u + 1, a1);
+        float bq[2][CTW][4];
+        read_b(0, bq[0]);
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            if (tap + 2 < 27) issue_a(tap + 2, aq[(tap + 2) % 3]);
+            if (tap + 1 < 27) read_b(tap + 1, bq[(tap + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < CPL; ++r)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int c = 0; c < CTW; ++c)
+                        acc[c][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[tap % 3][r * RT + rt], bq[tap & 1][c][r],
+                                                                          acc[c][rt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 

@@ -257,6 +257,8 @@ inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x
     return d;
 }
 
+inline void __builtin_amdgcn_sched_barrier(int) {}
+
 #define ENERF_LAUNCH(kern, grid, block, shmem, stream, ...) \
     emu::launch(true, dim3(grid), dim3(block), (size_t)(shmem), [&]() { kern(__VA_ARGS__); })
 #define ENERF_LAUNCH_SIMPLE(kern, grid, block, shmem, stream, ...) \
