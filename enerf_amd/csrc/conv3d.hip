@@ -248,8 +248,10 @@ __global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, c
 #pragma unroll 1
         for (int t = 0; t < ntaps; t += 2) {
             issue(t + 1 < ntaps ? t + 1 : ntaps - 1, b1, k1, a1);   // clamped: always loads, never branches
+            __builtin_amdgcn_sched_barrier(0);                      // keep the next tap's loads ahead of this tap's MFMAs
             compute(b0, k0, a0);
             issue(t + 2 < ntaps ? t + 2 : ntaps - 1, b0, k0, a0);
+            __builtin_amdgcn_sched_barrier(0);
             if (t + 1 < ntaps) compute(b1, k1, a1);
         }
     }
