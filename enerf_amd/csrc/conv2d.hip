@@ -68,29 +68,21 @@ void launch_conv2d_pack(const float* w, const float* bias, const float* bn_w, co
                         cin, cout, k, packed, scale, shift);
 }
 
-// CINP: padded input channels (4,8,16,32); RT: cout tiles of 16; K: 1/3/5; STR: 1/2; TH: output rows per tile
+// CINP: padded input channels (4,8,16,32); RT: cout tiles of 16; K: 1/3/5; STR: 1/2; TH: output rows per block
 // (x TW=32 columns = 2 column tiles per row); NCHW3: input is the (n,3,H,W) image batch.
-//
-// Persistent blocks + async-stage split: a block walks a contiguous run of output tiles; one *stage* =
-// (tile, 16-channel pass).  While stage s runs on the matrix cores, the global loads of stage s+1's input
-// tile are already in flight into registers; they are written to LDS after the post-compute barrier.
-// (Measured before this: memory and MFMA phases of co-resident blocks ran in lockstep and their times
-// added up — smooth0 took 115 us for 57 us of MFMA work + ~55 us of streaming.)
 template <int CINP, int RT, int K, int STR, int TH, bool NCHW3>
 __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, const float* __restrict__ scale,
                                                 const float* __restrict__ shift, const float* __restrict__ in,
                                                 float* __restrict__ out, const float* __restrict__ up,
                                                 const float* __restrict__ rgb_src, int out_stride, int cout,
                                                 int relu, int N, int Hi, int Wi, int Ho, int Wo, int Hc, int Wc,
-                                                int tiles_y, int tiles_x, int tiles_per_block) {
+                                                int tiles_y, int tiles_x) {
     constexpr int TW = 32, P = (K - 1) / 2;
     constexpr int CB = CINP >= 16 ? 16 : CINP, CPL = CB / 4, NCB = CINP / CB, KS = CINP / 4;
     constexpr int IH = (TH - 1) * STR + K, IW = (TW - 1) * STR + K;
     constexpr int NT = TH * (TW / 16), CTW = NT / 4;      // column tiles per block / per wave
     constexpr int QV = CB / 4 > 0 ? CB / 4 : 1;
     constexpr int NPX = IH * IW;
-    constexpr int NIT = NCHW3 ? (NPX + 255) / 256 : (NPX * QV + 255) / 256;   // staging loads per thread
-    constexpr int NAQ = K * CPL * RT;
     ENERF_DYN_SMEM(float, lds);
 
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
@@ -99,21 +91,47 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
         const int nblk = gridDim.x, q = nblk / 8, r = nblk % 8, xcd = bid % 8, kk = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
     }
-    const int total_tiles = N * tiles_y * tiles_x;
-    const int tile_begin = bid * tiles_per_block;
-    const int tile_end = min(tile_begin + tiles_per_block, total_tiles);
-    if (tile_begin >= tile_end) return;
-    const int nstages = (tile_end - tile_begin) * NCB;
-    const float* wl = wpk + lane;
+    const int tx = bid % tiles_x;
+    const int ty = (bid / tiles_x) % tiles_y;
+    const int n = bid / (tiles_x * tiles_y);
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * STR - P, ix0 = ox0 * STR - P;
 
-    // ---- staging: global -> registers (issue) and registers -> LDS (commit) for stage st ----
-    float4 sv[NIT];
-    bool sk[NIT];
-    auto stage_issue = [&](int st) {
-        const int tile = tile_begin + st / NCB, cb = st % NCB;
-        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-        const int iy0 = ty * TH * STR - P, ix0 = tx * TW * STR - P;
+    f32x4 acc[CTW][RT];
+#pragma unroll
+    for (int c = 0; c < CTW; ++c)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[c][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wl = wpk + lane;
+    constexpr int NAQ = K * CPL * RT;
+
+#pragma unroll 1
+    for (int cb = 0; cb < NCB; ++cb) {
+        auto issue_a = [&](int kh, float (&aq)[NAQ]) {         // weights of the taps (kh, 0..K-1) for this pass
+            const float* wt = wl + ((long long)(kh * K) * KS + cb * CPL) * RT * 64;
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                for (int r = 0; r < CPL; ++r)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        aq[(kw * CPL + r) * RT + rt] = wt[((long long)(kw * KS + r) * RT + rt) * 64];
+        };
+        // k<=3: the whole pass's weights are requested BEFORE the tile is staged, so their L2 latency hides
+        // behind the staging traffic; sched_barrier pins the loads here (hipcc otherwise sinks each load to
+        // just before its MFMA and waits vmcnt(0) on it).
+        float aq_all[K <= 3 ? K : 1][NAQ];
+        if (K <= 3) {
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh) issue_a(kh, aq_all[kh]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (cb > 0) __syncthreads();
         if (NCHW3) {
+            // image batch (n,3,Hi,Wi): one thread per tile pixel, three coalesced plane reads
+            constexpr int NIT = (NPX + 255) / 256;
+            float v0[NIT], v1[NIT], v2[NIT];
+            bool sk[NIT];
             const float* base = in + (long long)n * 3 * Hi * Wi;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -121,9 +139,19 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
                 const int ly = ic / IW, lx = ic - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
                 sk[it] = gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
                 const int off = sk[it] ? gy * Wi + gx : 0;
-                sv[it] = make_float4(base[off], base[Hi * Wi + off], base[2 * Hi * Wi + off], 0.f);
+                v0[it] = base[off]; v1[it] = base[Hi * Wi + off]; v2[it] = base[2 * Hi * Wi + off];
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = threadIdx.x + it * 256;
+                if (i < NPX)
+                    *reinterpret_cast<float4*>(lds + i * 4) =
+                        sk[it] ? make_float4(v0[it], v1[it], v2[it], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
+            constexpr int NIT = (NPX * QV + 255) / 256;
+            float4 sv[NIT];
+            bool sk[NIT];
             const float* base = in + (long long)n * Hi * Wi * CINP + cb * CB;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -134,49 +162,14 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
                 const int off = sk[it] ? gy * Wi + gx : 0;
                 sv[it] = *reinterpret_cast<const float4*>(base + (long long)off * CINP + q * 4);
             }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = threadIdx.x + it * 256;
+                if (i < NPX * QV)
+                    *reinterpret_cast<float4*>(lds + i * 4) = sk[it] ? sv[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
-    };
-    auto stage_commit = [&]() {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = threadIdx.x + it * 256;
-            if (i < (NCHW3 ? NPX : NPX * QV))
-                *reinterpret_cast<float4*>(lds + i * 4) = sk[it] ? sv[it] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-
-    f32x4 acc[CTW][RT];
-    stage_issue(0);
-#pragma unroll 1
-    for (int st = 0; st < nstages; ++st) {
-        const int tile = tile_begin + st / NCB, cb = st % NCB;
-        // weights of this pass: requested before the LDS commit so their latency hides behind it
-        auto issue_a = [&](int kh, float (&aq)[NAQ]) {
-            const float* wt = wl + ((long long)(kh * K) * KS + cb * CPL) * RT * 64;
-#pragma unroll
-            for (int kw = 0; kw < K; ++kw)
-#pragma unroll
-                for (int r = 0; r < CPL; ++r)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-                        aq[(kw * CPL + r) * RT + rt] = wt[((long long)(kw * KS + r) * RT + rt) * 64];
-        };
-        float aq_all[K <= 3 ? K : 1][NAQ];
-        if (K <= 3) {
-#pragma unroll
-            for (int kh = 0; kh < K; ++kh) issue_a(kh, aq_all[kh]);
-        }
-        if (cb == 0) {
-#pragma unroll
-            for (int c = 0; c < CTW; ++c)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[c][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        stage_commit();                                  // waits for this stage's loads, fills LDS
         __syncthreads();
-        stage_issue(st + 1 < nstages ? st + 1 : st);     // next stage's loads fly during this stage's MFMAs
-        __builtin_amdgcn_sched_barrier(0);
 
         auto compute = [&](int kh, const float (&aq)[NAQ]) {
 #pragma unroll
@@ -184,7 +177,7 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
                 float bv[CTW][4];
 #pragma unroll
                 for (int c = 0; c < CTW; ++c) {
-                    const int ct = wv * CTW + c, tr = ct / (TW / 16), tc = ct - tr * (TW / 16);
+                    const int tile = wv * CTW + c, tr = tile / (TW / 16), tc = tile - tr * (TW / 16);
                     const float* p = lds + ((tr * STR + kh) * IW + (tc * 16 + j) * STR + kw) * CB + g * CPL;
                     if (CPL == 4) {
                         const float4 tq = *reinterpret_cast<const float4*>(p);
@@ -222,75 +215,65 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
                 if (kh + 1 < K) compute(kh + 1, a1);
             }
         }
+    }
 
-        if (cb == NCB - 1) {
-            // ---- epilogue: BN/bias, optional x2 bilinear upsample-add of the coarser FPN map, ReLU ----
-            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-            const int oy0 = ty * TH, ox0 = tx * TW;
-            const float sy = ac_scale(Hc, Ho), sx = ac_scale(Wc, Wo);
+    // ---- epilogue: BN/bias, optional x2 bilinear upsample-add of the coarser FPN map, ReLU ----
+    const float sy = ac_scale(Hc, Ho), sx = ac_scale(Wc, Wo);
 #pragma unroll
-            for (int c = 0; c < CTW; ++c) {
-                const int ct = wv * CTW + c, tr = ct / (TW / 16), tc = ct - tr * (TW / 16);
-                const int oy = oy0 + tr, ox = ox0 + tc * 16 + j;
-                if (oy >= Ho || ox >= Wo) continue;
-                const long long o = ((long long)n * Ho + oy) * Wo + ox;
+    for (int c = 0; c < CTW; ++c) {
+        const int tile = wv * CTW + c, tr = tile / (TW / 16), tc = tile - tr * (TW / 16);
+        const int oy = oy0 + tr, ox = ox0 + tc * 16 + j;
+        if (oy >= Ho || ox >= Wo) continue;
+        const long long o = ((long long)n * Ho + oy) * Wo + ox;
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    const int c0 = rt * 16 + 4 * g;
-                    if (c0 == cout && rgb_src != nullptr) {
-                        // texel mode (smooth0 -> render gather source): the first idle lane group appends
-                        // [rgb*0.5+0.5 | 0] (unpreprocess utils.py:608 + cat network.py:34) behind the features
-                        const float* sp = rgb_src + (long long)n * 3 * Ho * Wo + (long long)oy * Wo + ox;
-                        *reinterpret_cast<float4*>(out + o * out_stride + c0) =
-                            make_float4(sp[0] * 0.5f + 0.5f, sp[(long long)Ho * Wo] * 0.5f + 0.5f,
-                                        sp[2LL * Ho * Wo] * 0.5f + 0.5f, 0.f);
-                    }
-                    if (c0 >= cout) continue;
-                    float y[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) y[r] = acc[c][rt][r] * scale[c0 + r] + shift[c0 + r];
-                    if (up != nullptr) {   // feature_net.py:24-25: F.interpolate(x, 2, bilinear, align_corners) + y
-                        const Lerp1 ly = ac_lerp(oy, sy, Hc), lx = ac_lerp(ox, sx, Wc);
-                        const float* ub = up + (long long)n * Hc * Wc * cout + c0;
-                        const float4 u00 = *reinterpret_cast<const float4*>(ub + ((long long)ly.i0 * Wc + lx.i0) * cout);
-                        const float4 u01 = *reinterpret_cast<const float4*>(ub + ((long long)ly.i0 * Wc + lx.i1) * cout);
-                        const float4 u10 = *reinterpret_cast<const float4*>(ub + ((long long)ly.i1 * Wc + lx.i0) * cout);
-                        const float4 u11 = *reinterpret_cast<const float4*>(ub + ((long long)ly.i1 * Wc + lx.i1) * cout);
-                        y[0] = ac_blend(ly, lx, u00.x, u01.x, u10.x, u11.x) + y[0];
-                        y[1] = ac_blend(ly, lx, u00.y, u01.y, u10.y, u11.y) + y[1];
-                        y[2] = ac_blend(ly, lx, u00.z, u01.z, u10.z, u11.z) + y[2];
-                        y[3] = ac_blend(ly, lx, u00.w, u01.w, u10.w, u11.w) + y[3];
-                    }
-                    if (relu) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.f);
-                    }
-                    *reinterpret_cast<float4*>(out + o * out_stride + c0) = make_float4(y[0], y[1], y[2], y[3]);
-                }
+        for (int rt = 0; rt < RT; ++rt) {
+            const int c0 = rt * 16 + 4 * g;
+            if (c0 == cout && rgb_src != nullptr) {
+                // texel mode (smooth0 -> render gather source): the first idle lane group appends
+                // [rgb*0.5+0.5 | 0] (unpreprocess utils.py:608 + cat network.py:34) behind the features
+                const float* sp = rgb_src + (long long)n * 3 * Ho * Wo + (long long)oy * Wo + ox;
+                *reinterpret_cast<float4*>(out + o * out_stride + c0) =
+                    make_float4(sp[0] * 0.5f + 0.5f, sp[(long long)Ho * Wo] * 0.5f + 0.5f,
+                                sp[2LL * Ho * Wo] * 0.5f + 0.5f, 0.f);
             }
+            if (c0 >= cout) continue;
+            float y[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = acc[c][rt][r] * scale[c0 + r] + shift[c0 + r];
+            if (up != nullptr) {            // feature_net.py:24-25: F.interpolate(x, 2, bilinear, align_corners) + y
+                const Lerp1 ly = ac_lerp(oy, sy, Hc), lx = ac_lerp(ox, sx, Wc);
+                const float* ub = up + (long long)n * Hc * Wc * cout + c0;
+                const float4 u00 = *reinterpret_cast<const float4*>(ub + ((long long)ly.i0 * Wc + lx.i0) * cout);
+                const float4 u01 = *reinterpret_cast<const float4*>(ub + ((long long)ly.i0 * Wc + lx.i1) * cout);
+                const float4 u10 = *reinterpret_cast<const float4*>(ub + ((long long)ly.i1 * Wc + lx.i0) * cout);
+                const float4 u11 = *reinterpret_cast<const float4*>(ub + ((long long)ly.i1 * Wc + lx.i1) * cout);
+                y[0] = ac_blend(ly, lx, u00.x, u01.x, u10.x, u11.x) + y[0];
+                y[1] = ac_blend(ly, lx, u00.y, u01.y, u10.y, u11.y) + y[1];
+                y[2] = ac_blend(ly, lx, u00.z, u01.z, u10.z, u11.z) + y[2];
+                y[3] = ac_blend(ly, lx, u00.w, u01.w, u10.w, u11.w) + y[3];
+            }
+            if (relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.f);
+            }
+            *reinterpret_cast<float4*>(out + o * out_stride + c0) = make_float4(y[0], y[1], y[2], y[3]);
         }
-        __syncthreads();                                  // everyone done reading LDS before the next commit
     }
 }
 
 template <int CINP, int RT, int K, int STR, int TH, bool NCHW3>
 static void launch_c2(const Conv2dDesc& L, const float* in, float* out, const float* up, int N, int Hi, int Wi, int Hc,
                       int Wc, hipStream_t st) {
+    const float* rgb_src = L.rgb_src;
+    const int out_stride = L.out_stride > 0 ? L.out_stride : L.cout;
     constexpr int P = (K - 1) / 2, CB = CINP >= 16 ? 16 : CINP;
     const int Ho = (Hi + 2 * P - K) / STR + 1, Wo = (Wi + 2 * P - K) / STR + 1;
     const int tiles_y = cdiv(Ho, TH), tiles_x = cdiv(Wo, 32);
     constexpr int IH = (TH - 1) * STR + K, IW = 31 * STR + K;
     const size_t shmem = (size_t)IH * IW * CB * sizeof(float);
-    const int total = N * tiles_y * tiles_x;
-    // persistent grid: about 4 co-resident blocks per CU (LDS tile <= 47 KB, <= 128 VGPR), each walking a
-    // contiguous run of tiles.  ENERF_CONV2D_TPB overrides tiles per block (A/B runs; 1 = one tile per block).
-    const char* e = getenv("ENERF_CONV2D_TPB");
-    int tpb = e ? atoi(e) : cdiv(total, 256 * 4);
-    if (tpb < 1) tpb = 1;
-    const unsigned grid = (unsigned)cdiv(total, tpb);
-    const int out_stride = L.out_stride > 0 ? L.out_stride : L.cout;
-    ENERF_LAUNCH((k_conv2d<CINP, RT, K, STR, TH, NCHW3>), grid, 256, shmem, st, L.w, L.scale, L.shift, in, out, up,
-                 L.rgb_src, out_stride, L.cout, L.relu, N, Hi, Wi, Ho, Wo, Hc, Wc, tiles_y, tiles_x, tpb);
+    const unsigned grid = (unsigned)((long long)N * tiles_y * tiles_x);
+    ENERF_LAUNCH((k_conv2d<CINP, RT, K, STR, TH, NCHW3>), grid, 256, shmem, st, L.w, L.scale, L.shift, in, out, up, rgb_src,
+                 out_stride, L.cout, L.relu, N, Hi, Wi, Ho, Wo, Hc, Wc, tiles_y, tiles_x);
 }
 
 // The eleven FeatureNet layers use exactly these shapes (feature_net.py:7-22).

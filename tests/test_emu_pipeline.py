@@ -190,12 +190,3 @@ def test_torch_feature_backend_still_matches(name):
     for k, v in out.items():
         _close(v.numpy(), gold["out/" + k], 2e-5, k)
 
-
-def test_conv2d_persistent_tile_loop(monkeypatch):
-    """Several tiles per persistent block (stage pipeline wraps across tiles), incl. a ragged last block."""
-    monkeypatch.setenv("ENERF_CONV2D_TPB", "3")
-    name = "small_s3_eval"
-    cfg, batch, gold = case_config(name), case_batch(name), load_golden(name)
-    out = _net(cfg)(batch)
-    for k, v in out.items():
-        _close(v.numpy(), gold["out/" + k], 2e-5, k)
