@@ -117,13 +117,21 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
                     for (int rt = 0; rt < RT; ++rt)
                         aq[(kw * CPL + r) * RT + rt] = wt[((long long)(kw * KS + r) * RT + rt) * 64];
         };
-        // k<=3: the whole pass's weights are requested BEFORE the tile is staged, so their L2 latency hides
-        // behind the staging traffic; sched_barrier pins the loads here (hipcc otherwise sinks each load to
-        // just before its MFMA and waits vmcnt(0) on it).
-        float aq_all[K <= 3 ? K : 1][NAQ];
-        if (K <= 3) {
+        // k<=3: operand pipeline as in conv3d.hip V2 — weights in a 3-deep register ring (tap t+2 requested
+        // while tap t runs; taps 0,1 requested BEFORE the tile is staged), LDS reads one tap ahead; order pinned
+        // with sched_barrier (hipcc otherwise sinks each weight load to its MFMA and waits vmcnt(0) on it).
+        constexpr int NAT = CPL * RT;
+        auto issue_tap = [&](int tap, float (&aq)[NAT]) {
+            const float* wt = wl + ((long long)tap * KS + cb * CPL) * RT * 64;
 #pragma unroll
-            for (int kh = 0; kh < K; ++kh) issue_a(kh, aq_all[kh]);
+            for (int r = 0; r < CPL; ++r)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) aq[r * RT + rt] = wt[(r * RT + rt) * 64];
+        };
+        float ar[3][NAT];
+        if (K <= 3) {
+            issue_tap(0, ar[0]);
+            if (K * K > 1) issue_tap(1, ar[1]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (cb > 0) __syncthreads();
@@ -200,8 +208,44 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
             }
         };
         if (K <= 3) {
+            const float* lbase[CTW];
 #pragma unroll
-            for (int kh = 0; kh < K; ++kh) compute(kh, aq_all[kh]);
+            for (int c = 0; c < CTW; ++c) {
+                const int tile = wv * CTW + c, tr = tile / (TW / 16), tc = tile - tr * (TW / 16);
+                lbase[c] = lds + ((tr * STR) * IW + (tc * 16 + j) * STR) * CB + g * CPL;
+            }
+            auto read_b = [&](int tap, float (&bv)[CTW][4]) {
+                const int off = ((tap / K) * IW + (tap % K)) * CB;
+#pragma unroll
+                for (int c = 0; c < CTW; ++c) {
+                    if (CPL == 4) {
+                        const float4 tq = *reinterpret_cast<const float4*>(lbase[c] + off);
+                        bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
+                    } else if (CPL == 2) {
+                        const float2 tq = *reinterpret_cast<const float2*>(lbase[c] + off);
+                        bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = 0.f; bv[c][3] = 0.f;
+                    } else {
+                        bv[c][0] = lbase[c][off]; bv[c][1] = 0.f; bv[c][2] = 0.f; bv[c][3] = 0.f;
+                    }
+                }
+            };
+            float bq[2][CTW][4];
+            read_b(0, bq[0]);
+#pragma unroll
+            for (int tap = 0; tap < K * K; ++tap) {
+                if (tap + 2 < K * K) issue_tap(tap + 2, ar[(tap + 2) % 3]);
+                if (tap + 1 < K * K) read_b(tap + 1, bq[(tap + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < CPL; ++r)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int c = 0; c < CTW; ++c)
+                            acc[c][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[tap % 3][r * RT + rt], bq[tap & 1][c][r],
+                                                                              acc[c][rt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else {
             float a0[NAQ], a1[NAQ];
             issue_a(0, a0);

@@ -525,7 +525,9 @@ static bool dispatch_s1_lds(const Conv3dDesc& L, const float* in, float* out, fl
                             hipStream_t st) {
     const int rt_total = cdiv(L.cout, 16);
     if (rt_total == 1) {
-        if (D % 4 == 0) launch_s1_lds<CIN, 1, 4>(L, in, out, out2, B, D, H, W, st);
+        const char* e = getenv("ENERF_CONV_BD");          // A/B knob: box depth 2 (3 blocks/CU) or 4 (2 blocks/CU)
+        const int bd = e ? atoi(e) : 4;
+        if (D % 4 == 0 && bd == 4) launch_s1_lds<CIN, 1, 4>(L, in, out, out2, B, D, H, W, st);
         else launch_s1_lds<CIN, 1, 2>(L, in, out, out2, B, D, H, W, st);
         return true;
     }
