@@ -27,6 +27,16 @@ namespace enerf {
 constexpr int kWave = 64;
 
 __host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// XCD-aware block order.  The dispatcher places block b on XCD b % 8 and every XCD has a private 4 MiB L2,
+// so with the natural order neighbouring blocks (which share gather footprints / halos) land on eight
+// different L2s and each L2 ends up fetching the whole input (measured: k_feature_volume fetched 6x its
+// input).  This bijection hands each XCD one contiguous run of logical block ids instead.  Speed only —
+// nothing depends on the placement being what we expect.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk / 8, r = nblk % 8, xcd = bid % 8, k = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
 __host__ __device__ __forceinline__ long long cdivl(long long a, long long b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------------------------------------

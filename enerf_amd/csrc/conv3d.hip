@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, c
     // a wave owns RT of the layer's rt_total row tiles (output-channel tiles of 16): tiny deep layers are
     // split over more waves this way (conv6 has only 80 voxel tiles but 4 row tiles)
     const int rsplit = rt_total / RT;
-    const long long wave_all = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long wave_all = ((long long)xcd_contiguous(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x) >> 6;
     const long long wave = wave_all / rsplit;
     const int rt_base = (int)(wave_all - wave * rsplit) * RT;
 
