@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
                                                 float* __restrict__ out, const float* __restrict__ up,
                                                 const float* __restrict__ rgb_src, int out_stride, int cout,
                                                 int relu, int N, int Hi, int Wi, int Ho, int Wo, int Hc, int Wc,
-                                                int tiles_y, int tiles_x) {
+                                                int tiles_y, int tiles_x, int xcd_swizzle) {
     constexpr int TW = 32, P = (K - 1) / 2;
     constexpr int CB = CINP >= 16 ? 16 : CINP, CPL = CB / 4, NCB = CINP / CB, KS = CINP / 4;
     constexpr int IH = (TH - 1) * STR + K, IW = (TW - 1) * STR + K;
@@ -86,11 +86,7 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
     ENERF_DYN_SMEM(float, lds);
 
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
-    int bid = blockIdx.x;
-    {   // XCD-contiguous block order (bijective), see conv3d.hip
-        const int nblk = gridDim.x, q = nblk / 8, r = nblk % 8, xcd = bid % 8, kk = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
-    }
+    const int bid = xcd_swizzle ? (int)xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int tx = bid % tiles_x;
     const int ty = (bid / tiles_x) % tiles_y;
     const int n = bid / (tiles_x * tiles_y);
@@ -310,6 +306,8 @@ static void launch_c2(const Conv2dDesc& L, const float* in, float* out, const fl
                       int Wc, hipStream_t st) {
     const float* rgb_src = L.rgb_src;
     const int out_stride = L.out_stride > 0 ? L.out_stride : L.cout;
+    const char* e = getenv("ENERF_XCD_SWIZZLE");
+    const int xs = e ? atoi(e) : 1;
     constexpr int P = (K - 1) / 2, CB = CINP >= 16 ? 16 : CINP;
     const int Ho = (Hi + 2 * P - K) / STR + 1, Wo = (Wi + 2 * P - K) / STR + 1;
     const int tiles_y = cdiv(Ho, TH), tiles_x = cdiv(Wo, 32);
@@ -317,7 +315,7 @@ static void launch_c2(const Conv2dDesc& L, const float* in, float* out, const fl
     const size_t shmem = (size_t)IH * IW * CB * sizeof(float);
     const unsigned grid = (unsigned)((long long)N * tiles_y * tiles_x);
     ENERF_LAUNCH((k_conv2d<CINP, RT, K, STR, TH, NCHW3>), grid, 256, shmem, st, L.w, L.scale, L.shift, in, out, up, rgb_src,
-                 out_stride, L.cout, L.relu, N, Hi, Wi, Ho, Wo, Hc, Wc, tiles_y, tiles_x);
+                 out_stride, L.cout, L.relu, N, Hi, Wi, Ho, Wo, Hc, Wc, tiles_y, tiles_x, xs);
 }
 
 // The eleven FeatureNet layers use exactly these shapes (feature_net.py:7-22).

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, c
     // a wave owns RT of the layer's rt_total row tiles (output-channel tiles of 16): tiny deep layers are
     // split over more waves this way (conv6 has only 80 voxel tiles but 4 row tiles)
     const int rsplit = rt_total / RT;
-    const long long wave_all = ((long long)xcd_contiguous(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x) >> 6;
+    const long long wave_all = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long wave = wave_all / rsplit;
     const int rt_base = (int)(wave_all - wave * rsplit) * RT;
 
@@ -356,7 +356,8 @@ __global__ __launch_bounds__(256, (BD == 4 ? 2 : 3)) void k_conv3d_s1_lds(   // 
 const float* __restrict__ wpk, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ in,
                                                        float* __restrict__ out, float* __restrict__ out2, int cout,
-                                                       int relu, int B, int D, int H, int W, int nbd, int nbh, int nbw) {
+                                                       int relu, int B, int D, int H, int W, int nbd, int nbh, int nbw,
+                                                       int xcd_swizzle) {
     constexpr int BH = 8, BW = 16;
     constexpr int CB = CIN >= 16 ? 16 : CIN;          // channels staged per pass
     constexpr int CPL = CB / 4;                         // channels per lane per LDS read
@@ -371,12 +372,7 @@ const float* __restrict__ wpk, const float* __restrict__ scale,
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
     // XCD-aware block order: consecutive block ids land on different XCDs (private L2s), so give each
     // XCD a contiguous run of boxes; neighbouring boxes (shared halos) then hit the same L2.
-    const int nblk = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, k = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    }
+    const int bid = xcd_swizzle ? (int)xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     int t = bid;
     const int bw = t % nbw; t /= nbw;
     const int bh = t % nbh; t /= nbh;
@@ -517,8 +513,9 @@ static void launch_s1_lds(const Conv3dDesc& L, const float* in, float* out, floa
     const int nbd = cdiv(D, BD), nbh = cdiv(H, 8), nbw = cdiv(W, 16);
     const size_t shmem = (size_t)(BD + 2) * 10 * 18 * CB * sizeof(float);
     const unsigned grid = (unsigned)((long long)B * nbd * nbh * nbw);
+    const char* e = getenv("ENERF_XCD_SWIZZLE");
     ENERF_LAUNCH((k_conv3d_s1_lds<CIN, RT, BD>), grid, 256, shmem, st, L.w, L.scale, L.shift, in, out, out2, L.cout,
-                 L.relu, B, D, H, W, nbd, nbh, nbw);
+                 L.relu, B, D, H, W, nbd, nbh, nbw, e ? atoi(e) : 1);
 }
 template <int CIN>
 static bool dispatch_s1_lds(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,

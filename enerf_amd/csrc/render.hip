@@ -190,12 +190,9 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
     const int TEX = 4 * R;
     const float* wlane = wl + lane;
 
-    // Each block owns one contiguous run of ray tiles (its waves interleave inside the run) and the runs are
-    // handed out XCD-contiguously, so an XCD's L2 only sees the texels / voxels of one band of the image.
-    const long long per_block = cdivl(ntiles, gridDim.x);
-    const long long run_begin = (long long)xcd_contiguous(blockIdx.x, gridDim.x) * per_block;
-    const long long run_end = run_begin + per_block < ntiles ? run_begin + per_block : ntiles;
-    for (long long tile = run_begin + wave_in_block; tile < run_end; tile += waves_per_block) {
+    // natural (round-robin) tile order: handing each XCD a contiguous run of tiles measured ~3 % slower
+    for (long long tile = (long long)blockIdx.x * waves_per_block + wave_in_block; tile < ntiles;
+         tile += (long long)gridDim.x * waves_per_block) {
         long long ray = tile * 16 + j;
         const bool rok = ray < nrays;
         const long long rr = rok ? ray : nrays - 1;

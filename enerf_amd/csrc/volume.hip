@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict_
                                                         const float* __restrict__ dv, int B, int S, int Hs, int Ws,
                                                         int D, int h, int w, float* __restrict__ vol) {
     constexpr int C = CQ * 4;
-    long long gid = (long long)xcd_contiguous(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // natural order: XCD-contiguous measured 30 % slower here
     long long nvox = (long long)B * D * h * w;
     long long vox = gid / CQ;
     int cq = (int)(gid - vox * CQ);
