@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
                                                 float* __restrict__ out, const float* __restrict__ up,
                                                 const float* __restrict__ rgb_src, int out_stride, int cout,
                                                 int relu, int N, int Hi, int Wi, int Ho, int Wo, int Hc, int Wc,
-                                                int tiles_y, int tiles_x, int xcd_swizzle) {
+                                                int tiles_y, int tiles_x) {
     constexpr int TW = 32, P = (K - 1) / 2;
     constexpr int CB = CINP >= 16 ? 16 : CINP, CPL = CB / 4, NCB = CINP / CB, KS = CINP / 4;
     constexpr int IH = (TH - 1) * STR + K, IW = (TW - 1) * STR + K;
@@ -86,7 +86,11 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
     ENERF_DYN_SMEM(float, lds);
 
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
-    const int bid = xcd_swizzle ? (int)xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    int bid = blockIdx.x;
+    {   // XCD-contiguous block order (bijective), see conv3d.hip
+        const int nblk = gridDim.x, q = nblk / 8, r = nblk % 8, xcd = bid % 8, kk = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
+    }
     const int tx = bid % tiles_x;
     const int ty = (bid / tiles_x) % tiles_y;
     const int n = bid / (tiles_x * tiles_y);
@@ -113,21 +117,13 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
                     for (int rt = 0; rt < RT; ++rt)
                         aq[(kw * CPL + r) * RT + rt] = wt[((long long)(kw * KS + r) * RT + rt) * 64];
         };
-        // k<=3: operand pipeline as in conv3d.hip V2 — weights in a 3-deep register ring (tap t+2 requested
-        // while tap t runs; taps 0,1 requested BEFORE the tile is staged), LDS reads one tap ahead; order pinned
-        // with sched_barrier (hipcc otherwise sinks each weight load to its MFMA and waits vmcnt(0) on it).
-        constexpr int NAT = CPL * RT;
-        auto issue_tap = [&](int tap, float (&aq)[NAT]) {
-            const float* wt = wl + ((long long)tap * KS + cb * CPL) * RT * 64;
-#pragma unroll
-            for (int r = 0; r < CPL; ++r)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) aq[r * RT + rt] = wt[(r * RT + rt) * 64];
-        };
-        float ar[3][NAT];
+        // k<=3: the whole pass's weights are requested BEFORE the tile is staged, so their L2 latency hides
+        // behind the staging traffic; sched_barrier pins the loads here (hipcc otherwise sinks each load to
+        // just before its MFMA and waits vmcnt(0) on it).
+        float aq_all[K <= 3 ? K : 1][NAQ];
         if (K <= 3) {
-            issue_tap(0, ar[0]);
-            if (K * K > 1) issue_tap(1, ar[1]);
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh) issue_a(kh, aq_all[kh]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (cb > 0) __syncthreads();
@@ -204,44 +200,8 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
             }
         };
         if (K <= 3) {
-            const float* lbase[CTW];
 #pragma unroll
-            for (int c = 0; c < CTW; ++c) {
-                const int tile = wv * CTW + c, tr = tile / (TW / 16), tc = tile - tr * (TW / 16);
-                lbase[c] = lds + ((tr * STR) * IW + (tc * 16 + j) * STR) * CB + g * CPL;
-            }
-            auto read_b = [&](int tap, float (&bv)[CTW][4]) {
-                const int off = ((tap / K) * IW + (tap % K)) * CB;
-#pragma unroll
-                for (int c = 0; c < CTW; ++c) {
-                    if (CPL == 4) {
-                        const float4 tq = *reinterpret_cast<const float4*>(lbase[c] + off);
-                        bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
-                    } else if (CPL == 2) {
-                        const float2 tq = *reinterpret_cast<const float2*>(lbase[c] + off);
-                        bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = 0.f; bv[c][3] = 0.f;
-                    } else {
-                        bv[c][0] = lbase[c][off]; bv[c][1] = 0.f; bv[c][2] = 0.f; bv[c][3] = 0.f;
-                    }
-                }
-            };
-            float bq[2][CTW][4];
-            read_b(0, bq[0]);
-#pragma unroll
-            for (int tap = 0; tap < K * K; ++tap) {
-                if (tap + 2 < K * K) issue_tap(tap + 2, ar[(tap + 2) % 3]);
-                if (tap + 1 < K * K) read_b(tap + 1, bq[(tap + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < CPL; ++r)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                        for (int c = 0; c < CTW; ++c)
-                            acc[c][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[tap % 3][r * RT + rt], bq[tap & 1][c][r],
-                                                                              acc[c][rt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int kh = 0; kh < K; ++kh) compute(kh, aq_all[kh]);
         } else {
             float a0[NAQ], a1[NAQ];
             issue_a(0, a0);
@@ -306,8 +266,6 @@ static void launch_c2(const Conv2dDesc& L, const float* in, float* out, const fl
                       int Wc, hipStream_t st) {
     const float* rgb_src = L.rgb_src;
     const int out_stride = L.out_stride > 0 ? L.out_stride : L.cout;
-    const char* e = getenv("ENERF_XCD_SWIZZLE");
-    const int xs = e ? atoi(e) : 1;
     constexpr int P = (K - 1) / 2, CB = CINP >= 16 ? 16 : CINP;
     const int Ho = (Hi + 2 * P - K) / STR + 1, Wo = (Wi + 2 * P - K) / STR + 1;
     const int tiles_y = cdiv(Ho, TH), tiles_x = cdiv(Wo, 32);
@@ -315,7 +273,7 @@ static void launch_c2(const Conv2dDesc& L, const float* in, float* out, const fl
     const size_t shmem = (size_t)IH * IW * CB * sizeof(float);
     const unsigned grid = (unsigned)((long long)N * tiles_y * tiles_x);
     ENERF_LAUNCH((k_conv2d<CINP, RT, K, STR, TH, NCHW3>), grid, 256, shmem, st, L.w, L.scale, L.shift, in, out, up, rgb_src,
-                 out_stride, L.cout, L.relu, N, Hi, Wi, Ho, Wo, Hc, Wc, tiles_y, tiles_x, xs);
+                 out_stride, L.cout, L.relu, N, Hi, Wi, Ho, Wo, Hc, Wc, tiles_y, tiles_x);
 }
 
 // The eleven FeatureNet layers use exactly these shapes (feature_net.py:7-22).
