@@ -150,16 +150,26 @@ def main():
         net._timer = None
         stages = timer.summary()
         result["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
-        # dominant single kernel: the fused level-1 render launch (k_render_rays<3,3>): 2 samples x H*W rays
+        # dominant single kernel: the fused level-1 render launch (k_render_rays<3,3,*>): 2 samples x H*W rays
         n_samples_total = H * W * cfg.cas.num_samples[1]
         flops = FLOP_PER_SAMPLE_L1 * n_samples_total if (S == 3) else None
         dur_ms = stages.get("render_1")
         if flops and dur_ms:
             ach = flops / (dur_ms * 1e-3) / 1e12
-            result["roofline"] = {"kernel": "k_render_rays<3,3> (level-1 fused render)", "bound": "mfma",
-                                  "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                                  "algorithmic_flops_per_launch": flops, "avg_launch_ms": dur_ms}
+            traffic, pmc_note, busy = None, None, None
+            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_render.json")     # separate rocprofv3 --pmc passes
+            if os.path.exists(pmc_path) and (H, W, S) == (512, 640, 3):
+                pmc = json.load(open(pmc_path))
+                traffic, pmc_note, busy = pmc["hbm_bytes_per_launch"], pmc["source"], pmc["mfma_busy_frac"]
+            result["roofline"] = {
+                "kernel": "k_render_rays<3,3> (level-1 fused render: sample placement + gathers + Agg/NeRF MLP + "
+                          "compositing)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                "algorithmic_flops_per_launch": flops, "avg_launch_ms": dur_ms,
+                "note": "achieved counts the reference's dense FLOPs (50,952/sample, SURVEY.md 8a); the kernel "
+                        "evaluates the view-independent halves of global_fc/color.0 once per point, so it issues "
+                        "201 instead of 369 MFMAs per 16 points", "mfma_pipe_busy_frac_pmc": busy,
+                "traffic_source": pmc_note, "algorithmic_bytes_per_launch": 92.4e6}
 
     # ---- CPU baseline: the oracle (torch CPU restatement of the reference) on this box's host cores ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
