@@ -2,6 +2,7 @@
 // network driver, error reporting.  No torch types; raw device pointers + sizes + a hipStream_t.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 
@@ -230,7 +231,7 @@ extern "C" {
 long long enerf_feature_net_packed_floats(void) {
     long long t = 0;
     for (int i = 0; i < 11; ++i) t += flayer_floats(kFeat[i]);
-    return t;
+    return t + 320;      // tail: raw lat0 weight (32x8) + bias (32) for the fused smooth0 kernel
 }
 int enerf_feature_net_pack(const enerf_featnet_raw_t* raw, float* packed, enerf_stream_t stream) {
     REQUIRE(raw && packed, "feature_net_pack: null pointer");
@@ -253,6 +254,8 @@ int enerf_feature_net_pack(const enerf_featnet_raw_t* raw, float* packed, enerf_
         }
         p += flayer_floats(f);
     }
+    hipMemcpyAsync(p, raw->lat0_w, 256 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    hipMemcpyAsync(p + 256, raw->lat0_b, 32 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
     return check_launch("feature_net_pack");
 }
 size_t enerf_feature_net_workspace_bytes(int n_img, int H, int W) {
@@ -294,11 +297,17 @@ int enerf_feature_net(const float* packed, const float* src_inps, int n_img, int
     rc |= launch_conv2d(d[5], c2a, c2, nullptr, n_img, H2, W2, 0, 0, st);              // conv2.1
     rc |= launch_conv2d(d[6], c2, feat_l0, nullptr, n_img, H2, W2, 0, 0, st);          // toplayer  -> level_0
     rc |= launch_conv2d(d[7], c1, f1pre, feat_l0, n_img, H1, W1, H2, W2, st);          // up2(feat2) + lat1(conv1)
-    rc |= launch_conv2d(d[8], c0, f0pre, f1pre, n_img, H, W, H1, W1, st);              // up2(feat1) + lat0(conv0)
     rc |= launch_conv2d(d[9], f1pre, feat_l1, nullptr, n_img, H1, W1, 0, 0, st);       // smooth1   -> level_1
     d[10].out_stride = l2_stride;
     d[10].rgb_src = (l2_stride == 12) ? src_inps : nullptr;
-    rc |= launch_conv2d(d[10], f0pre, feat_l2, nullptr, n_img, H, W, 0, 0, st);        // smooth0   -> level_2 / texels
+    const char* fuse = getenv("ENERF_FUSE_LAT0");                                       // A/B knob, default fused
+    if (fuse == nullptr || fuse[0] != '0') {
+        // smooth0(up2(feat1) + lat0(conv0)) in one kernel: the 32-channel full-res sum never touches HBM
+        launch_smooth0_fused(d[10], c0, f1pre, p, p + 256, feat_l2, n_img, H, W, st);
+    } else {
+        rc |= launch_conv2d(d[8], c0, f0pre, f1pre, n_img, H, W, H1, W1, st);          // up2(feat1) + lat0(conv0)
+        rc |= launch_conv2d(d[10], f0pre, feat_l2, nullptr, n_img, H, W, 0, 0, st);    // smooth0 -> level_2 / texels
+    }
     if (rc != 0) return fail(ENERF_EINVAL, "feature_net: unsupported layer shape");
     return check_launch("feature_net");
 }

@@ -276,6 +276,159 @@ static void launch_c2(const Conv2dDesc& L, const float* in, float* out, const fl
                  out_stride, L.cout, L.relu, N, Hi, Wi, Ho, Wo, Hc, Wc, tiles_y, tiles_x);
 }
 
+// =====================================================================================================
+// smooth0( up2(f1pre) + lat0(c0) )  — feature_net.py:32-35 — in ONE kernel.
+// The unfused chain writes the 32-channel full-resolution FPN sum (126 MB at 3x512x640) and reads it back
+// with halos; here each block rebuilds its haloed 10x34 tile of that sum in LDS from (a) the 8-channel c0
+// tile and (b) the half-resolution f1pre patch under it, 16 channels per pass:
+//     f0[px][m] = bilinear_ac(f1pre)[px][m] + (b_lat0[m] + sum_ci W_lat0[m][ci] * c0[px][ci]),  0 outside the image
+// and then runs the 3x3 32->8 convolution on the matrix cores exactly like k_conv2d (same packed weights,
+// same texel-mode epilogue).  HBM traffic per frame drops by ~290 MB and one launch disappears.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_smooth0_fused(const float* __restrict__ wpk, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ c0,
+                                                       const float* __restrict__ f1pre, const float* __restrict__ lat_w,
+                                                       const float* __restrict__ lat_b, float* __restrict__ out,
+                                                       const float* __restrict__ rgb_src, int out_stride, int N, int H,
+                                                       int W, int tiles_y, int tiles_x) {
+    constexpr int TH = 8, TW = 32, K = 3, IH = TH + 2, IW = TW + 2, NPX = IH * IW;     // 10 x 34 halo tile
+    constexpr int PH = 7, PW = 20, NPP = PH * PW;                                       // f1pre patch (half res)
+    constexpr int TS = 20;                                                              // tile row stride (16 ch + 4 pad)
+    constexpr int CTW = 4, KS = 8;
+    ENERF_DYN_SMEM(float, lds);
+    float* c0t = lds;                       // [NPX][8]
+    float* pat = c0t + NPX * 8;             // [NPP][16]   (channels of the current pass)
+    float* til = pat + NPP * 16;            // [NPX][TS]
+
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
+    const int bid = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+    const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int H1 = H / 2, W1 = W / 2;
+    const float sy = ac_scale(H1, H), sx = ac_scale(W1, W);
+    const int py0 = (int)(sy * (float)max(iy0, 0)), px0 = (int)(sx * (float)max(ix0, 0));   // patch origin (= lerp i0 of the first row/col)
+
+    // ---- c0 tile -> LDS (zero outside the image) ----
+    for (int i = threadIdx.x; i < NPX * 2; i += 256) {
+        const int px = i >> 1, q = i & 1, ly = px / IW, lx = px - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
+        const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const long long off = ok ? ((long long)n * H + gy) * W + gx : 0;
+        const float4 v = *reinterpret_cast<const float4*>(c0 + off * 8 + q * 4);
+        *reinterpret_cast<float4*>(c0t + i * 4) = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    f32x4 acc[CTW];
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wl = wpk + lane;
+    const int q4 = threadIdx.x & 3;          // this thread's channel quad inside a 16-channel pass (items stride 256)
+
+#pragma unroll 1
+    for (int cb = 0; cb < 2; ++cb) {
+        // weights of the 3x3 conv for this pass, requested first (latency hides behind the tile build)
+        float aq[9][4];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) aq[tap][r] = wl[((long long)tap * KS + cb * 4 + r) * 64];
+        // lat0 rows of this thread's 4 output channels m = cb*16 + q4*4 + (0..3)
+        float lw[4][8], lb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = cb * 16 + q4 * 4 + r;
+            const float4 w0 = *reinterpret_cast<const float4*>(lat_w + m * 8), w1 = *reinterpret_cast<const float4*>(lat_w + m * 8 + 4);
+            lw[r][0] = w0.x; lw[r][1] = w0.y; lw[r][2] = w0.z; lw[r][3] = w0.w;
+            lw[r][4] = w1.x; lw[r][5] = w1.y; lw[r][6] = w1.z; lw[r][7] = w1.w;
+            lb[r] = lat_b[m];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (cb > 0) __syncthreads();          // previous pass done with pat/til
+        // ---- f1pre patch (16 channels of this pass) -> LDS ----
+        for (int i = threadIdx.x; i < NPP * 4; i += 256) {
+            const int pp = i >> 2, q = i & 3, pr = pp / PW, pc = pp - pr * PW;
+            const int gy = min(py0 + pr, H1 - 1), gx = min(px0 + pc, W1 - 1);
+            *reinterpret_cast<float4*>(pat + i * 4) =
+                *reinterpret_cast<const float4*>(f1pre + (((long long)n * H1 + gy) * W1 + gx) * 32 + cb * 16 + q * 4);
+        }
+        __syncthreads();
+        // ---- build the FPN-sum tile: item = (pixel, channel quad) ----
+#pragma unroll 1
+        for (int i = threadIdx.x; i < NPX * 4; i += 256) {
+            const int px = i >> 2, ly = px / IW, lx = px - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const Lerp1 vy = ac_lerp(gy, sy, H1), vx = ac_lerp(gx, sx, W1);
+                const float* p00 = pat + ((vy.i0 - py0) * PW + (vx.i0 - px0)) * 16 + q4 * 4;
+                const float* p01 = pat + ((vy.i0 - py0) * PW + (vx.i1 - px0)) * 16 + q4 * 4;
+                const float* p10 = pat + ((vy.i1 - py0) * PW + (vx.i0 - px0)) * 16 + q4 * 4;
+                const float* p11 = pat + ((vy.i1 - py0) * PW + (vx.i1 - px0)) * 16 + q4 * 4;
+                const float4 u00 = *reinterpret_cast<const float4*>(p00), u01 = *reinterpret_cast<const float4*>(p01);
+                const float4 u10 = *reinterpret_cast<const float4*>(p10), u11 = *reinterpret_cast<const float4*>(p11);
+                const float4 ca = *reinterpret_cast<const float4*>(c0t + px * 8), cbv = *reinterpret_cast<const float4*>(c0t + px * 8 + 4);
+                float lat[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {    // nn.Conv2d(8,32,1): bias + dot (F.conv2d accumulates then adds bias; fp order differs only)
+                    float a = lw[r][0] * ca.x;
+                    a += lw[r][1] * ca.y; a += lw[r][2] * ca.z; a += lw[r][3] * ca.w;
+                    a += lw[r][4] * cbv.x; a += lw[r][5] * cbv.y; a += lw[r][6] * cbv.z; a += lw[r][7] * cbv.w;
+                    lat[r] = a + lb[r];
+                }
+                o.x = ac_blend(vy, vx, u00.x, u01.x, u10.x, u11.x) + lat[0];
+                o.y = ac_blend(vy, vx, u00.y, u01.y, u10.y, u11.y) + lat[1];
+                o.z = ac_blend(vy, vx, u00.z, u01.z, u10.z, u11.z) + lat[2];
+                o.w = ac_blend(vy, vx, u00.w, u01.w, u10.w, u11.w) + lat[3];
+            }
+            *reinterpret_cast<float4*>(til + px * TS + q4 * 4) = o;
+        }
+        __syncthreads();
+        // ---- 3x3 conv, 16 input channels of this pass, on the matrix cores ----
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+            float bv[CTW][4];
+#pragma unroll
+            for (int c = 0; c < CTW; ++c) {
+                const int ct = wv * CTW + c, tr = ct >> 1, tc = ct & 1;
+                const float4 tq = *reinterpret_cast<const float4*>(til + ((tr + kh) * IW + tc * 16 + j + kw) * TS + g * 4);
+                bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < CTW; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[tap][r], bv[c][r], acc[c], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: bias, channels-last / texel store (cout = 8) ----
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+        const int ct = wv * CTW + c, tr = ct >> 1, tc = ct & 1;
+        const int oy = oy0 + tr, ox = ox0 + tc * 16 + j;
+        if (oy >= H || ox >= W) continue;
+        const long long o = ((long long)n * H + oy) * W + ox;
+        const int ch0 = 4 * g;
+        if (ch0 == 8 && rgb_src != nullptr) {
+            const float* sp = rgb_src + (long long)n * 3 * H * W + (long long)oy * W + ox;
+            *reinterpret_cast<float4*>(out + o * out_stride + 8) =
+                make_float4(sp[0] * 0.5f + 0.5f, sp[(long long)H * W] * 0.5f + 0.5f, sp[2LL * H * W] * 0.5f + 0.5f, 0.f);
+        }
+        if (ch0 >= 8) continue;
+        *reinterpret_cast<float4*>(out + o * out_stride + ch0) =
+            make_float4(acc[c][0] * scale[ch0] + shift[ch0], acc[c][1] * scale[ch0 + 1] + shift[ch0 + 1],
+                        acc[c][2] * scale[ch0 + 2] + shift[ch0 + 2], acc[c][3] * scale[ch0 + 3] + shift[ch0 + 3]);
+    }
+}
+
+void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1pre, const float* lat_w, const float* lat_b,
+                          float* out, int N, int H, int W, hipStream_t st) {
+    const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
+    const size_t shmem = (size_t)(340 * 8 + 140 * 16 + 340 * 20) * sizeof(float);
+    const int out_stride = L.out_stride > 0 ? L.out_stride : 8;
+    ENERF_LAUNCH(k_smooth0_fused, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, L.w, L.scale, L.shift, c0, f1pre, lat_w,
+                 lat_b, out, L.rgb_src, out_stride, N, H, W, tiles_y, tiles_x);
+}
+
 // The eleven FeatureNet layers use exactly these shapes (feature_net.py:7-22).
 int launch_conv2d(const Conv2dDesc& L, const float* in, float* out, const float* up, int N, int Hi, int Wi, int Hc,
                   int Wc, hipStream_t st) {

@@ -63,6 +63,9 @@ void launch_conv2d_pack(const float* w, const float* bias, const float* bn_w, co
 // up (optional): coarser channels-last map (N,Hc,Wc,cout) added after a x2 align-corners bilinear upsample.
 int launch_conv2d(const Conv2dDesc& L, const float* in, float* out, const float* up, int N, int Hi, int Wi, int Hc,
                   int Wc, hipStream_t st);
+// smooth0(up2(f1pre) + lat0(c0)) fused (feature_net.py:32-35); L = smooth0's descriptor, lat_w/lat_b raw (32,8)/(32)
+void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1pre, const float* lat_w, const float* lat_b,
+                          float* out, int N, int H, int W, hipStream_t st);
 // texels from channels-last features at the render resolution + resized colours (general case)
 void launch_pack_texels_cl(const float* feat_cl, int C, const float* src_inps, int H, int W, int Hr, int Wr, int tex,
                            int n_img, float* out, hipStream_t st);

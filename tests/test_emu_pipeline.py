@@ -190,3 +190,13 @@ def test_torch_feature_backend_still_matches(name):
     for k, v in out.items():
         _close(v.numpy(), gold["out/" + k], 2e-5, k)
 
+
+
+def test_unfused_lat0_smooth0_path(monkeypatch):
+    """ENERF_FUSE_LAT0=0 keeps the separate lat0 / smooth0 launches (A/B switch) — same features."""
+    monkeypatch.setenv("ENERF_FUSE_LAT0", "0")
+    name = "tiny_s3"
+    cfg, batch, g = case_config(name), case_batch(name), load_golden(name)
+    net, lib = _net(cfg), emu_lib()
+    _, _, f2, _ = lib.feature_net(net._packed_weights("feature_net"), batch["src_inps"][0].contiguous(), 8)
+    _close(f2.permute(0, 3, 1, 2).numpy(), g["mid/feat_l2"], 5e-6, "feat_l2 unfused")
