@@ -319,3 +319,28 @@ int enerf_pack_texels_cl(const float* feat_cl, int C, const float* src_inps, int
     return check_launch("pack_texels_cl");
 }
 }  // extern "C"
+
+extern "C" {
+int enerf_gen_rays(const float* tar_ext, const float* tar_ixt, int B, int Hr, int Wr, float scale, float* rays,
+                   enerf_stream_t stream) {
+    REQUIRE(tar_ext && tar_ixt && rays && B > 0 && Hr > 0 && Wr > 0 && scale > 0.f, "gen_rays: bad arguments");
+    launch_gen_rays(tar_ext, tar_ixt, B, Hr, Wr, scale, rays, (hipStream_t)stream);
+    return check_launch("gen_rays");
+}
+int enerf_pack_rgb8(const float* rgb, int H, int W, int flip, unsigned char* out, enerf_stream_t stream) {
+    REQUIRE(rgb && out && H > 0 && W > 0, "pack_rgb8: bad arguments");
+    launch_pack_rgb8(rgb, H, W, flip, out, (hipStream_t)stream);
+    return check_launch("pack_rgb8");
+}
+int enerf_eval_stats(const float* pred_rgb, const float* gt_rgb, const int* mask, long long n_rgb,
+                     const float* pred_depth, const float* gt_depth, long long n_depth, double* acc,
+                     enerf_stream_t stream) {
+    REQUIRE(acc && n_rgb >= 0 && n_depth >= 0, "eval_stats: bad arguments");
+    if (n_rgb > 0) REQUIRE(pred_rgb && gt_rgb, "eval_stats: rgb pointers missing");
+    if (n_depth > 0) REQUIRE(pred_depth && gt_depth, "eval_stats: depth pointers missing");
+    hipMemsetAsync(acc, 0, 6 * sizeof(double), (hipStream_t)stream);
+    if (n_rgb + n_depth == 0) return ENERF_OK;
+    launch_eval_stats(pred_rgb, gt_rgb, mask, n_rgb, pred_depth, gt_depth, n_depth, acc, (hipStream_t)stream);
+    return check_launch("eval_stats");
+}
+}  // extern "C"

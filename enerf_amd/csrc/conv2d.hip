@@ -285,7 +285,8 @@ static void launch_c2(const Conv2dDesc& L, const float* in, float* out, const fl
 // and then runs the 3x3 32->8 convolution on the matrix cores exactly like k_conv2d (same packed weights,
 // same texel-mode epilogue).  HBM traffic per frame drops by ~290 MB and one launch disappears.
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_smooth0_fused(const float* __restrict__ wpk, const float* __restrict__ scale,
+__global__ __launch_bounds__(256, 3) void k_smooth0_fused(   // 47 KB LDS -> 3 blocks/CU
+    const float* __restrict__ wpk, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ c0,
                                                        const float* __restrict__ f1pre, const float* __restrict__ lat_w,
                                                        const float* __restrict__ lat_b, float* __restrict__ out,
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(256) void k_smooth0_fused(const float* __restrict__
     float* c0t = lds;                       // [NPX][8]
     float* pat = c0t + NPX * 8;             // [NPP][16]   (channels of the current pass)
     float* til = pat + NPP * 16;            // [NPX][TS]
+    float* lwt = til + NPX * TS;            // lat0 weight (32x8) + bias (32), staged once
 
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
     const int bid = (int)xcd_contiguous(blockIdx.x, gridDim.x);
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(256) void k_smooth0_fused(const float* __restrict__
     const float sy = ac_scale(H1, H), sx = ac_scale(W1, W);
     const int py0 = (int)(sy * (float)max(iy0, 0)), px0 = (int)(sx * (float)max(ix0, 0));   // patch origin (= lerp i0 of the first row/col)
 
+    for (int i = threadIdx.x; i < 288; i += 256) lwt[i] = i < 256 ? lat_w[i] : lat_b[i - 256];
     // ---- c0 tile -> LDS (zero outside the image) ----
     for (int i = threadIdx.x; i < NPX * 2; i += 256) {
         const int px = i >> 1, q = i & 1, ly = px / IW, lx = px - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
@@ -331,16 +334,6 @@ __global__ __launch_bounds__(256) void k_smooth0_fused(const float* __restrict__
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
             for (int r = 0; r < 4; ++r) aq[tap][r] = wl[((long long)tap * KS + cb * 4 + r) * 64];
-        // lat0 rows of this thread's 4 output channels m = cb*16 + q4*4 + (0..3)
-        float lw[4][8], lb[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = cb * 16 + q4 * 4 + r;
-            const float4 w0 = *reinterpret_cast<const float4*>(lat_w + m * 8), w1 = *reinterpret_cast<const float4*>(lat_w + m * 8 + 4);
-            lw[r][0] = w0.x; lw[r][1] = w0.y; lw[r][2] = w0.z; lw[r][3] = w0.w;
-            lw[r][4] = w1.x; lw[r][5] = w1.y; lw[r][6] = w1.z; lw[r][7] = w1.w;
-            lb[r] = lat_b[m];
-        }
         __builtin_amdgcn_sched_barrier(0);
         if (cb > 0) __syncthreads();          // previous pass done with pat/til
         // ---- f1pre patch (16 channels of this pass) -> LDS ----
@@ -367,11 +360,13 @@ __global__ __launch_bounds__(256) void k_smooth0_fused(const float* __restrict__
                 const float4 ca = *reinterpret_cast<const float4*>(c0t + px * 8), cbv = *reinterpret_cast<const float4*>(c0t + px * 8 + 4);
                 float lat[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {    // nn.Conv2d(8,32,1): bias + dot (F.conv2d accumulates then adds bias; fp order differs only)
-                    float a = lw[r][0] * ca.x;
-                    a += lw[r][1] * ca.y; a += lw[r][2] * ca.z; a += lw[r][3] * ca.w;
-                    a += lw[r][4] * cbv.x; a += lw[r][5] * cbv.y; a += lw[r][6] * cbv.z; a += lw[r][7] * cbv.w;
-                    lat[r] = a + lb[r];
+                for (int r = 0; r < 4; ++r) {    // nn.Conv2d(8,32,1): dot + bias; weights from LDS (4 distinct rows per wave: broadcast reads)
+                    const int m = cb * 16 + q4 * 4 + r;
+                    const float4 w0 = *reinterpret_cast<const float4*>(lwt + m * 8), w1 = *reinterpret_cast<const float4*>(lwt + m * 8 + 4);
+                    float a = w0.x * ca.x;
+                    a += w0.y * ca.y; a += w0.z * ca.z; a += w0.w * ca.w;
+                    a += w1.x * cbv.x; a += w1.y * cbv.y; a += w1.z * cbv.z; a += w1.w * cbv.w;
+                    lat[r] = a + lwt[256 + m];
                 }
                 o.x = ac_blend(vy, vx, u00.x, u01.x, u10.x, u11.x) + lat[0];
                 o.y = ac_blend(vy, vx, u00.y, u01.y, u10.y, u11.y) + lat[1];
@@ -423,7 +418,7 @@ __global__ __launch_bounds__(256) void k_smooth0_fused(const float* __restrict__
 void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1pre, const float* lat_w, const float* lat_b,
                           float* out, int N, int H, int W, hipStream_t st) {
     const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
-    const size_t shmem = (size_t)(340 * 8 + 140 * 16 + 340 * 20) * sizeof(float);
+    const size_t shmem = (size_t)(340 * 8 + 140 * 16 + 340 * 20 + 288) * sizeof(float);
     const int out_stride = L.out_stride > 0 ? L.out_stride : 8;
     ENERF_LAUNCH(k_smooth0_fused, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, L.w, L.scale, L.shift, c0, f1pre, lat_w,
                  lat_b, out, L.rgb_src, out_stride, N, H, W, tiles_y, tiles_x);

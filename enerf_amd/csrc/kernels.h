@@ -70,6 +70,13 @@ void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1p
 void launch_pack_texels_cl(const float* feat_cl, int C, const float* src_inps, int H, int W, int Hr, int Wr, int tex,
                            int n_img, float* out, hipStream_t st);
 
+// ---- io.hip (the steps before/after the path: SURVEY.md 8f rows 3,4) --------------------------------
+void launch_gen_rays(const float* tar_ext, const float* tar_ixt, int B, int Hr, int Wr, float scale, float* rays,
+                     hipStream_t st);
+void launch_pack_rgb8(const float* rgb, int H, int W, int flip, unsigned char* out, hipStream_t st);
+void launch_eval_stats(const float* pred_rgb, const float* gt_rgb, const int* mask, long long n_rgb,
+                       const float* pred_depth, const float* gt_depth, long long n_depth, double* acc, hipStream_t st);
+
 // ---- render.hip ---------------------------------------------------------------------------------
 using NerfRaw = enerf_nerf_raw_t;     // torch-layout parameter pointers of one NeRF (nerf.py:6-89)
 long long nerf_packed_floats(int feat_ch_plus3);

@@ -71,6 +71,9 @@ _SIGNATURES = {
     "enerf_nerf_packed_floats": (_ll, [_i]),
     "enerf_nerf_pack": (_i, [C.POINTER(NerfRaw), _i, _i, _f, _f]),
     "enerf_render_rays": (_i, [C.POINTER(RenderArgs), _f]),
+    "enerf_gen_rays": (_i, [_f, _f, _i, _i, _i, _fl, _f, _f]),
+    "enerf_pack_rgb8": (_i, [_f, _i, _i, _i, _f, _f]),
+    "enerf_eval_stats": (_i, [_f, _f, _f, _ll, _f, _f, _ll, _f, _f]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -256,6 +259,40 @@ class EnerfLib:
                        Wr, F, D, h, w, int(white_bkgd), float(render_scale))
         self._check(self.dll.enerf_render_rays(C.byref(a), self.stream_of(rays12)), "render_rays")
         return rgb, depth, weights
+
+
+    # -- the steps before / after the path ---------------------------------
+    def gen_rays(self, tar_ext, tar_ixt, Hr, Wr, scale):
+        """lib/datasets/enerf_utils.py:61-71 (full image) on device -> (B, Hr*Wr, 8)."""
+        B = tar_ext.shape[0]
+        rays = torch.empty((B, Hr * Wr, 8), dtype=torch.float32, device=tar_ext.device)
+        self._check(self.dll.enerf_gen_rays(_ptr(tar_ext), _ptr(tar_ixt), B, Hr, Wr, float(scale), _ptr(rays),
+                                            self.stream_of(rays)), "gen_rays")
+        return rays
+
+    def pack_rgb8(self, rgb, H, W, flip=True):
+        """gui_human.py:88-91: (H*W,3) float in [0,1] -> (H,W,3) uint8, vertically flipped for GL."""
+        out = torch.empty((H, W, 3), dtype=torch.uint8, device=rgb.device)
+        self._check(self.dll.enerf_pack_rgb8(_ptr(rgb), H, W, int(flip), out.data_ptr(), self.stream_of(rgb)),
+                    "pack_rgb8")
+        return out
+
+    def eval_stats(self, pred_rgb, gt_rgb, mask=None, pred_depth=None, gt_depth=None):
+        """evaluators/enerf.py:67-71,88-103 on device -> dict(psnr, abs, acc_2, acc_10); one 48-byte D2H copy."""
+        acc = torch.empty((6,), dtype=torch.float64, device=pred_rgb.device)
+        n_rgb = pred_rgb.numel() // 3
+        if mask is not None and (mask.dtype != torch.int32 or not mask.is_contiguous()):
+            raise EnerfError("mask must be a contiguous int32 tensor")
+        n_d = 0 if pred_depth is None else pred_depth.numel()
+        self._check(self.dll.enerf_eval_stats(_ptr(pred_rgb), _ptr(gt_rgb), None if mask is None else mask.data_ptr(),
+                                              n_rgb, _ptr(pred_depth), _ptr(gt_depth), n_d, acc.data_ptr(),
+                                              self.stream_of(pred_rgb)), "eval_stats")
+        a = acc.cpu().tolist()
+        import math
+        out = {"psnr": 10.0 * math.log10(a[1] / a[0]) if a[0] > 0 else float("inf")}
+        if n_d and a[3] > 0:
+            out.update(abs=a[2] / a[3], acc_2=a[4] / a[3], acc_10=a[5] / a[3])
+        return out
 
 
 _LIB: Optional[EnerfLib] = None

@@ -151,6 +151,20 @@ typedef struct {
 } enerf_render_args_t;
 int enerf_render_rays(const enerf_render_args_t* args, enerf_stream_t stream);
 
+/* ---- the steps before / after the path ----
+ * enerf_gen_rays: full-image rays of lib/datasets/enerf_utils.py:61-71 on device.  tar_ext (B,4,4),
+ *   tar_ixt (B,3,3); rays (B,Hr*Wr,8) = [o, d, x, y] at intrinsics scaled by `scale`.
+ * enerf_pack_rgb8: gui_human.py:88-91 (x255, uint8, optional vertical flip); rgb (H*W,3) -> out (H,W,3) bytes.
+ * enerf_eval_stats: evaluators/enerf.py:67-71,88-103.  acc (6 doubles, zeroed by this call):
+ *   {sum sq rgb err over mask==1 (x3 ch), its count, sum |depth-gt| over gt!=0, count, #(<2), #(<10)};
+ *   mask may be NULL (all pixels); pass n_depth = 0 to skip the depth part. */
+int enerf_gen_rays(const float* tar_ext, const float* tar_ixt, int B, int Hr, int Wr, float scale, float* rays,
+                   enerf_stream_t stream);
+int enerf_pack_rgb8(const float* rgb, int H, int W, int flip, unsigned char* out, enerf_stream_t stream);
+int enerf_eval_stats(const float* pred_rgb, const float* gt_rgb, const int* mask, long long n_rgb,
+                     const float* pred_depth, const float* gt_depth, long long n_depth, double* acc,
+                     enerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

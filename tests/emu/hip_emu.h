@@ -258,6 +258,18 @@ inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x
 }
 
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
+inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
+inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
+inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
+inline double atomicAdd(double* p, double v) {          // blocks run on several OS threads: real atomic
+    uint64_t* u = reinterpret_cast<uint64_t*>(p);
+    uint64_t old = __atomic_load_n(u, __ATOMIC_RELAXED), neu;
+    double od;
+    do { memcpy(&od, &old, 8); double nd = od + v; memcpy(&neu, &nd, 8);
+    } while (!__atomic_compare_exchange_n(u, &old, neu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    return od;
+}
 
 #define ENERF_LAUNCH(kern, grid, block, shmem, stream, ...) \
     emu::launch(true, dim3(grid), dim3(block), (size_t)(shmem), [&]() { kern(__VA_ARGS__); })
