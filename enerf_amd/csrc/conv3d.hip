@@ -357,8 +357,15 @@ const float* __restrict__ wpk, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ in,
                                                        float* __restrict__ out, float* __restrict__ out2, int cout,
                                                        int relu, int B, int D, int H, int W, int nbd, int nbh, int nbw,
-                                                       int xcd_swizzle) {
+                                                       int xcd_swizzle, int dbg, int stagger) {
     constexpr int BH = 8, BW = 16;
+    // Two identical blocks share a CU (LDS-limited) and, sharing the MFMA pipe fairly, stay in lockstep:
+    // both stage, both compute, both store at the same time, so the ~20 us of non-MFMA work never hides
+    // (phase ablation: 70 us MFMA + 23 us rest = 93 us).  Delaying the second block of each CU once by
+    // about one MFMA phase makes them ping-pong; later blocks inherit the offset.  The "second block" is
+    // guessed from the dispatch order (block b -> XCD b%8, 32 CUs per XCD filled round-robin): speed only.
+    if (stagger > 0 && ((blockIdx.x >> 3) >> 5) == 1)
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
     constexpr int CB = CIN >= 16 ? 16 : CIN;          // channels staged per pass
     constexpr int CPL = CB / 4;                         // channels per lane per LDS read
     constexpr int NCB = CIN / CB;
@@ -424,7 +431,8 @@ const float* __restrict__ wpk, const float* __restrict__ scale,
                 const int gx = x0 + dx - 1, gy = y0 + dy - 1, gz = z0 + dz - 1;
                 sk[it] = gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
                 const long long off = sk[it] ? (((long long)gz * H + gy) * W + gx) : 0;
-                sv[it] = *reinterpret_cast<const float4*>(inb + off * CIN + cb * CB + q * 4);
+                sv[it] = (dbg & 1) ? make_float4(1.f, 1.f, 1.f, 1.f)      // profiling aid: no staging loads
+                                   : *reinterpret_cast<const float4*>(inb + off * CIN + cb * CB + q * 4);
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -434,6 +442,7 @@ const float* __restrict__ wpk, const float* __restrict__ scale,
             }
         }
         __syncthreads();
+        if (dbg & 2) continue;                           // profiling aid: staging only, no MFMA phase
 
         const float* lbase[CTW];                        // this lane's voxel (tap 0,0,0) in each of its column tiles
 #pragma unroll
@@ -515,7 +524,8 @@ static void launch_s1_lds(const Conv3dDesc& L, const float* in, float* out, floa
     const unsigned grid = (unsigned)((long long)B * nbd * nbh * nbw);
     const char* e = getenv("ENERF_XCD_SWIZZLE");
     ENERF_LAUNCH((k_conv3d_s1_lds<CIN, RT, BD>), grid, 256, shmem, st, L.w, L.scale, L.shift, in, out, out2, L.cout,
-                 L.relu, B, D, H, W, nbd, nbh, nbw, e ? atoi(e) : 1);
+                 L.relu, B, D, H, W, nbd, nbh, nbw, e ? atoi(e) : 1, getenv("ENERF_CONV_DBG") ? atoi(getenv("ENERF_CONV_DBG")) : 0,
+                 getenv("ENERF_STAGGER") ? atoi(getenv("ENERF_STAGGER")) : 0);
 }
 template <int CIN>
 static bool dispatch_s1_lds(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,

@@ -258,6 +258,7 @@ inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x
 }
 
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_s_sleep(int) {}
 inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
 inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
 inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
