@@ -555,6 +555,16 @@ static long long conv_v2_min_vox() {
 
 void launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, float* out, float* out2, int B, int Di,
                    int Hi, int Wi, hipStream_t st) {
+    // tap-packed path for the Cout=8 stride-1 layers (conv0 of both levels, fused heads): 2/3 of the MFMAs
+    {
+        const char* e = getenv("ENERF_CONV_PK8");
+        if ((e == nullptr || e[0] != '0') && residual == nullptr && conv_v2_enabled() &&
+            (long long)B * Di * Hi * Wi >= conv_v2_min_vox() && launch_conv3d_pk8(L, in, out, out2, B, Di, Hi, Wi, st)) {
+            if (getenv("ENERF_TRACE")) fprintf(stderr, "[enerf] conv3d %d->%d vox=%lld : pk8\n", L.cin, L.cout,
+                                               (long long)B * Di * Hi * Wi);
+            return;
+        }
+    }
     // LDS-staged path: stride-1 layers with enough voxels to fill the chip and cout <= 32
     if (L.kind == kConvS1 && residual == nullptr && conv_v2_enabled() && L.cout <= 32 &&
         (long long)B * Di * Hi * Wi >= conv_v2_min_vox()) {

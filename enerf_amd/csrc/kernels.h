@@ -31,7 +31,13 @@ struct Conv3dDesc {
     const float* scale;     // per-cout epilogue scale (BN folded; 1 without BN), padded to 16*row tiles
     const float* shift;     // per-cout epilogue shift (0 without BN)
     int cin, cout, kind, relu;
+    const float* w_pk8;     // tap-packed image for stride-1 cout=8(+1) layers (conv3d_pk8.hip) or nullptr
 };
+// tap-packed variant for cout = 8 (+ optional depth row): see conv3d_pk8.hip
+long long conv3d_pk8_packed_floats(int cin);
+void launch_conv3d_pk8_pack(const float* w, const float* wd, int cin, float* packed, hipStream_t st);
+bool launch_conv3d_pk8(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,
+                       hipStream_t st);
 // number of floats of the packed weight image for a layer
 long long conv3d_packed_floats(int cin, int cout, int kind);
 // pack torch-layout weights (Conv3d: (cout,cin,3,3,3); ConvTranspose3d: (cin,cout,3,3,3)) + BN into
