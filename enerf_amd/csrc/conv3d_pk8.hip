@@ -196,6 +196,11 @@ static void launch_pk8(const Conv3dDesc& L, const float* in, float* out, float* 
 bool launch_conv3d_pk8(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,
                        hipStream_t st) {
     if (L.w_pk8 == nullptr || L.kind != kConvS1 || !(L.cout == 8 || (L.cout == 9 && out2 != nullptr))) return false;
+    // Measured on MI355X (same box, rocprofv3): Cin=16 conv0 80-88 us vs 94 us for the plain LDS kernel; Cin=32
+    // conv0 and the Cin=8 heads are no faster (fewer MFMAs, but 14/16 column efficiency, 15 % more blocks and a
+    // heavier epilogue eat the gain), so by default only Cin=16 takes this path.  ENERF_CONV_PK8=2 forces all.
+    const char* e = getenv("ENERF_CONV_PK8");
+    if (!(e && e[0] == '2') && L.cin != 16) return false;
     const bool bd4 = (D % 4 == 0);
     switch (L.cin) {
         case 8: bd4 ? launch_pk8<8, 4>(L, in, out, out2, B, D, H, W, st) : launch_pk8<8, 2>(L, in, out, out2, B, D, H, W, st); return true;

@@ -152,7 +152,7 @@ def test_conv3d_variants_agree_with_reference(force, monkeypatch):
         monkeypatch.setenv("ENERF_CONV_V1", "1")
     else:
         monkeypatch.setenv("ENERF_CONV_V2_MIN_VOX", "0")
-        monkeypatch.setenv("ENERF_CONV_PK8", "1" if force == "pk8" else "0")   # tap-packed Cout=8 kernel on/off
+        monkeypatch.setenv("ENERF_CONV_PK8", "2" if force == "pk8" else "0")   # tap-packed Cout=8 kernel: all layers / off
     name = "small_s3_eval"
     cfg, batch, gold = case_config(name), case_batch(name), load_golden(name)
     out = _net(cfg)(batch)
