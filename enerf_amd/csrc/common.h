@@ -18,11 +18,29 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ENERF_DYN_SMEM(type, name) \
     extern __shared__ __attribute__((aligned(16))) char enerf_dyn_smem_[]; \
     type* name = reinterpret_cast<type*>(enerf_dyn_smem_)
+// make a VGPR value opaque to the optimiser (stops loop-invariant hoisting of everything derived from it)
+#define ENERF_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#endif
+#ifdef ENERF_EMU
+#define ENERF_OPAQUE_V(x) (void)(x)
 #endif
 
 #include <stdint.h>
 
 namespace enerf {
+
+// ReLU as ONE v_max_f32.  fmaxf(x, 0.f) compiles to two (hipcc first canonicalises x with v_max_f32 x, x
+// because the kernels run in IEEE mode); on MFMA outputs that doubled the ~110 ReLUs per 16 points of the
+// render kernel.  Like fmaxf, a NaN input yields 0.
+__device__ __forceinline__ float relu1(float x) {
+#if defined(ENERF_EMU) || defined(ENERF_NO_RELU_ASM)
+    return fmaxf(x, 0.f);
+#else
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
+#endif
+}
 
 constexpr int kWave = 64;
 
@@ -79,12 +97,31 @@ struct Taps2 {
     int x0, x1, y0, y1;
     float w00, w01, w10, w11;  // (y0,x0) (y0,x1) (y1,x0) (y1,x1)
 };
+// 24-bit integer multiply (full-rate v_mul_u32_u24; v_mul_lo_u32 is quarter rate).  Only for operands that are
+// image/volume coordinates and extents (< 2^24, launchers check) with a product < 2^32.
+__device__ __forceinline__ int mul24(int a, int b) {
+#ifdef ENERF_EMU
+    return a * b;
+#else
+    return __mul24(a, b);
+#endif
+}
+
 template <bool BORDER>
 __host__ __device__ __forceinline__ Taps2 gs_taps2(float ix, float iy, int W, int H) {
     Taps2 t;
-    if (BORDER) {  // clip_coordinates: min(size-1, max(ix, 0))
+    if (BORDER) {  // clip_coordinates: min(size-1, max(ix, 0)); fmaxf maps NaN to 0 like ATen's ::max
         ix = fminf((float)(W - 1), fmaxf(ix, 0.f));
         iy = fminf((float)(H - 1), fmaxf(iy, 0.f));
+        // After clipping every tap is inside the image except x1 == W (y1 == H), which only happens at
+        // ix == W-1 where its weight is exactly 0: no validity tests, one clamp per axis.
+        const float fx = floorf(ix), fy = floorf(iy);
+        t.x0 = (int)fx; t.y0 = (int)fy;
+        t.x1 = t.x0 + 1 < W ? t.x0 + 1 : W - 1;
+        t.y1 = t.y0 + 1 < H ? t.y0 + 1 : H - 1;
+        const float tx1 = ix - fx, ty1 = iy - fy, tx0 = (fx + 1.f) - ix, ty0 = (fy + 1.f) - iy;
+        t.w00 = tx0 * ty0; t.w01 = tx1 * ty0; t.w10 = tx0 * ty1; t.w11 = tx1 * ty1;
+        return t;
     }
     // guard against NaN / huge values before the float->int conversion (result is then all-zero taps)
     bool finite = (ix > -1e8f) && (ix < 1e8f) && (iy > -1e8f) && (iy < 1e8f);

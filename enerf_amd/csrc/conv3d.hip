@@ -555,6 +555,16 @@ static long long conv_v2_min_vox() {
 
 void launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, float* out, float* out2, int B, int Di,
                    int Hi, int Wi, hipStream_t st) {
+    // persistent producer/consumer kernel (conv3d_ws.hip); ENERF_CONV_WS=1 routes every eligible layer through it
+    {
+        const char* e = getenv("ENERF_CONV_WS");
+        if (e != nullptr && e[0] == '1' && residual == nullptr && conv_v2_enabled() &&
+            (long long)B * Di * Hi * Wi >= conv_v2_min_vox() && launch_conv3d_ws(L, in, out, out2, B, Di, Hi, Wi, st)) {
+            if (getenv("ENERF_TRACE")) fprintf(stderr, "[enerf] conv3d %d->%d vox=%lld : ws\n", L.cin, L.cout,
+                                               (long long)B * Di * Hi * Wi);
+            return;
+        }
+    }
     // tap-packed path for the Cout=8 stride-1 layers (conv0 of both levels, fused heads): 2/3 of the MFMAs
     {
         const char* e = getenv("ENERF_CONV_PK8");

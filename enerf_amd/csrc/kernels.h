@@ -36,6 +36,8 @@ struct Conv3dDesc {
 // tap-packed variant for cout = 8 (+ optional depth row): see conv3d_pk8.hip
 long long conv3d_pk8_packed_floats(int cin);
 void launch_conv3d_pk8_pack(const float* w, const float* wd, int cin, float* packed, hipStream_t st);
+bool launch_conv3d_ws(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,
+                      hipStream_t st);   // persistent producer/consumer variant, cout <= 16 (conv3d_ws.hip)
 bool launch_conv3d_pk8(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,
                        hipStream_t st);
 // number of floats of the packed weight image for a layer

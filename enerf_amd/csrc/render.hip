@@ -140,7 +140,7 @@ __device__ __forceinline__ f32x4 lds4(const float* p) {     // 16-byte aligned L
     return f32x4{t.x, t.y, t.z, t.w};
 }
 __device__ __forceinline__ f32x4 relu4(f32x4 a) {
-    return f32x4{fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f)};
+    return f32x4{relu1(a[0]), relu1(a[1]), relu1(a[2]), relu1(a[3])};
 }
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b, float acc) {
     acc += a[0] * b[0]; acc += a[1] * b[1]; acc += a[2] * b[2]; acc += a[3] * b[3];
@@ -204,8 +204,10 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
         const float rn = q2.x, rf = q2.y, vn = q2.z, vf = q2.w;
         // normalised (x,y) of the ray inside the feature volume: network.py:37 then utils.py:457
         const float gxv = (ru / (float)(a.Wr - 1)) * 2.f - 1.f, gyv = (rv / (float)(a.Hr - 1)) * 2.f - 1.f;
-        const float* volb = a.vol + (long long)b * a.D * a.h * a.w * 8 + 2 * g;
-        const float* texb = a.tex + (long long)b * S * a.Hr * a.Wr * TEX + g * R;
+        // 32-bit element offsets from the (uniform) tensor bases: one saddr+voffset load per tap instead of a
+        // 64-bit pointer add per tap (the launcher checks both tensors hold < 2^32 floats)
+        const unsigned voff = (unsigned)b * (unsigned)(a.D * a.h * a.w * 8) + 2u * g;
+        const unsigned toff = (unsigned)b * (unsigned)(S * a.Hr * a.Wr * TEX) + (unsigned)(g * R);
         const float rcpW = fast_rcp((float)(a.Wr - 1)), rcpH = fast_rcp((float)(a.Hr - 1));
         const int view_stride = a.Hr * a.Wr * TEX;     // < 2^31 floats (checked by the launcher)
         const float* camb = cam + (long long)b * S * kCamStride;
@@ -233,24 +235,36 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
                                    : (z - vn) * fast_rcp(clamp_min(vf - vn, 1e-6f));
 
             // ---------- voxel feature: trilinear, zeros padding (utils.py:457) ----------
+            // Per axis: two corner indices clamped for addressing, corner weights zeroed outside the volume
+            // (zeros padding); the 8 taps are products/sums of those.  Non-finite coordinates -> all-zero taps.
             float vox[2] = {0.f, 0.f};
             {
                 float ix = gs_unnorm(gxv, a.w), iy = gs_unnorm(gyv, a.h), iz = gs_unnorm(dn * 2.f - 1.f, a.D);
-                bool fin = (ix > -1e8f) && (ix < 1e8f) && (iy > -1e8f) && (iy < 1e8f) && (iz > -1e8f) && (iz < 1e8f);
-                if (!fin) { ix = iy = iz = -10.f; }
-                float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-                int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-                float wx1 = ix - fx, wy1 = iy - fy, wz1 = iz - fz;
-                float wx0 = (float)(x0 + 1) - ix, wy0 = (float)(y0 + 1) - iy, wz0 = (float)(z0 + 1) - iz;
+                ix = fabsf(ix) < 1e8f ? ix : -10.f;
+                iy = fabsf(iy) < 1e8f ? iy : -10.f;
+                iz = fabsf(iz) < 1e8f ? iz : -10.f;
+                const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+                const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+                float wx[2] = {(fx + 1.f) - ix, ix - fx}, wy[2] = {(fy + 1.f) - iy, iy - fy}, wz[2] = {(fz + 1.f) - iz, iz - fz};
+                int xo[2], yo[2], zo[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int xx = x0 + c, yy = y0 + c, zc = z0 + c;
+                    wx[c] = (unsigned)xx < (unsigned)a.w ? wx[c] : 0.f;
+                    wy[c] = (unsigned)yy < (unsigned)a.h ? wy[c] : 0.f;
+                    wz[c] = (unsigned)zc < (unsigned)a.D ? wz[c] : 0.f;
+                    xo[c] = min(max(xx, 0), a.w - 1);
+                    yo[c] = mul24(min(max(yy, 0), a.h - 1), a.w);
+                    zo[c] = mul24(min(max(zc, 0), a.D - 1), a.h * a.w);
+                }
+                float wxy[4];                         // (wx*wy)*wz: ATen's association
+#pragma unroll
+                for (int c = 0; c < 4; ++c) wxy[c] = wx[c & 1] * wy[c >> 1];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {           // order tnw,tne,tsw,tse,bnw,bne,bsw,bse
-                    int xx = x0 + (c & 1), yy = y0 + ((c >> 1) & 1), zc = z0 + (c >> 2);
-                    float wgt = ((c & 1) ? wx1 : wx0) * (((c >> 1) & 1) ? wy1 : wy0) * ((c >> 2) ? wz1 : wz0);
-                    bool ok = xx >= 0 && xx < a.w && yy >= 0 && yy < a.h && zc >= 0 && zc < a.D;
-                    // unconditional load from the clamped voxel, zero weight when outside (zeros padding)
-                    int xc = min(max(xx, 0), a.w - 1), yc = min(max(yy, 0), a.h - 1), zk = min(max(zc, 0), a.D - 1);
-                    float2 t = *reinterpret_cast<const float2*>(volb + ((zk * a.h + yc) * a.w + xc) * 8);
-                    wgt = ok ? wgt : 0.f;
+                    const float wgt = wxy[c & 3] * wz[c >> 2];
+                    const unsigned vo = (unsigned)(zo[c >> 2] + yo[(c >> 1) & 1] + xo[c & 1]) * 8u + voff;
+                    const float2 t = *reinterpret_cast<const float2*>(a.vol + vo);
                     vox[0] += t.x * wgt;
                     vox[1] += t.y * wgt;
                 }
@@ -270,11 +284,12 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
                 float rz = fast_rcp(clamp_min(pz, 1e-6f));
                 float gx = ((px * rz) * rcpW) * 2.f - 1.f, gy = ((py * rz) * rcpH) * 2.f - 1.f;
                 Taps2 t = gs_taps2<true>(gs_unnorm(gx, a.Wr), gs_unnorm(gy, a.Hr), a.Wr, a.Hr);
-                const float* tb = texb + s * view_stride;
-                const float* p00 = tb + (t.y0 * a.Wr + t.x0) * TEX;
-                const float* p01 = tb + (t.y0 * a.Wr + t.x1) * TEX;
-                const float* p10 = tb + (t.y1 * a.Wr + t.x0) * TEX;
-                const float* p11 = tb + (t.y1 * a.Wr + t.x1) * TEX;
+                const unsigned tb = toff + (unsigned)(s * view_stride);
+                const int r0 = mul24(t.y0, a.Wr), r1 = mul24(t.y1, a.Wr);
+                const float* p00 = a.tex + (tb + (unsigned)mul24(r0 + t.x0, TEX));
+                const float* p01 = a.tex + (tb + (unsigned)mul24(r0 + t.x1, TEX));
+                const float* p10 = a.tex + (tb + (unsigned)mul24(r1 + t.x0, TEX));
+                const float* p11 = a.tex + (tb + (unsigned)mul24(r1 + t.x1, TEX));
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     float acc = p00[r] * t.w00;
@@ -307,7 +322,7 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
                     va[t] = ENERF_MFMA(wlane[L.view + t * 64], dsel[s], va[t]);
                 }
 #pragma unroll
-                for (int r = 0; r < R; ++r) av[s][r] = x[s][r] + fmaxf(va[r >> 2][r & 3], 0.f);
+                for (int r = 0; r < R; ++r) av[s][r] = x[s][r] + relu1(va[r >> 2][r & 3]);
             }
             float var[R], mean[R];
 #pragma unroll
@@ -346,7 +361,7 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
                         gf[s][u] = ENERF_MFMA(wlane[L.glob + (((0 * R + r) * 2 + u) << 6)], av[s][r], gf[s][u]);
                 gf[s][0] = relu4(gf[s][0]); gf[s][1] = relu4(gf[s][1]);
                 float part = dot4(gf[s][1], aggw1, dot4(gf[s][0], aggw0, 0.f));
-                aw[s] = fmaxf(group_sum(part) + aggb, 0.f);
+                aw[s] = relu1(group_sum(part) + aggb);
             }
             {   // softmax over views
                 float m = aw[0];
@@ -418,7 +433,7 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
                 float part = 0.f;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) part = dot4(relu4(cc[v]), lds4(wl + L.col2 + v * 16 + 4 * g), part);
-                cl[s] = fmaxf(group_sum(part) + c2b, 0.f);
+                cl[s] = relu1(group_sum(part) + c2b);
             }
             {   // softmax over views (nerf.py:41)
                 float m = cl[0];
@@ -502,7 +517,10 @@ int launch_render_rays(const RenderArgs& a, hipStream_t st) {
     const int R = (a.F + 3) / 4;
     size_t shmem = ((size_t)nerf_layout(a.F).total + (size_t)a.B * a.S * kCamStride + (size_t)a.B * 3) * sizeof(float);
     if (shmem > 64 * 1024) return -2;
-    if ((long long)a.S * a.Hr * a.Wr * 4 * R >= (1LL << 31) || (long long)a.D * a.h * a.w * 8 >= (1LL << 31)) return -5;
+    // 32-bit element offsets and 24-bit index multiplies inside the kernel
+    if ((long long)a.B * a.S * a.Hr * a.Wr * 4 * R >= (1LL << 32) || (long long)a.B * a.D * a.h * a.w * 8 >= (1LL << 32) ||
+        (long long)a.Hr * a.Wr >= (1LL << 23) || (long long)a.h * a.w >= (1LL << 23) || a.D >= (1 << 23))
+        return -5;
     long long ntiles = cdivl((long long)a.B * a.N, 16);
     long long blocks = cdivl(ntiles, 4);
     // Persistent waves: the weight image (40-56 KB) is staged into LDS once per block, so launch only as

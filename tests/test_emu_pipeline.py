@@ -144,7 +144,7 @@ def test_empty_ray_list():
     assert out["rgb"].shape == (1, 0, 3) and out["weights"].shape == (1, 0, 2)
 
 
-@pytest.mark.parametrize("force", ["v1", "v2", "pk8"])
+@pytest.mark.parametrize("force", ["v1", "v2", "pk8", "ws", "ws4"])
 def test_conv3d_variants_agree_with_reference(force, monkeypatch):
     """Both conv3d code paths (global-load V1 incl. the row-split small-layer form, LDS-staged V2) on a
     case whose volumes are not multiples of the 8x16 LDS box (h,w = 16,24 / 8,12 / 4,6)."""
@@ -153,6 +153,10 @@ def test_conv3d_variants_agree_with_reference(force, monkeypatch):
     else:
         monkeypatch.setenv("ENERF_CONV_V2_MIN_VOX", "0")
         monkeypatch.setenv("ENERF_CONV_PK8", "2" if force == "pk8" else "0")   # tap-packed Cout=8 kernel: all layers / off
+        if force.startswith("ws"):                                              # persistent producer/consumer kernel
+            monkeypatch.setenv("ENERF_CONV_WS", "1")
+            monkeypatch.setenv("ENERF_CONV_WS_BD", "4" if force == "ws4" else "2")
+            monkeypatch.setenv("ENERF_CONV_WS_BLOCKS", "3")                     # several boxes per persistent block
     name = "small_s3_eval"
     cfg, batch, gold = case_config(name), case_batch(name), load_golden(name)
     out = _net(cfg)(batch)

@@ -3,7 +3,7 @@ import re, subprocess, sys, os
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "enerf_amd", "csrc")
 files = sys.argv[1:] or ["geometry", "volume", "conv3d", "render"]
 for f in files:
-    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast",
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "-fno-slp-vectorize",
                           "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, f + ".hip"), "-o", "/dev/null"],
                          capture_output=True, text=True).stderr
     cur = {}
