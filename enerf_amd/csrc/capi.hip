@@ -94,6 +94,10 @@ int enerf_build_feature_volume(const float* feat, const float* proj, const float
     REQUIRE(feat && proj && depth_values && vol, "build_feature_volume: null pointer");
     REQUIRE(C == 8 || C == 16 || C == 32, "build_feature_volume: C=%d unsupported (8/16/32)", C);
     REQUIRE(B > 0 && S > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0, "build_feature_volume: bad shape");
+    REQUIRE((long long)B * S * Hs * Ws * C < (1LL << 32) && (long long)Hs * Ws < (1LL << 23),
+            "build_feature_volume: source features too large for 32-bit gather offsets");
+    REQUIRE((long long)B * D * h * w * (C / 4) < (1LL << 31) && (long long)h * w < (1LL << 23),
+            "build_feature_volume: volume too large for 32-bit voxel indices");
     launch_feature_volume(feat, proj, depth_values, B, S, C, Hs, Ws, D, h, w, vol, (hipStream_t)stream);
     return check_launch("build_feature_volume");
 }

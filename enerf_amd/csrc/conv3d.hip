@@ -112,6 +112,28 @@ void launch_conv3d_pack(const float* w, const float* w2, int cout1, const float*
                         cout, kind, packed, scale, shift);
 }
 
+// 256 B of zeros: loads of padding taps are pointed here (any CIN <= 64 floats from a lane's channel offset)
+__device__ float g_conv_zeros[128];
+
+// Input-voxel offset (per axis, relative to the tile's tap-(0,0,0) voxel) of tap t.
+//   conv (stride 1/2): t = (kd*3+kh)*3+kw, offsets = (kd,kh,kw).
+//   convT stride 2: parity class (pd,ph,pw) has (1+pd)(1+ph)(1+pw) taps, offset dq in {0,1} per axis.
+template <int KIND>
+__device__ __forceinline__ void tap_offsets(int t, int ntw, int nth, int pd, int ph, int pw, int& od, int& oh, int& ow) {
+    if (KIND == kConvT2) {
+        const int tw = (ntw == 2) ? (t & 1) : 0;
+        const int t2 = (ntw == 2) ? (t >> 1) : t;
+        const int th = (nth == 2) ? (t2 & 1) : 0;
+        const int td = (nth == 2) ? (t2 >> 1) : t2;
+        int k;
+        convt_axis(pd, td, k, od);
+        convt_axis(ph, th, k, oh);
+        convt_axis(pw, tw, k, ow);
+    } else {
+        ow = t % 3; oh = (t / 3) % 3; od = t / 9;
+    }
+}
+
 // ---- the implicit-GEMM kernel ---------------------------------------------------------------------
 // CIN: input channels (8,16,32,64); RT: cout row tiles of 16; KIND; CT: 16-voxel column tiles per wave.
 template <int CIN, int RT, int KIND, int CT>
@@ -128,21 +150,23 @@ __global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, c
     // a wave owns RT of the layer's rt_total row tiles (output-channel tiles of 16): tiny deep layers are
     // split over more waves this way (conv6 has only 80 voxel tiles but 4 row tiles)
     const int rsplit = rt_total / RT;
-    const long long wave_all = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long long wave = wave_all / rsplit;
-    const int rt_base = (int)(wave_all - wave * rsplit) * RT;
+    // wave-uniform by construction; readfirstlane tells the compiler, so the tile decomposition below runs on
+    // the scalar unit (it was ~1200 VALU of 64-bit divisions per wave, a third of a conv1 wave's time)
+    const int wave_all = (int)blockIdx.x * (int)(blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave = wave_all / rsplit;
+    const int rt_base = (wave_all - wave * rsplit) * RT;
 
     // ---- which voxels does this wave own? ----
     // conv: n = B*Do*Ho*Wo output voxels in raster order.  convT: per parity class, n = B*Di*Hi*Wi
-    // "q" positions; classes are laid out back to back in units of CT-tile groups.
-    const long long n = (KIND == kConvT2) ? (long long)B * Di * Hi * Wi : (long long)B * Do * Ho * Wo;
-    const long long tiles = cdivl(n, 16);
-    const long long groups = cdivl(tiles, CT);
+    // "q" positions; classes are laid out back to back in units of CT-tile groups.  (n < 2^31: launcher)
+    const int n = (KIND == kConvT2) ? B * Di * Hi * Wi : B * Do * Ho * Wo;
+    const int tiles = cdiv(n, 16);
+    const int groups = cdiv(tiles, CT);
     int cls = 0;
-    long long grp = wave;
+    int grp = wave;
     if (KIND == kConvT2) {
-        cls = (int)(wave / groups);
-        grp = wave - (long long)cls * groups;
+        cls = wave / groups;
+        grp = wave - cls * groups;
         if (cls >= 8) return;
     } else if (wave >= groups) {
         return;
@@ -151,16 +175,23 @@ __global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, c
 
     int vb[CT], vd[CT], vh[CT], vw[CT];
     bool vok[CT];
+    {
+        const int dw = (KIND == kConvT2) ? Wi : Wo, dh = (KIND == kConvT2) ? Hi : Ho, dd = (KIND == kConvT2) ? Di : Do;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        long long v = (grp * CT + ct) * 16 + j;
-        vok[ct] = v < n;
-        long long vv = vok[ct] ? v : 0;
-        int dw = (KIND == kConvT2) ? Wi : Wo, dh = (KIND == kConvT2) ? Hi : Ho, dd = (KIND == kConvT2) ? Di : Do;
-        vw[ct] = (int)(vv % dw); vv /= dw;
-        vh[ct] = (int)(vv % dh); vv /= dh;
-        vd[ct] = (int)(vv % dd);
-        vb[ct] = (int)(vv / dd);
+        for (int ct = 0; ct < CT; ++ct) {
+            const int v0 = (grp * CT + ct) * 16;             // uniform: scalar div/mod, lanes add j and carry
+            int r = v0 / dw;
+            const int w0 = v0 - r * dw;
+            int q = r / dh;
+            const int h0 = r - q * dh;
+            const int b0 = q / dd, d0 = q - b0 * dd;
+            vok[ct] = v0 + j < n;
+            vw[ct] = w0 + j; vh[ct] = h0; vd[ct] = d0; vb[ct] = b0;
+            while (vw[ct] >= dw) {
+                vw[ct] -= dw;
+                if (++vh[ct] == dh) { vh[ct] = 0; if (++vd[ct] == dd) { vd[ct] = 0; ++vb[ct]; } }
+            }
+        }
     }
 
     f32x4 acc[CT][RT];
@@ -173,38 +204,45 @@ __global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, c
               ntw = (KIND == kConvT2) ? 1 + pw : 3;
     const int ntaps = ntd * nth * ntw;
     const int tap0 = (KIND == kConvT2) ? convt_class_offset(cls) : 0;
-    const float* wl = wpk + lane + (long long)rt_base * 64;
+    const float* wl = wpk + lane + rt_base * 64;
     constexpr int NA = KS * RT;                       // A operands (weights) per tap
 
-    // One tap's operands: all loads are UNCONDITIONAL (out-of-range voxels read voxel 0 and are zeroed
-    // afterwards with a select) and issued back to back, and taps are double-buffered, so a tap's ~10
-    // L2 round trips overlap the previous tap's MFMAs instead of serialising behind exec-mask branches
-    // and per-load s_waitcnt vmcnt(0) (which is what hipcc emits for `ok ? *p : 0`).
-    auto issue = [&](int t, float4 (&bq)[CT][NB], bool (&bok)[CT], float (&aq)[NA]) {
-        int td, th, tw;
-        if (KIND == kConvT2) {
-            tw = (ntw == 2) ? (t & 1) : 0;
-            const int t2 = (ntw == 2) ? (t >> 1) : t;
-            th = (nth == 2) ? (t2 & 1) : 0;
-            td = (nth == 2) ? (t2 >> 1) : t2;
-        } else {
-            tw = t % 3; th = (t / 3) % 3; td = t / 9;
+    // Per column tile: the input voxel index of tap (0,0,0) and a 9-bit mask of the per-axis offsets that fall
+    // inside the volume.  A tap's address is then base + (uniform tap offset) and its validity one and+compare; loads of
+    // padding taps are redirected to a block of zeros, so no per-value select is needed afterwards.
+    // (Before: ~35 VALU of 64-bit index math, six compares and eight selects per tile and tap against 8-16
+    // MFMAs — these layers were VALU-bound at 5-7x their MFMA time.)
+    int vbase[CT];
+    unsigned vmask[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        constexpr int s = (KIND == kConvS2) ? 2 : 1;
+        const int id0 = (KIND == kConvT2) ? vd[ct] : vd[ct] * s - 1, ih0 = (KIND == kConvT2) ? vh[ct] : vh[ct] * s - 1,
+                  iw0 = (KIND == kConvT2) ? vw[ct] : vw[ct] * s - 1;
+        vbase[ct] = ((vb[ct] * Di + id0) * Hi + ih0) * Wi + iw0;
+        unsigned m = 0;                                  // bit k / 3+k / 6+k: offset k valid along d / h / w
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            m |= ((unsigned)(id0 + k) < (unsigned)Di ? 1u : 0u) << k;
+            m |= ((unsigned)(ih0 + k) < (unsigned)Hi ? 1u : 0u) << (3 + k);
+            m |= ((unsigned)(iw0 + k) < (unsigned)Wi ? 1u : 0u) << (6 + k);
         }
+        vmask[ct] = vok[ct] ? m : 0u;
+    }
+    const float* zeros = g_conv_zeros + g * CPL;
+
+    // One tap's operands: all loads are UNCONDITIONAL and issued back to back, and taps are double-buffered,
+    // so a tap's ~10 L2 round trips overlap the previous tap's MFMAs instead of serialising behind exec-mask
+    // branches and per-load s_waitcnt vmcnt(0) (which is what hipcc emits for `ok ? *p : 0`).
+    auto issue = [&](int t, float4 (&bq)[CT][NB], float (&aq)[NA]) {
+        int od, oh, ow;
+        tap_offsets<KIND>(t, ntw, nth, pd, ph, pw, od, oh, ow);
+        const int toff = (od * Hi + oh) * Wi + ow;         // uniform
+        const unsigned sel = (1u << od) | (8u << oh) | (64u << ow);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            int id, ih, iw;
-            if (KIND == kConvT2) {
-                int k, dq;
-                convt_axis(pd, td, k, dq); id = vd[ct] + dq;
-                convt_axis(ph, th, k, dq); ih = vh[ct] + dq;
-                convt_axis(pw, tw, k, dq); iw = vw[ct] + dq;
-            } else {
-                constexpr int s = (KIND == kConvS2) ? 2 : 1;
-                id = vd[ct] * s - 1 + td; ih = vh[ct] * s - 1 + th; iw = vw[ct] * s - 1 + tw;
-            }
-            bok[ct] = vok[ct] && id >= 0 && id < Di && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi;
-            const long long off = bok[ct] ? ((((long long)vb[ct] * Di + id) * Hi + ih) * Wi + iw) : 0;
-            const float* p = in + off * CIN + g * CPL;
+            const bool ok = (vmask[ct] & sel) == sel;
+            const float* p = ok ? in + (long long)(vbase[ct] + toff) * CIN + g * CPL : zeros;
 #pragma unroll
             for (int cb = 0; cb < NB; ++cb) {
                 if (CPL == 4) {
@@ -221,14 +259,13 @@ __global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, c
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) aq[ks * RT + rt] = wt[(ks * rt_total + rt) * 64];
     };
-    auto compute = [&](const float4 (&bq)[CT][NB], const bool (&bok)[CT], const float (&aq)[NA]) {
+    auto compute = [&](const float4 (&bq)[CT][NB], const float (&aq)[NA]) {
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
             float bv[CT][4];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                bv[ct][0] = bok[ct] ? bq[ct][cb].x : 0.f; bv[ct][1] = bok[ct] ? bq[ct][cb].y : 0.f;
-                bv[ct][2] = bok[ct] ? bq[ct][cb].z : 0.f; bv[ct][3] = bok[ct] ? bq[ct][cb].w : 0.f;
+                bv[ct][0] = bq[ct][cb].x; bv[ct][1] = bq[ct][cb].y; bv[ct][2] = bq[ct][cb].z; bv[ct][3] = bq[ct][cb].w;
             }
 #pragma unroll
             for (int r = 0; r < CPL; ++r)
@@ -242,17 +279,16 @@ __global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, c
     };
     {
         float4 b0[CT][NB], b1[CT][NB];
-        bool k0[CT], k1[CT];
         float a0[NA], a1[NA];
-        issue(0, b0, k0, a0);
+        issue(0, b0, a0);
 #pragma unroll 1
         for (int t = 0; t < ntaps; t += 2) {
-            issue(t + 1 < ntaps ? t + 1 : ntaps - 1, b1, k1, a1);   // clamped: always loads, never branches
+            issue(t + 1 < ntaps ? t + 1 : ntaps - 1, b1, a1);       // clamped: always loads, never branches
             __builtin_amdgcn_sched_barrier(0);                      // keep the next tap's loads ahead of this tap's MFMAs
-            compute(b0, k0, a0);
-            issue(t + 2 < ntaps ? t + 2 : ntaps - 1, b0, k0, a0);
+            compute(b0, a0);
+            issue(t + 2 < ntaps ? t + 2 : ntaps - 1, b0, a0);
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < ntaps) compute(b1, k1, a1);
+            if (t + 1 < ntaps) compute(b1, a1);
         }
     }
 
@@ -287,7 +323,7 @@ __global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, c
             }
             if (relu) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.f);
+                for (int r = 0; r < 4; ++r) y[r] = relu1(y[r]);
             }
             *reinterpret_cast<float4*>(out + o * cout + c0) = make_float4(y[0], y[1], y[2], y[3]);
         }

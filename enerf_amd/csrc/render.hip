@@ -272,6 +272,8 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
 
             // ---------- per-view image features + direction code (utils.py:698-720) ----------
             float x[S][R], dsel[S];
+            // (Tried: each lane group projecting ONE view and handing taps/direction round with lane broadcasts —
+            // 170 fewer VALU per 16 points but 36 ds_bpermute on the critical path: 201 -> 215 us.  Not kept.)
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const float* c = camb + s * kCamStride;
@@ -310,6 +312,7 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
                 float dot = tx * sx + ty * sy + tz * sz;
                 dsel[s] = g == 0 ? ex * eir : (g == 1 ? ey * eir : (g == 2 ? ez * eir : dot));
             }
+
 
             // ---------- Agg (nerf.py:74-89) ----------
             float av[S][R];

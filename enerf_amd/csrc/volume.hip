@@ -13,54 +13,87 @@
 
 namespace enerf {
 
+// The CQ lanes of a voxel share its geometry, so they also share the work: lane q projects the voxel into
+// view s0+q (homography, perspective divide, bilinear taps: ~130 VALU with the IEEE divides the reference
+// rounding needs) and the group then walks the views, each lane fetching the taps of the view in turn from
+// its owner with one lane broadcast per value.  Before, every lane projected every view — 4x (level 1) and
+// 8x (level 0) redundant VALU in a kernel that is VALU- not HBM-bound (48+37 us against a 16 us HBM floor).
 template <int CQ>  // CQ = C/4 lanes per voxel
 __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict__ feat, const float* __restrict__ proj,
                                                         const float* __restrict__ dv, int B, int S, int Hs, int Ws,
-                                                        int D, int h, int w, float* __restrict__ vol) {
+                                                        int D, int h, int w, float inv_w, float* __restrict__ vol) {
     constexpr int C = CQ * 4;
-    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // natural order: XCD-contiguous measured 30 % slower here
-    long long nvox = (long long)B * D * h * w;
-    long long vox = gid / CQ;
-    int cq = (int)(gid - vox * CQ);
-    if (vox >= nvox) return;
-    int hw = h * w;
-    int b = (int)(vox / ((long long)D * hw));
-    int rem = (int)(vox - (long long)b * D * hw);
-    int p = rem % hw;
-    int y = p / w, x = p - y * w;
-    float depth = dv[vox];                      // (B,D,h,w) has the same linear index as the voxel
-    float fx = (float)x, fy = (float)y;
-    float half_w = (float)((Ws - 1) / 2.0), half_h = (float)((Hs - 1) / 2.0);   // utils.py:82-83
+    // natural block order (XCD-contiguous measured 30 % slower here).  Voxel -> (b, d, y, x) without per-lane
+    // 64-bit divisions: the block's first voxel is decomposed once on the scalar unit, lanes add their offset
+    // and carry (the launcher guarantees B*D*h*w*CQ < 2^31).
+    const int hw = h * w;
+    const unsigned nvox = (unsigned)B * D * hw;
+    const unsigned vox0 = blockIdx.x * (256 / CQ);                            // uniform
+    const unsigned plane0 = vox0 / (unsigned)hw, p0 = vox0 - plane0 * (unsigned)hw;
+    const unsigned b0 = plane0 / (unsigned)D;
+    const int cq = threadIdx.x & (CQ - 1);
+    const unsigned vox_raw = vox0 + (threadIdx.x / CQ);
+    const bool live = vox_raw < nvox;
+    const unsigned vox = live ? vox_raw : nvox - 1;        // dead lanes shadow the last voxel (they take part in the broadcasts)
+    const int lane = threadIdx.x & 63, lead = lane & ~(CQ - 1);
+    unsigned p = p0 + (vox - vox0), pl = plane0;
+    while (p >= (unsigned)hw) { p -= (unsigned)hw; ++pl; }
+    int b = (int)b0;
+    while (pl >= (unsigned)(b + 1) * (unsigned)D) ++b;
+    // y = p / w through a float reciprocal with an exact fix-up (p < 2^23, launcher-checked)
+    int y = (int)((float)p * inv_w), x = (int)p - y * w;
+    if (x < 0) { --y; x += w; }
+    if (x >= w) { ++y; x -= w; }
+    const float depth = dv[vox];                      // (B,D,h,w) has the same linear index as the voxel
+    const float fx = (float)x, fy = (float)y;
+    // utils.py:82-83 divide by the Python scalars (W_S-1)/2, (H_S-1)/2: ATen's GPU kernel multiplies by the
+    // reciprocal for a scalar divisor (BinaryDivTrueKernel), so this is the reference's device arithmetic
+    const float inv_half_w = 1.f / (float)((Ws - 1) / 2.0), inv_half_h = 1.f / (float)((Hs - 1) / 2.0);
+    const unsigned img = (unsigned)(Hs * Ws * C);      // floats per source view (launcher: B*S*img < 2^32)
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < S; ++s) {
-        const float* P = proj + ((long long)b * S + s) * 12;
-        float px = P[0] * fx + P[1] * fy + P[2] + P[3] / depth;       // utils.py:72
-        float py = P[4] * fx + P[5] * fy + P[6] + P[7] / depth;
-        float pz = P[8] * fx + P[9] * fy + P[10] + P[11] / depth;
-        float z = clamp_min(pz, 1e-6f);                                // utils.py:80
-        float gx = (px / z) / half_w - 1.f, gy = (py / z) / half_h - 1.f;
-        Taps2 t = gs_taps2<false>(gs_unnorm(gx, Ws), gs_unnorm(gy, Hs), Ws, Hs);
-        const float* f = feat + ((long long)b * S + s) * Hs * Ws * C + cq * 4;
-        const float4 v00 = *reinterpret_cast<const float4*>(f + ((long long)t.y0 * Ws + t.x0) * C);
-        const float4 v01 = *reinterpret_cast<const float4*>(f + ((long long)t.y0 * Ws + t.x1) * C);
-        const float4 v10 = *reinterpret_cast<const float4*>(f + ((long long)t.y1 * Ws + t.x0) * C);
-        const float4 v11 = *reinterpret_cast<const float4*>(f + ((long long)t.y1 * Ws + t.x1) * C);
-        float4 r;
-        r.x = v00.x * t.w00; r.x += v01.x * t.w01; r.x += v10.x * t.w10; r.x += v11.x * t.w11;
-        r.y = v00.y * t.w00; r.y += v01.y * t.w01; r.y += v10.y * t.w10; r.y += v11.y * t.w11;
-        r.z = v00.z * t.w00; r.z += v01.z * t.w01; r.z += v10.z * t.w10; r.z += v11.z * t.w11;
-        r.w = v00.w * t.w00; r.w += v01.w * t.w01; r.w += v10.w * t.w10; r.w += v11.w * t.w11;
-        s1.x += r.x; s1.y += r.y; s1.z += r.z; s1.w += r.w;
-        s2.x += r.x * r.x; s2.y += r.y * r.y; s2.z += r.z * r.z; s2.w += r.w * r.w;
+    for (int s0 = 0; s0 < S; s0 += CQ) {
+        // ---- this lane's view ----
+        const int sv = min(s0 + cq, S - 1);
+        const float* P = proj + (b * S + sv) * 12;
+        const float px = P[0] * fx + P[1] * fy + P[2] + P[3] / depth;       // utils.py:72
+        const float py = P[4] * fx + P[5] * fy + P[6] + P[7] / depth;
+        const float pz = P[8] * fx + P[9] * fy + P[10] + P[11] / depth;
+        const float z = clamp_min(pz, 1e-6f);                                // utils.py:80
+        const float gx = (px / z) * inv_half_w - 1.f, gy = (py / z) * inv_half_h - 1.f;
+        const Taps2 t = gs_taps2<false>(gs_unnorm(gx, Ws), gs_unnorm(gy, Hs), Ws, Hs);
+        const unsigned vb = (unsigned)(b * S + sv) * img;
+        const int r0 = mul24(t.y0, Ws), r1 = mul24(t.y1, Ws);
+        const int my_o[4] = {(int)(vb + (unsigned)mul24(r0 + t.x0, C)), (int)(vb + (unsigned)mul24(r0 + t.x1, C)),
+                             (int)(vb + (unsigned)mul24(r1 + t.x0, C)), (int)(vb + (unsigned)mul24(r1 + t.x1, C))};
+        const float my_w[4] = {t.w00, t.w01, t.w10, t.w11};
+        // ---- the group's views in turn ----
+#pragma unroll
+        for (int k = 0; k < CQ; ++k) {
+            if (s0 + k >= S) break;                                          // uniform
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const unsigned o = (unsigned)__shfl(my_o[c], lead + k) + (unsigned)(cq * 4);
+                const float wgt = __shfl(my_w[c], lead + k);
+                const float4 v = *reinterpret_cast<const float4*>(feat + o);
+                if (c == 0) { r.x = v.x * wgt; r.y = v.y * wgt; r.z = v.z * wgt; r.w = v.w * wgt; }
+                else { r.x += v.x * wgt; r.y += v.y * wgt; r.z += v.z * wgt; r.w += v.w * wgt; }
+            }
+            s1.x += r.x; s1.y += r.y; s1.z += r.z; s1.w += r.w;
+            s2.x += r.x * r.x; s2.y += r.y * r.y; s2.z += r.z * r.z; s2.w += r.w * r.w;
+        }
     }
-    float fs = (float)S;                                               // utils.py:345
+    // utils.py:345 `div_(S)`: with a Python scalar divisor ATen's GPU kernel multiplies by the reciprocal
+    // (BinaryDivTrueKernel: is_cpu_scalar -> MulFunctor(1/b)), so this is the reference's device arithmetic;
+    // the CPU oracle divides, which differs by <= 1 ulp of the mean.
+    const float inv_s = 1.f / (float)S;
     float4 o;
     float m;
-    m = s1.x / fs; o.x = s2.x / fs - m * m;
-    m = s1.y / fs; o.y = s2.y / fs - m * m;
-    m = s1.z / fs; o.z = s2.z / fs - m * m;
-    m = s1.w / fs; o.w = s2.w / fs - m * m;
-    *reinterpret_cast<float4*>(vol + vox * C + cq * 4) = o;
+    m = s1.x * inv_s; o.x = s2.x * inv_s - m * m;
+    m = s1.y * inv_s; o.y = s2.y * inv_s - m * m;
+    m = s1.z * inv_s; o.z = s2.z * inv_s - m * m;
+    m = s1.w * inv_s; o.w = s2.w * inv_s - m * m;
+    if (live) *reinterpret_cast<float4*>(vol + (long long)vox * C + cq * 4) = o;
 }
 
 void launch_feature_volume(const float* feat_nhwc, const float* proj, const float* dv, int B, int S, int C, int Hs,
@@ -68,9 +101,9 @@ void launch_feature_volume(const float* feat_nhwc, const float* proj, const floa
     long long threads = (long long)B * D * h * w * (C / 4);
     unsigned grid = (unsigned)cdivl(threads, 256);
     switch (C) {
-        case 32: ENERF_LAUNCH_SIMPLE(k_feature_volume<8>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, vol); break;
-        case 16: ENERF_LAUNCH_SIMPLE(k_feature_volume<4>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, vol); break;
-        case 8: ENERF_LAUNCH_SIMPLE(k_feature_volume<2>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, vol); break;
+        case 32: ENERF_LAUNCH(k_feature_volume<8>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, 1.f / (float)w, vol); break;
+        case 16: ENERF_LAUNCH(k_feature_volume<4>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, 1.f / (float)w, vol); break;
+        case 8: ENERF_LAUNCH(k_feature_volume<2>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, 1.f / (float)w, vol); break;
         default: break;   // validated by the C-ABI layer
     }
 }

@@ -234,6 +234,12 @@ inline float __shfl(float v, int src, int width = 64) {
     auto buf = emu::wave_exchange(v);
     return buf[0][(unsigned)src % emu::kWave];
 }
+inline int __shfl(int v, int src, int width = 64) {
+    float f; memcpy(&f, &v, 4);
+    f = __shfl(f, src, width);
+    memcpy(&v, &f, 4);
+    return v;
+}
 inline int __shfl_xor(int v, int mask, int width = 64) {
     float f; memcpy(&f, &v, 4);
     f = __shfl_xor(f, mask, width);
@@ -258,6 +264,7 @@ inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x
 }
 
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only ever applied to wave-uniform values
 inline void __builtin_amdgcn_s_sleep(int) {}
 inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
 inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
