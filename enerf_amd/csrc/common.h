@@ -29,16 +29,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace enerf {
 
-// ReLU as ONE v_max_f32.  fmaxf(x, 0.f) compiles to two (hipcc first canonicalises x with v_max_f32 x, x
+// ReLU as ONE instruction.  fmaxf(x, 0.f) compiles to two (hipcc first canonicalises x with v_max_f32 x, x
 // because the kernels run in IEEE mode); on MFMA outputs that doubled the ~110 ReLUs per 16 points of the
-// render kernel.  Like fmaxf, a NaN input yields 0.
+// render kernel.  v_med3_f32(x, 0, FLT_MAX) is the same function for finite x (NaN -> 0 like fmaxf; +inf ->
+// FLT_MAX; with +inf as the bound hipcc folds it back into the two-instruction max) and, being a compiler
+// intrinsic rather than inline asm, keeps the MFMA->VALU hazard wait states hipcc inserts (an inline-asm
+// v_max_f32 on MFMA results read stale registers in the C=32 render variant: caught by the GPU parity tests).
 __device__ __forceinline__ float relu1(float x) {
-#if defined(ENERF_EMU) || defined(ENERF_NO_RELU_ASM)
+#if defined(ENERF_EMU) || defined(ENERF_NO_RELU_MED3)
     return fmaxf(x, 0.f);
 #else
-    float y;
-    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-    return y;
+    return __builtin_amdgcn_fmed3f(x, 0.f, 3.402823466e+38f);
 #endif
 }
 
@@ -100,7 +101,7 @@ struct Taps2 {
 // 24-bit integer multiply (full-rate v_mul_u32_u24; v_mul_lo_u32 is quarter rate).  Only for operands that are
 // image/volume coordinates and extents (< 2^24, launchers check) with a product < 2^32.
 __device__ __forceinline__ int mul24(int a, int b) {
-#ifdef ENERF_EMU
+#if defined(ENERF_EMU) || defined(ENERF_NO_MUL24)
     return a * b;
 #else
     return __mul24(a, b);
