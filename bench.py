@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--views", type=int, default=3)
     ap.add_argument("--miopen-benchmark", action="store_true", help="experiment: let MIOpen search conv algos")
+    ap.add_argument("--overlap", action="store_true",
+                    help="enqueue FPN levels 1-2 on a second HIP stream next to the level-0 cost volume (default: one stream)")
     ap.add_argument("--feature-backend", choices=["hip", "torch"], default="hip",
                     help="FeatureNet on the HIP matrix-core path (default) or in PyTorch-ROCm/MIOpen")
     args = ap.parse_args()
@@ -95,6 +97,7 @@ def main():
 
     cfg = EnerfConfig.dtu_eval()
     net = _seeded_network(cfg, dev, feature_backend=args.feature_backend)
+    net.overlap = bool(args.overlap)
     H, W, S = args.height, args.width, args.views
     batch_np = make_batch(H, W, S, cfg, seed=rank, textured=True)
     batch = {k: torch.from_numpy(v).to(dev) for k, v in batch_np.items()}
@@ -132,7 +135,8 @@ def main():
             "vs_baseline": fps / BASELINE_FPS_RTX3090, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"DTU generalizable eval (dtu_pretrain.yaml, render_if False,True, "
                                    f"volume_planes 48,8), {H}x{W}, {S} src views, one target view per step",
-                       "feature_net": args.feature_backend, "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world} (no collectives)"},
+                       "feature_net": args.feature_backend, "streams": 2 if (args.overlap and args.feature_backend == "hip") else 1,
+                       "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world} (no collectives)"},
         }
 
     # ---- per-stage HIP-event timings + roofline of the dominant kernel (rank 0, not in the timed region) ----

@@ -276,6 +276,16 @@ size_t enerf_feature_net_workspace_bytes(int n_img, int H, int W) {
 int enerf_feature_net(const float* packed, const float* src_inps, int n_img, int H, int W, float* feat_l0,
                       float* feat_l1, float* feat_l2, int l2_stride, void* workspace, size_t workspace_bytes,
                       enerf_stream_t stream) {
+    return enerf_feature_net_stage(packed, src_inps, n_img, H, W, feat_l0, feat_l1, feat_l2, l2_stride, workspace,
+                                   workspace_bytes, ENERF_FEAT_ALL, stream);
+}
+int enerf_feature_net_stage(const float* packed, const float* src_inps, int n_img, int H, int W, float* feat_l0,
+                            float* feat_l1, float* feat_l2, int l2_stride, void* workspace, size_t workspace_bytes,
+                            int stage, enerf_stream_t stream) {
+    REQUIRE(stage >= ENERF_FEAT_ALL && stage <= ENERF_FEAT_LEVEL2, "feature_net: unknown stage %d", stage);
+    const bool trunk = stage == ENERF_FEAT_ALL || stage == ENERF_FEAT_TRUNK;
+    const bool lvl1 = stage == ENERF_FEAT_ALL || stage == ENERF_FEAT_LEVEL1;
+    const bool lvl2 = stage == ENERF_FEAT_ALL || stage == ENERF_FEAT_LEVEL2;
     REQUIRE(packed && src_inps && feat_l0 && feat_l1 && feat_l2 && workspace, "feature_net: null pointer");
     REQUIRE(n_img > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "feature_net: H,W (%d,%d) must be divisible by 4", H, W);
     REQUIRE(l2_stride == 8 || l2_stride == 12, "feature_net: l2_stride must be 8 (features) or 12 (texels)");
@@ -299,24 +309,30 @@ int enerf_feature_net(const float* packed, const float* src_inps, int n_img, int
     float *c1a = take(p1 * 16), *c1 = take(p1 * 16), *f1pre = take(p1 * 32);
     float *c2a = take(p2 * 32), *c2 = take(p2 * 32);
     int rc = 0;
-    rc |= launch_conv2d(d[0], src_inps, c0a, nullptr, n_img, H, W, 0, 0, st);          // conv0.0 (NCHW image in)
-    rc |= launch_conv2d(d[1], c0a, c0, nullptr, n_img, H, W, 0, 0, st);                // conv0.1
-    rc |= launch_conv2d(d[2], c0, c1a, nullptr, n_img, H, W, 0, 0, st);                // conv1.0 (s2)
-    rc |= launch_conv2d(d[3], c1a, c1, nullptr, n_img, H1, W1, 0, 0, st);              // conv1.1
-    rc |= launch_conv2d(d[4], c1, c2a, nullptr, n_img, H1, W1, 0, 0, st);              // conv2.0 (s2)
-    rc |= launch_conv2d(d[5], c2a, c2, nullptr, n_img, H2, W2, 0, 0, st);              // conv2.1
-    rc |= launch_conv2d(d[6], c2, feat_l0, nullptr, n_img, H2, W2, 0, 0, st);          // toplayer  -> level_0
-    rc |= launch_conv2d(d[7], c1, f1pre, feat_l0, n_img, H1, W1, H2, W2, st);          // up2(feat2) + lat1(conv1)
-    rc |= launch_conv2d(d[9], f1pre, feat_l1, nullptr, n_img, H1, W1, 0, 0, st);       // smooth1   -> level_1
-    d[10].out_stride = l2_stride;
-    d[10].rgb_src = (l2_stride == 12) ? src_inps : nullptr;
-    const char* fuse = getenv("ENERF_FUSE_LAT0");                                       // A/B knob, default fused
-    if (fuse == nullptr || fuse[0] != '0') {
-        // smooth0(up2(feat1) + lat0(conv0)) in one kernel: the 32-channel full-res sum never touches HBM
-        launch_smooth0_fused(d[10], c0, f1pre, p, p + 256, feat_l2, n_img, H, W, st);
-    } else {
-        rc |= launch_conv2d(d[8], c0, f0pre, f1pre, n_img, H, W, H1, W1, st);          // up2(feat1) + lat0(conv0)
-        rc |= launch_conv2d(d[10], f0pre, feat_l2, nullptr, n_img, H, W, 0, 0, st);    // smooth0 -> level_2 / texels
+    if (trunk) {
+        rc |= launch_conv2d(d[0], src_inps, c0a, nullptr, n_img, H, W, 0, 0, st);      // conv0.0 (NCHW image in)
+        rc |= launch_conv2d(d[1], c0a, c0, nullptr, n_img, H, W, 0, 0, st);            // conv0.1
+        rc |= launch_conv2d(d[2], c0, c1a, nullptr, n_img, H, W, 0, 0, st);            // conv1.0 (s2)
+        rc |= launch_conv2d(d[3], c1a, c1, nullptr, n_img, H1, W1, 0, 0, st);          // conv1.1
+        rc |= launch_conv2d(d[4], c1, c2a, nullptr, n_img, H1, W1, 0, 0, st);          // conv2.0 (s2)
+        rc |= launch_conv2d(d[5], c2a, c2, nullptr, n_img, H2, W2, 0, 0, st);          // conv2.1
+        rc |= launch_conv2d(d[6], c2, feat_l0, nullptr, n_img, H2, W2, 0, 0, st);      // toplayer  -> level_0
+    }
+    if (lvl1) {
+        rc |= launch_conv2d(d[7], c1, f1pre, feat_l0, n_img, H1, W1, H2, W2, st);      // up2(feat2) + lat1(conv1)
+        rc |= launch_conv2d(d[9], f1pre, feat_l1, nullptr, n_img, H1, W1, 0, 0, st);   // smooth1   -> level_1
+    }
+    if (lvl2) {
+        d[10].out_stride = l2_stride;
+        d[10].rgb_src = (l2_stride == 12) ? src_inps : nullptr;
+        const char* fuse = getenv("ENERF_FUSE_LAT0");                                   // A/B knob, default fused
+        if (fuse == nullptr || fuse[0] != '0') {
+            // smooth0(up2(feat1) + lat0(conv0)) in one kernel: the 32-channel full-res sum never touches HBM
+            launch_smooth0_fused(d[10], c0, f1pre, p, p + 256, feat_l2, n_img, H, W, st);
+        } else {
+            rc |= launch_conv2d(d[8], c0, f0pre, f1pre, n_img, H, W, H1, W1, st);      // up2(feat1) + lat0(conv0)
+            rc |= launch_conv2d(d[10], f0pre, feat_l2, nullptr, n_img, H, W, 0, 0, st);  // smooth0 -> level_2 / texels
+        }
     }
     if (rc != 0) return fail(ENERF_EINVAL, "feature_net: unsupported layer shape");
     return check_launch("feature_net");

@@ -265,6 +265,41 @@ __device__ __forceinline__ float slice_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 32));
     return v;
 }
+// Softmax moments of one pixel's D planes, register-resident: every plane value is loaded once (all loads in
+// flight together) and exp'd once; lane slice sl handles planes sl, sl+4, ...  The sums run in the same order as
+// the streaming form in k_depth_regression, so the results are bit-identical to it.
+template <int MK>
+__device__ __forceinline__ void depth_moments_regs(const float* pr, const float* dp, int D, int hw, int sl, int depth_inv,
+                                                   float& mu, float& var) {
+    float e[MK], v[MK];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kk = 0; kk < MK; ++kk) {
+        const int k = sl + 4 * kk;
+        const bool in = k < D;
+        const long long o = (long long)(in ? k : 0) * hw;
+        const float x = pr[o], d = dp[o];
+        e[kk] = in ? x : -INFINITY;
+        v[kk] = depth_inv ? 1.f / clamp_min(d, 1e-6f) : d;
+        m = fmaxf(m, e[kk]);
+    }
+    m = slice_max(m);
+    float se = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < MK; ++kk)
+        if (sl + 4 * kk < D) { e[kk] = expf(e[kk] - m); se += e[kk]; }
+    se = slice_sum(se);
+    mu = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < MK; ++kk)
+        if (sl + 4 * kk < D) { e[kk] = e[kk] / se; mu += e[kk] * v[kk]; }
+    mu = slice_sum(mu);
+    var = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < MK; ++kk)
+        if (sl + 4 * kk < D) { const float dd = v[kk] - mu; var += e[kk] * (dd * dd); }
+    var = slice_sum(var);
+}
 __global__ __launch_bounds__(256) void k_depth_regression(const float* __restrict__ prob, const float* __restrict__ dv,
                                                           int B, int D, int h, int w, int depth_inv,
                                                           float* __restrict__ depth, float* __restrict__ std) {
@@ -277,29 +312,34 @@ __global__ __launch_bounds__(256) void k_depth_regression(const float* __restric
     const int b = (int)(ii / hw), p = (int)(ii - (long long)b * hw);
     const float* pr = prob + (long long)b * D * hw + p;
     const float* dp = dv + (long long)b * D * hw + p;
-    float m = -INFINITY;
-    for (int k = sl; k < D; k += 4) m = fmaxf(m, pr[(long long)k * hw]);
-    m = slice_max(m);
-    float se = 0.f;
-    for (int k = sl; k < D; k += 4) se += expf(pr[(long long)k * hw] - m);
-    se = slice_sum(se);
-    float mu = 0.f;
-    for (int k = sl; k < D; k += 4) {
-        float pk = expf(pr[(long long)k * hw] - m) / se;
-        float v = dp[(long long)k * hw];
-        if (depth_inv) v = 1.f / clamp_min(v, 1e-6f);
-        mu += pk * v;
+    float mu, var;
+    if (D <= 16) depth_moments_regs<4>(pr, dp, D, hw, sl, depth_inv, mu, var);
+    else if (D <= 64) depth_moments_regs<16>(pr, dp, D, hw, sl, depth_inv, mu, var);
+    else {
+        float m = -INFINITY;
+        for (int k = sl; k < D; k += 4) m = fmaxf(m, pr[(long long)k * hw]);
+        m = slice_max(m);
+        float se = 0.f;
+        for (int k = sl; k < D; k += 4) se += expf(pr[(long long)k * hw] - m);
+        se = slice_sum(se);
+        mu = 0.f;
+        for (int k = sl; k < D; k += 4) {
+            float pk = expf(pr[(long long)k * hw] - m) / se;
+            float v = dp[(long long)k * hw];
+            if (depth_inv) v = 1.f / clamp_min(v, 1e-6f);
+            mu += pk * v;
+        }
+        mu = slice_sum(mu);
+        var = 0.f;
+        for (int k = sl; k < D; k += 4) {
+            float pk = expf(pr[(long long)k * hw] - m) / se;
+            float v = dp[(long long)k * hw];
+            if (depth_inv) v = 1.f / clamp_min(v, 1e-6f);
+            float dd = v - mu;
+            var += pk * (dd * dd);
+        }
+        var = slice_sum(var);
     }
-    mu = slice_sum(mu);
-    float var = 0.f;
-    for (int k = sl; k < D; k += 4) {
-        float pk = expf(pr[(long long)k * hw] - m) / se;
-        float v = dp[(long long)k * hw];
-        if (depth_inv) v = 1.f / clamp_min(v, 1e-6f);
-        float dd = v - mu;
-        var += pk * (dd * dd);
-    }
-    var = slice_sum(var);
     if (ok && sl == 0) {
         depth[i] = mu;
         std[i] = sqrtf(clamp_min(var, 1e-10f));

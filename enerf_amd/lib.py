@@ -58,6 +58,7 @@ _SIGNATURES = {
     "enerf_feature_net_pack": (_i, [C.POINTER(FeatNetRaw), _f, _f]),
     "enerf_feature_net_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "enerf_feature_net": (_i, [_f, _f, _i, _i, _i, _f, _f, _f, _i, _f, C.c_size_t, _f]),
+    "enerf_feature_net_stage": (_i, [_f, _f, _i, _i, _i, _f, _f, _f, _i, _f, C.c_size_t, _i, _f]),
     "enerf_pack_texels_cl": (_i, [_f, _i, _f, _i, _i, _i, _i, _i, _i, _f, _f]),
     "enerf_get_proj_mats": (_i, [_f, _f, _f, _f, _i, _i, _fl, _fl, _f, _f]),
     "enerf_get_depth_values": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f]),
@@ -147,8 +148,10 @@ class EnerfLib:
                     "feature_net_pack")
         return packed
 
-    def feature_net(self, packed, src_inps, l2_stride=8, workspace=None):
-        """src_inps (n,3,H,W) -> channels-last (n,H/4,W/4,32), (n,H/2,W/2,16), (n,H,W,l2_stride)."""
+    FEAT_ALL, FEAT_TRUNK, FEAT_LEVEL1, FEAT_LEVEL2 = 0, 1, 2, 3
+
+    def feature_net_alloc(self, src_inps, l2_stride=8, workspace=None):
+        """Output / workspace tensors of the FeatureNet for ``src_inps`` (n,3,H,W)."""
         n, _, H, W = src_inps.shape
         dev = src_inps.device
         need = self.dll.enerf_feature_net_workspace_bytes(n, H, W)
@@ -157,6 +160,20 @@ class EnerfLib:
         f0 = torch.empty((n, H // 4, W // 4, 32), dtype=torch.float32, device=dev)
         f1 = torch.empty((n, H // 2, W // 2, 16), dtype=torch.float32, device=dev)
         f2 = torch.empty((n, H, W, l2_stride), dtype=torch.float32, device=dev)
+        return f0, f1, f2, workspace
+
+    def feature_net_stage(self, packed, src_inps, bufs, stage, l2_stride=8):
+        """One stage (FEAT_TRUNK / FEAT_LEVEL1 / FEAT_LEVEL2, or FEAT_ALL) on the current stream."""
+        n, _, H, W = src_inps.shape
+        f0, f1, f2, workspace = bufs
+        self._check(self.dll.enerf_feature_net_stage(_ptr(packed), _ptr(src_inps), n, H, W, _ptr(f0), _ptr(f1),
+                                                     _ptr(f2), l2_stride, _ptr(workspace), workspace.numel() * 4,
+                                                     int(stage), self.stream_of(src_inps)), "feature_net_stage")
+
+    def feature_net(self, packed, src_inps, l2_stride=8, workspace=None):
+        """src_inps (n,3,H,W) -> channels-last (n,H/4,W/4,32), (n,H/2,W/2,16), (n,H,W,l2_stride)."""
+        n, _, H, W = src_inps.shape
+        f0, f1, f2, workspace = self.feature_net_alloc(src_inps, l2_stride, workspace)
         self._check(self.dll.enerf_feature_net(_ptr(packed), _ptr(src_inps), n, H, W, _ptr(f0), _ptr(f1), _ptr(f2),
                                                l2_stride, _ptr(workspace), workspace.numel() * 4,
                                                self.stream_of(src_inps)), "feature_net")

@@ -214,10 +214,19 @@ class Network(nn.Module):
     """
 
     def __init__(self, cfg: Optional[EnerfConfig] = None, human: bool = False, lib: Optional[EnerfLib] = None,
-                 check_nan: bool = False, feature_backend: str = "hip"):
+                 check_nan: bool = False, feature_backend: str = "hip", overlap: bool = False):
         super().__init__()
         if feature_backend not in ("hip", "torch"):
             raise ValueError("feature_backend must be 'hip' or 'torch'")
+        # overlap=True (HIP FeatureNet on a GPU only): the level-0 cost volume needs feature level_0 only, so the
+        # rest of the FPN (level_1, level_2/texels: 0.19 of the 1.09 ms frame) is enqueued on a second HIP stream
+        # next to the level-0 cost regularisation; events order the consumers.  Same kernels, bit-identical
+        # results.  Measured on MI355X: the kernels do overlap in time but each slows down by what the other
+        # takes (the fused smooth0 blocks hold 141 of the 160 KB of LDS per CU, so the conv3d blocks queue for
+        # LDS): 927 -> 931 FPS.  Off by default — one stream keeps the frame graph-capturable.
+        self.overlap = overlap
+        self._side_stream = None
+        self._feat_events = {}
         # "torch": FeatureNet in PyTorch-ROCm/MIOpen (north_star's split); "hip": enerf_feature_net on the
         # matrix cores, channels-last outputs (SURVEY.md §8f row 2 — MIOpen was 49 % of the frame).
         self.feature_backend = feature_backend
@@ -287,9 +296,27 @@ class Network(nn.Module):
         """HIP FeatureNet: channels-last (B,S,h,w,C) maps tagged ``_enerf_cl``; level_2 optionally comes
         out as ready render texels (tagged ``_enerf_tex``) when it is only used for the full-res render."""
         B, S, C, H, W = x.shape
-        f0, f1, f2, self._feat_ws = self.lib.feature_net(self._packed_weights("feature_net"),
-                                                        x.reshape(B * S, C, H, W).contiguous(),
-                                                        12 if texel_level2 else 8, self._feat_ws)
+        lib, packed = self.lib, self._packed_weights("feature_net")
+        src = x.reshape(B * S, C, H, W).contiguous()
+        stride = 12 if texel_level2 else 8
+        self._feat_events = {}
+        if self.overlap and x.is_cuda:
+            bufs = lib.feature_net_alloc(src, stride, self._feat_ws)
+            f0, f1, f2, self._feat_ws = bufs
+            lib.feature_net_stage(packed, src, bufs, lib.FEAT_TRUNK, stride)          # -> level_0, caller's stream
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=x.device)
+            main, side = torch.cuda.current_stream(x.device), self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                lib.feature_net_stage(packed, src, bufs, lib.FEAT_LEVEL1, stride)     # -> level_1
+                self._feat_events[1] = side.record_event()
+                lib.feature_net_stage(packed, src, bufs, lib.FEAT_LEVEL2, stride)     # -> level_2 / texels
+                self._feat_events[2] = side.record_event()
+            # the buffers were allocated on `main`; every consumer (and so every later reuse by the caching
+            # allocator) is ordered after these events through _wait_feat
+        else:
+            f0, f1, f2, self._feat_ws = lib.feature_net(packed, src, stride, self._feat_ws)
         feats = {"level_0": f0.view(B, S, H // 4, W // 4, 32), "level_1": f1.view(B, S, H // 2, W // 2, 16),
                  "level_2": f2.view(B, S, H, W, f2.shape[-1])}
         for k, v in feats.items():
@@ -298,8 +325,16 @@ class Network(nn.Module):
             feats["level_2"]._enerf_tex = True
         return feats
 
+    def _wait_feat(self, feat_level: int):
+        """Order the current stream after the side-stream stage that produces feature ``level_{feat_level}``."""
+        for lv, ev in list(self._feat_events.items()):
+            if lv <= feat_level:
+                torch.cuda.current_stream().wait_event(ev)
+                del self._feat_events[lv]
+
     def _texels(self, level, batch, im_feat):
         """unpreprocess + cat as the channels-last gather source (network.py:28-34); cached per frame."""
+        self._wait_feat(2)
         if getattr(im_feat, "_enerf_tex", False):
             return im_feat
         key = (level, im_feat.data_ptr(), batch["src_inps"].data_ptr())
@@ -385,6 +420,7 @@ class Network(nn.Module):
                 h, w = int(H * cas.volume_scale[i]), int(W * cas.volume_scale[i])
                 f = feats[f"level_{i}"]
                 if hip_feats:
+                    self._wait_feat(i)
                     feat_cl = f                                   # already (B,S,Hs,Ws,C)
                     Hs, Ws, C = f.shape[2:]
                     if i == 2 and C != 8:
@@ -434,6 +470,7 @@ class Network(nn.Module):
                 if self.check_nan and bool(ret_i["rgb"].isnan().any()):
                     raise RuntimeError(f"NaN in rgb_level{i}")
                 ret.update({f"{k}_level{i}": v for k, v in ret_i.items()})
+            self._wait_feat(2)              # never leave side-stream work un-joined (e.g. no level rendered level_2)
         if self._timer is not None:
             self._timer.end()
         return ret

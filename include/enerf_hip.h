@@ -74,6 +74,17 @@ size_t enerf_feature_net_workspace_bytes(int n_img, int H, int W);
 int enerf_feature_net(const float* packed, const float* src_inps, int n_img, int H, int W, float* feat_l0,
                       float* feat_l1, float* feat_l2, int l2_stride, void* workspace, size_t workspace_bytes,
                       enerf_stream_t stream);
+/* The same network in three independently enqueueable stages, so a host can overlap the level-0 cost volume
+ * (which needs feat_l0 only) with the rest of the FPN on a second stream:
+ *   ENERF_FEAT_TRUNK  conv0.0 .. conv2.1, toplayer  -> feat_l0           (feature_net.py:27-31)
+ *   ENERF_FEAT_LEVEL1 lat1 + up2 + smooth1          -> feat_l1           (feature_net.py:32-33,36; needs TRUNK)
+ *   ENERF_FEAT_LEVEL2 lat0 + up2 + smooth0          -> feat_l2 / texels  (feature_net.py:34-35;    needs LEVEL1)
+ * Same arguments as enerf_feature_net (same workspace across the three calls); ordering between stages issued on
+ * different streams is the caller's job (events).  ENERF_FEAT_ALL == enerf_feature_net. */
+enum { ENERF_FEAT_ALL = 0, ENERF_FEAT_TRUNK = 1, ENERF_FEAT_LEVEL1 = 2, ENERF_FEAT_LEVEL2 = 3 };
+int enerf_feature_net_stage(const float* packed, const float* src_inps, int n_img, int H, int W, float* feat_l0,
+                            float* feat_l1, float* feat_l2, int l2_stride, void* workspace, size_t workspace_bytes,
+                            int stage, enerf_stream_t stream);
 /* texels from channels-last features already at the render resolution (level-0 rendering with the HIP
  * FeatureNet): out (n_img,Hr,Wr,tex) = [feat (C) | bilinear_ac(src*0.5+0.5) (3) | 0]. */
 int enerf_pack_texels_cl(const float* feat_cl, int C, const float* src_inps, int H, int W, int Hr, int Wr, int tex,

@@ -183,6 +183,13 @@ def test_hip_feature_net_matches_reference_feature_maps():
     assert torch.equal(t2[..., :8], f2)
     _close(t2[..., 8:11].permute(0, 3, 1, 2).numpy(), (src * 0.5 + 0.5).numpy(), 1e-7, "texel rgb")
     assert float(t2[..., 11].abs().max()) == 0.0
+    # the three-stage form the two-stream host path uses (enerf_feature_net_stage) produces the same maps
+    bufs = lib.feature_net_alloc(src, 12)
+    for stage in (lib.FEAT_TRUNK, lib.FEAT_LEVEL1, lib.FEAT_LEVEL2):
+        lib.feature_net_stage(net._packed_weights("feature_net"), src, bufs, stage, 12)
+    assert torch.equal(bufs[0], f0) and torch.equal(bufs[1], f1) and torch.equal(bufs[2], t2)
+    with pytest.raises(Exception):
+        lib.feature_net_stage(net._packed_weights("feature_net"), src, bufs, 7, 12)
 
 
 @pytest.mark.parametrize("name", ["tiny_s3", "small_s3_eval"])
