@@ -27,7 +27,8 @@ sys.path.insert(0, ROOT)
 
 BASELINE_FPS_RTX3090 = 21.778975517304048      # BASELINE.md §1 / README.md:121
 PEAK_F32_MFMA_TFLOPS = 157.3                   # MI355X_MICROARCH.md
-FLOP_PER_SAMPLE_L1 = 50952                     # SURVEY.md §8a (a14+a15 derivation, S=3, F=11)
+FLOP_PER_SAMPLE_L1 = 50952                     # SURVEY.md §8a (a14+a15 derivation, S=3, F=11): reference dense count
+MFMA_TILES_PER_16 = 201                        # 16x16x4 fp32 MFMA tiles k_render_rays issues per 16 samples (render.hip header)
 
 
 class StageTimer:
@@ -159,7 +160,12 @@ def main():
         flops = FLOP_PER_SAMPLE_L1 * n_samples_total if (S == 3) else None
         dur_ms = stages.get("render_1")
         if flops and dur_ms:
-            ach = flops / (dur_ms * 1e-3) / 1e12
+            # Algorithmic FLOPs per sample: the MLP after the exact factoring of the two
+            # view-shared linear layers = 201 MFMA tiles of 16x16x4 per 16 samples = 25,728 FLOP/sample on the
+            # matrix cores.  SURVEY.md 8a's 50,952 is the reference's dense count of the same arithmetic (369
+            # tiles); it is reported next to it, not used for `frac` (it would exceed the peak).
+            mfma_flops = MFMA_TILES_PER_16 * 2 * 16 * 16 * 4 / 16.0 * n_samples_total
+            ach = mfma_flops / (dur_ms * 1e-3) / 1e12
             traffic, pmc_note, busy = None, None, None
             pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_render.json")     # separate rocprofv3 --pmc passes
             if os.path.exists(pmc_path) and (H, W, S) == (512, 640, 3):
@@ -169,11 +175,13 @@ def main():
                 "kernel": "k_render_rays<3,3> (level-1 fused render: sample placement + gathers + Agg/NeRF MLP + "
                           "compositing)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                "algorithmic_flops_per_launch": flops, "avg_launch_ms": dur_ms,
-                "note": "achieved counts the reference's dense FLOPs (50,952/sample, SURVEY.md 8a); the kernel "
-                        "evaluates the view-independent halves of global_fc/color.0 once per point, so it issues "
-                        "201 instead of 369 MFMAs per 16 points", "mfma_pipe_busy_frac_pmc": busy,
-                "traffic_source": pmc_note, "algorithmic_bytes_per_launch": 92.4e6}
+                "algorithmic_flops_per_launch": mfma_flops, "avg_launch_ms": dur_ms,
+                "reference_dense_flops_per_launch": flops,
+                "reference_dense_tflops": flops / (dur_ms * 1e-3) / 1e12,
+                "note": "achieved = 25,728 FLOP/sample (201 fp32 16x16x4 MFMA tiles per 16 samples, the MLP with the "
+                        "view-independent halves of global_fc/color.0 evaluated once per point) x 655,360 samples / "
+                        "launch time; the reference's dense count of the same maths is 50,952 FLOP/sample (369 tiles)",
+                "mfma_pipe_busy_frac_pmc": busy, "traffic_source": pmc_note, "algorithmic_bytes_per_launch": 92.4e6}
 
     # ---- CPU baseline: the oracle (torch CPU restatement of the reference) on this box's host cores ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
