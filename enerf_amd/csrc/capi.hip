@@ -214,8 +214,11 @@ int enerf_nerf_pack(const enerf_nerf_raw_t* raw, int F, int viewdir_agg, float* 
 int enerf_render_rays(const enerf_render_args_t* a, enerf_stream_t stream) {
     REQUIRE(a, "render_rays: null args");
     if (a->N == 0 && a->B > 0) return ENERF_OK;              // empty ray list (e.g. an all-false mask_at_box)
-    REQUIRE(a->rays12 && a->tex && a->vol && a->src_exts && a->src_ixts && a->tar_ext && a->packed && a->rgb &&
-                a->depth && a->weights, "render_rays: null pointer");
+    REQUIRE((a->rays12 || a->rays8) && a->tex && a->vol && a->src_exts && a->src_ixts && a->tar_ext && a->packed &&
+                a->rgb && a->depth && a->weights, "render_rays: null pointer");
+    if (a->rays8)
+        REQUIRE(a->depth_map && a->std_map && a->nf_map && a->map_h > 0 && a->map_w > 0,
+                "render_rays: fused build_rays needs depth/std/near_far maps and their size");
     REQUIRE(a->B > 0 && a->N >= 0 && a->Hr > 1 && a->Wr > 1 && a->D > 0 && a->h > 0 && a->w > 0, "render_rays: bad shape");
     if (a->N == 0) return ENERF_OK;
     int rc = launch_render_rays(*a, (hipStream_t)stream);

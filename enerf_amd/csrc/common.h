@@ -193,4 +193,44 @@ __host__ __device__ __forceinline__ bool inv4x4(const double* m, double* inv) {
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// build_rays (utils.py:390-420) for one ray: xN align-corners upsample of {depth, std, near_far} gathered at
+// the ray's integer (u, v), per-ray [near, far] clamped into the volume bounds.  Shared by k_build_rays and
+// the fused prologue of k_render_rays so both produce the same bits.
+// ---------------------------------------------------------------------------------------------
+struct RayBounds {
+    float rn, rf, vn, vf;
+};
+__device__ __forceinline__ RayBounds ray_bounds(float ru, float rv, const float* __restrict__ pd,
+                                                const float* __restrict__ ps, const float* __restrict__ n0,
+                                                int h, int w, int Hr, int Wr, int depth_inv) {
+    int u = (int)ru, v = (int)rv;                            // .long(): truncation
+    u = u < 0 ? u + Wr : u;                                  // python negative indexing
+    v = v < 0 ? v + Hr : v;
+    u = u < 0 ? 0 : (u > Wr - 1 ? Wr - 1 : u);
+    v = v < 0 ? 0 : (v > Hr - 1 ? Hr - 1 : v);
+    const Lerp1 ly = ac_lerp(v, ac_scale(h, Hr), h), lx = ac_lerp(u, ac_scale(w, Wr), w);
+    const int o00 = ly.i0 * w + lx.i0, o01 = ly.i0 * w + lx.i1, o10 = ly.i1 * w + lx.i0, o11 = ly.i1 * w + lx.i1;
+    const float* n1 = n0 + h * w;
+    float d, s, a0, a1;
+    if ((h == Hr) && (w == Wr)) {
+        d = pd[o00]; s = ps[o00]; a0 = n0[o00]; a1 = n1[o00];
+    } else {
+        d = ac_blend(ly, lx, pd[o00], pd[o01], pd[o10], pd[o11]);
+        s = ac_blend(ly, lx, ps[o00], ps[o01], ps[o10], ps[o11]);
+        a0 = ac_blend(ly, lx, n0[o00], n0[o01], n0[o10], n0[o11]);
+        a1 = ac_blend(ly, lx, n1[o00], n1[o01], n1[o10], n1[o11]);
+    }
+    RayBounds r;
+    if (depth_inv) {              // utils.py:402-407
+        r.rn = d + s; if (r.rn > a0) r.rn = a0;
+        r.rf = d - s; if (r.rf < a1) r.rf = a1;
+    } else {                      // utils.py:409-413
+        r.rn = d - s; if (r.rn < a0) r.rn = a0;
+        r.rf = d + s; if (r.rf > a1) r.rf = a1;
+    }
+    r.vn = a0; r.vf = a1;
+    return r;
+}
+
 }  // namespace enerf

@@ -366,38 +366,11 @@ __global__ __launch_bounds__(256) void k_build_rays(const float* __restrict__ ra
     const float* r = rays8 + i * 8;
     float rv[8];
     for (int k = 0; k < 8; ++k) rv[k] = r[k];
-    int u = (int)rv[6], v = (int)rv[7];                     // .long(): truncation
-    u = u < 0 ? u + Wr : u;                                  // python negative indexing
-    v = v < 0 ? v + Hr : v;
-    u = u < 0 ? 0 : (u > Wr - 1 ? Wr - 1 : u);
-    v = v < 0 ? 0 : (v > Hr - 1 ? Hr - 1 : v);
-    Lerp1 ly = ac_lerp(v, ac_scale(h, Hr), h), lx = ac_lerp(u, ac_scale(w, Wr), w);
-    int o00 = ly.i0 * w + lx.i0, o01 = ly.i0 * w + lx.i1, o10 = ly.i1 * w + lx.i0, o11 = ly.i1 * w + lx.i1;
-    const float* pd = depth + (long long)b * h * w;
-    const float* ps = std + (long long)b * h * w;
-    const float* n0 = nf + (long long)b * 2 * h * w;
-    const float* n1 = n0 + h * w;
-    bool same = (h == Hr) && (w == Wr);
-    float d, s, a0, a1;
-    if (same) {
-        d = pd[o00]; s = ps[o00]; a0 = n0[o00]; a1 = n1[o00];
-    } else {
-        d = ac_blend(ly, lx, pd[o00], pd[o01], pd[o10], pd[o11]);
-        s = ac_blend(ly, lx, ps[o00], ps[o01], ps[o10], ps[o11]);
-        a0 = ac_blend(ly, lx, n0[o00], n0[o01], n0[o10], n0[o11]);
-        a1 = ac_blend(ly, lx, n1[o00], n1[o01], n1[o10], n1[o11]);
-    }
-    float rn, rf;
-    if (depth_inv) {              // utils.py:402-407
-        rn = d + s; if (rn > a0) rn = a0;
-        rf = d - s; if (rf < a1) rf = a1;
-    } else {                      // utils.py:409-413
-        rn = d - s; if (rn < a0) rn = a0;
-        rf = d + s; if (rf > a1) rf = a1;
-    }
+    const RayBounds rb = ray_bounds(rv[6], rv[7], depth + (long long)b * h * w, std + (long long)b * h * w,
+                                    nf + (long long)b * 2 * h * w, h, w, Hr, Wr, depth_inv);
     float* o = rays12 + i * 12;
     for (int k = 0; k < 8; ++k) o[k] = rv[k];
-    o[8] = rn; o[9] = rf; o[10] = a0; o[11] = a1;
+    o[8] = rb.rn; o[9] = rb.rf; o[10] = rb.vn; o[11] = rb.vf;
 }
 void launch_build_rays(const float* rays8, const float* depth, const float* std, const float* nf, int B, int N, int h,
                        int w, int Hr, int Wr, int depth_inv, float* rays12, hipStream_t st) {

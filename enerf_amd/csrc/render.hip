@@ -197,11 +197,22 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
         const bool rok = ray < nrays;
         const long long rr = rok ? ray : nrays - 1;
         const int b = (int)(rr / a.N);
-        const float* rp = a.rays12 + rr * 12;
-        const float4 q0 = *reinterpret_cast<const float4*>(rp), q1 = *reinterpret_cast<const float4*>(rp + 4),
-                     q2 = *reinterpret_cast<const float4*>(rp + 8);
-        const float ox = q0.x, oy = q0.y, oz = q0.z, dx = q0.w, dy = q1.x, dz = q1.y, ru = q1.z, rv = q1.w;
-        const float rn = q2.x, rf = q2.y, vn = q2.z, vf = q2.w;
+        float ox, oy, oz, dx, dy, dz, ru, rv, rn, rf, vn, vf;
+        if (a.rays8 != nullptr) {      // fused build_rays (uniform branch): 8-float ray + the level's depth/std/near_far maps
+            const float* rp = a.rays8 + rr * 8;
+            const float4 q0 = *reinterpret_cast<const float4*>(rp), q1 = *reinterpret_cast<const float4*>(rp + 4);
+            ox = q0.x; oy = q0.y; oz = q0.z; dx = q0.w; dy = q1.x; dz = q1.y; ru = q1.z; rv = q1.w;
+            const long long mo = (long long)b * a.map_h * a.map_w;
+            const RayBounds rb = ray_bounds(ru, rv, a.depth_map + mo, a.std_map + mo, a.nf_map + 2 * mo, a.map_h, a.map_w,
+                                            a.Hr, a.Wr, a.depth_inv);
+            rn = rb.rn; rf = rb.rf; vn = rb.vn; vf = rb.vf;
+        } else {
+            const float* rp = a.rays12 + rr * 12;
+            const float4 q0 = *reinterpret_cast<const float4*>(rp), q1 = *reinterpret_cast<const float4*>(rp + 4),
+                         q2 = *reinterpret_cast<const float4*>(rp + 8);
+            ox = q0.x; oy = q0.y; oz = q0.z; dx = q0.w; dy = q1.x; dz = q1.y; ru = q1.z; rv = q1.w;
+            rn = q2.x; rf = q2.y; vn = q2.z; vf = q2.w;
+        }
         // normalised (x,y) of the ray inside the feature volume: network.py:37 then utils.py:457
         const float gxv = (ru / (float)(a.Wr - 1)) * 2.f - 1.f, gyv = (rv / (float)(a.Hr - 1)) * 2.f - 1.f;
         // 32-bit element offsets from the (uniform) tensor bases: one saddr+voffset load per tap instead of a

@@ -14,7 +14,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libenerf_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _f = C.c_void_p     # device float*
 _i = C.c_int
@@ -45,7 +45,8 @@ class RenderArgs(C.Structure):
                                    "depth", "weights")]
                 + [(n, _i) for n in ("B", "N", "S", "n_samples", "depth_inv", "Hr", "Wr", "F", "D", "h", "w",
                                      "white_bkgd")]
-                + [("render_scale", _fl)])
+                + [("render_scale", _fl)]
+                + [(n, _f) for n in ("rays8", "depth_map", "std_map", "nf_map")] + [("map_h", _i), ("map_w", _i)])
 
 
 _SIGNATURES = {
@@ -263,17 +264,28 @@ class EnerfLib:
         return packed
 
     def render_rays(self, rays12, tex, vol, src_exts, src_ixts, tar_ext, packed, *, n_samples, depth_inv, F,
-                    render_scale, white_bkgd=False):
+                    render_scale, white_bkgd=False, maps=None):
+        """``rays12`` (B,N,12) from build_rays — or, with ``maps=(depth, std, near_far)`` of the level, the
+        8-float rays (B,N,8): build_rays then runs inside the render kernel."""
         B, N = rays12.shape[:2]
+        if (rays12.shape[-1] != 12) != (maps is not None):
+            raise EnerfError("render_rays: pass (B,N,12) rays, or (B,N,8) rays together with maps=(depth,std,near_far)")
         S, Hr, Wr = tex.shape[1:4]
         _, D, h, w, _ = vol.shape
         dev = rays12.device
         rgb = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
         depth = torch.empty((B, N), dtype=torch.float32, device=dev)
         weights = torch.empty((B, N, n_samples), dtype=torch.float32, device=dev)
-        a = RenderArgs(_ptr(rays12), _ptr(tex), _ptr(vol), _ptr(src_exts), _ptr(src_ixts), _ptr(tar_ext),
+        if maps is None:
+            fused = (None, None, None, None, 0, 0)
+            r12 = _ptr(rays12)
+        else:
+            md, ms, mn = maps
+            fused = (_ptr(rays12), _ptr(md), _ptr(ms), _ptr(mn), int(md.shape[-2]), int(md.shape[-1]))
+            r12 = None
+        a = RenderArgs(r12, _ptr(tex), _ptr(vol), _ptr(src_exts), _ptr(src_ixts), _ptr(tar_ext),
                        _ptr(packed), _ptr(rgb), _ptr(depth), _ptr(weights), B, N, S, n_samples, int(depth_inv), Hr,
-                       Wr, F, D, h, w, int(white_bkgd), float(render_scale))
+                       Wr, F, D, h, w, int(white_bkgd), float(render_scale), *fused)
         self._check(self.dll.enerf_render_rays(C.byref(a), self.stream_of(rays12)), "render_rays")
         return rgb, depth, weights
 

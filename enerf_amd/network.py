@@ -225,6 +225,7 @@ class Network(nn.Module):
         # takes (the fused smooth0 blocks hold 141 of the 160 KB of LDS per CU, so the conv3d blocks queue for
         # LDS): 927 -> 931 FPS.  Off by default — one stream keeps the frame graph-capturable.
         self.overlap = overlap
+        self.fuse_build_rays = True         # forward(): build_rays in the render kernel's prologue (same bits)
         self._side_stream = None
         self._feat_events = {}
         # "torch": FeatureNet in PyTorch-ROCm/MIOpen (north_star's split); "hip": enerf_feature_net on the
@@ -375,11 +376,14 @@ class Network(nn.Module):
             raise RuntimeError("render_rays: nerf_model must be this network's nerf_{level}")
         tex = self._texels(level, batch, im_feat)
         self._mark(f"texels_{level}")
+        # internal fast path of forward(): 8-float rays + the level's (depth, std, near_far) maps — build_rays
+        # (utils.py:390-420) then runs in the render kernel's prologue instead of as its own launch
+        maps = kwargs.get("_build_rays_maps", None)
         rgb, depth, weights = self.lib.render_rays(
             rays.contiguous(), tex, vol, batch["src_exts"].contiguous(), batch["src_ixts"].contiguous(),
             batch["tar_ext"].contiguous(), self._packed_weights(name), n_samples=cas.num_samples[level],
             depth_inv=cas.depth_inv[level], F=cas.nerf_model_feat_ch[level] + 3,
-            render_scale=cas.render_scale[level], white_bkgd=self.cfg.white_bkgd)
+            render_scale=cas.render_scale[level], white_bkgd=self.cfg.white_bkgd, maps=maps)
         self._mark(f"render_{level}")
         return {"rgb": rgb, "depth": depth, "weights": weights}
 
@@ -450,16 +454,21 @@ class Network(nn.Module):
                 if not cas.render_if[i]:
                     continue
                 Hr, Wr = int(H * cas.render_scale[i]), int(W * cas.render_scale[i])
-                rays = lib.build_rays(batch[f"rays_{i}"].contiguous(), depth, std, near_far, Hr, Wr,
-                                      cas.depth_inv[i])
-                self._mark(f"build_rays_{i}")
                 masked = self.human and "mask_at_box" in batch and i == cas.num - 1
+                rays8 = batch[f"rays_{i}"].contiguous()
+                extra = {}
+                if self.fuse_build_rays and not masked and rays8.shape[1] <= int(self.cfg.chunk_size):
+                    rays = rays8                                     # build_rays runs inside the render launch
+                    extra["_build_rays_maps"] = (depth, std, near_far)
+                else:
+                    rays = lib.build_rays(rays8, depth, std, near_far, Hr, Wr, cas.depth_inv[i])
+                    self._mark(f"build_rays_{i}")
                 if masked:
                     mask = batch["mask_at_box"].bool().reshape(1, -1)
                     rays = rays[mask][None]
                 ret_i = self.batchify_rays(rays=rays, feature_volume=feat3d, batch=batch,
                                            im_feat=feats[f"level_{cas.render_im_feat_level[i]}"],
-                                           nerf_model=getattr(self, f"nerf_{i}"), level=i)
+                                           nerf_model=getattr(self, f"nerf_{i}"), level=i, **extra)
                 if masked:
                     rgb = torch.zeros((1, mask.shape[1], 3), dtype=torch.float32, device=src.device)
                     if int(mask.sum()) > 1:

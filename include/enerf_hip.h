@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ENERF_ABI_VERSION 1
+#define ENERF_ABI_VERSION 2
 #define ENERF_OK 0
 #define ENERF_EINVAL (-1)   /* bad argument / unsupported shape */
 #define ENERF_ELAUNCH (-2)  /* HIP launch error */
@@ -159,6 +159,13 @@ typedef struct {
     float* weights;        /* (B,N,n_samples) */
     int B, N, S, n_samples, depth_inv, Hr, Wr, F, D, h, w, white_bkgd;
     float render_scale;
+    /* Optional fused build_rays (utils.py:390-420): when rays8 != NULL, rays12 is ignored and every ray's
+     * [near, far | volume near, far] is derived inside the kernel from the 8-float rays and the level's
+     * depth / std (B,map_h,map_w) and near_far (B,2,map_h,map_w) maps, exactly as enerf_build_rays does
+     * (same device function) — one launch and a 48 B/ray round trip less.  ABI >= 2. */
+    const float* rays8;
+    const float *depth_map, *std_map, *nf_map;
+    int map_h, map_w;
 } enerf_render_args_t;
 int enerf_render_rays(const enerf_render_args_t* args, enerf_stream_t stream);
 

@@ -170,6 +170,23 @@ def test_conv3d_variants_agree_with_reference(force, monkeypatch):
         _close(v.numpy(), gold["out/" + k], 2e-5, k)
 
 
+def test_fused_build_rays_equals_separate_launch():
+    """forward() folds build_rays into the render kernel's prologue (same device function): bit-identical."""
+    name = "tiny_s3"
+    cfg, batch = case_config(name), case_batch(name)
+    net = _net(cfg)
+    assert net.fuse_build_rays
+    a = net(batch)
+    net.fuse_build_rays = False
+    b = net(batch)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    lib = emu_lib()
+    with pytest.raises(Exception):                      # 8-float rays without the maps (and vice versa) are rejected
+        lib.render_rays(torch.zeros(1, 4, 8), None, None, None, None, None, None, n_samples=2, depth_inv=False, F=11,
+                        render_scale=1.0)
+
+
 def test_hip_feature_net_matches_reference_feature_maps():
     """enerf_feature_net (conv2d.hip) against the reference FeatureNet's three outputs, plain and texel mode."""
     name = "tiny_s3"
