@@ -278,17 +278,27 @@ __global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, c
         }
     };
     {
-        float4 b0[CT][NB], b1[CT][NB];
-        float a0[NA], a1[NA];
-        issue(0, b0, a0);
+        // PF-deep operand ring: the loads of taps t+1 .. t+PF-1 are in flight while tap t runs on the matrix core.
+        // These layers are a latency chain (a tap = 8-16 MFMAs = 0.1-0.3 us against ~0.7 us per L2 round trip).
+        // Measured on MI355X: depth 3-4 is 10-18 % faster for the 27-tap stride-2 layers, but 10-20 % SLOWER for
+        // the transposed layers (1-8 taps per parity class: the ring only adds redundant clamped loads) and no
+        // better for the small stride-1 layers, which keep depth 2.  Depth is capped by registers.
+        constexpr int REGS_PER_TAP = CT * NB * 4 + NA;
+        constexpr int PF = KIND != kConvS2 ? 2 : (REGS_PER_TAP <= 24 ? 4 : (REGS_PER_TAP <= 40 ? 3 : 2));
+        float4 bq[PF][CT][NB];
+        float aq[PF][NA];
+#pragma unroll
+        for (int k = 0; k < PF - 1; ++k) issue(k < ntaps ? k : ntaps - 1, bq[k], aq[k]);
 #pragma unroll 1
-        for (int t = 0; t < ntaps; t += 2) {
-            issue(t + 1 < ntaps ? t + 1 : ntaps - 1, b1, a1);       // clamped: always loads, never branches
-            __builtin_amdgcn_sched_barrier(0);                      // keep the next tap's loads ahead of this tap's MFMAs
-            compute(b0, a0);
-            issue(t + 2 < ntaps ? t + 2 : ntaps - 1, b0, a0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < ntaps) compute(b1, a1);
+        for (int t = 0; t < ntaps; t += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int tn = t + k + PF - 1;                       // clamped: always loads, never branches
+                issue(tn < ntaps ? tn : ntaps - 1, bq[(k + PF - 1) % PF], aq[(k + PF - 1) % PF]);
+                __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of this tap's MFMAs
+                if (t + k < ntaps) compute(bq[k], aq[k]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
