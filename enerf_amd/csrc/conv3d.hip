@@ -137,7 +137,7 @@ __device__ __forceinline__ void tap_offsets(int t, int ntw, int nth, int pd, int
 // ---- the implicit-GEMM kernel ---------------------------------------------------------------------
 // CIN: input channels (8,16,32,64); RT: cout row tiles of 16; KIND; CT: 16-voxel column tiles per wave.
 template <int CIN, int RT, int KIND, int CT>
-__global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, const float* __restrict__ scale,
+__global__ __launch_bounds__(KIND == kConvT2 ? 512 : 256) void k_conv3d(const float* __restrict__ wpk, const float* __restrict__ scale,
                                                 const float* __restrict__ shift, const float* __restrict__ in,
                                                 const float* __restrict__ residual, float* __restrict__ out,
                                                 float* __restrict__ out2, int cout, int relu, int B, int Di, int Hi,
@@ -165,9 +165,12 @@ __global__ __launch_bounds__(256) void k_conv3d(const float* __restrict__ wpk, c
     int cls = 0;
     int grp = wave;
     if (KIND == kConvT2) {
-        cls = wave / groups;
-        grp = wave - cls * groups;
-        if (cls >= 8) return;
+        // the eight parity classes of one group of q-tiles are eight consecutive waves = one 512-thread block:
+        // they read the same inputs and write the two halves of the same 64-B output lines from one CU at about
+        // the same time (class-major order spread them over different XCDs and moments: half-line writes)
+        grp = wave >> 3;
+        cls = wave & 7;
+        if (grp >= groups) return;
     } else if (wave >= groups) {
         return;
     }
@@ -351,8 +354,9 @@ static void launch_one(const Conv3dDesc& L, const float* in, const float* residu
     long long n = (KIND == kConvT2) ? (long long)B * Di * Hi * Wi : (long long)B * Do * Ho * Wo;
     long long groups = cdivl(cdivl(n, 16), CT);
     long long waves = ((KIND == kConvT2) ? groups * 8 : groups) * (rt_total / RT);
-    unsigned grid = (unsigned)cdivl(waves, 4);
-    ENERF_LAUNCH((k_conv3d<CIN, RT, KIND, CT>), grid, 256, 0, st, L.w, L.scale, L.shift, in, residual, out, out2, L.cout,
+    constexpr int WPB = (KIND == kConvT2) ? 8 : 4;                      // waves per block
+    unsigned grid = (unsigned)cdivl(waves, WPB);
+    ENERF_LAUNCH((k_conv3d<CIN, RT, KIND, CT>), grid, WPB * 64, 0, st, L.w, L.scale, L.shift, in, residual, out, out2, L.cout,
                  L.relu, B, Di, Hi, Wi, Do, Ho, Wo, rt_total);
 }
 
