@@ -204,10 +204,13 @@ __global__ __launch_bounds__(256) void k_depth_values(const float* __restrict__ 
                                                       const float* __restrict__ pnf, int B, int D, int h, int w, int hp,
                                                       int wp, int depth_inv, float* __restrict__ dv,
                                                       float* __restrict__ nf_out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int hw = h * w;
-    if (i >= B * hw) return;
-    int b = i / hw, p = i - b * hw;
+    // one thread per (plane, pixel): level 0 has 64x80 pixels x 48 planes — a thread per pixel left the chip idle
+    // behind a 48-step serial loop of IEEE divides (10 us); the per-pixel [near, far] is recomputed per plane
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int hw = h * w;
+    if (i >= B * D * hw) return;
+    const int b = i / (D * hw), r = i - b * (D * hw);
+    const int k = r / hw, p = r - k * hw;
     float nn, ff;
     if (pdepth == nullptr) {
         nn = near_far[b * 2 + 0];
@@ -230,25 +233,19 @@ __global__ __launch_bounds__(256) void k_depth_values(const float* __restrict__ 
         nn = 1.f / lo;            // utils.py:128
         ff = 1.f / hi;
     }
-    float first = 0.f, last = 0.f;
-    float inn = 1.f / nn, iff = 1.f / ff;
-    for (int k = 0; k < D; ++k) {
-        float t = linspace01(k, D);
-        float v = depth_inv ? 1.f / (inn + t * (iff - inn)) : nn + t * (ff - nn);
-        dv[((long long)b * D + k) * hw + p] = v;
-        if (k == 0) first = v;
-        if (k == D - 1) last = v;
+    const float inn = 1.f / nn, iff = 1.f / ff;
+    const float t = linspace01(k, D);
+    const float v = depth_inv ? 1.f / (inn + t * (iff - inn)) : nn + t * (ff - nn);
+    dv[i] = v;                                   // (B,D,h,w): the thread index is the element index
+    if (k == 0 || k == D - 1) {                  // utils.py:149-150 (k == 0 == D-1 writes both)
+        const float e = depth_inv ? 1.f / clamp_min(v, 1e-6f) : v;
+        if (k == 0) nf_out[((long long)b * 2 + 0) * hw + p] = e;
+        if (k == D - 1) nf_out[((long long)b * 2 + 1) * hw + p] = e;
     }
-    if (depth_inv) {             // utils.py:149-150
-        first = 1.f / clamp_min(first, 1e-6f);
-        last = 1.f / clamp_min(last, 1e-6f);
-    }
-    nf_out[((long long)b * 2 + 0) * hw + p] = first;
-    nf_out[((long long)b * 2 + 1) * hw + p] = last;
 }
 void launch_depth_values(const float* near_far, const float* pdepth, const float* pstd, const float* pnf, int B, int D,
                          int h, int w, int hp, int wp, int depth_inv, float* dv, float* nf_out, hipStream_t st) {
-    ENERF_LAUNCH_SIMPLE(k_depth_values, cdiv(B * h * w, 256), 256, 0, st, near_far, pdepth, pstd, pnf, B, D, h, w, hp,
+    ENERF_LAUNCH_SIMPLE(k_depth_values, cdiv(B * D * h * w, 256), 256, 0, st, near_far, pdepth, pstd, pnf, B, D, h, w, hp,
                         wp, depth_inv, dv, nf_out);
 }
 
