@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--views", type=int, default=3)
     ap.add_argument("--miopen-benchmark", action="store_true", help="experiment: let MIOpen search conv algos")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay one captured HIP graph per frame (enerf_amd/graph.py) instead of enqueueing ~38 launches")
     ap.add_argument("--overlap", action="store_true",
                     help="enqueue FPN levels 1-2 on a second HIP stream next to the level-0 cost volume (default: one stream)")
     ap.add_argument("--feature-backend", choices=["hip", "torch"], default="hip",
@@ -103,8 +105,15 @@ def main():
     batch_np = make_batch(H, W, S, cfg, seed=rank, textured=True)
     batch = {k: torch.from_numpy(v).to(dev) for k, v in batch_np.items()}
 
-    def step():
-        return net(batch)
+    if args.graph:                                      # whole-frame HIP graph replay instead of eager enqueue
+        from enerf_amd.graph import GraphedFrame
+        frame = GraphedFrame(net, batch)
+
+        def step():
+            return frame(batch)
+    else:
+        def step():
+            return net(batch)
 
     for _ in range(args.warmup):
         step()
@@ -136,12 +145,12 @@ def main():
             "vs_baseline": fps / BASELINE_FPS_RTX3090, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"DTU generalizable eval (dtu_pretrain.yaml, render_if False,True, "
                                    f"volume_planes 48,8), {H}x{W}, {S} src views, one target view per step",
-                       "feature_net": args.feature_backend, "streams": 2 if (args.overlap and args.feature_backend == "hip") else 1,
+                       "feature_net": args.feature_backend, "streams": 2 if (args.overlap and args.feature_backend == "hip") else 1, "hip_graph": bool(args.graph),
                        "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world} (no collectives)"},
         }
 
     # ---- per-stage HIP-event timings + roofline of the dominant kernel (rank 0, not in the timed region) ----
-    if rank == 0 and not args.no_stages:
+    if rank == 0 and not args.no_stages and not args.graph:
         t0 = time.perf_counter()                      # host-side enqueue cost (no device sync inside)
         for _ in range(20):
             step()

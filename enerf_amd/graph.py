@@ -1,0 +1,45 @@
+"""Whole-frame HIP graph: capture one ``Network.forward`` — ~38 kernel launches and their
+ctypes/torch bookkeeping (0.26 ms of host time per 1.09 ms frame) — once, replay it per frame.
+
+    frame = GraphedFrame(net, example_batch)      # captures on a side stream; static input/output buffers
+    out = frame(batch)                            # copies the batch into the static inputs, one hipGraphLaunch
+
+The graph holds the shapes and the weights' packed images of the capture; re-capture after load_state_dict /
+a shape change.  Works because the HIP path never synchronises, allocates only through torch's (graph-aware)
+caching allocator and takes every pointer from tensors that stay alive inside the graph's private pool."""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+
+class GraphedFrame:
+    def __init__(self, net, batch: Dict[str, torch.Tensor], warmup: int = 2):
+        if net.training:
+            raise RuntimeError("GraphedFrame: call net.eval() first")
+        if getattr(net, "overlap", False):
+            raise RuntimeError("GraphedFrame: capture needs the single-stream path (overlap=False)")
+        self.net = net
+        self.static_in = {k: v.clone() if torch.is_tensor(v) else v for k, v in batch.items()}
+        with torch.no_grad():
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(max(1, warmup)):          # packs weights, sizes workspaces, warms the allocator
+                    net(self.static_in)
+            torch.cuda.current_stream().wait_stream(s)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_out = net(self.static_in)
+
+    def __call__(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                dst = self.static_in[k]
+                if dst.shape != v.shape:
+                    raise RuntimeError(f"GraphedFrame: '{k}' changed shape {tuple(dst.shape)} -> {tuple(v.shape)}; re-capture")
+                if dst.data_ptr() != v.data_ptr():
+                    dst.copy_(v, non_blocking=True)
+        self.graph.replay()
+        return self.static_out                      # static buffers: valid until the next call

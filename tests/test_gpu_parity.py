@@ -172,6 +172,22 @@ def test_two_stream_overlap_is_bit_identical_to_single_stream():
     assert net._side_stream is not None and not net._feat_events
 
 
+def test_whole_frame_hip_graph_replay_matches_eager():
+    """enerf_amd.graph.GraphedFrame: one captured forward replayed on new inputs == eager forward, bit for bit."""
+    from enerf_amd.graph import GraphedFrame
+    cfg = EnerfConfig.dtu_eval()
+    net = _net(cfg)
+    batches = [_to({k: torch.from_numpy(v) for k, v in make_batch(256, 320, 3, cfg, seed=s, textured=True).items()})
+               for s in range(3)]
+    eager = [{k: v.clone() for k, v in net(b).items()} for b in batches]
+    frame = GraphedFrame(net, batches[0])
+    for b, e in zip(batches, eager):
+        out = frame(b)
+        torch.cuda.synchronize()
+        for k in e:
+            assert torch.equal(out[k], e[k]), k
+
+
 def test_lego_shape_800x800_4views():
     """BASELINE config 3 shapes (H=W=800, S=4, planes 64,8, both levels): runs, finite, deterministic."""
     cfg = EnerfConfig()
