@@ -164,6 +164,31 @@ def main():
         net._timer = None
         stages = timer.summary()
         result["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
+        # the reference's own protocol (run.py:62-76: synchronize, time network(batch), synchronize): per-frame latency
+        lat = []
+        for _ in range(200):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            lat.append(1e3 * (time.perf_counter() - t1))
+        lat.sort()
+        result["latency_ms"] = {"p50": round(lat[len(lat) // 2], 4), "p95": round(lat[int(len(lat) * 0.95)], 4),
+                                "mean": round(sum(lat) / len(lat), 4), "protocol": "sync per frame (run.py:62-76), 200 frames"}
+        # per-stage rooflines (algorithmic FLOP or compulsory bytes of the 512x640/3-view frame)
+        if (H, W, S) == (512, 640, 3):
+            sr = {}
+            for name, gf in (("cost_reg_0", 5.63), ("cost_reg_1", 11.04)):
+                if stages.get(name):
+                    a = gf / stages[name]                               # GFLOP / ms = TFLOP/s
+                    sr[name] = {"bound": "mfma", "achieved": round(a, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(a / PEAK_F32_MFMA_TFLOPS, 4), "algorithmic_gflop": gf}
+            for name, mb in (("volume_0", 39.4), ("volume_1", 57.6)):
+                if stages.get(name):
+                    a = mb / stages[name]                               # MB / ms = GB/s
+                    sr[name] = {"bound": "hbm", "achieved": round(a, 1), "peak": 8000.0, "unit": "GB/s",
+                                "frac": round(a / 8000.0, 4), "algorithmic_mbytes": mb}
+            result["stage_roofline"] = sr
         # dominant single kernel: the fused level-1 render launch (k_render_rays<3,3,*>): 2 samples x H*W rays
         n_samples_total = H * W * cfg.cas.num_samples[1]
         flops = FLOP_PER_SAMPLE_L1 * n_samples_total if (S == 3) else None
