@@ -175,6 +175,23 @@ def main():
         lat.sort()
         result["latency_ms"] = {"p50": round(lat[len(lat) // 2], 4), "p95": round(lat[int(len(lat) * 0.95)], 4),
                                 "mean": round(sum(lat) / len(lat), 4), "protocol": "sync per frame (run.py:62-76), 200 frames"}
+        # throughput when several target views share one forward (same API, batch dimension): not the headline
+        # (BASELINE's metric is one target view per step) — shows what the small cascade layers leave idle at B=1
+        try:
+            Bn = 4
+            bb = {k: torch.from_numpy(v).to(dev) for k, v in make_batch(H, W, S, cfg, seed=rank, textured=True, B=Bn).items()}
+            for _ in range(5):
+                net(bb)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(50):
+                net(bb)
+            torch.cuda.synchronize()
+            result["batched_throughput"] = {"target_views_per_forward": Bn,
+                                            "frames_per_s": round(Bn * 50 / (time.perf_counter() - t1), 1)}
+            del bb
+        except Exception as e:                                   # never let an extra break the contract line
+            result["batched_throughput"] = {"error": str(e)[:200]}
         # per-stage rooflines (algorithmic FLOP or compulsory bytes of the 512x640/3-view frame)
         if (H, W, S) == (512, 640, 3):
             sr = {}
