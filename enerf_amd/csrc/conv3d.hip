@@ -605,6 +605,16 @@ static long long conv_v2_min_vox() {
 
 void launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, float* out, float* out2, int B, int Di,
                    int Hi, int Wi, hipStream_t st) {
+    // LDS-staged stride-2 path (conv1 of both nets): ENERF_CONV_S2_LDS=0 falls back to the global-load kernel
+    if (L.kind == kConvS2 && residual == nullptr && out2 == nullptr && conv_v2_enabled()) {
+        const char* e = getenv("ENERF_CONV_S2_LDS");
+        if ((e == nullptr || e[0] != '0') && (long long)B * Di * Hi * Wi >= 32 * conv_v2_min_vox() &&   // level-1 conv1 (19.7 -> 14.1 us); level 0 is no faster
+            launch_conv3d_s2_lds(L, in, out, B, Di, Hi, Wi, st)) {
+            if (getenv("ENERF_TRACE")) fprintf(stderr, "[enerf] conv3d %d->%d vox=%lld : s2 lds\n", L.cin, L.cout,
+                                               (long long)B * Di * Hi * Wi);
+            return;
+        }
+    }
     // persistent producer/consumer kernel (conv3d_ws.hip); ENERF_CONV_WS=1 routes every eligible layer through it
     {
         const char* e = getenv("ENERF_CONV_WS");

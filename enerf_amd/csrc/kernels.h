@@ -38,6 +38,8 @@ long long conv3d_pk8_packed_floats(int cin);
 void launch_conv3d_pk8_pack(const float* w, const float* wd, int cin, float* packed, hipStream_t st);
 bool launch_conv3d_ws(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,
                       hipStream_t st);   // persistent producer/consumer variant, cout <= 16 (conv3d_ws.hip)
+bool launch_conv3d_s2_lds(const Conv3dDesc& L, const float* in, float* out, int B, int Di, int Hi, int Wi,
+                          hipStream_t st);   // LDS-staged stride-2 variant, Cin = 8, Cout <= 16 (conv3d_s2.hip)
 bool launch_conv3d_pk8(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,
                        hipStream_t st);
 // number of floats of the packed weight image for a layer
