@@ -313,8 +313,13 @@ int enerf_feature_net_stage(const float* packed, const float* src_inps, int n_im
     float *c2a = take(p2 * 32), *c2 = take(p2 * 32);
     int rc = 0;
     if (trunk) {
-        rc |= launch_conv2d(d[0], src_inps, c0a, nullptr, n_img, H, W, 0, 0, st);      // conv0.0 (NCHW image in)
-        rc |= launch_conv2d(d[1], c0a, c0, nullptr, n_img, H, W, 0, 0, st);            // conv0.1
+        const char* f0 = getenv("ENERF_FUSE_CONV0");                                   // A/B knob, default fused
+        if (f0 == nullptr || f0[0] != '0') {
+            launch_conv0_fused(d[0], d[1], src_inps, c0, n_img, H, W, st);             // conv0.1(conv0.0(image))
+        } else {
+            rc |= launch_conv2d(d[0], src_inps, c0a, nullptr, n_img, H, W, 0, 0, st);  // conv0.0 (NCHW image in)
+            rc |= launch_conv2d(d[1], c0a, c0, nullptr, n_img, H, W, 0, 0, st);        // conv0.1
+        }
         rc |= launch_conv2d(d[2], c0, c1a, nullptr, n_img, H, W, 0, 0, st);            // conv1.0 (s2)
         rc |= launch_conv2d(d[3], c1a, c1, nullptr, n_img, H1, W1, 0, 0, st);          // conv1.1
         rc |= launch_conv2d(d[4], c1, c2a, nullptr, n_img, H1, W1, 0, 0, st);          // conv2.0 (s2)

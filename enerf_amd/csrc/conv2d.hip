@@ -277,6 +277,135 @@ static void launch_c2(const Conv2dDesc& L, const float* in, float* out, const fl
 }
 
 // =====================================================================================================
+// conv0.1( conv0.0( image ) )  — feature_net.py:7-9 (two ConvBnReLU 3x3, 3 -> 8 -> 8 at full resolution) in ONE
+// kernel.  Unfused, the 8-channel intermediate (31 MB at 3x512x640) is written and read back with halos and the
+// first layer is a 23 us launch against a 10 us floor.  Here a block stages the 12x36 image patch of its 8x32
+// output tile (NCHW planes -> [pixel][4] texels), evaluates conv0.0 + BN + ReLU on the matrix cores for the
+// 10x34 haloed tile (22 column tiles, 1.33x halo recompute of a 1-k-step layer) straight into LDS — zero outside
+// the image, which is conv0.1's padding — and runs conv0.1 from there exactly like k_conv2d<8,...>.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_conv0_fused(const float* __restrict__ w0, const float* __restrict__ scale0,
+                                                     const float* __restrict__ shift0, const float* __restrict__ w1,
+                                                     const float* __restrict__ scale1, const float* __restrict__ shift1,
+                                                     const float* __restrict__ img, float* __restrict__ out, int N, int H,
+                                                     int W, int tiles_y, int tiles_x) {
+    constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, NPX = IH * IW;      // conv0.1 input tile (10 x 34)
+    constexpr int PH = IH + 2, PW = IW + 2, NPP = PH * PW;                        // image patch (12 x 36)
+    constexpr int NT0 = (NPX + 15) / 16;                                          // column tiles of stage 1 (22)
+    constexpr int CTW = 4;
+    ENERF_DYN_SMEM(float, lds);
+    float* pat = lds;                   // [NPP][4]   image texels (4th channel 0)
+    float* til = lds + NPP * 4;         // [NPX][8]   conv0.0 output tile
+
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
+    const int bid = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+    const int oy0 = ty * TH, ox0 = tx * TW;
+
+    // weights of both layers (9 + 18 A operands per lane), requested before the staging traffic
+    float a0[9], a1[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        a0[t] = w0[t * 64 + lane];
+        a1[t][0] = w1[(t * 2 + 0) * 64 + lane];
+        a1[t][1] = w1[(t * 2 + 1) * 64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {   // ---- image patch -> LDS: one thread per patch pixel, three coalesced plane reads, zero outside ----
+        constexpr int NIT = (NPP + 255) / 256;
+        float v0[NIT], v1[NIT], v2[NIT];
+        bool sk[NIT];
+        const float* base = img + (long long)n * 3 * H * W;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = threadIdx.x + it * 256, ic = i < NPP ? i : NPP - 1;
+            const int ly = ic / PW, lx = ic - ly * PW, gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
+            sk[it] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int off = sk[it] ? gy * W + gx : 0;
+            v0[it] = base[off]; v1[it] = base[H * W + off]; v2[it] = base[2 * H * W + off];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = threadIdx.x + it * 256;
+            if (i < NPP)
+                *reinterpret_cast<float4*>(pat + i * 4) =
+                    sk[it] ? make_float4(v0[it], v1[it], v2[it], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 1: conv0.0 + BN + ReLU on the haloed tile -> LDS (lane group g supplies input channel g) ----
+    {
+        float sc[4], sh[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sc[r] = scale0[(4 * g + r) & 15]; sh[r] = shift0[(4 * g + r) & 15]; }
+#pragma unroll 1
+        for (int tile = wv; tile < NT0; tile += 4) {
+            const int p = tile * 16 + j, pc = p < NPX ? p : NPX - 1;
+            const int ly = pc / IW, lx = pc - ly * IW;
+            const float* pb = pat + (ly * PW + lx) * 4 + g;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], pb[((t / 3) * PW + (t % 3)) * 4], acc, 0, 0, 0);
+            const int gy = oy0 - 1 + ly, gx = ox0 - 1 + lx;
+            const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            if (p < NPX && g < 2) {
+                float4 o;
+                o.x = inside ? relu1(acc[0] * sc[0] + sh[0]) : 0.f;
+                o.y = inside ? relu1(acc[1] * sc[1] + sh[1]) : 0.f;
+                o.z = inside ? relu1(acc[2] * sc[2] + sh[2]) : 0.f;
+                o.w = inside ? relu1(acc[3] * sc[3] + sh[3]) : 0.f;
+                *reinterpret_cast<float4*>(til + p * 8 + 4 * g) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 2: conv0.1 (8 -> 8) from the LDS tile ----
+    f32x4 acc[CTW];
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int kh = t / 3, kw = t - kh * 3;
+        float bv[CTW][2];
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+            const int ct = wv * CTW + c, tr = ct >> 1, tc = ct & 1;
+            const float2 tq = *reinterpret_cast<const float2*>(til + ((tr + kh) * IW + tc * 16 + j + kw) * 8 + g * 2);
+            bv[c][0] = tq.x; bv[c][1] = tq.y;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < CTW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t][r], bv[c][r], acc[c], 0, 0, 0);
+    }
+    // ---- epilogue: BN + ReLU, channels-last store (cout = 8) ----
+    if (g < 2) {
+        const int ch0 = 4 * g;
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+            const int ct = wv * CTW + c, tr = ct >> 1, tc = ct & 1;
+            const int oy = oy0 + tr, ox = ox0 + tc * 16 + j;
+            if (oy >= H || ox >= W) continue;
+            const long long o = ((long long)n * H + oy) * W + ox;
+            *reinterpret_cast<float4*>(out + o * 8 + ch0) =
+                make_float4(relu1(acc[c][0] * scale1[ch0] + shift1[ch0]), relu1(acc[c][1] * scale1[ch0 + 1] + shift1[ch0 + 1]),
+                            relu1(acc[c][2] * scale1[ch0 + 2] + shift1[ch0 + 2]), relu1(acc[c][3] * scale1[ch0 + 3] + shift1[ch0 + 3]));
+        }
+    }
+}
+
+void launch_conv0_fused(const Conv2dDesc& L0, const Conv2dDesc& L1, const float* img, float* out, int N, int H, int W,
+                        hipStream_t st) {
+    const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
+    const size_t shmem = (size_t)(12 * 36 * 4 + 10 * 34 * 8) * sizeof(float);
+    ENERF_LAUNCH(k_conv0_fused, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, L0.w, L0.scale, L0.shift, L1.w, L1.scale,
+                 L1.shift, img, out, N, H, W, tiles_y, tiles_x);
+}
+
+// =====================================================================================================
 // smooth0( up2(f1pre) + lat0(c0) )  — feature_net.py:32-35 — in ONE kernel.
 // The unfused chain writes the 32-channel full-resolution FPN sum (126 MB at 3x512x640) and reads it back
 // with halos; here each block rebuilds its haloed 10x34 tile of that sum in LDS from (a) the 8-channel c0

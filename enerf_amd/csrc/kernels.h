@@ -73,6 +73,9 @@ void launch_conv2d_pack(const float* w, const float* bias, const float* bn_w, co
 // up (optional): coarser channels-last map (N,Hc,Wc,cout) added after a x2 align-corners bilinear upsample.
 int launch_conv2d(const Conv2dDesc& L, const float* in, float* out, const float* up, int N, int Hi, int Wi, int Hc,
                   int Wc, hipStream_t st);
+// conv0.1(conv0.0(image)) fused (feature_net.py:7-9): L0/L1 = the two layers' descriptors, img (N,3,H,W) -> out (N,H,W,8)
+void launch_conv0_fused(const Conv2dDesc& L0, const Conv2dDesc& L1, const float* img, float* out, int N, int H, int W,
+                        hipStream_t st);
 // smooth0(up2(f1pre) + lat0(c0)) fused (feature_net.py:32-35); L = smooth0's descriptor, lat_w/lat_b raw (32,8)/(32)
 void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1pre, const float* lat_w, const float* lat_b,
                           float* out, int N, int H, int W, hipStream_t st);
