@@ -301,7 +301,7 @@ int enerf_feature_net_stage(const float* packed, const float* src_inps, int n_im
         const FLayer& f = kFeat[i];
         long long wf = conv2d_packed_floats(f.cin, f.cout, f.k);
         int cp = cdiv(f.cout, 16) * 16;
-        d[i] = {p, p + wf, p + wf + cp, f.cin, f.cout, f.k, f.stride, f.relu, 0, nullptr};
+        d[i] = {p, p + wf, p + wf + cp, f.cin, f.cout, f.k, f.stride, f.relu, 0, nullptr, nullptr, nullptr};
         p += flayer_floats(f);
     }
     const long long p0 = (long long)n_img * H * W, p1 = p0 / 4, p2 = p1 / 4;
@@ -323,8 +323,15 @@ int enerf_feature_net_stage(const float* packed, const float* src_inps, int n_im
         rc |= launch_conv2d(d[2], c0, c1a, nullptr, n_img, H, W, 0, 0, st);            // conv1.0 (s2)
         rc |= launch_conv2d(d[3], c1a, c1, nullptr, n_img, H1, W1, 0, 0, st);          // conv1.1
         rc |= launch_conv2d(d[4], c1, c2a, nullptr, n_img, H1, W1, 0, 0, st);          // conv2.0 (s2)
-        rc |= launch_conv2d(d[5], c2a, c2, nullptr, n_img, H2, W2, 0, 0, st);          // conv2.1
-        rc |= launch_conv2d(d[6], c2, feat_l0, nullptr, n_img, H2, W2, 0, 0, st);      // toplayer  -> level_0
+        const char* ft = getenv("ENERF_FUSE_TOP");                                     // A/B knob, default fused
+        if (ft == nullptr || ft[0] != '0') {
+            d[5].chain_w = d[6].w;                                                     // toplayer (1x1, bias) runs in
+            d[5].chain_shift = d[6].shift;                                             // conv2.1's epilogue -> level_0
+            rc |= launch_conv2d(d[5], c2a, feat_l0, nullptr, n_img, H2, W2, 0, 0, st);
+        } else {
+            rc |= launch_conv2d(d[5], c2a, c2, nullptr, n_img, H2, W2, 0, 0, st);      // conv2.1
+            rc |= launch_conv2d(d[6], c2, feat_l0, nullptr, n_img, H2, W2, 0, 0, st);  // toplayer  -> level_0
+        }
     }
     if (lvl1) {
         rc |= launch_conv2d(d[7], c1, f1pre, feat_l0, n_img, H1, W1, H2, W2, st);      // up2(feat2) + lat1(conv1)

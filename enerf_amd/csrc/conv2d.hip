@@ -70,13 +70,18 @@ void launch_conv2d_pack(const float* w, const float* bias, const float* bn_w, co
 
 // CINP: padded input channels (4,8,16,32); RT: cout tiles of 16; K: 1/3/5; STR: 1/2; TH: output rows per block
 // (x TW=32 columns = 2 column tiles per row); NCHW3: input is the (n,3,H,W) image batch.
-template <int CINP, int RT, int K, int STR, int TH, bool NCHW3>
+// CHAIN: a following 1x1 convolution (RT*16 -> 32 channels, bias, no activation: FeatureNet.toplayer) is applied in the
+// epilogue.  This layer's D registers (rows 16rt+4g+r of pixel j) are exactly the B operands of the next layer's
+// k-steps in the standard packed-weight order (ci = 16cb + 4g + r), so the chained layer is 8*RT more MFMAs per
+// column tile on values that never leave the registers; this layer's own output is not stored.
+template <int CINP, int RT, int K, int STR, int TH, bool NCHW3, bool CHAIN = false>
 __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, const float* __restrict__ scale,
                                                 const float* __restrict__ shift, const float* __restrict__ in,
                                                 float* __restrict__ out, const float* __restrict__ up,
                                                 const float* __restrict__ rgb_src, int out_stride, int cout,
                                                 int relu, int N, int Hi, int Wi, int Ho, int Wo, int Hc, int Wc,
-                                                int tiles_y, int tiles_x) {
+                                                int tiles_y, int tiles_x, const float* __restrict__ chain_w,
+                                                const float* __restrict__ chain_shift) {
     constexpr int TW = 32, P = (K - 1) / 2;
     constexpr int CB = CINP >= 16 ? 16 : CINP, CPL = CB / 4, NCB = CINP / CB, KS = CINP / 4;
     constexpr int IH = (TH - 1) * STR + K, IW = (TW - 1) * STR + K;
@@ -217,6 +222,39 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
         }
     }
 
+    if (CHAIN) {      // ---- epilogue with the chained 1x1 layer (see above); all lanes run the MFMAs, stores are guarded ----
+        float ca[RT * 4][2], sc[RT][4], sh[RT][4];
+#pragma unroll
+        for (int ks = 0; ks < RT * 4; ++ks) {
+            ca[ks][0] = chain_w[(ks * 2 + 0) * 64 + lane];
+            ca[ks][1] = chain_w[(ks * 2 + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sc[rt][r] = scale[rt * 16 + 4 * g + r]; sh[rt][r] = shift[rt * 16 + 4 * g + r]; }
+        const float4 b0 = *reinterpret_cast<const float4*>(chain_shift + 4 * g), b1 = *reinterpret_cast<const float4*>(chain_shift + 16 + 4 * g);
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+            f32x4 t0 = f32x4{b0.x, b0.y, b0.z, b0.w}, t1 = f32x4{b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float yv = acc[c][rt][r] * sc[rt][r] + sh[rt][r];
+                    if (relu) yv = relu1(yv);
+                    t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[rt * 4 + r][0], yv, t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[rt * 4 + r][1], yv, t1, 0, 0, 0);
+                }
+            const int tile = wv * CTW + c, tr = tile / (TW / 16), tc = tile - tr * (TW / 16);
+            const int oy = oy0 + tr, ox = ox0 + tc * 16 + j;
+            if (oy >= Ho || ox >= Wo) continue;
+            float* op = out + (((long long)n * Ho + oy) * Wo + ox) * 32 + 4 * g;
+            *reinterpret_cast<float4*>(op) = make_float4(t0[0], t0[1], t0[2], t0[3]);
+            *reinterpret_cast<float4*>(op + 16) = make_float4(t1[0], t1[1], t1[2], t1[3]);
+        }
+        return;
+    }
     // ---- epilogue: BN/bias, optional x2 bilinear upsample-add of the coarser FPN map, ReLU ----
     const float sy = ac_scale(Hc, Ho), sx = ac_scale(Wc, Wo);
 #pragma unroll
@@ -261,7 +299,7 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
     }
 }
 
-template <int CINP, int RT, int K, int STR, int TH, bool NCHW3>
+template <int CINP, int RT, int K, int STR, int TH, bool NCHW3, bool CHAIN = false>
 static void launch_c2(const Conv2dDesc& L, const float* in, float* out, const float* up, int N, int Hi, int Wi, int Hc,
                       int Wc, hipStream_t st) {
     const float* rgb_src = L.rgb_src;
@@ -272,8 +310,8 @@ static void launch_c2(const Conv2dDesc& L, const float* in, float* out, const fl
     constexpr int IH = (TH - 1) * STR + K, IW = 31 * STR + K;
     const size_t shmem = (size_t)IH * IW * CB * sizeof(float);
     const unsigned grid = (unsigned)((long long)N * tiles_y * tiles_x);
-    ENERF_LAUNCH((k_conv2d<CINP, RT, K, STR, TH, NCHW3>), grid, 256, shmem, st, L.w, L.scale, L.shift, in, out, up, rgb_src,
-                 out_stride, L.cout, L.relu, N, Hi, Wi, Ho, Wo, Hc, Wc, tiles_y, tiles_x);
+    ENERF_LAUNCH((k_conv2d<CINP, RT, K, STR, TH, NCHW3, CHAIN>), grid, 256, shmem, st, L.w, L.scale, L.shift, in, out, up,
+                 rgb_src, out_stride, L.cout, L.relu, N, Hi, Wi, Ho, Wo, Hc, Wc, tiles_y, tiles_x, L.chain_w, L.chain_shift);
 }
 
 // =====================================================================================================
@@ -563,7 +601,10 @@ int launch_conv2d(const Conv2dDesc& L, const float* in, float* out, const float*
         case 8 * 10000 + 16 * 100 + 52: launch_c2<8, 1, 5, 2, 4, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;   // conv1.0
         case 16 * 10000 + 16 * 100 + 31: launch_c2<16, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // conv1.1
         case 16 * 10000 + 32 * 100 + 52: launch_c2<16, 2, 5, 2, 4, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // conv2.0
-        case 32 * 10000 + 32 * 100 + 31: launch_c2<32, 2, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // conv2.1
+        case 32 * 10000 + 32 * 100 + 31:                                                                                   // conv2.1 (+ toplayer)
+            if (L.chain_w != nullptr) launch_c2<32, 2, 3, 1, 8, false, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
+            else launch_c2<32, 2, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
+            return 0;
         case 32 * 10000 + 32 * 100 + 11: launch_c2<32, 2, 1, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // toplayer
         case 16 * 10000 + 32 * 100 + 11: launch_c2<16, 2, 1, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // lat1
         case 8 * 10000 + 32 * 100 + 11: launch_c2<8, 2, 1, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;   // lat0

@@ -64,6 +64,8 @@ struct Conv2dDesc {
     int cin, cout, k, stride, relu;
     int out_stride;        // floats between consecutive output pixels (0 = cout)
     const float* rgb_src;  // texel mode: (n,3,Ho,Wo) images appended as [rgb*0.5+0.5 | 0] behind the features
+    const float* chain_w;      // packed weights / shift (bias) of a following 1x1 conv (cout -> 32) applied in the
+    const float* chain_shift;  // epilogue instead of storing this layer's output (conv2.1 -> toplayer), or nullptr
 };
 long long conv2d_packed_floats(int cin, int cout, int k);
 void launch_conv2d_pack(const float* w, const float* bias, const float* bn_w, const float* bn_b, const float* bn_mean,

@@ -225,6 +225,7 @@ def test_unfused_lat0_smooth0_path(monkeypatch):
     """ENERF_FUSE_LAT0=0 keeps the separate lat0 / smooth0 launches (A/B switch) — same features."""
     monkeypatch.setenv("ENERF_FUSE_LAT0", "0")
     monkeypatch.setenv("ENERF_FUSE_CONV0", "0")        # and the separate conv0.0 / conv0.1 launches
+    monkeypatch.setenv("ENERF_FUSE_TOP", "0")          # and toplayer as its own launch
     name = "tiny_s3"
     cfg, batch, g = case_config(name), case_batch(name), load_golden(name)
     net, lib = _net(cfg), emu_lib()
