@@ -582,8 +582,11 @@ static bool dispatch_s1_lds(const Conv3dDesc& L, const float* in, float* out, fl
                             hipStream_t st) {
     const int rt_total = cdiv(L.cout, 16);
     if (rt_total == 1) {
-        const char* e = getenv("ENERF_CONV_BD");          // A/B knob: box depth 2 (3 blocks/CU) or 4 (2 blocks/CU)
-        const int bd = e ? atoi(e) : 4;
+        // box depth 4 (2 blocks/CU, fewer halo reads) for layers that fill the chip, depth 2 for the mid-size ones
+        // (level-1 conv2: 160 boxes of depth 4 leave 96 CUs idle).  ENERF_CONV_BD=2|4 forces one (A/B knob).
+        const char* e = getenv("ENERF_CONV_BD");
+        const long long boxes4 = (long long)B * cdiv(D, 4) * cdiv(H, 8) * cdiv(W, 16);
+        const int bd = e ? atoi(e) : (boxes4 >= 256 ? 4 : 2);   // measured: L0 conv2 20 -> 12.5 us; 480-box layers stay at 4
         if (D % 4 == 0 && bd == 4) launch_s1_lds<CIN, 1, 4>(L, in, out, out2, B, D, H, W, st);
         else launch_s1_lds<CIN, 1, 2>(L, in, out, out2, B, D, H, W, st);
         return true;
