@@ -401,14 +401,14 @@ static bool dispatch_cin(const Conv3dDesc& L, const float* in, const float* resi
 // re-read of activations through the TA/L1 path that bounds V1; A operands (weights) still stream from
 // L1/L2 as 256-B coalesced loads, one per CTW MFMAs.
 // =====================================================================================================
-template <int CIN, int RT, int BD>
+template <int CIN, int RT, int BD, int BH = 8>
 __global__ __launch_bounds__(256, (BD == 4 ? 2 : 3)) void k_conv3d_s1_lds(   // = co-resident blocks/CU the LDS box allows
 const float* __restrict__ wpk, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ in,
                                                        float* __restrict__ out, float* __restrict__ out2, int cout,
                                                        int relu, int B, int D, int H, int W, int nbd, int nbh, int nbw,
                                                        int xcd_swizzle, int dbg, int stagger) {
-    constexpr int BH = 8, BW = 16;
+    constexpr int BW = 16;                              // box = BD x BH x 16 outputs (BH = 8, or 4 for mid-size layers)
     // Two identical blocks share a CU (LDS-limited) and, sharing the MFMA pipe fairly, stay in lockstep:
     // both stage, both compute, both store at the same time, so the ~20 us of non-MFMA work never hides
     // (phase ablation: 70 us MFMA + 23 us rest = 93 us).  Delaying the second block of each CU once by
@@ -565,15 +565,15 @@ const float* __restrict__ wpk, const float* __restrict__ scale,
     }
 }
 
-template <int CIN, int RT, int BD>
+template <int CIN, int RT, int BD, int BH = 8>
 static void launch_s1_lds(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,
                           hipStream_t st) {
     constexpr int CB = CIN >= 16 ? 16 : CIN;
-    const int nbd = cdiv(D, BD), nbh = cdiv(H, 8), nbw = cdiv(W, 16);
-    const size_t shmem = (size_t)(BD + 2) * 10 * 18 * CB * sizeof(float);
+    const int nbd = cdiv(D, BD), nbh = cdiv(H, BH), nbw = cdiv(W, 16);
+    const size_t shmem = (size_t)(BD + 2) * (BH + 2) * 18 * CB * sizeof(float);
     const unsigned grid = (unsigned)((long long)B * nbd * nbh * nbw);
     const char* e = getenv("ENERF_XCD_SWIZZLE");
-    ENERF_LAUNCH((k_conv3d_s1_lds<CIN, RT, BD>), grid, 256, shmem, st, L.w, L.scale, L.shift, in, out, out2, L.cout,
+    ENERF_LAUNCH((k_conv3d_s1_lds<CIN, RT, BD, BH>), grid, 256, shmem, st, L.w, L.scale, L.shift, in, out, out2, L.cout,
                  L.relu, B, D, H, W, nbd, nbh, nbw, e ? atoi(e) : 1, getenv("ENERF_CONV_DBG") ? atoi(getenv("ENERF_CONV_DBG")) : 0,
                  getenv("ENERF_STAGGER") ? atoi(getenv("ENERF_STAGGER")) : 0);
 }
@@ -587,7 +587,10 @@ static bool dispatch_s1_lds(const Conv3dDesc& L, const float* in, float* out, fl
         const char* e = getenv("ENERF_CONV_BD");
         const long long boxes4 = (long long)B * cdiv(D, 4) * cdiv(H, 8) * cdiv(W, 16);
         const int bd = e ? atoi(e) : (boxes4 >= 256 ? 4 : 2);   // measured: L0 conv2 20 -> 12.5 us; 480-box layers stay at 4
+        const char* eh = getenv("ENERF_CONV_BH");         // A/B knob: box height 8 or 4
+        const int bh = eh ? atoi(eh) : (boxes4 >= 256 ? 8 : 4);   // mid-size layers: 2 x 4 x 16 boxes, 4x the blocks
         if (D % 4 == 0 && bd == 4) launch_s1_lds<CIN, 1, 4>(L, in, out, out2, B, D, H, W, st);
+        else if (bh == 4) launch_s1_lds<CIN, 1, 2, 4>(L, in, out, out2, B, D, H, W, st);
         else launch_s1_lds<CIN, 1, 2>(L, in, out, out2, B, D, H, W, st);
         return true;
     }
