@@ -611,6 +611,16 @@ static long long conv_v2_min_vox() {
 
 void launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, float* out, float* out2, int B, int Di,
                    int Hi, int Wi, hipStream_t st) {
+    // LDS-staged transposed path (conv11 of both nets, 16 -> 8): ENERF_CONV_T2_LDS=0 falls back to the global-load kernel
+    if (L.kind == kConvT2 && out2 == nullptr && conv_v2_enabled()) {
+        const char* e = getenv("ENERF_CONV_T2_LDS");
+        if ((e == nullptr || e[0] != '0') && 8LL * B * Di * Hi * Wi >= 32 * conv_v2_min_vox() &&       // level-1 conv11: 30.8 -> 25.3 us; level 0 is slower (19 vs 15)
+            launch_conv3d_t2_lds(L, in, residual, out, B, Di, Hi, Wi, st)) {
+            if (getenv("ENERF_TRACE")) fprintf(stderr, "[enerf] conv3d %d->%d vox=%lld : t2 lds\n", L.cin, L.cout,
+                                               (long long)B * Di * Hi * Wi);
+            return;
+        }
+    }
     // LDS-staged stride-2 path (conv1 of both nets): ENERF_CONV_S2_LDS=0 falls back to the global-load kernel
     if (L.kind == kConvS2 && residual == nullptr && out2 == nullptr && conv_v2_enabled()) {
         const char* e = getenv("ENERF_CONV_S2_LDS");

@@ -40,6 +40,8 @@ bool launch_conv3d_ws(const Conv3dDesc& L, const float* in, float* out, float* o
                       hipStream_t st);   // persistent producer/consumer variant, cout <= 16 (conv3d_ws.hip)
 bool launch_conv3d_s2_lds(const Conv3dDesc& L, const float* in, float* out, int B, int Di, int Hi, int Wi,
                           hipStream_t st);   // LDS-staged stride-2 variant, Cin = 8, Cout <= 16 (conv3d_s2.hip)
+bool launch_conv3d_t2_lds(const Conv3dDesc& L, const float* in, const float* residual, float* out, int B, int Di, int Hi,
+                          int Wi, hipStream_t st);   // LDS-staged transposed variant, 16 -> 8 (conv3d_t2.hip)
 bool launch_conv3d_pk8(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,
                        hipStream_t st);
 // number of floats of the packed weight image for a layer

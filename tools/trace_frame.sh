@@ -9,7 +9,7 @@ f = glob.glob("/tmp/p_tr/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 rows = [r for r in rows if "enerf" in r["Kernel_Name"]]
 # last frame = from the last k_conv2d<4 (conv0.0) on
-idx = max(i for i, r in enumerate(rows) if "k_conv2d<4" in r["Kernel_Name"])
+idx = max(i for i, r in enumerate(rows) if "k_conv0_fused" in r["Kernel_Name"] or "k_conv2d<4" in r["Kernel_Name"])
 fr = rows[idx:]
 t0 = int(fr[0]["Start_Timestamp"])
 for r in fr:
