@@ -136,8 +136,11 @@ __device__ __forceinline__ void tap_offsets(int t, int ntw, int nth, int pd, int
 
 // ---- the implicit-GEMM kernel ---------------------------------------------------------------------
 // CIN: input channels (8,16,32,64); RT: cout row tiles of 16; KIND; CT: 16-voxel column tiles per wave.
-template <int CIN, int RT, int KIND, int CT>
-__global__ __launch_bounds__(KIND == kConvT2 ? 512 : 256) void k_conv3d(const float* __restrict__ wpk, const float* __restrict__ scale,
+// SPLIT (1, 3 or 9): the 27 taps of a stride-1/2 layer are split (by kd, or by (kd,kh)) over SPLIT waves of one block (one tile group per
+// block) and the partial sums are reduced through LDS.  The small deep layers (80-640 tiles) are a pure latency
+// chain of one L2 round trip per tap: a third of the chain is worth more than the idle lanes it costs.
+template <int CIN, int RT, int KIND, int CT, int SPLIT = 1>
+__global__ __launch_bounds__(KIND == kConvT2 ? 512 : (SPLIT * 64 > 256 ? SPLIT * 64 : 256)) void k_conv3d(const float* __restrict__ wpk, const float* __restrict__ scale,
                                                 const float* __restrict__ shift, const float* __restrict__ in,
                                                 const float* __restrict__ residual, float* __restrict__ out,
                                                 float* __restrict__ out2, int cout, int relu, int B, int Di, int Hi,
@@ -152,7 +155,9 @@ __global__ __launch_bounds__(KIND == kConvT2 ? 512 : 256) void k_conv3d(const fl
     const int rsplit = rt_total / RT;
     // wave-uniform by construction; readfirstlane tells the compiler, so the tile decomposition below runs on
     // the scalar unit (it was ~1200 VALU of 64-bit divisions per wave, a third of a conv1 wave's time)
-    const int wave_all = (int)blockIdx.x * (int)(blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int sp = SPLIT > 1 ? wave_in_block : 0;                   // which third of the taps (SPLIT > 1: one tile group per block)
+    const int wave_all = SPLIT > 1 ? (int)blockIdx.x : (int)blockIdx.x * (int)(blockDim.x >> 6) + wave_in_block;
     const int wave = wave_all / rsplit;
     const int rt_base = (wave_all - wave * rsplit) * RT;
 
@@ -290,19 +295,41 @@ __global__ __launch_bounds__(KIND == kConvT2 ? 512 : 256) void k_conv3d(const fl
         constexpr int PF = KIND != kConvS2 ? 2 : (REGS_PER_TAP <= 24 ? 4 : (REGS_PER_TAP <= 40 ? 3 : 2));
         float4 bq[PF][CT][NB];
         float aq[PF][NA];
+        const int tbeg = SPLIT > 1 ? sp * (27 / SPLIT) : 0, tend = SPLIT > 1 ? tbeg + 27 / SPLIT : ntaps;
 #pragma unroll
-        for (int k = 0; k < PF - 1; ++k) issue(k < ntaps ? k : ntaps - 1, bq[k], aq[k]);
+        for (int k = 0; k < PF - 1; ++k) issue(tbeg + k < tend ? tbeg + k : tend - 1, bq[k], aq[k]);
 #pragma unroll 1
-        for (int t = 0; t < ntaps; t += PF) {
+        for (int t = tbeg; t < tend; t += PF) {
 #pragma unroll
             for (int k = 0; k < PF; ++k) {
                 const int tn = t + k + PF - 1;                       // clamped: always loads, never branches
-                issue(tn < ntaps ? tn : ntaps - 1, bq[(k + PF - 1) % PF], aq[(k + PF - 1) % PF]);
+                issue(tn < tend ? tn : tend - 1, bq[(k + PF - 1) % PF], aq[(k + PF - 1) % PF]);
                 __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of this tap's MFMAs
-                if (t + k < ntaps) compute(bq[k], aq[k]);
+                if (t + k < tend) compute(bq[k], aq[k]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+    }
+    if (SPLIT > 1) {      // reduce the per-kd partial sums into wave 0 (fixed order: deterministic)
+        __shared__ float red[(SPLIT > 1 ? SPLIT - 1 : 1) * CT * RT * 4 * 64];
+        if (sp > 0) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[(((sp - 1) * CT + ct) * RT + rt) * 256 + r * 64 + lane] = acc[ct][rt][r];
+        }
+        __syncthreads();
+        if (sp > 0) return;
+#pragma unroll
+        for (int s2 = 0; s2 < SPLIT - 1; ++s2)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[ct][rt][r] += red[((s2 * CT + ct) * RT + rt) * 256 + r * 64 + lane];
     }
 
     // ---- epilogue: BN scale/shift, skip add, ReLU; lane owns channels rt*16+4g..+3 of voxel j ----
@@ -343,7 +370,7 @@ __global__ __launch_bounds__(KIND == kConvT2 ? 512 : 256) void k_conv3d(const fl
     }
 }
 
-template <int CIN, int RT, int KIND, int CT>
+template <int CIN, int RT, int KIND, int CT, int SPLIT = 1>
 static void launch_one(const Conv3dDesc& L, const float* in, const float* residual, float* out, float* out2, int B,
                        int Di, int Hi, int Wi, hipStream_t st) {
     int Do, Ho, Wo;
@@ -354,9 +381,9 @@ static void launch_one(const Conv3dDesc& L, const float* in, const float* residu
     long long n = (KIND == kConvT2) ? (long long)B * Di * Hi * Wi : (long long)B * Do * Ho * Wo;
     long long groups = cdivl(cdivl(n, 16), CT);
     long long waves = ((KIND == kConvT2) ? groups * 8 : groups) * (rt_total / RT);
-    constexpr int WPB = (KIND == kConvT2) ? 8 : 4;                      // waves per block
+    constexpr int WPB = SPLIT > 1 ? 1 : ((KIND == kConvT2) ? 8 : 4);    // tile groups ("logical waves") per block
     unsigned grid = (unsigned)cdivl(waves, WPB);
-    ENERF_LAUNCH((k_conv3d<CIN, RT, KIND, CT>), grid, WPB * 64, 0, st, L.w, L.scale, L.shift, in, residual, out, out2, L.cout,
+    ENERF_LAUNCH((k_conv3d<CIN, RT, KIND, CT, SPLIT>), grid, WPB * SPLIT * 64, 0, st, L.w, L.scale, L.shift, in, residual, out, out2, L.cout,
                  L.relu, B, Di, Hi, Wi, Do, Ho, Wo, rt_total);
 }
 
@@ -372,7 +399,14 @@ static bool dispatch_rt(const Conv3dDesc& L, const float* in, const float* resid
     const long long tiles = cdivl(n, 16);
     const int ct_default = rt_total == 1 ? 4 : (rt_total == 2 ? 2 : 1);
     const bool small = cdivl(tiles, ct_default) < 1024;      // fewer waves than SIMDs: split finer
-    if (small) { launch_one<CIN, 1, KIND, 1>(L, in, residual, out, out2, B, Di, Hi, Wi, st); return true; }
+    if (small) {
+        const char* e = getenv("ENERF_CONV_SPLIT");                  // A/B knob: 0 = one wave per tile group, 3 / 9 = tap split
+        const int split = e ? atoi(e) : 3;
+        if (KIND != kConvT2 && CIN >= 16 && split == 9) launch_one<CIN, 1, KIND, 1, (KIND != kConvT2 && CIN >= 16 ? 9 : 1)>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
+        else if (KIND != kConvT2 && CIN >= 16 && split == 3) launch_one<CIN, 1, KIND, 1, (KIND != kConvT2 && CIN >= 16 ? 3 : 1)>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
+        else launch_one<CIN, 1, KIND, 1>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
+        return true;
+    }
     switch (rt_total) {
         case 1: launch_one<CIN, 1, KIND, 4>(L, in, residual, out, out2, B, Di, Hi, Wi, st); return true;
         case 2: launch_one<CIN, 2, KIND, 2>(L, in, residual, out, out2, B, Di, Hi, Wi, st); return true;
