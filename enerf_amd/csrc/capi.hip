@@ -89,6 +89,18 @@ int enerf_get_depth_values(const float* near_far, const float* prev_depth, const
                         near_far_out, (hipStream_t)stream);
     return check_launch("get_depth_values");
 }
+int enerf_level_prep(const float* src_ixts, const float* src_exts, const float* tar_ixt, const float* tar_ext, int B,
+                     int S, float src_scale, float tar_scale, float* proj, const float* near_far,
+                     const float* prev_depth, const float* prev_std, const float* prev_near_far, int D, int h, int w,
+                     int hp, int wp, int depth_inv, float* depth_values, float* near_far_out, enerf_stream_t stream) {
+    REQUIRE(src_ixts && src_exts && tar_ixt && tar_ext && proj && B > 0 && S > 0, "level_prep: bad projection arguments");
+    REQUIRE(depth_values && near_far_out && D > 0 && h > 0 && w > 0, "level_prep: bad depth arguments");
+    if (prev_depth) REQUIRE(prev_std && prev_near_far && hp > 0 && wp > 0, "level_prep: incomplete previous level");
+    else REQUIRE(near_far, "level_prep: near_far required at level 0");
+    launch_level_prep(src_ixts, src_exts, tar_ixt, tar_ext, S, src_scale, tar_scale, proj, near_far, prev_depth, prev_std,
+                      prev_near_far, B, D, h, w, hp, wp, depth_inv, depth_values, near_far_out, (hipStream_t)stream);
+    return check_launch("level_prep");
+}
 int enerf_build_feature_volume(const float* feat, const float* proj, const float* depth_values, int B, int S, int C,
                                int Hs, int Ws, int D, int h, int w, float* vol, enerf_stream_t stream) {
     REQUIRE(feat && proj && depth_values && vol, "build_feature_volume: null pointer");

@@ -164,12 +164,11 @@ __device__ __forceinline__ void k_times_e(const float* K, const float* E, float 
         }
     }
 }
-__global__ void k_proj_mats(const float* __restrict__ src_ixts, const float* __restrict__ src_exts,
-                            const float* __restrict__ tar_ixt, const float* __restrict__ tar_ext, int B, int S,
-                            float src_scale, float tar_scale, float* __restrict__ proj) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * S) return;
-    int b = i / S;
+// one (b, s) projection matrix (get_proj_mats utils.py:35-55), fp64 like torch.inverse's LU on these sizes
+__device__ __forceinline__ void proj_one(int i, const float* __restrict__ src_ixts, const float* __restrict__ src_exts,
+                                         const float* __restrict__ tar_ixt, const float* __restrict__ tar_ext, int S,
+                                         float src_scale, float tar_scale, float* __restrict__ proj) {
+    const int b = i / S;
     double t44[16], tinv[16], s34[12];
     k_times_e(tar_ixt + b * 9, tar_ext + b * 16, tar_scale, t44);
     t44[12] = t44[13] = t44[14] = 0.0;
@@ -185,6 +184,13 @@ __global__ void k_proj_mats(const float* __restrict__ src_ixts, const float* __r
             proj[i * 12 + r * 4 + c] = (float)a;
         }
 }
+__global__ void k_proj_mats(const float* __restrict__ src_ixts, const float* __restrict__ src_exts,
+                            const float* __restrict__ tar_ixt, const float* __restrict__ tar_ext, int B, int S,
+                            float src_scale, float tar_scale, float* __restrict__ proj) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * S) return;
+    proj_one(i, src_ixts, src_exts, tar_ixt, tar_ext, S, src_scale, tar_scale, proj);
+}
 void launch_proj_mats(const float* src_ixts, const float* src_exts, const float* tar_ixt, const float* tar_ext, int B,
                       int S, float src_scale, float tar_scale, float* proj, hipStream_t st) {
     ENERF_LAUNCH_SIMPLE(k_proj_mats, cdiv(B * S, 64), 64, 0, st, src_ixts, src_exts, tar_ixt, tar_ext, B, S, src_scale,
@@ -199,11 +205,22 @@ void launch_proj_mats(const float* src_ixts, const float* src_exts, const float*
 // [1/min(d+s, nf0), 1/max(d-s, nf1)] and D planes in between.
 // torch.linspace(0,1,D): step=1/(D-1); t_k = k<D/2 ? step*k : 1 - step*(D-1-k).
 // -------------------------------------------------------------------------------------------------
+// Optional piggy-backed get_proj_mats of the same level (enerf_level_prep): the B*S fp64 inverses are a 4.7 us
+// latency chain in a launch of their own; here the last block's first threads run them next to the plane writes.
+struct ProjJob {
+    const float *src_ixts, *src_exts, *tar_ixt, *tar_ext;
+    float* proj;          // nullptr: no projection matrices in this launch
+    int S;
+    float src_scale, tar_scale;
+};
 __global__ __launch_bounds__(256) void k_depth_values(const float* __restrict__ near_far,
                                                       const float* __restrict__ pdepth, const float* __restrict__ pstd,
                                                       const float* __restrict__ pnf, int B, int D, int h, int w, int hp,
                                                       int wp, int depth_inv, float* __restrict__ dv,
-                                                      float* __restrict__ nf_out) {
+                                                      float* __restrict__ nf_out, ProjJob pj) {
+    if (pj.proj != nullptr && blockIdx.x == gridDim.x - 1)
+        for (int q = threadIdx.x; q < B * pj.S; q += blockDim.x)
+            proj_one(q, pj.src_ixts, pj.src_exts, pj.tar_ixt, pj.tar_ext, pj.S, pj.src_scale, pj.tar_scale, pj.proj);
     // one thread per (plane, pixel): level 0 has 64x80 pixels x 48 planes — a thread per pixel left the chip idle
     // behind a 48-step serial loop of IEEE divides (10 us); the per-pixel [near, far] is recomputed per plane
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -245,8 +262,17 @@ __global__ __launch_bounds__(256) void k_depth_values(const float* __restrict__ 
 }
 void launch_depth_values(const float* near_far, const float* pdepth, const float* pstd, const float* pnf, int B, int D,
                          int h, int w, int hp, int wp, int depth_inv, float* dv, float* nf_out, hipStream_t st) {
+    ProjJob none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0.f};
     ENERF_LAUNCH_SIMPLE(k_depth_values, cdiv(B * D * h * w, 256), 256, 0, st, near_far, pdepth, pstd, pnf, B, D, h, w, hp,
-                        wp, depth_inv, dv, nf_out);
+                        wp, depth_inv, dv, nf_out, none);
+}
+void launch_level_prep(const float* src_ixts, const float* src_exts, const float* tar_ixt, const float* tar_ext, int S,
+                       float src_scale, float tar_scale, float* proj, const float* near_far, const float* pdepth,
+                       const float* pstd, const float* pnf, int B, int D, int h, int w, int hp, int wp, int depth_inv,
+                       float* dv, float* nf_out, hipStream_t st) {
+    ProjJob pj = {src_ixts, src_exts, tar_ixt, tar_ext, proj, S, src_scale, tar_scale};
+    ENERF_LAUNCH_SIMPLE(k_depth_values, cdiv(B * D * h * w, 256), 256, 0, st, near_far, pdepth, pstd, pnf, B, D, h, w, hp,
+                        wp, depth_inv, dv, nf_out, pj);
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -15,6 +15,10 @@ void launch_proj_mats(const float* src_ixts, const float* src_exts, const float*
                       int S, float src_scale, float tar_scale, float* proj, hipStream_t st);
 void launch_depth_values(const float* near_far, const float* pdepth, const float* pstd, const float* pnf, int B, int D,
                          int h, int w, int hp, int wp, int depth_inv, float* dv, float* nf_out, hipStream_t st);
+void launch_level_prep(const float* src_ixts, const float* src_exts, const float* tar_ixt, const float* tar_ext, int S,
+                       float src_scale, float tar_scale, float* proj, const float* near_far, const float* pdepth,
+                       const float* pstd, const float* pnf, int B, int D, int h, int w, int hp, int wp, int depth_inv,
+                       float* dv, float* nf_out, hipStream_t st);     // proj_mats + depth_values in one launch
 void launch_depth_regression(const float* prob, const float* dv, int B, int D, int h, int w, int depth_inv,
                              float* depth, float* std, hipStream_t st);
 void launch_build_rays(const float* rays8, const float* depth, const float* std, const float* nf, int B, int N, int h,

@@ -63,6 +63,7 @@ _SIGNATURES = {
     "enerf_pack_texels_cl": (_i, [_f, _i, _f, _i, _i, _i, _i, _i, _i, _f, _f]),
     "enerf_get_proj_mats": (_i, [_f, _f, _f, _f, _i, _i, _fl, _fl, _f, _f]),
     "enerf_get_depth_values": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f]),
+    "enerf_level_prep": (_i, [_f, _f, _f, _f, _i, _i, _fl, _fl, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f]),
     "enerf_build_feature_volume": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f]),
     "enerf_cost_reg_packed_floats": (_ll, [_i, _i]),
     "enerf_cost_reg_pack": (_i, [C.POINTER(CostRegRaw), _f, _f]),
@@ -213,6 +214,25 @@ class EnerfLib:
                                                     int(depth_inv), _ptr(dv), _ptr(nf), self.stream_of(dv)),
                     "get_depth_values")
         return dv, nf
+
+    def level_prep(self, src_ixts, src_exts, tar_ixt, tar_ext, src_scale, tar_scale, near_far, prev, D, h, w, depth_inv):
+        """get_proj_mats + get_depth_values of one level in one launch -> (proj, depth_values, near_far)."""
+        B, S = src_ixts.shape[:2]
+        dev = src_ixts.device
+        proj = torch.empty((B, S, 3, 4), dtype=torch.float32, device=dev)
+        dv = torch.empty((B, D, h, w), dtype=torch.float32, device=dev)
+        nf = torch.empty((B, 2, h, w), dtype=torch.float32, device=dev)
+        if prev is None:
+            pd = ps = pn = None
+            hp = wp = 0
+        else:
+            pd, ps, pn = prev
+            hp, wp = pd.shape[-2:]
+        self._check(self.dll.enerf_level_prep(_ptr(src_ixts), _ptr(src_exts), _ptr(tar_ixt), _ptr(tar_ext), B, S,
+                                              float(src_scale), float(tar_scale), _ptr(proj), _ptr(near_far), _ptr(pd),
+                                              _ptr(ps), _ptr(pn), D, h, w, hp, wp, int(depth_inv), _ptr(dv), _ptr(nf),
+                                              self.stream_of(dv)), "level_prep")
+        return proj, dv, nf
 
     def build_feature_volume(self, feat_cl, proj, dv, Cc):
         B, S, Hs, Ws = feat_cl.shape[:4]

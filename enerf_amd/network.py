@@ -432,14 +432,14 @@ class Network(nn.Module):
                 else:
                     C, Hs, Ws = f.shape[2:]
                     feat_cl = lib.channels_last(f.reshape(B * S, C, Hs * Ws), B * S, C, Hs * Ws).view(B, S, Hs, Ws, C)
-                proj = lib.get_proj_mats(batch["src_ixts"].contiguous(), batch["src_exts"].contiguous(),
-                                         batch["tar_ixt"].contiguous(), batch["tar_ext"].contiguous(),
-                                         cas.im_feat_scale[i], cas.volume_scale[i])
                 if prev is not None and not cas.depth_inv[i - 1]:
                     raise RuntimeError("cascade levels after a depth-space level are undefined in the "
                                        "reference (utils.py:130)")
-                dv, near_far = lib.get_depth_values(batch["near_far"].contiguous(), prev, B, D, h, w,
-                                                    cas.depth_inv[i])
+                # get_proj_mats + get_depth_values of the level, one launch
+                proj, dv, near_far = lib.level_prep(batch["src_ixts"].contiguous(), batch["src_exts"].contiguous(),
+                                                    batch["tar_ixt"].contiguous(), batch["tar_ext"].contiguous(),
+                                                    cas.im_feat_scale[i], cas.volume_scale[i],
+                                                    batch["near_far"].contiguous(), prev, D, h, w, cas.depth_inv[i])
                 self._mark(f"prep_{i}")
                 vol = lib.build_feature_volume(feat_cl, proj, dv, C)
                 self._mark(f"volume_{i}")

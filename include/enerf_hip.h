@@ -100,6 +100,12 @@ int enerf_get_proj_mats(const float* src_ixts, const float* src_exts, const floa
 int enerf_get_depth_values(const float* near_far, const float* prev_depth, const float* prev_std,
                            const float* prev_near_far, int B, int D, int h, int w, int hp, int wp, int depth_inv,
                            float* depth_values, float* near_far_out, enerf_stream_t stream);
+/* get_proj_mats + get_depth_values of one cascade level in ONE launch (both only depend on the batch and the
+ * previous level): same arguments and outputs as the two calls above. */
+int enerf_level_prep(const float* src_ixts, const float* src_exts, const float* tar_ixt, const float* tar_ext, int B,
+                     int S, float src_scale, float tar_scale, float* proj, const float* near_far,
+                     const float* prev_depth, const float* prev_std, const float* prev_near_far, int D, int h, int w,
+                     int hp, int wp, int depth_inv, float* depth_values, float* near_far_out, enerf_stream_t stream);
 
 /* ---- homo_warp + build_feature_volume (utils.py:57-95, 322-349), fused.
  * feat (B,S,Hs,Ws,C) channels-last, C in {8,16,32}; vol (B,D,h,w,C). ---- */
