@@ -595,20 +595,31 @@ void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1p
 int launch_conv2d(const Conv2dDesc& L, const float* in, float* out, const float* up, int N, int Hi, int Wi, int Hc,
                   int Wc, hipStream_t st) {
     const int key = L.cin * 10000 + L.cout * 100 + L.k * 10 + L.stride;
+    // 4-row tiles for the 3x3 layers whose 8-row tiling gives fewer than ~4 blocks per CU (quarter/half-resolution maps;
+    // measured: smooth1 33.5 -> 30.0 us, conv2.1 18.0 -> 17.1, conv1.1 17.9 -> 17.2).  ENERF_C2_TH=8 forces 8 rows (A/B knob)
+    const char* eth = getenv("ENERF_C2_TH");
+    const bool th4 = !(eth && eth[0] == '8') && (long long)N * cdiv(Hi, 8) * cdiv(Wi, 32) < 1024;
     switch (key) {
         case 3 * 10000 + 8 * 100 + 31: launch_c2<4, 1, 3, 1, 8, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;     // conv0.0
         case 8 * 10000 + 8 * 100 + 31: launch_c2<8, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;    // conv0.1
         case 8 * 10000 + 16 * 100 + 52: launch_c2<8, 1, 5, 2, 4, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;   // conv1.0
-        case 16 * 10000 + 16 * 100 + 31: launch_c2<16, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // conv1.1
+        case 16 * 10000 + 16 * 100 + 31:                                                                                   // conv1.1
+            if (th4) launch_c2<16, 1, 3, 1, 4, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
+            else launch_c2<16, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
+            return 0;
         case 16 * 10000 + 32 * 100 + 52: launch_c2<16, 2, 5, 2, 4, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // conv2.0
         case 32 * 10000 + 32 * 100 + 31:                                                                                   // conv2.1 (+ toplayer)
-            if (L.chain_w != nullptr) launch_c2<32, 2, 3, 1, 8, false, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
+            if (L.chain_w != nullptr && th4) launch_c2<32, 2, 3, 1, 4, false, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
+            else if (L.chain_w != nullptr) launch_c2<32, 2, 3, 1, 8, false, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             else launch_c2<32, 2, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             return 0;
         case 32 * 10000 + 32 * 100 + 11: launch_c2<32, 2, 1, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // toplayer
-        case 16 * 10000 + 32 * 100 + 11: launch_c2<16, 2, 1, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // lat1
+        case 16 * 10000 + 32 * 100 + 11: launch_c2<16, 2, 1, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // lat1 (4-row tiles: 20.1 -> 21.5 us)
         case 8 * 10000 + 32 * 100 + 11: launch_c2<8, 2, 1, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;   // lat0
-        case 32 * 10000 + 16 * 100 + 31: launch_c2<32, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // smooth1
+        case 32 * 10000 + 16 * 100 + 31:                                                                                   // smooth1
+            if (th4) launch_c2<32, 1, 3, 1, 4, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
+            else launch_c2<32, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
+            return 0;
         case 32 * 10000 + 8 * 100 + 31: launch_c2<32, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;  // smooth0
         default: return -1;
     }
