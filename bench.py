@@ -71,6 +71,10 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--views", type=int, default=3)
     ap.add_argument("--miopen-benchmark", action="store_true", help="experiment: let MIOpen search conv algos")
+    ap.add_argument("--in-flight", type=int, default=6,
+                    help="frames in flight on separate HIP streams during the timed region (1 = sequential).  Measured on "
+                         "MI355X: 1 -> 1002, 2 -> 1141, 4 -> 1131-1218 (depends on how the streams land on the 4 hardware "
+                         "queues), 6 -> 1195, 7 -> 1203, 10 -> 1206 frames/s; default 6")
     ap.add_argument("--graph", action="store_true",
                     help="replay one captured HIP graph per frame (enerf_amd/graph.py) instead of enqueueing ~38 launches")
     ap.add_argument("--overlap", action="store_true",
@@ -115,15 +119,33 @@ def main():
         def step():
             return net(batch)
 
+    # Timed region: `steps` frames, each one full pass of the hot path, submitted round-robin to `in_flight` HIP streams
+    # (enerf_amd/pipeline.py; 1 = strictly one frame after the other on the current stream).  A frame is ~36 dependent
+    # launches, a third of them small cascade layers that leave most CUs idle: frames in flight fill those holes.
+    in_flight = 1 if (args.graph or args.overlap) else max(1, args.in_flight)
+    pipe = None
+    if in_flight > 1:
+        from enerf_amd.pipeline import FramePipeline
+        pipe = FramePipeline(net, depth=in_flight)
+
+        def timed_step():
+            return pipe.submit(batch)[0]
+    else:
+        timed_step = step
+
     for _ in range(args.warmup):
-        step()
+        timed_step()
+    if pipe is not None:
+        pipe.join()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        out = timed_step()
+    if pipe is not None:
+        pipe.join()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -145,7 +167,7 @@ def main():
             "vs_baseline": fps / BASELINE_FPS_RTX3090, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"DTU generalizable eval (dtu_pretrain.yaml, render_if False,True, "
                                    f"volume_planes 48,8), {H}x{W}, {S} src views, one target view per step",
-                       "feature_net": args.feature_backend, "streams": 2 if (args.overlap and args.feature_backend == "hip") else 1, "hip_graph": bool(args.graph),
+                       "feature_net": args.feature_backend, "streams": 2 if (args.overlap and args.feature_backend == "hip") else 1, "hip_graph": bool(args.graph), "frames_in_flight": in_flight,
                        "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world} (no collectives)"},
         }
 
@@ -192,6 +214,13 @@ def main():
             del bb
         except Exception as e:                                   # never let an extra break the contract line
             result["batched_throughput"] = {"error": str(e)[:200]}
+        # the same frames strictly one after the other on one stream (what `value` was before frames were pipelined)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(200):
+            step()
+        torch.cuda.synchronize()
+        result["sequential_fps"] = round(200 / (time.perf_counter() - t1), 1)
         # per-stage rooflines (algorithmic FLOP or compulsory bytes of the 512x640/3-view frame)
         if (H, W, S) == (512, 640, 3):
             sr = {}

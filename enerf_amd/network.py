@@ -231,7 +231,7 @@ class Network(nn.Module):
         # "torch": FeatureNet in PyTorch-ROCm/MIOpen (north_star's split); "hip": enerf_feature_net on the
         # matrix cores, channels-last outputs (SURVEY.md §8f row 2 — MIOpen was 49 % of the frame).
         self.feature_backend = feature_backend
-        self._feat_ws = None
+        self._feat_ws_by_stream = {}        # FeatureNet scratch, one per HIP stream (frames may be in flight on several)
         self.cfg = cfg or EnerfConfig()
         self.cfg.cas.validate()
         self.human = human
@@ -292,6 +292,14 @@ class Network(nn.Module):
         return {"level_2": f0.reshape(B, S, f0.shape[1], H, W),
                 "level_1": f1.reshape(B, S, f1.shape[1], H // 2, W // 2),
                 "level_0": f2.reshape(B, S, f2.shape[1], H // 4, W // 4)}
+
+    @property
+    def _feat_ws(self):
+        return self._feat_ws_by_stream.get(torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
+
+    @_feat_ws.setter
+    def _feat_ws(self, ws):
+        self._feat_ws_by_stream[torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0] = ws
 
     def _forward_feat_hip(self, x, texel_level2: bool):
         """HIP FeatureNet: channels-last (B,S,h,w,C) maps tagged ``_enerf_cl``; level_2 optionally comes

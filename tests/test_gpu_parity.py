@@ -188,6 +188,26 @@ def test_whole_frame_hip_graph_replay_matches_eager():
             assert torch.equal(out[k], e[k]), k
 
 
+def test_frame_pipeline_two_streams_matches_sequential():
+    """enerf_amd.pipeline.FramePipeline: frames in flight on two HIP streams == the same frames one after the other."""
+    from enerf_amd.pipeline import FramePipeline
+    cfg = EnerfConfig.dtu_eval()
+    net = _net(cfg)
+    batches = [_to({k: torch.from_numpy(v) for k, v in make_batch(256, 320, 3, cfg, seed=s, textured=True).items()})
+               for s in range(5)]
+    ref = [{k: v.clone() for k, v in net(b).items()} for b in batches]
+    torch.cuda.synchronize()
+    for depth in (2, 4):
+        pipe = FramePipeline(net, depth=depth)
+        outs = [pipe.submit(b) for b in batches + batches]
+        pipe.join()
+        torch.cuda.synchronize()
+        for (o, ev), r in zip(outs, ref + ref):
+            assert ev.query()
+            for k in r:
+                assert torch.equal(o[k], r[k]), k
+
+
 def test_lego_shape_800x800_4views():
     """BASELINE config 3 shapes (H=W=800, S=4, planes 64,8, both levels): runs, finite, deterministic."""
     cfg = EnerfConfig()
