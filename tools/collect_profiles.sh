@@ -8,10 +8,10 @@ export TMPDIR=/tmp
 TAG=${1:-rXX}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
 cd $R && python bench.py > $O/${TAG}_bench.json 2> $O/bench.err; tail -c 400 $O/${TAG}_bench.json; echo
 cd /tmp
-BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stages"
+BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stages --in-flight 1"   # one frame at a time: clean per-kernel durations
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o p -- $BENCH > $O/stats.log 2>&1
 cp $(find /tmp/p_stats -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats.csv
-PB="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-stages"
+PB="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-stages --in-flight 1"
 i=0
 for ctr in "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do

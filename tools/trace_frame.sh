@@ -2,7 +2,7 @@
 # kernel timeline of the last frame (start/end relative to frame start, queue id) — to see stream overlap
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/p_tr -o p -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-stages "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/p_tr -o p -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-stages --in-flight 1 "$@" > /dev/null 2>&1
 python - <<'PY'
 import csv, glob, re
 f = glob.glob("/tmp/p_tr/**/*kernel_trace.csv", recursive=True)[0]
