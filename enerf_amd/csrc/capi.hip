@@ -256,7 +256,7 @@ extern "C" {
 long long enerf_feature_net_packed_floats(void) {
     long long t = 0;
     for (int i = 0; i < 11; ++i) t += flayer_floats(kFeat[i]);
-    return t + 320;      // tail: raw lat0 weight (32x8) + bias (32) for the fused smooth0 kernel
+    return t + 320 + 3072;   // tail: raw lat0 weight (32x8) + bias (32) for the fused smooth0 kernel, then smooth0's P/Q image
 }
 int enerf_feature_net_pack(const enerf_featnet_raw_t* raw, float* packed, enerf_stream_t stream) {
     REQUIRE(raw && packed, "feature_net_pack: null pointer");
@@ -281,6 +281,7 @@ int enerf_feature_net_pack(const enerf_featnet_raw_t* raw, float* packed, enerf_
     }
     hipMemcpyAsync(p, raw->lat0_w, 256 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
     hipMemcpyAsync(p + 256, raw->lat0_b, 32 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    launch_conv2d_pq_pack(raw->smooth0_w, 32, p + 320, (hipStream_t)stream);             // tap-packed smooth0 (conv2d.hip PK)
     return check_launch("feature_net_pack");
 }
 size_t enerf_feature_net_workspace_bytes(int n_img, int H, int W) {
@@ -355,7 +356,7 @@ int enerf_feature_net_stage(const float* packed, const float* src_inps, int n_im
         const char* fuse = getenv("ENERF_FUSE_LAT0");                                   // A/B knob, default fused
         if (fuse == nullptr || fuse[0] != '0') {
             // smooth0(up2(feat1) + lat0(conv0)) in one kernel: the 32-channel full-res sum never touches HBM
-            launch_smooth0_fused(d[10], c0, f1pre, p, p + 256, feat_l2, n_img, H, W, st);
+            launch_smooth0_fused(d[10], c0, f1pre, p, p + 256, p + 320, feat_l2, n_img, H, W, st);
         } else {
             rc |= launch_conv2d(d[8], c0, f0pre, f1pre, n_img, H, W, H1, W1, st);      // up2(feat1) + lat0(conv0)
             rc |= launch_conv2d(d[10], f0pre, feat_l2, nullptr, n_img, H, W, 0, 0, st);  // smooth0 -> level_2 / texels

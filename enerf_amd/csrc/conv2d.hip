@@ -452,6 +452,12 @@ void launch_conv0_fused(const Conv2dDesc& L0, const Conv2dDesc& L1, const float*
 // and then runs the 3x3 32->8 convolution on the matrix cores exactly like k_conv2d (same packed weights,
 // same texel-mode epilogue).  HBM traffic per frame drops by ~290 MB and one launch disappears.
 // =====================================================================================================
+// PK (tap packing, as conv3d_pk8.hip): Cout = 8 uses half of the 16 MFMA rows, so each (kh, k-step) issues
+//   P: rows 0-7 = W[kw=0], rows 8-15 = W[kw=2]      Q: rows 0-7 = W[kw=1]
+// on the SAME B operand (the tile pixel at column position p); a product in column p belongs to output x = p+1
+// (kw=0), p (kw=1) or p-1 (kw=2), recombined after the K loop with two lane permutes per register.  A 16-column
+// tile then yields 14 outputs, the block tile is 8 x 28: 24 instead of 36 MFMAs per column tile and pass.
+template <bool PK>
 __global__ __launch_bounds__(256, 3) void k_smooth0_fused(   // 47 KB LDS -> 3 blocks/CU
     const float* __restrict__ wpk, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ c0,
@@ -459,7 +465,8 @@ __global__ __launch_bounds__(256, 3) void k_smooth0_fused(   // 47 KB LDS -> 3 b
                                                        const float* __restrict__ lat_b, float* __restrict__ out,
                                                        const float* __restrict__ rgb_src, int out_stride, int N, int H,
                                                        int W, int tiles_y, int tiles_x) {
-    constexpr int TH = 8, TW = 32, K = 3, IH = TH + 2, IW = TW + 2, NPX = IH * IW;     // 10 x 34 halo tile
+    constexpr int TH = 8, TW = PK ? 28 : 32, K = 3, IH = TH + 2, IW = TW + 2, NPX = IH * IW;   // 10 x 34 (30) halo tile
+    constexpr int OW = PK ? 14 : 16;                                                    // outputs per column tile
     constexpr int PH = 7, PW = 20, NPP = PH * PW;                                       // f1pre patch (half res)
     constexpr int TS = 20;                                                              // tile row stride (16 ch + 4 pad)
     constexpr int CTW = 4, KS = 8;
@@ -487,20 +494,32 @@ __global__ __launch_bounds__(256, 3) void k_smooth0_fused(   // 47 KB LDS -> 3 b
         *reinterpret_cast<float4*>(c0t + i * 4) = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    f32x4 acc[CTW];
+    f32x4 acc[CTW], accP[PK ? CTW : 1];      // PK: acc = Q (kw=1), accP = P (kw=0 | kw=2)
 #pragma unroll
     for (int c = 0; c < CTW; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* wl = wpk + lane;
+#pragma unroll
+    for (int c = 0; c < (PK ? CTW : 1); ++c) accP[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wl = wpk + lane;            // PK: the P/Q image [((kh*8 + ks)*2 + pq)*64 + lane]
     const int q4 = threadIdx.x & 3;          // this thread's channel quad inside a 16-channel pass (items stride 256)
 
 #pragma unroll 1
     for (int cb = 0; cb < 2; ++cb) {
         // weights of the 3x3 conv for this pass, requested first (latency hides behind the tile build)
-        float aq[9][4];
+        float aq[PK ? 6 : 9][4];              // PK: [kh*2 + pq][r]
+        if (PK) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
+            for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) aq[tap][r] = wl[((long long)tap * KS + cb * 4 + r) * 64];
+                for (int r = 0; r < 4; ++r) {
+                    aq[kh * 2 + 0][r] = wl[((kh * KS + cb * 4 + r) * 2 + 0) * 64];
+                    aq[kh * 2 + 1][r] = wl[((kh * KS + cb * 4 + r) * 2 + 1) * 64];
+                }
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) aq[tap][r] = wl[((long long)tap * KS + cb * 4 + r) * 64];
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (cb > 0) __syncthreads();          // previous pass done with pat/til
         // ---- f1pre patch (16 channels of this pass) -> LDS ----
@@ -544,30 +563,59 @@ __global__ __launch_bounds__(256, 3) void k_smooth0_fused(   // 47 KB LDS -> 3 b
         }
         __syncthreads();
         // ---- 3x3 conv, 16 input channels of this pass, on the matrix cores ----
+        if (PK) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int kh = tap / 3, kw = tap - kh * 3;
-            float bv[CTW][4];
+            for (int kh = 0; kh < 3; ++kh) {
+                float bv[CTW][4];
 #pragma unroll
-            for (int c = 0; c < CTW; ++c) {
-                const int ct = wv * CTW + c, tr = ct >> 1, tc = ct & 1;
-                const float4 tq = *reinterpret_cast<const float4*>(til + ((tr + kh) * IW + tc * 16 + j + kw) * TS + g * 4);
-                bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
+                for (int c = 0; c < CTW; ++c) {
+                    const int ct = wv * CTW + c, tr = ct >> 1, tc = ct & 1;
+                    const float4 tq = *reinterpret_cast<const float4*>(til + ((tr + kh) * IW + tc * OW + j) * TS + g * 4);
+                    bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < CTW; ++c) {
+                        accP[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[kh * 2 + 0][r], bv[c][r], accP[c], 0, 0, 0);
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[kh * 2 + 1][r], bv[c][r], acc[c], 0, 0, 0);
+                    }
             }
+        } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap - kh * 3;
+                float bv[CTW][4];
 #pragma unroll
-                for (int c = 0; c < CTW; ++c)
-                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[tap][r], bv[c][r], acc[c], 0, 0, 0);
+                for (int c = 0; c < CTW; ++c) {
+                    const int ct = wv * CTW + c, tr = ct >> 1, tc = ct & 1;
+                    const float4 tq = *reinterpret_cast<const float4*>(til + ((tr + kh) * IW + tc * 16 + j + kw) * TS + g * 4);
+                    bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < CTW; ++c)
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[tap][r], bv[c][r], acc[c], 0, 0, 0);
+            }
         }
     }
 
     // ---- epilogue: bias, channels-last / texel store (cout = 8) ----
 #pragma unroll
     for (int c = 0; c < CTW; ++c) {
+        float y[4];
+        if (PK) {     // out[x] = Q[x] + P.lo[x-1] + P.hi[x+1]: lanes (g, j-1) and (g+2, j+1); every lane takes part in the permutes
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                y[r] = acc[c][r] + __shfl(accP[c][r], lane - 1) + __shfl(accP[c][r], lane + 33);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = acc[c][r];
+        }
         const int ct = wv * CTW + c, tr = ct >> 1, tc = ct & 1;
-        const int oy = oy0 + tr, ox = ox0 + tc * 16 + j;
-        if (oy >= H || ox >= W) continue;
+        const int oy = oy0 + tr, ox = PK ? ox0 + tc * OW + j - 1 : ox0 + tc * 16 + j;
+        if (oy >= H || ox >= W || (PK && (j < 1 || j > OW))) continue;
         const long long o = ((long long)n * H + oy) * W + ox;
         const int ch0 = 4 * g;
         if (ch0 == 8 && rgb_src != nullptr) {
@@ -577,18 +625,44 @@ __global__ __launch_bounds__(256, 3) void k_smooth0_fused(   // 47 KB LDS -> 3 b
         }
         if (ch0 >= 8) continue;
         *reinterpret_cast<float4*>(out + o * out_stride + ch0) =
-            make_float4(acc[c][0] * scale[ch0] + shift[ch0], acc[c][1] * scale[ch0 + 1] + shift[ch0 + 1],
-                        acc[c][2] * scale[ch0 + 2] + shift[ch0 + 2], acc[c][3] * scale[ch0 + 3] + shift[ch0 + 3]);
+            make_float4(y[0] * scale[ch0] + shift[ch0], y[1] * scale[ch0 + 1] + shift[ch0 + 1],
+                        y[2] * scale[ch0 + 2] + shift[ch0 + 2], y[3] * scale[ch0 + 3] + shift[ch0 + 3]);
     }
 }
 
+// P/Q weight image of a 3x3 Cout=8 layer for the PK variant: packed[((kh*KS + ks)*2 + pq)*64 + lane], lane = (g, i):
+// P: i < 8 -> W[i][ci][kh][0], i >= 8 -> W[i-8][ci][kh][2];  Q: i < 8 -> W[i][ci][kh][1], else 0;  ci = 16(ks/4) + 4g + ks%4
+__global__ __launch_bounds__(256) void k_conv2d_pq_pack(const float* __restrict__ w, int cin, float* __restrict__ packed) {
+    const int KS = cin / 4, total = 3 * KS * 2 * 64;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int lane = i & 63, pq = (i >> 6) & 1, q = i >> 7, ks = q % KS, kh = q / KS;
+    const int g = lane >> 4, row = lane & 15, ci = (ks / 4) * 16 + 4 * g + (ks & 3);
+    float v = 0.f;
+    if (pq == 0) v = w[(((row & 7) * cin + ci) * 3 + kh) * 3 + (row < 8 ? 0 : 2)];
+    else if (row < 8) v = w[((row * cin + ci) * 3 + kh) * 3 + 1];
+    packed[i] = v;
+}
+void launch_conv2d_pq_pack(const float* w, int cin, float* packed, hipStream_t st) {
+    const int total = 3 * (cin / 4) * 2 * 64;
+    ENERF_LAUNCH_SIMPLE(k_conv2d_pq_pack, (unsigned)cdiv(total, 256), 256, 0, st, w, cin, packed);
+}
+
 void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1pre, const float* lat_w, const float* lat_b,
-                          float* out, int N, int H, int W, hipStream_t st) {
+                          const float* w_pq, float* out, int N, int H, int W, hipStream_t st) {
+    const int out_stride = L.out_stride > 0 ? L.out_stride : 8;
+    const char* e = getenv("ENERF_SMOOTH0_PK");                      // A/B knob: 0 = plain 8x32 tiles
+    if (w_pq != nullptr && !(e && e[0] == '0')) {
+        const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 28);
+        const size_t shmem = (size_t)(300 * 8 + 140 * 16 + 300 * 20 + 288) * sizeof(float);
+        ENERF_LAUNCH(k_smooth0_fused<true>, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, w_pq, L.scale, L.shift, c0,
+                     f1pre, lat_w, lat_b, out, L.rgb_src, out_stride, N, H, W, tiles_y, tiles_x);
+        return;
+    }
     const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
     const size_t shmem = (size_t)(340 * 8 + 140 * 16 + 340 * 20 + 288) * sizeof(float);
-    const int out_stride = L.out_stride > 0 ? L.out_stride : 8;
-    ENERF_LAUNCH(k_smooth0_fused, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, L.w, L.scale, L.shift, c0, f1pre, lat_w,
-                 lat_b, out, L.rgb_src, out_stride, N, H, W, tiles_y, tiles_x);
+    ENERF_LAUNCH(k_smooth0_fused<false>, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, L.w, L.scale, L.shift, c0, f1pre,
+                 lat_w, lat_b, out, L.rgb_src, out_stride, N, H, W, tiles_y, tiles_x);
 }
 
 // The eleven FeatureNet layers use exactly these shapes (feature_net.py:7-22).

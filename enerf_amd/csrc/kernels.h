@@ -85,8 +85,10 @@ int launch_conv2d(const Conv2dDesc& L, const float* in, float* out, const float*
 void launch_conv0_fused(const Conv2dDesc& L0, const Conv2dDesc& L1, const float* img, float* out, int N, int H, int W,
                         hipStream_t st);
 // smooth0(up2(f1pre) + lat0(c0)) fused (feature_net.py:32-35); L = smooth0's descriptor, lat_w/lat_b raw (32,8)/(32)
+// w_pq: the layer's P/Q tap-packed image (launch_conv2d_pq_pack) or nullptr for the plain 8x32 tiling
 void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1pre, const float* lat_w, const float* lat_b,
-                          float* out, int N, int H, int W, hipStream_t st);
+                          const float* w_pq, float* out, int N, int H, int W, hipStream_t st);
+void launch_conv2d_pq_pack(const float* w, int cin, float* packed, hipStream_t st);   // 3*(cin/4)*2*64 floats
 // texels from channels-last features at the render resolution + resized colours (general case)
 void launch_pack_texels_cl(const float* feat_cl, int C, const float* src_inps, int H, int W, int Hr, int Wr, int tex,
                            int n_img, float* out, hipStream_t st);

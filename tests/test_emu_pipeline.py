@@ -187,8 +187,11 @@ def test_fused_build_rays_equals_separate_launch():
                         render_scale=1.0)
 
 
-def test_hip_feature_net_matches_reference_feature_maps():
-    """enerf_feature_net (conv2d.hip) against the reference FeatureNet's three outputs, plain and texel mode."""
+@pytest.mark.parametrize("smooth0_pk", ["1", "0"])
+def test_hip_feature_net_matches_reference_feature_maps(smooth0_pk, monkeypatch):
+    """enerf_feature_net (conv2d.hip) against the reference FeatureNet's three outputs, plain and texel mode;
+    with the tap-packed (8x28 tiles) and the plain (8x32) fused smooth0 kernel."""
+    monkeypatch.setenv("ENERF_SMOOTH0_PK", smooth0_pk)
     name = "tiny_s3"
     cfg, batch, g = case_config(name), case_batch(name), load_golden(name)
     net, lib = _net(cfg), emu_lib()
