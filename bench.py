@@ -75,6 +75,8 @@ def main():
                     help="frames in flight on separate HIP streams during the timed region (1 = sequential).  Measured on "
                          "MI355X: 1 -> 1002, 2 -> 1141, 4 -> 1131-1218 (depends on how the streams land on the 4 hardware "
                          "queues), 6 -> 1195, 7 -> 1203, 10 -> 1206 frames/s; default 6")
+    ap.add_argument("--no-throughput-tuning", action="store_true",
+                    help="keep the single-frame kernel choices inside the frame pipeline (enerf_amd/pipeline.py THROUGHPUT_KNOBS)")
     ap.add_argument("--graph", action="store_true",
                     help="replay one captured HIP graph per frame (enerf_amd/graph.py) instead of enqueueing ~38 launches")
     ap.add_argument("--overlap", action="store_true",
@@ -126,7 +128,7 @@ def main():
     pipe = None
     if in_flight > 1:
         from enerf_amd.pipeline import FramePipeline
-        pipe = FramePipeline(net, depth=in_flight)
+        pipe = FramePipeline(net, depth=in_flight, throughput_tuning=not args.no_throughput_tuning)
 
         def timed_step():
             return pipe.submit(batch)[0]
@@ -147,6 +149,8 @@ def main():
     if pipe is not None:
         pipe.join()
     torch.cuda.synchronize()
+    if pipe is not None:
+        pipe.close()                                    # the measurements below use the default (latency) kernel choices
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -168,6 +172,7 @@ def main():
             "config": {"workload": f"DTU generalizable eval (dtu_pretrain.yaml, render_if False,True, "
                                    f"volume_planes 48,8), {H}x{W}, {S} src views, one target view per step",
                        "feature_net": args.feature_backend, "streams": 2 if (args.overlap and args.feature_backend == "hip") else 1, "hip_graph": bool(args.graph), "frames_in_flight": in_flight,
+                       "throughput_tuning": bool(pipe is not None and not args.no_throughput_tuning),
                        "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world} (no collectives)"},
         }
 

@@ -14,13 +14,22 @@ Buffers: each frame allocates from its own stream's pool of torch's caching allo
 FeatureNet workspace per stream.  A submitted batch must stay alive and unmodified until its event has fired."""
 from __future__ import annotations
 
+import os
 from typing import Dict, Tuple
 
 import torch
 
+# Kernel-variant choices that differ between "one frame as fast as possible" and "most frames per second": with
+# several frames in flight the matrix pipes are shared, so variants that issue fewer MFMAs win even where they are
+# slower in isolation (measured on MI355X, 6 frames in flight: 1216 -> 1234 -> 1244 frames/s; one frame at a time the
+# same switches cost 2 %).  The library reads these per launch; they are set only while a pipeline is open and only
+# if the user has not set them.  Results change at the 1e-6 level (different summation order), not bit for bit.
+THROUGHPUT_KNOBS = {"ENERF_CONV_PK8": "2",       # tap-packed conv3d for every Cout=8(+1) layer, not just where it is faster alone
+                    "ENERF_RENDER_OCC": "2"}     # render kernel at 2 blocks/CU (no spills) instead of 3
+
 
 class FramePipeline:
-    def __init__(self, net, depth: int = 2):
+    def __init__(self, net, depth: int = 2, throughput_tuning: bool = False):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         if getattr(net, "overlap", False):
@@ -28,6 +37,19 @@ class FramePipeline:
         self.net = net
         self.streams = [torch.cuda.Stream() for _ in range(depth)]
         self._i = 0
+        self._restore = {}
+        if throughput_tuning:
+            for k, v in THROUGHPUT_KNOBS.items():
+                if k not in os.environ:
+                    self._restore[k] = None
+                    os.environ[k] = v
+
+    def close(self):
+        """Wait for everything submitted and undo the throughput knobs."""
+        self.join()
+        for k in self._restore:
+            os.environ.pop(k, None)
+        self._restore = {}
 
     def submit(self, batch: Dict[str, torch.Tensor]) -> Tuple[Dict[str, torch.Tensor], torch.cuda.Event]:
         s = self.streams[self._i % len(self.streams)]
