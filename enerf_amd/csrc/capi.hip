@@ -2,11 +2,28 @@
 // network driver, error reporting.  No torch types; raw device pointers + sizes + a hipStream_t.
 #include <stdarg.h>
 #include <stdio.h>
-#include <stdlib.h>
 
 #include "kernels.h"
 
 using namespace enerf;
+
+namespace enerf {
+int device_cu_count() {
+#ifdef ENERF_EMU
+    return 256;
+#else
+    static int cached[64];                         // per device ordinal; 0 = not queried yet (benign race: same value)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+#endif
+}
+}  // namespace enerf
 
 namespace {
 thread_local char g_err[512] = "";
@@ -154,8 +171,13 @@ size_t enerf_cost_reg_workspace_bytes(int full, int B, int D, int h, int w) {
     return (size_t)f * sizeof(float);
 }
 int enerf_cost_reg(const float* packed, int in_channels, int full, const float* vol, int B, int D, int h, int w,
-                   float* feat, float* prob, void* workspace, size_t workspace_bytes, enerf_stream_t stream) {
+                   float* feat, float* prob, void* workspace, size_t workspace_bytes, const enerf_options_t* options,
+                   enerf_stream_t stream) {
     REQUIRE(packed && vol && feat && prob && workspace, "cost_reg: null pointer");
+    REQUIRE(in_channels == 8 || in_channels == 16 || in_channels == 32, "cost_reg: in_channels=%d unsupported (8/16/32)",
+            in_channels);
+    REQUIRE(B > 0 && D > 0 && h > 0 && w > 0, "cost_reg: bad shape");
+    const Options opt = resolve_options(options);
     int div = full ? 8 : 4;
     REQUIRE(D % div == 0 && h % div == 0 && w % div == 0, "cost_reg: D,h,w (%d,%d,%d) must be divisible by %d", D, h, w, div);
     if (workspace_bytes < enerf_cost_reg_workspace_bytes(full, B, D, h, w))
@@ -178,22 +200,24 @@ int enerf_cost_reg(const float* packed, int in_channels, int full, const float* 
     float *c0 = take(n0 * 8), *c1 = take(n1 * 16), *c2 = take(n1 * 16), *c3 = take(n2 * 32), *c4 = take(n2 * 32);
     float *y9 = take(n1 * 16), *y11 = take(n0 * 8);
     int i = 0;
-    launch_conv3d(desc[i++], vol, nullptr, c0, nullptr, B, D, h, w, st);                    // conv0
-    launch_conv3d(desc[i++], c0, nullptr, c1, nullptr, B, D, h, w, st);                     // conv1 (s2)
-    launch_conv3d(desc[i++], c1, nullptr, c2, nullptr, B, D / 2, h / 2, w / 2, st);         // conv2
-    launch_conv3d(desc[i++], c2, nullptr, c3, nullptr, B, D / 2, h / 2, w / 2, st);         // conv3 (s2)
-    launch_conv3d(desc[i++], c3, nullptr, c4, nullptr, B, D / 4, h / 4, w / 4, st);         // conv4
+    bool ok = true;
+    ok &= launch_conv3d(desc[i++], vol, nullptr, c0, nullptr, B, D, h, w, opt, st);                    // conv0
+    ok &= launch_conv3d(desc[i++], c0, nullptr, c1, nullptr, B, D, h, w, opt, st);                     // conv1 (s2)
+    ok &= launch_conv3d(desc[i++], c1, nullptr, c2, nullptr, B, D / 2, h / 2, w / 2, opt, st);         // conv2
+    ok &= launch_conv3d(desc[i++], c2, nullptr, c3, nullptr, B, D / 2, h / 2, w / 2, opt, st);         // conv3 (s2)
+    ok &= launch_conv3d(desc[i++], c3, nullptr, c4, nullptr, B, D / 4, h / 4, w / 4, opt, st);         // conv4
     const float* x = c4;
     if (full) {
         float *c5 = take(n3 * 64), *c6 = take(n3 * 64), *y7 = take(n2 * 32);
-        launch_conv3d(desc[i++], c4, nullptr, c5, nullptr, B, D / 4, h / 4, w / 4, st);     // conv5 (s2)
-        launch_conv3d(desc[i++], c5, nullptr, c6, nullptr, B, D / 8, h / 8, w / 8, st);     // conv6
-        launch_conv3d(desc[i++], c6, c4, y7, nullptr, B, D / 8, h / 8, w / 8, st);          // conv4 + conv7
+        ok &= launch_conv3d(desc[i++], c4, nullptr, c5, nullptr, B, D / 4, h / 4, w / 4, opt, st);     // conv5 (s2)
+        ok &= launch_conv3d(desc[i++], c5, nullptr, c6, nullptr, B, D / 8, h / 8, w / 8, opt, st);     // conv6
+        ok &= launch_conv3d(desc[i++], c6, c4, y7, nullptr, B, D / 8, h / 8, w / 8, opt, st);          // conv4 + conv7
         x = y7;
     }
-    launch_conv3d(desc[i++], x, c2, y9, nullptr, B, D / 4, h / 4, w / 4, st);               // conv2 + conv9
-    launch_conv3d(desc[i++], y9, c0, y11, nullptr, B, D / 2, h / 2, w / 2, st);             // conv0 + conv11
-    launch_conv3d(desc[i++], y11, nullptr, feat, prob, B, D, h, w, st);                     // feat_conv ++ depth_conv
+    ok &= launch_conv3d(desc[i++], x, c2, y9, nullptr, B, D / 4, h / 4, w / 4, opt, st);               // conv2 + conv9
+    ok &= launch_conv3d(desc[i++], y9, c0, y11, nullptr, B, D / 2, h / 2, w / 2, opt, st);             // conv0 + conv11
+    ok &= launch_conv3d(desc[i++], y11, nullptr, feat, prob, B, D, h, w, opt, st);                     // feat_conv ++ depth_conv
+    if (!ok) return fail(ENERF_EINVAL, "cost_reg: a layer shape has no kernel (in_channels=%d full=%d)", in_channels, full);
     return check_launch("cost_reg");
 }
 
@@ -291,13 +315,14 @@ size_t enerf_feature_net_workspace_bytes(int n_img, int H, int W) {
 }
 int enerf_feature_net(const float* packed, const float* src_inps, int n_img, int H, int W, float* feat_l0,
                       float* feat_l1, float* feat_l2, int l2_stride, void* workspace, size_t workspace_bytes,
-                      enerf_stream_t stream) {
+                      const enerf_options_t* options, enerf_stream_t stream) {
     return enerf_feature_net_stage(packed, src_inps, n_img, H, W, feat_l0, feat_l1, feat_l2, l2_stride, workspace,
-                                   workspace_bytes, ENERF_FEAT_ALL, stream);
+                                   workspace_bytes, ENERF_FEAT_ALL, options, stream);
 }
 int enerf_feature_net_stage(const float* packed, const float* src_inps, int n_img, int H, int W, float* feat_l0,
                             float* feat_l1, float* feat_l2, int l2_stride, void* workspace, size_t workspace_bytes,
-                            int stage, enerf_stream_t stream) {
+                            int stage, const enerf_options_t* options, enerf_stream_t stream) {
+    const Options opt = resolve_options(options);
     REQUIRE(stage >= ENERF_FEAT_ALL && stage <= ENERF_FEAT_LEVEL2, "feature_net: unknown stage %d", stage);
     const bool trunk = stage == ENERF_FEAT_ALL || stage == ENERF_FEAT_TRUNK;
     const bool lvl1 = stage == ENERF_FEAT_ALL || stage == ENERF_FEAT_LEVEL1;
@@ -326,8 +351,7 @@ int enerf_feature_net_stage(const float* packed, const float* src_inps, int n_im
     float *c2a = take(p2 * 32), *c2 = take(p2 * 32);
     int rc = 0;
     if (trunk) {
-        const char* f0 = getenv("ENERF_FUSE_CONV0");                                   // A/B knob, default fused
-        if (f0 == nullptr || f0[0] != '0') {
+        if (!opt.featnet_unfused) {
             launch_conv0_fused(d[0], d[1], src_inps, c0, n_img, H, W, st);             // conv0.1(conv0.0(image))
         } else {
             rc |= launch_conv2d(d[0], src_inps, c0a, nullptr, n_img, H, W, 0, 0, st);  // conv0.0 (NCHW image in)
@@ -336,8 +360,7 @@ int enerf_feature_net_stage(const float* packed, const float* src_inps, int n_im
         rc |= launch_conv2d(d[2], c0, c1a, nullptr, n_img, H, W, 0, 0, st);            // conv1.0 (s2)
         rc |= launch_conv2d(d[3], c1a, c1, nullptr, n_img, H1, W1, 0, 0, st);          // conv1.1
         rc |= launch_conv2d(d[4], c1, c2a, nullptr, n_img, H1, W1, 0, 0, st);          // conv2.0 (s2)
-        const char* ft = getenv("ENERF_FUSE_TOP");                                     // A/B knob, default fused
-        if (ft == nullptr || ft[0] != '0') {
+        if (!opt.featnet_unfused) {
             d[5].chain_w = d[6].w;                                                     // toplayer (1x1, bias) runs in
             d[5].chain_shift = d[6].shift;                                             // conv2.1's epilogue -> level_0
             rc |= launch_conv2d(d[5], c2a, feat_l0, nullptr, n_img, H2, W2, 0, 0, st);
@@ -353,10 +376,10 @@ int enerf_feature_net_stage(const float* packed, const float* src_inps, int n_im
     if (lvl2) {
         d[10].out_stride = l2_stride;
         d[10].rgb_src = (l2_stride == 12) ? src_inps : nullptr;
-        const char* fuse = getenv("ENERF_FUSE_LAT0");                                   // A/B knob, default fused
-        if (fuse == nullptr || fuse[0] != '0') {
+        if (!opt.featnet_unfused) {
             // smooth0(up2(feat1) + lat0(conv0)) in one kernel: the 32-channel full-res sum never touches HBM
-            launch_smooth0_fused(d[10], c0, f1pre, p, p + 256, p + 320, feat_l2, n_img, H, W, st);
+            launch_smooth0_fused(d[10], c0, f1pre, p, p + 256, opt.featnet_smooth0_plain ? nullptr : p + 320, feat_l2, n_img,
+                                 H, W, st);
         } else {
             rc |= launch_conv2d(d[8], c0, f0pre, f1pre, n_img, H, W, H1, W1, st);      // up2(feat1) + lat0(conv0)
             rc |= launch_conv2d(d[10], f0pre, feat_l2, nullptr, n_img, H, W, 0, 0, st);  // smooth0 -> level_2 / texels

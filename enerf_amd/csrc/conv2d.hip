@@ -12,7 +12,6 @@
 //
 // First layer (Cin=3): input is the NCHW image batch; it is staged as [pixel][4] (4th channel 0) so a
 // tap is one k-step with lane group g supplying channel g.
-#include <stdlib.h>
 
 #include "kernels.h"
 
@@ -651,8 +650,7 @@ void launch_conv2d_pq_pack(const float* w, int cin, float* packed, hipStream_t s
 void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1pre, const float* lat_w, const float* lat_b,
                           const float* w_pq, float* out, int N, int H, int W, hipStream_t st) {
     const int out_stride = L.out_stride > 0 ? L.out_stride : 8;
-    const char* e = getenv("ENERF_SMOOTH0_PK");                      // A/B knob: 0 = plain 8x32 tiles
-    if (w_pq != nullptr && !(e && e[0] == '0')) {
+    if (w_pq != nullptr) {                                             // tap-packed 8x28 tiles (nullptr: plain 8x32)
         const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 28);
         const size_t shmem = (size_t)(300 * 8 + 140 * 16 + 300 * 20 + 288) * sizeof(float);
         ENERF_LAUNCH(k_smooth0_fused<true>, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, w_pq, L.scale, L.shift, c0,
@@ -670,9 +668,8 @@ int launch_conv2d(const Conv2dDesc& L, const float* in, float* out, const float*
                   int Wc, hipStream_t st) {
     const int key = L.cin * 10000 + L.cout * 100 + L.k * 10 + L.stride;
     // 4-row tiles for the 3x3 layers whose 8-row tiling gives fewer than ~4 blocks per CU (quarter/half-resolution maps;
-    // measured: smooth1 33.5 -> 30.0 us, conv2.1 18.0 -> 17.1, conv1.1 17.9 -> 17.2).  ENERF_C2_TH=8 forces 8 rows (A/B knob)
-    const char* eth = getenv("ENERF_C2_TH");
-    const bool th4 = !(eth && eth[0] == '8') && (long long)N * cdiv(Hi, 8) * cdiv(Wi, 32) < 1024;
+    // measured: smooth1 33.5 -> 30.0 us, conv2.1 18.0 -> 17.1, conv1.1 17.9 -> 17.2).
+    const bool th4 = (long long)N * cdiv(Hi, 8) * cdiv(Wi, 32) < 1024;
     switch (key) {
         case 3 * 10000 + 8 * 100 + 31: launch_c2<4, 1, 3, 1, 8, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;     // conv0.0
         case 8 * 10000 + 8 * 100 + 31: launch_c2<8, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;    // conv0.1

@@ -17,8 +17,6 @@
 // fp32 MFMA is exact fp32 (a k-ordered fmaf chain), which keeps the 1e-3 PSNR parity bar.
 //
 // Roofline: MFMA-bound (fp32 157.3 TF peak).  Algorithmic FLOPs = 2*27*cin*cout per output voxel (s1).
-#include <stdio.h>
-#include <stdlib.h>
 
 #include "kernels.h"
 
@@ -400,10 +398,8 @@ static bool dispatch_rt(const Conv3dDesc& L, const float* in, const float* resid
     const int ct_default = rt_total == 1 ? 4 : (rt_total == 2 ? 2 : 1);
     const bool small = cdivl(tiles, ct_default) < 1024;      // fewer waves than SIMDs: split finer
     if (small) {
-        const char* e = getenv("ENERF_CONV_SPLIT");                  // A/B knob: 0 = one wave per tile group, 3 / 9 = tap split
-        const int split = e ? atoi(e) : 3;
-        if (KIND != kConvT2 && CIN >= 16 && split == 9) launch_one<CIN, 1, KIND, 1, (KIND != kConvT2 && CIN >= 16 ? 9 : 1)>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
-        else if (KIND != kConvT2 && CIN >= 16 && split == 3) launch_one<CIN, 1, KIND, 1, (KIND != kConvT2 && CIN >= 16 ? 3 : 1)>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
+        // taps split by kd over three waves + LDS reduction (a 9-way split and no split both measured slower)
+        if (KIND != kConvT2 && CIN >= 16) launch_one<CIN, 1, KIND, 1, (KIND != kConvT2 && CIN >= 16 ? 3 : 1)>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
         else launch_one<CIN, 1, KIND, 1>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
         return true;
     }
@@ -440,16 +436,11 @@ __global__ __launch_bounds__(256, (BD == 4 ? 2 : 3)) void k_conv3d_s1_lds(   // 
 const float* __restrict__ wpk, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ in,
                                                        float* __restrict__ out, float* __restrict__ out2, int cout,
-                                                       int relu, int B, int D, int H, int W, int nbd, int nbh, int nbw,
-                                                       int xcd_swizzle, int dbg, int stagger) {
+                                                       int relu, int B, int D, int H, int W, int nbd, int nbh, int nbw) {
     constexpr int BW = 16;                              // box = BD x BH x 16 outputs (BH = 8, or 4 for mid-size layers)
-    // Two identical blocks share a CU (LDS-limited) and, sharing the MFMA pipe fairly, stay in lockstep:
-    // both stage, both compute, both store at the same time, so the ~20 us of non-MFMA work never hides
-    // (phase ablation: 70 us MFMA + 23 us rest = 93 us).  Delaying the second block of each CU once by
-    // about one MFMA phase makes them ping-pong; later blocks inherit the offset.  The "second block" is
-    // guessed from the dispatch order (block b -> XCD b%8, 32 CUs per XCD filled round-robin): speed only.
-    if (stagger > 0 && ((blockIdx.x >> 3) >> 5) == 1)
-        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    // (Two identical blocks share a CU and stay in lockstep — both stage, both compute, both store at the same time;
+    // a phase ablation gave 70 us MFMA + 23 us rest = 93 us.  Staggering the second block of each CU by one MFMA
+    // phase, and s_setprio tickets, were measured and changed nothing: not kept.)
     constexpr int CB = CIN >= 16 ? 16 : CIN;          // channels staged per pass
     constexpr int CPL = CB / 4;                         // channels per lane per LDS read
     constexpr int NCB = CIN / CB;
@@ -463,7 +454,7 @@ const float* __restrict__ wpk, const float* __restrict__ scale,
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
     // XCD-aware block order: consecutive block ids land on different XCDs (private L2s), so give each
     // XCD a contiguous run of boxes; neighbouring boxes (shared halos) then hit the same L2.
-    const int bid = xcd_swizzle ? (int)xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int bid = (int)xcd_contiguous(blockIdx.x, gridDim.x);
     int t = bid;
     const int bw = t % nbw; t /= nbw;
     const int bh = t % nbh; t /= nbh;
@@ -515,8 +506,7 @@ const float* __restrict__ wpk, const float* __restrict__ scale,
                 const int gx = x0 + dx - 1, gy = y0 + dy - 1, gz = z0 + dz - 1;
                 sk[it] = gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
                 const long long off = sk[it] ? (((long long)gz * H + gy) * W + gx) : 0;
-                sv[it] = (dbg & 1) ? make_float4(1.f, 1.f, 1.f, 1.f)      // profiling aid: no staging loads
-                                   : *reinterpret_cast<const float4*>(inb + off * CIN + cb * CB + q * 4);
+                sv[it] = *reinterpret_cast<const float4*>(inb + off * CIN + cb * CB + q * 4);
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -526,7 +516,6 @@ const float* __restrict__ wpk, const float* __restrict__ scale,
             }
         }
         __syncthreads();
-        if (dbg & 2) continue;                           // profiling aid: staging only, no MFMA phase
 
         const float* lbase[CTW];                        // this lane's voxel (tap 0,0,0) in each of its column tiles
 #pragma unroll
@@ -606,10 +595,8 @@ static void launch_s1_lds(const Conv3dDesc& L, const float* in, float* out, floa
     const int nbd = cdiv(D, BD), nbh = cdiv(H, BH), nbw = cdiv(W, 16);
     const size_t shmem = (size_t)(BD + 2) * (BH + 2) * 18 * CB * sizeof(float);
     const unsigned grid = (unsigned)((long long)B * nbd * nbh * nbw);
-    const char* e = getenv("ENERF_XCD_SWIZZLE");
     ENERF_LAUNCH((k_conv3d_s1_lds<CIN, RT, BD, BH>), grid, 256, shmem, st, L.w, L.scale, L.shift, in, out, out2, L.cout,
-                 L.relu, B, D, H, W, nbd, nbh, nbw, e ? atoi(e) : 1, getenv("ENERF_CONV_DBG") ? atoi(getenv("ENERF_CONV_DBG")) : 0,
-                 getenv("ENERF_STAGGER") ? atoi(getenv("ENERF_STAGGER")) : 0);
+                 L.relu, B, D, H, W, nbd, nbh, nbw);
 }
 template <int CIN>
 static bool dispatch_s1_lds(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,
@@ -617,12 +604,10 @@ static bool dispatch_s1_lds(const Conv3dDesc& L, const float* in, float* out, fl
     const int rt_total = cdiv(L.cout, 16);
     if (rt_total == 1) {
         // box depth 4 (2 blocks/CU, fewer halo reads) for layers that fill the chip, depth 2 for the mid-size ones
-        // (level-1 conv2: 160 boxes of depth 4 leave 96 CUs idle).  ENERF_CONV_BD=2|4 forces one (A/B knob).
-        const char* e = getenv("ENERF_CONV_BD");
+        // (level-1 conv2: 160 boxes of depth 4 leave 96 CUs idle).
         const long long boxes4 = (long long)B * cdiv(D, 4) * cdiv(H, 8) * cdiv(W, 16);
-        const int bd = e ? atoi(e) : (boxes4 >= 256 ? 4 : 2);   // measured: L0 conv2 20 -> 12.5 us; 480-box layers stay at 4
-        const char* eh = getenv("ENERF_CONV_BH");         // A/B knob: box height 8 or 4
-        const int bh = eh ? atoi(eh) : (boxes4 >= 256 ? 8 : 4);   // mid-size layers: 2 x 4 x 16 boxes, 4x the blocks
+        const int bd = boxes4 >= 256 ? 4 : 2;   // measured: L0 conv2 20 -> 12.5 us; 480-box layers stay at 4
+        const int bh = boxes4 >= 256 ? 8 : 4;   // mid-size layers: 2 x 4 x 16 boxes, 4x the blocks
         if (D % 4 == 0 && bd == 4) launch_s1_lds<CIN, 1, 4>(L, in, out, out2, B, D, H, W, st);
         else if (bh == 4) launch_s1_lds<CIN, 1, 2, 4>(L, in, out, out2, B, D, H, W, st);
         else launch_s1_lds<CIN, 1, 2>(L, in, out, out2, B, D, H, W, st);
@@ -631,63 +616,27 @@ static bool dispatch_s1_lds(const Conv3dDesc& L, const float* in, float* out, fl
     if (rt_total == 2) { launch_s1_lds<CIN, 2, 2>(L, in, out, out2, B, D, H, W, st); return true; }
     return false;
 }
-// Tuning/test switches (read per call; getenv is ~100 ns against a >10 us launch):
-//   ENERF_CONV_V1=1            force the global-load kernel everywhere (A/B runs)
-//   ENERF_CONV_V2_MIN_VOX=n    smallest layer (output voxels) routed to the LDS-staged kernel
-static int conv_v2_enabled() {
-    const char* e = getenv("ENERF_CONV_V1");
-    return (e && e[0] == '1') ? 0 : 1;
-}
-static long long conv_v2_min_vox() {
-    const char* e = getenv("ENERF_CONV_V2_MIN_VOX");
-    return e ? atoll(e) : 16384;
-}
-
-void launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, float* out, float* out2, int B, int Di,
-                   int Hi, int Wi, hipStream_t st) {
-    // LDS-staged transposed path (conv11 of both nets, 16 -> 8): ENERF_CONV_T2_LDS=0 falls back to the global-load kernel
-    if (L.kind == kConvT2 && out2 == nullptr && conv_v2_enabled()) {
-        const char* e = getenv("ENERF_CONV_T2_LDS");
-        if ((e == nullptr || e[0] != '0') && 8LL * B * Di * Hi * Wi >= 32 * conv_v2_min_vox() &&       // level-1 conv11: 30.8 -> 25.3 us; level 0 is slower (19 vs 15)
-            launch_conv3d_t2_lds(L, in, residual, out, B, Di, Hi, Wi, st)) {
-            if (getenv("ENERF_TRACE")) fprintf(stderr, "[enerf] conv3d %d->%d vox=%lld : t2 lds\n", L.cin, L.cout,
-                                               (long long)B * Di * Hi * Wi);
-            return;
-        }
-    }
-    // LDS-staged stride-2 path (conv1 of both nets): ENERF_CONV_S2_LDS=0 falls back to the global-load kernel
-    if (L.kind == kConvS2 && residual == nullptr && out2 == nullptr && conv_v2_enabled()) {
-        const char* e = getenv("ENERF_CONV_S2_LDS");
-        if ((e == nullptr || e[0] != '0') && (long long)B * Di * Hi * Wi >= 32 * conv_v2_min_vox() &&   // level-1 conv1 (19.7 -> 14.1 us); level 0 is no faster
-            launch_conv3d_s2_lds(L, in, out, B, Di, Hi, Wi, st)) {
-            if (getenv("ENERF_TRACE")) fprintf(stderr, "[enerf] conv3d %d->%d vox=%lld : s2 lds\n", L.cin, L.cout,
-                                               (long long)B * Di * Hi * Wi);
-            return;
-        }
-    }
-    // persistent producer/consumer kernel (conv3d_ws.hip); ENERF_CONV_WS=1 routes every eligible layer through it
-    {
-        const char* e = getenv("ENERF_CONV_WS");
-        if (e != nullptr && e[0] == '1' && residual == nullptr && conv_v2_enabled() &&
-            (long long)B * Di * Hi * Wi >= conv_v2_min_vox() && launch_conv3d_ws(L, in, out, out2, B, Di, Hi, Wi, st)) {
-            if (getenv("ENERF_TRACE")) fprintf(stderr, "[enerf] conv3d %d->%d vox=%lld : ws\n", L.cin, L.cout,
-                                               (long long)B * Di * Hi * Wi);
-            return;
-        }
-    }
+// Kernel selection.  `o` carries the caller's explicit choices (enerf_options_t; nothing is read from the environment).
+// Returns false for a layer shape no kernel handles (the C entry reports ENERF_EINVAL).
+bool launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, float* out, float* out2, int B, int Di,
+                   int Hi, int Wi, const Options& o, hipStream_t st) {
+    const bool lds_ok = !o.conv3d_global_only;
+    const long long min_vox = o.conv3d_lds_min_voxels > 0 ? o.conv3d_lds_min_voxels : 16384;
+    const long long vox_in = (long long)B * Di * Hi * Wi;
+    // LDS-staged transposed path (conv11 of both nets, 16 -> 8).  Level-1 conv11: 30.8 -> 25.3 us; level 0 is slower (19 vs 15)
+    if (L.kind == kConvT2 && out2 == nullptr && lds_ok && 8 * vox_in >= 32 * min_vox &&
+        launch_conv3d_t2_lds(L, in, residual, out, B, Di, Hi, Wi, st))
+        return true;
+    // LDS-staged stride-2 path (conv1 of both nets).  Level-1 conv1: 19.7 -> 14.1 us; level 0 is no faster
+    if (L.kind == kConvS2 && residual == nullptr && out2 == nullptr && lds_ok && vox_in >= 32 * min_vox &&
+        launch_conv3d_s2_lds(L, in, out, B, Di, Hi, Wi, st))
+        return true;
     // tap-packed path for the Cout=8 stride-1 layers (conv0 of both levels, fused heads): 2/3 of the MFMAs
-    {
-        const char* e = getenv("ENERF_CONV_PK8");
-        if ((e == nullptr || e[0] != '0') && residual == nullptr && conv_v2_enabled() &&
-            (long long)B * Di * Hi * Wi >= conv_v2_min_vox() && launch_conv3d_pk8(L, in, out, out2, B, Di, Hi, Wi, st)) {
-            if (getenv("ENERF_TRACE")) fprintf(stderr, "[enerf] conv3d %d->%d vox=%lld : pk8\n", L.cin, L.cout,
-                                               (long long)B * Di * Hi * Wi);
-            return;
-        }
-    }
+    if (o.conv3d_pk8 != 1 && residual == nullptr && lds_ok && vox_in >= min_vox &&
+        launch_conv3d_pk8(L, in, out, out2, B, Di, Hi, Wi, o.conv3d_pk8 == 2, st))
+        return true;
     // LDS-staged path: stride-1 layers with enough voxels to fill the chip and cout <= 32
-    if (L.kind == kConvS1 && residual == nullptr && conv_v2_enabled() && L.cout <= 32 &&
-        (long long)B * Di * Hi * Wi >= conv_v2_min_vox()) {
+    if (L.kind == kConvS1 && residual == nullptr && lds_ok && L.cout <= 32 && vox_in >= min_vox) {
         bool ok = false;
         switch (L.cin) {
             case 8: ok = dispatch_s1_lds<8>(L, in, out, out2, B, Di, Hi, Wi, st); break;
@@ -695,16 +644,13 @@ void launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, 
             case 32: ok = dispatch_s1_lds<32>(L, in, out, out2, B, Di, Hi, Wi, st); break;
             default: break;
         }
-        if (getenv("ENERF_TRACE")) fprintf(stderr, "[enerf] conv3d %d->%d vox=%lld : %s\n", L.cin, L.cout,
-                                           (long long)B * Di * Hi * Wi, ok ? "V2 lds" : "V1");
-        if (ok) return;
+        if (ok) return true;
     }
-
     switch (L.kind) {
-        case kConvS1: dispatch_cin<kConvS1>(L, in, residual, out, out2, B, Di, Hi, Wi, st); break;
-        case kConvS2: dispatch_cin<kConvS2>(L, in, residual, out, out2, B, Di, Hi, Wi, st); break;
-        case kConvT2: dispatch_cin<kConvT2>(L, in, residual, out, out2, B, Di, Hi, Wi, st); break;
-        default: break;
+        case kConvS1: return dispatch_cin<kConvS1>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
+        case kConvS2: return dispatch_cin<kConvS2>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
+        case kConvT2: return dispatch_cin<kConvT2>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
+        default: return false;
     }
 }
 

@@ -11,7 +11,6 @@
 // after the whole K loop, with two lane permutes per register.  A 16-column tile therefore yields 14 outputs
 // (columns 1..14); boxes advance 14 voxels in x.  72 instead of 108 MFMAs per row tile at Cin=16, and
 // 9 instead of 27 LDS reads.  Same LDS-staged box, operand rings and epilogue conventions as conv3d.hip V2.
-#include <stdlib.h>
 
 #include "kernels.h"
 
@@ -194,16 +193,16 @@ static void launch_pk8(const Conv3dDesc& L, const float* in, float* out, float* 
                  W, nbd, nbh, nbw);
 }
 bool launch_conv3d_pk8(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,
-                       hipStream_t st) {
+                       bool all_layers, hipStream_t st) {
     if (L.w_pk8 == nullptr || L.kind != kConvS1 || !(L.cout == 8 || (L.cout == 9 && out2 != nullptr))) return false;
     // Measured on MI355X (same box, rocprofv3): Cin=16 conv0 80-88 us vs 94 us for the plain LDS kernel; Cin=32
     // conv0 and the Cin=8 heads are no faster (fewer MFMAs, but 14/16 column efficiency, 15 % more blocks and a
-    // heavier epilogue eat the gain), so by default only Cin=16 takes this path.  ENERF_CONV_PK8=2 forces all.
+    // heavier epilogue eat the gain), so by default only Cin=16 takes this path; `all_layers`
+    // (enerf_options_t.conv3d_pk8 == 2) routes every Cout=8(+1) layer here.
     // Re-measured after the VALU work: the Cin=8 fused heads gain at level 1 only (655,360 voxels: 54.3 -> 50.6 us; level 0:
     // 20.9 -> 24.2 us), so they take this path above 512 K voxels.
-    const char* e = getenv("ENERF_CONV_PK8");
     const bool big = (long long)B * D * H * W >= (1LL << 19);
-    if (!(e && e[0] == '2') && !(L.cin == 16 || (L.cin == 8 && big))) return false;
+    if (!all_layers && !(L.cin == 16 || (L.cin == 8 && big))) return false;
     const bool bd4 = (D % 4 == 0);
     switch (L.cin) {
         case 8: bd4 ? launch_pk8<8, 4>(L, in, out, out2, B, D, H, W, st) : launch_pk8<8, 2>(L, in, out, out2, B, D, H, W, st); return true;

@@ -6,6 +6,12 @@
 
 namespace enerf {
 
+// Explicit kernel-variant choices (include/enerf_hip.h: enerf_options_t); a NULL pointer at the C ABI means all zero.
+using Options = enerf_options_t;
+inline Options resolve_options(const enerf_options_t* o) { return o ? *o : Options{}; }
+// number of compute units of the current device (queried once per device; 256 on MI355X)
+int device_cu_count();
+
 // ---- geometry.hip -------------------------------------------------------------------------------
 void launch_channels_last(const float* src, float* dst, int n, int C, long long P, int Cpad, hipStream_t st);
 void launch_channels_first(const float* src, float* dst, int n, int C, long long P, int Cpad, hipStream_t st);
@@ -40,14 +46,12 @@ struct Conv3dDesc {
 // tap-packed variant for cout = 8 (+ optional depth row): see conv3d_pk8.hip
 long long conv3d_pk8_packed_floats(int cin);
 void launch_conv3d_pk8_pack(const float* w, const float* wd, int cin, float* packed, hipStream_t st);
-bool launch_conv3d_ws(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,
-                      hipStream_t st);   // persistent producer/consumer variant, cout <= 16 (conv3d_ws.hip)
 bool launch_conv3d_s2_lds(const Conv3dDesc& L, const float* in, float* out, int B, int Di, int Hi, int Wi,
                           hipStream_t st);   // LDS-staged stride-2 variant, Cin = 8, Cout <= 16 (conv3d_s2.hip)
 bool launch_conv3d_t2_lds(const Conv3dDesc& L, const float* in, const float* residual, float* out, int B, int Di, int Hi,
                           int Wi, hipStream_t st);   // LDS-staged transposed variant, 16 -> 8 (conv3d_t2.hip)
 bool launch_conv3d_pk8(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,
-                       hipStream_t st);
+                       bool all_layers, hipStream_t st);
 // number of floats of the packed weight image for a layer
 long long conv3d_packed_floats(int cin, int cout, int kind);
 // pack torch-layout weights (Conv3d: (cout,cin,3,3,3); ConvTranspose3d: (cin,cout,3,3,3)) + BN into
@@ -59,8 +63,9 @@ void launch_conv3d_pack(const float* w, const float* w2, int cout1, const float*
 // in: (B, Di, Hi, Wi, cin) channels-last; out: (B, Do, Ho, Wo, cout_store); residual (same shape as out) optional.
 // cout_store lets the fused heads write feat (8 ch) and prob (1 ch) to two tensors: if out2 != nullptr,
 // channels [0,8) go to out (stride 8) and channel 8 goes to out2 (stride 1).
-void launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, float* out, float* out2, int B, int Di,
-                   int Hi, int Wi, hipStream_t st);
+// Returns false when no kernel handles the layer shape (nothing launched).
+bool launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, float* out, float* out2, int B, int Di,
+                   int Hi, int Wi, const Options& o, hipStream_t st);
 
 // ---- conv2d.hip (FeatureNet) ----------------------------------------------------------------------
 struct Conv2dDesc {
@@ -87,7 +92,7 @@ void launch_conv0_fused(const Conv2dDesc& L0, const Conv2dDesc& L1, const float*
 // smooth0(up2(f1pre) + lat0(c0)) fused (feature_net.py:32-35); L = smooth0's descriptor, lat_w/lat_b raw (32,8)/(32)
 // w_pq: the layer's P/Q tap-packed image (launch_conv2d_pq_pack) or nullptr for the plain 8x32 tiling
 void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1pre, const float* lat_w, const float* lat_b,
-                          const float* w_pq, float* out, int N, int H, int W, hipStream_t st);
+                          const float* w_pq, float* out, int N, int H, int W, hipStream_t st);   // w_pq == nullptr: plain tiling
 void launch_conv2d_pq_pack(const float* w, int cin, float* packed, hipStream_t st);   // 3*(cin/4)*2*64 floats
 // texels from channels-last features at the render resolution + resized colours (general case)
 void launch_pack_texels_cl(const float* feat_cl, int C, const float* src_inps, int H, int W, int Hr, int Wr, int tex,

@@ -21,8 +21,6 @@
 // point instead of once per view (201 instead of 369 MFMAs per 16 points at S=3, C=8).
 //
 // Roofline: MFMA-bound (fp32 157.3 TF).  Algorithmic FLOPs/point: SURVEY.md §8a (50,952 at level 1).
-#include <stdlib.h>
-
 #include "kernels.h"
 
 namespace enerf {
@@ -513,10 +511,6 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
     }
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
 template <int R, int OCC>
 static int dispatch_s(const RenderArgs& a, unsigned grid, size_t shmem, hipStream_t st) {
     switch (a.S) {
@@ -539,9 +533,11 @@ int launch_render_rays(const RenderArgs& a, hipStream_t st) {
     long long blocks = cdivl(ntiles, 4);
     // Persistent waves: the weight image (40-56 KB) is staged into LDS once per block, so launch only as
     // many blocks as are co-resident (OCC per CU x 256 CUs) and let each wave stride over ray tiles.
-    // Tuning knobs (A/B runs): ENERF_RENDER_OCC (2|3), ENERF_RENDER_WAVES_PER_CU_X (grid multiplier).
-    const int occ = env_int("ENERF_RENDER_OCC", 3);   // 3 blocks/CU (168 VGPR, 12 spilled) measured 4 % faster than 2
-    const long long resident = 256LL * occ * env_int("ENERF_RENDER_GRID_X", 1);
+    // enerf_options_t.render_blocks_per_cu: 3 blocks/CU (168 VGPR, 12 spilled) measured 4 % faster than 2 for one frame
+    // at a time; 2 (no spills) wins when several frames share the matrix pipes.
+    const Options o = resolve_options(a.options);
+    const int occ = o.render_blocks_per_cu == 2 ? 2 : 3;
+    const long long resident = (long long)device_cu_count() * occ;
     unsigned grid = (unsigned)(blocks < resident ? blocks : resident);
     if (grid == 0) return 0;
     if (R == 3) return occ == 3 ? dispatch_s<3, 3>(a, grid, shmem, st) : dispatch_s<3, 2>(a, grid, shmem, st);   // C = 8

@@ -32,8 +32,17 @@ class GraphedFrame:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.static_out = net(self.static_in)
+        # the graph holds raw addresses of the packed weight images and the FeatureNet scratch, which live OUTSIDE the
+        # graph's private pool: keep them alive here and refuse to replay once the network has replaced them
+        self._held = {k: v[0] for k, v in net._packed.items()}
+        self._held_ws = dict(net._feat_ws_by_stream)
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        for k, t in self._held.items():
+            ent = self.net._packed.get(k)
+            if ent is None or ent[0] is not t:
+                raise RuntimeError("GraphedFrame: the network's weights changed (load_state_dict / .to()) after capture; "
+                                   "re-capture the frame")
         for k, v in batch.items():
             if torch.is_tensor(v):
                 dst = self.static_in[k]

@@ -14,7 +14,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libenerf_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _f = C.c_void_p     # device float*
 _i = C.c_int
@@ -40,13 +40,32 @@ class NerfRaw(C.Structure):
                                   "lr0_w", "lr0_b", "sigma_w", "sigma_b", "col0_w", "col0_b", "col2_w", "col2_b")]
 
 
+class Options(C.Structure):
+    """``enerf_options_t``: explicit kernel-variant choices, passed per call (all zero = defaults)."""
+    _fields_ = [("conv3d_global_only", _i), ("conv3d_lds_min_voxels", _ll), ("conv3d_pk8", _i),
+                ("featnet_unfused", _i), ("featnet_smooth0_plain", _i), ("render_blocks_per_cu", _i)]
+
+    def __repr__(self):
+        return "Options(" + ", ".join(f"{n}={getattr(self, n)}" for n, _ in self._fields_ if getattr(self, n)) + ")"
+
+
+# what "most frames per second" prefers over "one frame as fast as possible" (enerf_amd/pipeline.py)
+def throughput_options() -> "Options":
+    return Options(conv3d_pk8=2, render_blocks_per_cu=2)
+
+
+def _opt(o):
+    return None if o is None else C.byref(o)
+
+
 class RenderArgs(C.Structure):
     _fields_ = ([(n, _f) for n in ("rays12", "tex", "vol", "src_exts", "src_ixts", "tar_ext", "packed", "rgb",
                                    "depth", "weights")]
                 + [(n, _i) for n in ("B", "N", "S", "n_samples", "depth_inv", "Hr", "Wr", "F", "D", "h", "w",
                                      "white_bkgd")]
                 + [("render_scale", _fl)]
-                + [(n, _f) for n in ("rays8", "depth_map", "std_map", "nf_map")] + [("map_h", _i), ("map_w", _i)])
+                + [(n, _f) for n in ("rays8", "depth_map", "std_map", "nf_map")] + [("map_h", _i), ("map_w", _i)]
+                + [("options", C.POINTER(Options))])
 
 
 _SIGNATURES = {
@@ -58,8 +77,8 @@ _SIGNATURES = {
     "enerf_feature_net_packed_floats": (_ll, []),
     "enerf_feature_net_pack": (_i, [C.POINTER(FeatNetRaw), _f, _f]),
     "enerf_feature_net_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
-    "enerf_feature_net": (_i, [_f, _f, _i, _i, _i, _f, _f, _f, _i, _f, C.c_size_t, _f]),
-    "enerf_feature_net_stage": (_i, [_f, _f, _i, _i, _i, _f, _f, _f, _i, _f, C.c_size_t, _i, _f]),
+    "enerf_feature_net": (_i, [_f, _f, _i, _i, _i, _f, _f, _f, _i, _f, C.c_size_t, C.POINTER(Options), _f]),
+    "enerf_feature_net_stage": (_i, [_f, _f, _i, _i, _i, _f, _f, _f, _i, _f, C.c_size_t, _i, C.POINTER(Options), _f]),
     "enerf_pack_texels_cl": (_i, [_f, _i, _f, _i, _i, _i, _i, _i, _i, _f, _f]),
     "enerf_get_proj_mats": (_i, [_f, _f, _f, _f, _i, _i, _fl, _fl, _f, _f]),
     "enerf_get_depth_values": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f]),
@@ -68,7 +87,7 @@ _SIGNATURES = {
     "enerf_cost_reg_packed_floats": (_ll, [_i, _i]),
     "enerf_cost_reg_pack": (_i, [C.POINTER(CostRegRaw), _f, _f]),
     "enerf_cost_reg_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
-    "enerf_cost_reg": (_i, [_f, _i, _i, _f, _i, _i, _i, _i, _f, _f, _f, C.c_size_t, _f]),
+    "enerf_cost_reg": (_i, [_f, _i, _i, _f, _i, _i, _i, _i, _f, _f, _f, C.c_size_t, C.POINTER(Options), _f]),
     "enerf_depth_regression": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f, _f]),
     "enerf_build_rays": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f]),
     "enerf_nerf_packed_floats": (_ll, [_i]),
@@ -164,20 +183,21 @@ class EnerfLib:
         f2 = torch.empty((n, H, W, l2_stride), dtype=torch.float32, device=dev)
         return f0, f1, f2, workspace
 
-    def feature_net_stage(self, packed, src_inps, bufs, stage, l2_stride=8):
+    def feature_net_stage(self, packed, src_inps, bufs, stage, l2_stride=8, options=None):
         """One stage (FEAT_TRUNK / FEAT_LEVEL1 / FEAT_LEVEL2, or FEAT_ALL) on the current stream."""
         n, _, H, W = src_inps.shape
         f0, f1, f2, workspace = bufs
         self._check(self.dll.enerf_feature_net_stage(_ptr(packed), _ptr(src_inps), n, H, W, _ptr(f0), _ptr(f1),
                                                      _ptr(f2), l2_stride, _ptr(workspace), workspace.numel() * 4,
-                                                     int(stage), self.stream_of(src_inps)), "feature_net_stage")
+                                                     int(stage), _opt(options), self.stream_of(src_inps)),
+                    "feature_net_stage")
 
-    def feature_net(self, packed, src_inps, l2_stride=8, workspace=None):
+    def feature_net(self, packed, src_inps, l2_stride=8, workspace=None, options=None):
         """src_inps (n,3,H,W) -> channels-last (n,H/4,W/4,32), (n,H/2,W/2,16), (n,H,W,l2_stride)."""
         n, _, H, W = src_inps.shape
         f0, f1, f2, workspace = self.feature_net_alloc(src_inps, l2_stride, workspace)
         self._check(self.dll.enerf_feature_net(_ptr(packed), _ptr(src_inps), n, H, W, _ptr(f0), _ptr(f1), _ptr(f2),
-                                               l2_stride, _ptr(workspace), workspace.numel() * 4,
+                                               l2_stride, _ptr(workspace), workspace.numel() * 4, _opt(options),
                                                self.stream_of(src_inps)), "feature_net")
         return f0, f1, f2, workspace
 
@@ -248,7 +268,7 @@ class EnerfLib:
         self._check(self.dll.enerf_cost_reg_pack(C.byref(raw), _ptr(packed), self.stream_of(packed)), "cost_reg_pack")
         return packed
 
-    def cost_reg(self, packed, in_channels, full, vol, workspace=None):
+    def cost_reg(self, packed, in_channels, full, vol, workspace=None, options=None):
         B, D, h, w, _ = vol.shape
         need = self.dll.enerf_cost_reg_workspace_bytes(int(full), B, D, h, w)
         if workspace is None or workspace.numel() * 4 < need:
@@ -256,7 +276,7 @@ class EnerfLib:
         feat = torch.empty((B, D, h, w, 8), dtype=torch.float32, device=vol.device)
         prob = torch.empty((B, D, h, w), dtype=torch.float32, device=vol.device)
         self._check(self.dll.enerf_cost_reg(_ptr(packed), in_channels, int(full), _ptr(vol), B, D, h, w, _ptr(feat),
-                                            _ptr(prob), _ptr(workspace), workspace.numel() * 4,
+                                            _ptr(prob), _ptr(workspace), workspace.numel() * 4, _opt(options),
                                             self.stream_of(vol)), "cost_reg")
         return feat, prob
 
@@ -284,7 +304,7 @@ class EnerfLib:
         return packed
 
     def render_rays(self, rays12, tex, vol, src_exts, src_ixts, tar_ext, packed, *, n_samples, depth_inv, F,
-                    render_scale, white_bkgd=False, maps=None):
+                    render_scale, white_bkgd=False, maps=None, options=None):
         """``rays12`` (B,N,12) from build_rays — or, with ``maps=(depth, std, near_far)`` of the level, the
         8-float rays (B,N,8): build_rays then runs inside the render kernel."""
         B, N = rays12.shape[:2]
@@ -305,7 +325,8 @@ class EnerfLib:
             r12 = None
         a = RenderArgs(r12, _ptr(tex), _ptr(vol), _ptr(src_exts), _ptr(src_ixts), _ptr(tar_ext),
                        _ptr(packed), _ptr(rgb), _ptr(depth), _ptr(weights), B, N, S, n_samples, int(depth_inv), Hr,
-                       Wr, F, D, h, w, int(white_bkgd), float(render_scale), *fused)
+                       Wr, F, D, h, w, int(white_bkgd), float(render_scale), *fused,
+                       None if options is None else C.pointer(options))
         self._check(self.dll.enerf_render_rays(C.byref(a), self.stream_of(rays12)), "render_rays")
         return rgb, depth, weights
 

@@ -24,7 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .config import EnerfConfig
-from .lib import ConvBn, CostRegRaw, EnerfLib, FeatNetRaw, NerfRaw, get_lib
+from .lib import ConvBn, CostRegRaw, EnerfLib, FeatNetRaw, NerfRaw, Options, get_lib
 
 
 # --------------------------------------------------------------------------------------------------
@@ -242,7 +242,8 @@ class Network(nn.Module):
         for i in range(cas.num):
             setattr(self, f"cost_reg_{i}", CostRegParams(int(32 * (2 ** (-i))), full=(i != 0)))   # network.py:15-20
             setattr(self, f"nerf_{i}", NerfParams(cas.nerf_model_feat_ch[i] + 3, self.cfg.viewdir_agg))
-        self._packed: Dict[str, torch.Tensor] = {}
+        self._packed: Dict[str, tuple] = {}           # name -> (packed image, ready event or None, stream id)
+        self.options: Optional[Options] = None        # enerf_options_t for every launch of forward(); None = defaults
         self._tex_cache = None
         self._timer = None                  # optional stage timer (bench.py): .begin()/.mark(name)/.end()
 
@@ -268,21 +269,43 @@ class Network(nn.Module):
         self.invalidate_packed()
         return super().load_state_dict(*a, **k)
 
-    def train(self, mode: bool = True):
-        self.invalidate_packed()
-        return super().train(mode)
+    # train()/eval() do NOT invalidate: the packed images fold the BN *running* statistics whatever the mode, and a
+    # captured HIP graph (enerf_amd/graph.py) or a frame in flight may hold their addresses.
 
     def _packed_weights(self, name: str) -> torch.Tensor:
-        if name not in self._packed:
+        """MFMA operand image of a sub-module, packed lazily by a device kernel on the stream of the first caller.
+        Another stream (FramePipeline, the FeatureNet side stream) waits on the pack's event before reading it."""
+        ent = self._packed.get(name)
+        if ent is None:
             m = getattr(self, name)
             dev = next(m.parameters()).device
             if isinstance(m, CostRegParams):
-                self._packed[name] = self.lib.cost_reg_pack(m.raw(), dev)
+                t = self.lib.cost_reg_pack(m.raw(), dev)
             elif isinstance(m, FeatureNet):
-                self._packed[name] = self.lib.feature_net_pack(m.raw(), dev)
+                t = self.lib.feature_net_pack(m.raw(), dev)
             else:
-                self._packed[name] = self.lib.nerf_pack(m.raw(), m.feat_ch, m.viewdir_agg, dev)
-        return self._packed[name]
+                t = self.lib.nerf_pack(m.raw(), m.feat_ch, m.viewdir_agg, dev)
+            if t.is_cuda:
+                st = torch.cuda.current_stream(dev)
+                ent = (t, st.record_event(), st.cuda_stream)
+            else:
+                ent = (t, None, 0)
+            self._packed[name] = ent
+        t, ev, sid = ent
+        if ev is not None:
+            cur = torch.cuda.current_stream(t.device)
+            if cur.cuda_stream != sid and not ev.query():
+                cur.wait_event(ev)
+        return t
+
+    def prepare(self):
+        """Pack every weight image now, on the current stream (e.g. before opening a FramePipeline or capturing a graph)."""
+        names = ["feature_net"] if self.feature_backend == "hip" else []
+        for i in range(self.cfg.cas.num):
+            names += [f"cost_reg_{i}", f"nerf_{i}"]
+        for n in names:
+            self._packed_weights(n)
+        return self
 
     # -- reference surface -----------------------------------------------------------------------
     def forward_feat(self, x):
@@ -301,7 +324,7 @@ class Network(nn.Module):
     def _feat_ws(self, ws):
         self._feat_ws_by_stream[torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0] = ws
 
-    def _forward_feat_hip(self, x, texel_level2: bool):
+    def _forward_feat_hip(self, x, texel_level2: bool, options=None):
         """HIP FeatureNet: channels-last (B,S,h,w,C) maps tagged ``_enerf_cl``; level_2 optionally comes
         out as ready render texels (tagged ``_enerf_tex``) when it is only used for the full-res render."""
         B, S, C, H, W = x.shape
@@ -312,20 +335,20 @@ class Network(nn.Module):
         if self.overlap and x.is_cuda:
             bufs = lib.feature_net_alloc(src, stride, self._feat_ws)
             f0, f1, f2, self._feat_ws = bufs
-            lib.feature_net_stage(packed, src, bufs, lib.FEAT_TRUNK, stride)          # -> level_0, caller's stream
+            lib.feature_net_stage(packed, src, bufs, lib.FEAT_TRUNK, stride, options)          # -> level_0, caller's stream
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(device=x.device)
             main, side = torch.cuda.current_stream(x.device), self._side_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                lib.feature_net_stage(packed, src, bufs, lib.FEAT_LEVEL1, stride)     # -> level_1
+                lib.feature_net_stage(packed, src, bufs, lib.FEAT_LEVEL1, stride, options)     # -> level_1
                 self._feat_events[1] = side.record_event()
-                lib.feature_net_stage(packed, src, bufs, lib.FEAT_LEVEL2, stride)     # -> level_2 / texels
+                lib.feature_net_stage(packed, src, bufs, lib.FEAT_LEVEL2, stride, options)     # -> level_2 / texels
                 self._feat_events[2] = side.record_event()
             # the buffers were allocated on `main`; every consumer (and so every later reuse by the caching
             # allocator) is ordered after these events through _wait_feat
         else:
-            f0, f1, f2, self._feat_ws = lib.feature_net(packed, src, stride, self._feat_ws)
+            f0, f1, f2, self._feat_ws = lib.feature_net(packed, src, stride, self._feat_ws, options)
         feats = {"level_0": f0.view(B, S, H // 4, W // 4, 32), "level_1": f1.view(B, S, H // 2, W // 2, 16),
                  "level_2": f2.view(B, S, H, W, f2.shape[-1])}
         for k, v in feats.items():
@@ -391,7 +414,8 @@ class Network(nn.Module):
             rays.contiguous(), tex, vol, batch["src_exts"].contiguous(), batch["src_ixts"].contiguous(),
             batch["tar_ext"].contiguous(), self._packed_weights(name), n_samples=cas.num_samples[level],
             depth_inv=cas.depth_inv[level], F=cas.nerf_model_feat_ch[level] + 3,
-            render_scale=cas.render_scale[level], white_bkgd=self.cfg.white_bkgd, maps=maps)
+            render_scale=cas.render_scale[level], white_bkgd=self.cfg.white_bkgd, maps=maps,
+            options=kwargs.get("_options", self.options))
         self._mark(f"render_{level}")
         return {"rgb": rgb, "depth": depth, "weights": weights}
 
@@ -405,6 +429,9 @@ class Network(nn.Module):
 
     def forward(self, batch):
         """network.py:76-113 / network_human.py:69-119."""
+        return self._forward(batch, self.options)
+
+    def _forward(self, batch, options):
         if self.training:
             raise NotImplementedError("enerf_amd.Network: the HIP path is inference-only for now "
                                       "(training backward is SURVEY.md §8f row 1); call .eval()")
@@ -420,8 +447,8 @@ class Network(nn.Module):
                 # level_2 is only ever the im_feat of a full-resolution render: emit it as texels directly
                 uses = [i for i in range(cas.num) if cas.render_if[i] and cas.render_im_feat_level[i] == 2]
                 tex2 = bool(uses) and all(cas.render_scale[i] == 1.0 and cas.im_ibr_scale[i] == 1.0 for i in uses) \
-                    and all(cas.nerf_model_feat_ch[i] == 8 for i in uses)
-                feats = self._forward_feat_hip(src, tex2)
+                    and all(cas.nerf_model_feat_ch[i] == 8 for i in uses) and cas.num <= 2   # level_2 never feeds a cost volume
+                feats = self._forward_feat_hip(src, tex2, options)
             else:
                 feats = self.forward_feat(src)
             self._mark("feature_net")
@@ -453,7 +480,7 @@ class Network(nn.Module):
                 self._mark(f"volume_{i}")
                 name = f"cost_reg_{i}"
                 m = getattr(self, name)
-                feat3d, prob = lib.cost_reg(self._packed_weights(name), m.in_channels, m.full, vol)
+                feat3d, prob = lib.cost_reg(self._packed_weights(name), m.in_channels, m.full, vol, options=options)
                 feat3d._enerf_channels_last = True      # (B,D,h,w,8); render_rays also accepts (B,8,D,h,w)
                 self._mark(f"cost_reg_{i}")
                 depth, std = lib.depth_regression(prob, dv, cas.depth_inv[i])
@@ -476,7 +503,7 @@ class Network(nn.Module):
                     rays = rays[mask][None]
                 ret_i = self.batchify_rays(rays=rays, feature_volume=feat3d, batch=batch,
                                            im_feat=feats[f"level_{cas.render_im_feat_level[i]}"],
-                                           nerf_model=getattr(self, f"nerf_{i}"), level=i, **extra)
+                                           nerf_model=getattr(self, f"nerf_{i}"), level=i, _options=options, **extra)
                 if masked:
                     rgb = torch.zeros((1, mask.shape[1], 3), dtype=torch.float32, device=src.device)
                     if int(mask.sum()) > 1:

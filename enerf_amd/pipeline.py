@@ -14,50 +14,55 @@ Buffers: each frame allocates from its own stream's pool of torch's caching allo
 FeatureNet workspace per stream.  A submitted batch must stay alive and unmodified until its event has fired."""
 from __future__ import annotations
 
-import os
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
+
+from .lib import Options, throughput_options
 
 # Kernel-variant choices that differ between "one frame as fast as possible" and "most frames per second": with
 # several frames in flight the matrix pipes are shared, so variants that issue fewer MFMAs win even where they are
 # slower in isolation (measured on MI355X, 6 frames in flight: 1216 -> 1234 -> 1244 frames/s; one frame at a time the
-# same switches cost 2 %).  The library reads these per launch; they are set only while a pipeline is open and only
-# if the user has not set them.  Results change at the 1e-6 level (different summation order), not bit for bit.
-THROUGHPUT_KNOBS = {"ENERF_CONV_PK8": "2",       # tap-packed conv3d for every Cout=8(+1) layer, not just where it is faster alone
-                    "ENERF_RENDER_OCC": "2"}     # render kernel at 2 blocks/CU (no spills) instead of 3
+# same switches cost 2 %).  They are an explicit ``enerf_options_t`` (lib.throughput_options(): tap-packed conv3d for
+# every Cout=8 layer, render kernel at 2 blocks/CU) handed to every launch of the frames submitted HERE — nothing
+# process-global is touched, other users of the same Network keep its own ``net.options``.  Results change at the
+# 1e-6 level (different summation order), not bit for bit.
 
 
 class FramePipeline:
-    def __init__(self, net, depth: int = 2, throughput_tuning: bool = False):
+    def __init__(self, net, depth: int = 2, throughput_tuning: bool = False, options: Optional[Options] = None):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         if getattr(net, "overlap", False):
             raise RuntimeError("FramePipeline: use overlap=False (each frame already owns a stream)")
         self.net = net
+        self.options = options if options is not None else (throughput_options() if throughput_tuning else net.options)
+        # weight images are packed lazily by device kernels: do it now on the caller's stream, then let every pipeline
+        # stream start after it (a cold pipeline would otherwise pack on streams[0] while streams[1] reads)
+        net.prepare()
         self.streams = [torch.cuda.Stream() for _ in range(depth)]
+        cur = torch.cuda.current_stream()
+        for s in self.streams:
+            s.wait_stream(cur)
         self._i = 0
-        self._restore = {}
-        if throughput_tuning:
-            for k, v in THROUGHPUT_KNOBS.items():
-                if k not in os.environ:
-                    self._restore[k] = None
-                    os.environ[k] = v
 
     def close(self):
-        """Wait for everything submitted and undo the throughput knobs."""
+        """Wait for everything submitted."""
         self.join()
-        for k in self._restore:
-            os.environ.pop(k, None)
-        self._restore = {}
 
     def submit(self, batch: Dict[str, torch.Tensor]) -> Tuple[Dict[str, torch.Tensor], torch.cuda.Event]:
+        """Outputs are allocated from the pipeline stream's pool; they are marked as used by the caller's current
+        stream (``record_stream``), so consuming them there after ``wait_event(done)`` and dropping them is safe.
+        A consumer on yet another stream must call ``record_stream`` itself."""
+        cur = torch.cuda.current_stream()
         s = self.streams[self._i % len(self.streams)]
         self._i += 1
-        s.wait_stream(torch.cuda.current_stream())       # inputs produced on the caller's stream
+        s.wait_stream(cur)                               # inputs produced on the caller's stream
         with torch.cuda.stream(s):
-            out = self.net(batch)
+            out = self.net._forward(batch, self.options)
             done = s.record_event()
+        for v in out.values():
+            v.record_stream(cur)
         return out, done
 
     def join(self):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ENERF_ABI_VERSION 2
+#define ENERF_ABI_VERSION 3
 #define ENERF_OK 0
 #define ENERF_EINVAL (-1)   /* bad argument / unsupported shape */
 #define ENERF_ELAUNCH (-2)  /* HIP launch error */
@@ -32,6 +32,20 @@ typedef void* enerf_stream_t; /* hipStream_t */
 
 int enerf_abi_version(void);
 const char* enerf_last_error(void);
+
+/* ---- kernel-variant choices, passed EXPLICITLY per call (ABI >= 3; no environment variables are read).
+ * Every entry point that has more than one kernel variant takes a `const enerf_options_t*`; NULL (or a
+ * zero-filled struct) selects the defaults, which are the single-frame-latency choices measured on MI355X.
+ * Results of different variants agree to fp32 re-association (<= 2e-5 relative), not bit for bit. */
+typedef struct {
+    int conv3d_global_only;          /* 1: every 3-D conv through the global-load kernel (A/B, tests); 0: auto */
+    long long conv3d_lds_min_voxels; /* smallest layer (output voxels) routed to the LDS-staged kernels; 0 = 16384 */
+    int conv3d_pk8;                  /* tap-packed Cout=8 kernel: 0 = where it is faster alone (Cin=16, big heads),
+                                        1 = never, 2 = every Cout=8(+1) layer (fewest MFMAs: throughput mode) */
+    int featnet_unfused;             /* 1: one launch per FeatureNet layer (no conv0/toplayer/lat0 fusions) */
+    int featnet_smooth0_plain;       /* 1: plain 8x32 tiling in the fused smooth0 kernel instead of tap packing */
+    int render_blocks_per_cu;        /* 0 = auto (3); 2 or 3 resident 256-thread blocks per CU in k_render_rays */
+} enerf_options_t;
 
 /* ---- layout adapters at the PyTorch boundary (FeatureNet output is NCHW, network.py:58-67) ---- */
 /* (n, C, P) -> (n, P, Cpad), pad channels zero-filled;  and back (drops the padding). */
@@ -73,7 +87,7 @@ int enerf_feature_net_pack(const enerf_featnet_raw_t* raw, float* packed, enerf_
 size_t enerf_feature_net_workspace_bytes(int n_img, int H, int W);
 int enerf_feature_net(const float* packed, const float* src_inps, int n_img, int H, int W, float* feat_l0,
                       float* feat_l1, float* feat_l2, int l2_stride, void* workspace, size_t workspace_bytes,
-                      enerf_stream_t stream);
+                      const enerf_options_t* options, enerf_stream_t stream);
 /* The same network in three independently enqueueable stages, so a host can overlap the level-0 cost volume
  * (which needs feat_l0 only) with the rest of the FPN on a second stream:
  *   ENERF_FEAT_TRUNK  conv0.0 .. conv2.1, toplayer  -> feat_l0           (feature_net.py:27-31)
@@ -84,7 +98,7 @@ int enerf_feature_net(const float* packed, const float* src_inps, int n_img, int
 enum { ENERF_FEAT_ALL = 0, ENERF_FEAT_TRUNK = 1, ENERF_FEAT_LEVEL1 = 2, ENERF_FEAT_LEVEL2 = 3 };
 int enerf_feature_net_stage(const float* packed, const float* src_inps, int n_img, int H, int W, float* feat_l0,
                             float* feat_l1, float* feat_l2, int l2_stride, void* workspace, size_t workspace_bytes,
-                            int stage, enerf_stream_t stream);
+                            int stage, const enerf_options_t* options, enerf_stream_t stream);
 /* texels from channels-last features already at the render resolution (level-0 rendering with the HIP
  * FeatureNet): out (n_img,Hr,Wr,tex) = [feat (C) | bilinear_ac(src*0.5+0.5) (3) | 0]. */
 int enerf_pack_texels_cl(const float* feat_cl, int C, const float* src_inps, int H, int W, int Hr, int Wr, int tex,
@@ -125,7 +139,8 @@ int enerf_cost_reg_pack(const enerf_costreg_raw_t* raw, float* packed, enerf_str
 size_t enerf_cost_reg_workspace_bytes(int full, int B, int D, int h, int w);
 /* vol (B,D,h,w,in_channels) -> feat (B,D,h,w,8), prob (B,D,h,w).  D,h,w divisible by 4 (8 if full). */
 int enerf_cost_reg(const float* packed, int in_channels, int full, const float* vol, int B, int D, int h, int w,
-                   float* feat, float* prob, void* workspace, size_t workspace_bytes, enerf_stream_t stream);
+                   float* feat, float* prob, void* workspace, size_t workspace_bytes, const enerf_options_t* options,
+                   enerf_stream_t stream);
 
 /* ---- depth_regression (utils.py:658-667) ---- */
 int enerf_depth_regression(const float* prob, const float* depth_values, int B, int D, int h, int w, int depth_inv,
@@ -172,6 +187,7 @@ typedef struct {
     const float* rays8;
     const float *depth_map, *std_map, *nf_map;
     int map_h, map_w;
+    const enerf_options_t* options; /* NULL = defaults (ABI >= 3) */
 } enerf_render_args_t;
 int enerf_render_rays(const enerf_render_args_t* args, enerf_stream_t stream);
 

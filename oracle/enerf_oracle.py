@@ -11,7 +11,7 @@ build container, runs them on seeded inputs and commits the tensors under ``test
 agree bit-for-bit on the same torch build because the same torch primitives are applied in the same
 order).  The third-party arithmetic at the boundary is torch's (``F.grid_sample``,
 ``F.interpolate``, ``conv3d``, ``softmax``, ``softplus``, ``var``, ``cumprod``, ``inverse``); their
-tap/weight semantics are restated explicitly in ``oracle/primitives.py`` and checked against torch.
+tap/weight semantics are restated explicitly in ``enerf_amd/csrc/common.h`` and checked against torch.
 
 Every function cites the reference lines it follows (paths relative to /root/reference).
 All weights come from a reference ``state_dict`` (names: SURVEY.md §8b).

@@ -28,18 +28,34 @@ def test_hip_library_builds_and_exports_all_symbols():
     assert set(_declared()) <= exported, set(_declared()) - exported
     lib = EnerfLib(LIB_PATH)                              # dlopen + ABI version; no compute calls here
     from enerf_amd.lib import ABI_VERSION
-    assert lib.dll.enerf_abi_version() == ABI_VERSION == 2
+    assert lib.dll.enerf_abi_version() == ABI_VERSION == 3
     assert lib.dll.enerf_nerf_packed_floats(11) > 0 and lib.dll.enerf_cost_reg_packed_floats(16, 1) > 0
 
 
-def test_gfx950_code_object_contains_mfma():
-    """The product kernels really are CDNA4 matrix-core code (not a generic fallback)."""
+def test_gfx950_code_object_contains_mfma(tmp_path):
+    """The product kernels really are CDNA4 matrix-core code (not a generic fallback): unbundle the gfx950 code
+    objects into a temp dir, disassemble, and count the fp32 MFMA instruction the kernels are written around."""
+    import shutil
     from enerf_amd.lib import LIB_PATH
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not os.path.exists(objdump) or not os.path.exists(LIB_PATH):
         pytest.skip("llvm-objdump or library not available")
-    out = subprocess.run([objdump, "--offloading", LIB_PATH], capture_output=True, text=True).stdout
+    lib = shutil.copy(LIB_PATH, tmp_path / "lib.so")          # --offloading extracts next to its input
+    out = subprocess.run([objdump, "--offloading", str(lib)], capture_output=True, text=True, cwd=tmp_path).stdout
     assert "gfx950" in out
+    cos = sorted(p for p in os.listdir(tmp_path) if "gfx950" in p)
+    assert cos, "no gfx950 code object in the library"
+    n_mfma, other = 0, set()
+    for co in cos:
+        dis = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(tmp_path / co)], capture_output=True, text=True).stdout
+        for m in re.findall(r"\bv_mfma_[a-z0-9_]+", dis):
+            if m == "v_mfma_f32_16x16x4_f32":
+                n_mfma += 1
+            else:
+                other.add(m)
+    assert n_mfma > 5000, n_mfma                             # render + conv2d + conv3d kernels (17 k in round 1)
+    assert not other, other                                  # exact-fp32 path: no reduced-precision MFMA shapes
+    assert not [p for p in os.listdir(os.path.dirname(LIB_PATH)) if "hipv4" in p], "code objects leaked into the package"
 
 
 def test_missing_library_fails_loudly(tmp_path):

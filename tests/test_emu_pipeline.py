@@ -144,28 +144,29 @@ def test_empty_ray_list():
     assert out["rgb"].shape == (1, 0, 3) and out["weights"].shape == (1, 0, 2)
 
 
-@pytest.mark.parametrize("force", ["v1", "v2", "pk8", "ws", "ws4"])
-def test_conv3d_variants_agree_with_reference(force, monkeypatch):
-    """Both conv3d code paths (global-load V1 incl. the row-split small-layer form, LDS-staged V2) on a
-    case whose volumes are not multiples of the 8x16 LDS box (h,w = 16,24 / 8,12 / 4,6)."""
+@pytest.mark.parametrize("force", ["v1", "v2", "pk8"])
+def test_conv3d_variants_agree_with_reference(force):
+    """Both conv3d code paths (global-load V1 incl. the row-split small-layer form, LDS-staged V2, tap-packed) on a
+    case whose volumes are not multiples of the 8x16 LDS box (h,w = 16,24 / 8,12 / 4,6); variants are chosen through
+    the explicit enerf_options_t, not the environment."""
+    from enerf_amd.lib import Options
     if force == "v1":
-        monkeypatch.setenv("ENERF_CONV_V1", "1")
+        opt = Options(conv3d_global_only=1)
     else:
-        monkeypatch.setenv("ENERF_CONV_V2_MIN_VOX", "0")
-        monkeypatch.setenv("ENERF_CONV_PK8", "2" if force == "pk8" else "0")   # tap-packed Cout=8 kernel: all layers / off
-        if force.startswith("ws"):                                              # persistent producer/consumer kernel
-            monkeypatch.setenv("ENERF_CONV_WS", "1")
-            monkeypatch.setenv("ENERF_CONV_WS_BD", "4" if force == "ws4" else "2")
-            monkeypatch.setenv("ENERF_CONV_WS_BLOCKS", "3")                     # several boxes per persistent block
+        opt = Options(conv3d_lds_min_voxels=1, conv3d_pk8=2 if force == "pk8" else 1)   # tap-packed kernel: all layers / off
     name = "small_s3_eval"
     cfg, batch, gold = case_config(name), case_batch(name), load_golden(name)
-    out = _net(cfg)(batch)
+    net = _net(cfg)
+    net.options = opt
+    out = net(batch)
     for k, v in out.items():
         _close(v.numpy(), gold["out/" + k], 2e-5, k)
     # and the level-0 network (MinCostRegNet, Cin=32: two LDS channel passes)
     name = "tiny_s3"
     cfg, batch, gold = case_config(name), case_batch(name), load_golden(name)
-    out = _net(cfg)(batch)
+    net = _net(cfg)
+    net.options = opt
+    out = net(batch)
     for k, v in out.items():
         _close(v.numpy(), gold["out/" + k], 2e-5, k)
 
@@ -187,26 +188,27 @@ def test_fused_build_rays_equals_separate_launch():
                         render_scale=1.0)
 
 
-@pytest.mark.parametrize("smooth0_pk", ["1", "0"])
-def test_hip_feature_net_matches_reference_feature_maps(smooth0_pk, monkeypatch):
+@pytest.mark.parametrize("smooth0_plain", [0, 1])
+def test_hip_feature_net_matches_reference_feature_maps(smooth0_plain):
     """enerf_feature_net (conv2d.hip) against the reference FeatureNet's three outputs, plain and texel mode;
     with the tap-packed (8x28 tiles) and the plain (8x32) fused smooth0 kernel."""
-    monkeypatch.setenv("ENERF_SMOOTH0_PK", smooth0_pk)
+    from enerf_amd.lib import Options
+    opt = Options(featnet_smooth0_plain=smooth0_plain)
     name = "tiny_s3"
     cfg, batch, g = case_config(name), case_batch(name), load_golden(name)
     net, lib = _net(cfg), emu_lib()
     src = batch["src_inps"][0].contiguous()
-    f0, f1, f2, _ = lib.feature_net(net._packed_weights("feature_net"), src, 8)
+    f0, f1, f2, _ = lib.feature_net(net._packed_weights("feature_net"), src, 8, options=opt)
     for a, k in ((f0, "feat_l0"), (f1, "feat_l1"), (f2, "feat_l2")):
         _close(a.permute(0, 3, 1, 2).numpy(), g["mid/" + k], 5e-6, k)
-    _, _, t2, _ = lib.feature_net(net._packed_weights("feature_net"), src, 12)
+    _, _, t2, _ = lib.feature_net(net._packed_weights("feature_net"), src, 12, options=opt)
     assert torch.equal(t2[..., :8], f2)
     _close(t2[..., 8:11].permute(0, 3, 1, 2).numpy(), (src * 0.5 + 0.5).numpy(), 1e-7, "texel rgb")
     assert float(t2[..., 11].abs().max()) == 0.0
     # the three-stage form the two-stream host path uses (enerf_feature_net_stage) produces the same maps
     bufs = lib.feature_net_alloc(src, 12)
     for stage in (lib.FEAT_TRUNK, lib.FEAT_LEVEL1, lib.FEAT_LEVEL2):
-        lib.feature_net_stage(net._packed_weights("feature_net"), src, bufs, stage, 12)
+        lib.feature_net_stage(net._packed_weights("feature_net"), src, bufs, stage, 12, opt)
     assert torch.equal(bufs[0], f0) and torch.equal(bufs[1], f1) and torch.equal(bufs[2], t2)
     with pytest.raises(Exception):
         lib.feature_net_stage(net._packed_weights("feature_net"), src, bufs, 7, 12)
@@ -224,13 +226,13 @@ def test_torch_feature_backend_still_matches(name):
 
 
 
-def test_unfused_lat0_smooth0_path(monkeypatch):
-    """ENERF_FUSE_LAT0=0 keeps the separate lat0 / smooth0 launches (A/B switch) — same features."""
-    monkeypatch.setenv("ENERF_FUSE_LAT0", "0")
-    monkeypatch.setenv("ENERF_FUSE_CONV0", "0")        # and the separate conv0.0 / conv0.1 launches
-    monkeypatch.setenv("ENERF_FUSE_TOP", "0")          # and toplayer as its own launch
+def test_unfused_lat0_smooth0_path():
+    """enerf_options_t.featnet_unfused keeps one launch per FeatureNet layer (separate conv0.0 / conv0.1, toplayer,
+    lat0 / smooth0) — same features."""
+    from enerf_amd.lib import Options
     name = "tiny_s3"
     cfg, batch, g = case_config(name), case_batch(name), load_golden(name)
     net, lib = _net(cfg), emu_lib()
-    _, _, f2, _ = lib.feature_net(net._packed_weights("feature_net"), batch["src_inps"][0].contiguous(), 8)
+    _, _, f2, _ = lib.feature_net(net._packed_weights("feature_net"), batch["src_inps"][0].contiguous(), 8,
+                                  options=Options(featnet_unfused=1))
     _close(f2.permute(0, 3, 1, 2).numpy(), g["mid/feat_l2"], 5e-6, "feat_l2 unfused")

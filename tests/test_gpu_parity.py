@@ -13,12 +13,12 @@ from enerf_amd.synth import make_batch
 from oracle import enerf_oracle as O
 from golden_cases import CASES, case_batch, case_config, load_golden, load_weights
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU (run with -m gpu on the MI355X box)")]
 REL_TOL = 1e-4
 
 
 def _dev():
-    assert torch.cuda.is_available(), "gpu tests need a GPU"
     return torch.device("cuda:0")
 
 
@@ -214,8 +214,7 @@ def test_frame_pipeline_two_streams_matches_sequential():
     for (o, _), r in zip(outs, ref):
         for k in r:
             assert _rel(o[k].cpu(), r[k].cpu()) < 2e-5, (k, _rel(o[k].cpu(), r[k].cpu()))
-    import os
-    assert "ENERF_CONV_PK8" not in os.environ
+    assert net.options is None                       # the pipeline's choices never leak into the network
 
 
 def test_lego_shape_800x800_4views():

@@ -50,13 +50,18 @@ def test_io_rows_emulated():
     _check(emu_lib(), torch.device("cpu"))
 
 
+_needs_gpu = pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+
+
 @pytest.mark.gpu
+@_needs_gpu
 def test_io_rows_gpu():
     from enerf_amd.lib import get_lib
     _check(get_lib(), torch.device("cuda:0"))
 
 
 @pytest.mark.gpu
+@_needs_gpu
 def test_device_rays_render_identically():
     """A frame rendered from device-generated rays equals the frame rendered from the host-built rays."""
     from enerf_amd.lib import get_lib
