@@ -35,6 +35,14 @@ CASES = {
                          human=True, inter="none"),
     "small_s3_eval": dict(H=64, W=96, S=3, planes=(16, 8), render_if=(False, True), seed=4, textured=True,
                           human=False, inter="maps"),
+    # BASELINE config 3 at reduced size: the reference's own lego.yaml (S=4, render_if True,True, planes 64,8), lego
+    # pinhole intrinsics and near_far [2.5, 5.5] (enerf_amd.synth.make_lego_batch)
+    "lego_small": dict(H=64, W=64, S=4, planes=(64, 8), render_if=(True, True), seed=5, human=False, inter="maps",
+                       rig="lego", cfg_file="configs/enerf/nerf/lego.yaml"),
+    # BASELINE config 4 at reduced size: zjumocap_eval.yaml (network_human, planes 32,8, render_if False,True) with
+    # 4 source views and the projected-bbox mask_at_box (enerf_amd.synth.make_zju_batch)
+    "zju_small": dict(H=64, W=64, S=4, planes=(32, 8), render_if=(False, True), seed=6, human=True, inter="maps",
+                      rig="zju", cfg_file="configs/enerf/zjumocap_eval.yaml"),
 }
 
 
@@ -57,12 +65,18 @@ def seeded_state_dict(net) -> dict:
 def run_case(name: str) -> None:
     from oracle.ref_loader import load_reference
     from enerf_amd.config import EnerfConfig
-    from enerf_amd.synth import make_batch
+    from enerf_amd.synth import make_batch, make_lego_batch, make_zju_batch
 
     c = CASES[name]
-    opts = ["enerf.cas_config.volume_planes", ",".join(map(str, c["planes"])),
-            "enerf.cas_config.render_if", ",".join(map(str, c["render_if"]))]
-    cfg, ref_network = load_reference("configs/enerf/dtu_pretrain.yaml", opts)
+    if "cfg_file" in c:                            # the reference's own yaml for that dataset, no overrides
+        cfg, ref_network = load_reference(c["cfg_file"], [])
+        assert tuple(cfg.enerf.cas_config.volume_planes) == c["planes"]
+        assert tuple(cfg.enerf.cas_config.render_if) == c["render_if"]
+        assert cfg.network_module.endswith("network_human") == c["human"]
+    else:
+        opts = ["enerf.cas_config.volume_planes", ",".join(map(str, c["planes"])),
+                "enerf.cas_config.render_if", ",".join(map(str, c["render_if"]))]
+        cfg, ref_network = load_reference("configs/enerf/dtu_pretrain.yaml", opts)
     if c["human"]:
         from lib.networks.enerf import network_human as ref_network  # noqa: F811
     from lib.networks.enerf import utils as ref_utils
@@ -81,8 +95,13 @@ def run_case(name: str) -> None:
         np.savez_compressed(wpath, **wnp)
 
     ecfg = EnerfConfig.from_yacs(cfg)
-    batch_np = make_batch(c["H"], c["W"], c["S"], ecfg, seed=c["seed"], textured=c["textured"],
-                          mask_box=c["human"])
+    if c.get("rig") == "lego":
+        batch_np = make_lego_batch(c["H"], c["W"], c["S"], ecfg, seed=c["seed"])
+    elif c.get("rig") == "zju":
+        batch_np = make_zju_batch(c["H"], c["W"], c["S"], ecfg, seed=c["seed"])
+    else:
+        batch_np = make_batch(c["H"], c["W"], c["S"], ecfg, seed=c["seed"], textured=c["textured"],
+                              mask_box=c["human"])
     batch = {k: torch.from_numpy(v) for k, v in batch_np.items()}
 
     # record stage boundaries by wrapping the reference's own functions (no reference code is edited)

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from enerf_amd.config import EnerfConfig
-from enerf_amd.synth import make_batch
+from enerf_amd.synth import make_batch, make_lego_batch, make_zju_batch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -17,6 +17,8 @@ CASES = {
     "tiny_s2": dict(H=32, W=64, S=2, planes=(8, 8), render_if=(True, True), seed=2, textured=True, human=False),
     "tiny_s4_mask": dict(H=32, W=64, S=4, planes=(8, 8), render_if=(False, True), seed=3, textured=True, human=True),
     "small_s3_eval": dict(H=64, W=96, S=3, planes=(16, 8), render_if=(False, True), seed=4, textured=True, human=False),
+    "lego_small": dict(H=64, W=64, S=4, planes=(64, 8), render_if=(True, True), seed=5, human=False, rig="lego"),
+    "zju_small": dict(H=64, W=64, S=4, planes=(32, 8), render_if=(False, True), seed=6, human=True, rig="zju"),
 }
 
 
@@ -27,8 +29,13 @@ def case_config(name: str) -> EnerfConfig:
 
 def case_batch(name: str, as_torch: bool = True) -> dict:
     c = CASES[name]
-    b = make_batch(c["H"], c["W"], c["S"], case_config(name), seed=c["seed"], textured=c["textured"],
-                   mask_box=c["human"])
+    if c.get("rig") == "lego":
+        b = make_lego_batch(c["H"], c["W"], c["S"], case_config(name), seed=c["seed"])
+    elif c.get("rig") == "zju":
+        b = make_zju_batch(c["H"], c["W"], c["S"], case_config(name), seed=c["seed"])
+    else:
+        b = make_batch(c["H"], c["W"], c["S"], case_config(name), seed=c["seed"], textured=c["textured"],
+                       mask_box=c["human"])
     return {k: torch.from_numpy(v) for k, v in b.items()} if as_torch else b
 
 
