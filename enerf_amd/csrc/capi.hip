@@ -25,8 +25,9 @@ int device_cu_count() {
 }
 }  // namespace enerf
 
-namespace {
-thread_local char g_err[512] = "";
+namespace enerf {
+static thread_local char g_err[512] = "";
+const char* last_error() { return g_err; }
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -39,8 +40,8 @@ int check_launch(const char* what) {
     if (e != hipSuccess) return fail(ENERF_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
     return ENERF_OK;
 }
-#define REQUIRE(cond, ...) \
-    do { if (!(cond)) return fail(ENERF_EINVAL, __VA_ARGS__); } while (0)
+}  // namespace enerf
+namespace {
 
 // ---- cost-reg layer table ------------------------------------------------------------------------
 struct LayerSpec { int idx, cin, cout, kind, relu, bn; };
@@ -71,7 +72,7 @@ long long layer_floats(const LayerSpec& s) {
 extern "C" {
 
 int enerf_abi_version(void) { return ENERF_ABI_VERSION; }
-const char* enerf_last_error(void) { return g_err; }
+const char* enerf_last_error(void) { return last_error(); }
 
 int enerf_channels_last(const float* src, float* dst, int n, int C, long long P, int Cpad, enerf_stream_t stream) {
     REQUIRE(src && dst && n > 0 && C > 0 && P > 0 && Cpad >= C, "channels_last: bad arguments");
@@ -224,7 +225,7 @@ int enerf_cost_reg(const float* packed, int in_channels, int full, const float* 
 int enerf_depth_regression(const float* prob, const float* depth_values, int B, int D, int h, int w, int depth_inv,
                            float* depth, float* std, enerf_stream_t stream) {
     REQUIRE(prob && depth_values && depth && std && B > 0 && D > 0 && h > 0 && w > 0, "depth_regression: bad arguments");
-    launch_depth_regression(prob, depth_values, B, D, h, w, depth_inv, depth, std, (hipStream_t)stream);
+    launch_depth_regression(prob, depth_values, B, D, h, w, depth_inv, depth, std, nullptr, (hipStream_t)stream);
     return check_launch("depth_regression");
 }
 int enerf_build_rays(const float* rays8, const float* depth, const float* std, const float* near_far, int B, int N,
@@ -256,6 +257,7 @@ int enerf_render_rays(const enerf_render_args_t* a, enerf_stream_t stream) {
         REQUIRE(a->depth_map && a->std_map && a->nf_map && a->map_h > 0 && a->map_w > 0,
                 "render_rays: fused build_rays needs depth/std/near_far maps and their size");
     REQUIRE(a->B > 0 && a->N >= 0 && a->Hr > 1 && a->Wr > 1 && a->D > 0 && a->h > 0 && a->w > 0, "render_rays: bad shape");
+    if (a->ray_index) REQUIRE(a->ray_count && a->B == 1, "render_rays: ray_index needs ray_count and B == 1");
     if (a->N == 0) return ENERF_OK;
     int rc = launch_render_rays(*a, (hipStream_t)stream);
     if (rc != 0)

@@ -1,0 +1,346 @@
+// frame.hip — the whole-frame driver enerf_forward (Network.forward, network.py:76-113 / network_human.py:69-119) and
+// the device-side mask_at_box compaction (network_human.py:90-93).  The cascade loop the reference runs in Python is a
+// plan (buffer carving) + ~25 kernel enqueues here, in one C call, on one stream, with no host synchronisation.
+#include <string.h>
+
+#include "kernels.h"
+
+using namespace enerf;
+
+namespace enerf {
+
+// =====================================================================================================================
+// mask_at_box -> ascending list of selected ray positions (rays[mask_at_box], network_human.py:93).  Three tiny launches:
+// per-block counts (1024 elements a block), an exclusive scan of the block counts by one block (also the total),
+// and the scatter, which redoes the in-block scan in LDS.  Stable order, so the compacted depth/weights rows match the
+// reference's boolean-mask indexing.  HBM-bound byte work: n bytes in, 4*count bytes out.
+// =====================================================================================================================
+constexpr int kMaskPerThread = 4;
+constexpr int kMaskPerBlock = 256 * kMaskPerThread;
+
+__device__ __forceinline__ bool mask_set(const unsigned char* m, int eb, long long i, long long n) {
+    if (i >= n) return false;
+    if (eb == 1) return m[i] != 0;
+    const unsigned char* p = m + i * eb;
+    unsigned v = 0;
+    for (int k = 0; k < eb; ++k) v |= p[k];
+    return v != 0;
+}
+// in-block exclusive scan of one int per thread (256 threads); returns the block total through `total`
+__device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int& total) {
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int add = t >= off ? sh[t - off] : 0;
+        __syncthreads();
+        sh[t] += add;
+        __syncthreads();
+    }
+    total = sh[255];
+    const int excl = sh[t] - v;
+    __syncthreads();
+    return excl;
+}
+__global__ __launch_bounds__(256) void k_mask_count(const unsigned char* __restrict__ mask, int eb, long long n,
+                                                    int* __restrict__ block_counts) {
+    __shared__ int sh[256];
+    const long long base = (long long)blockIdx.x * kMaskPerBlock + (long long)threadIdx.x * kMaskPerThread;
+    int c = 0;
+    for (int k = 0; k < kMaskPerThread; ++k) c += mask_set(mask, eb, base + k, n) ? 1 : 0;
+    int total;
+    block_exclusive_scan(c, sh, total);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void k_mask_scan(const int* __restrict__ block_counts, int nblocks,
+                                                   int* __restrict__ block_offsets, int* __restrict__ count) {
+    __shared__ int sh[256];
+    int carry = 0;
+    for (int base = 0; base < nblocks; base += 256) {
+        const int i = base + (int)threadIdx.x;
+        const int v = i < nblocks ? block_counts[i] : 0;
+        int total;
+        const int excl = block_exclusive_scan(v, sh, total);
+        if (i < nblocks) block_offsets[i] = carry + excl;
+        carry += total;
+    }
+    if (threadIdx.x == 0) count[0] = carry;
+}
+__global__ __launch_bounds__(256) void k_mask_scatter(const unsigned char* __restrict__ mask, int eb, long long n,
+                                                      const int* __restrict__ block_offsets, int* __restrict__ index) {
+    __shared__ int sh[256];
+    const long long base = (long long)blockIdx.x * kMaskPerBlock + (long long)threadIdx.x * kMaskPerThread;
+    bool f[kMaskPerThread];
+    int c = 0;
+    for (int k = 0; k < kMaskPerThread; ++k) { f[k] = mask_set(mask, eb, base + k, n); c += f[k] ? 1 : 0; }
+    int total;
+    int o = block_offsets[blockIdx.x] + block_exclusive_scan(c, sh, total);
+    for (int k = 0; k < kMaskPerThread; ++k)
+        if (f[k]) index[o++] = (int)(base + k);
+}
+size_t mask_compact_workspace_bytes(long long n) { return (size_t)(2 * cdivl(n > 0 ? n : 1, kMaskPerBlock)) * sizeof(int); }
+void launch_mask_compact(const void* mask, int elem_bytes, long long n, int* index, int* count, void* workspace,
+                         hipStream_t st) {
+    const int nb = (int)cdivl(n, kMaskPerBlock);
+    int* counts = (int*)workspace;
+    int* offsets = counts + nb;
+    const unsigned char* m = (const unsigned char*)mask;
+    ENERF_LAUNCH(k_mask_count, (unsigned)nb, 256, 0, st, m, elem_bytes, n, counts);
+    ENERF_LAUNCH(k_mask_scan, 1u, 256, 0, st, counts, nb, offsets, count);
+    ENERF_LAUNCH(k_mask_scatter, (unsigned)nb, 256, 0, st, m, elem_bytes, n, offsets, index);
+}
+
+// =====================================================================================================================
+// Frame plan: shapes of every level and the carving of the caller's workspace.
+// =====================================================================================================================
+namespace {
+struct LevelPlan {
+    int D, h, w, C, Hs, Ws;            // volume extent; cost-volume feature channels and source-map size
+    int Hr, Wr, render, masked, F, Ns; // render extent, flags, nerf feature width (C_f + 3), samples per ray
+    long long n_rays;
+    // workspace offsets (floats)
+    size_t proj, dv, nf, vol, feat3d, prob, depth, std, dmvs, tex, rays;
+};
+struct FramePlan {
+    int tex2, hip_feats;
+    size_t f[3], featnet_ws, featnet_ws_bytes, costreg_ws, costreg_ws_bytes;
+    size_t ray_index, ray_count, mask_ws;          // float-sized slots
+    LevelPlan L[ENERF_MAX_LEVELS];
+    size_t total_floats;
+};
+inline int scaled(int n, double s) { return (int)((double)n * s); }      // python: int(H * scale)
+
+int make_plan(const enerf_frame_args_t* a, FramePlan* P) {
+    REQUIRE(a, "forward: null args");
+    const enerf_cascade_t& c = a->cas;
+    REQUIRE(c.num >= 1 && c.num <= ENERF_MAX_LEVELS, "forward: cas_config.num=%d unsupported (1..%d)", c.num, ENERF_MAX_LEVELS);
+    REQUIRE(a->B > 0 && a->S >= 2 && a->S <= 4 && a->H > 0 && a->W > 0 && a->H % 4 == 0 && a->W % 4 == 0,
+            "forward: bad batch shape B=%d S=%d H=%d W=%d (S in 2..4, H and W divisible by 4)", a->B, a->S, a->H, a->W);
+    REQUIRE(a->src_inps && a->src_exts && a->src_ixts && a->tar_ext && a->tar_ixt && a->near_far, "forward: null batch tensor");
+    const int nf = (a->feats_nchw[0] != nullptr) + (a->feats_nchw[1] != nullptr) + (a->feats_nchw[2] != nullptr);
+    REQUIRE(nf == 0 || nf == 3, "forward: feats_nchw needs all three levels or none");
+    P->hip_feats = nf == 0;
+    if (P->hip_feats) REQUIRE(a->feature_net_packed, "forward: feature_net_packed missing");
+    // level_2 is only ever the im_feat of a full-resolution render: then the FeatureNet emits it as render texels
+    int uses = 0, all_full = 1;
+    for (int i = 0; i < c.num; ++i)
+        if (c.render_if[i] && c.render_im_feat_level[i] == 2) {
+            ++uses;
+            all_full &= (c.render_scale[i] == 1.0 && c.im_ibr_scale[i] == 1.0 && c.nerf_model_feat_ch[i] == 8);
+        }
+    P->tex2 = P->hip_feats && uses > 0 && all_full && c.num <= 2;
+    size_t off = 0;
+    auto take = [&](size_t nfloats) { size_t r = off; off += (nfloats + 63) / 64 * 64; return r; };   // 256-B aligned
+    const long long n_img = (long long)a->B * a->S;
+    const int fh[3] = {a->H / 4, a->H / 2, a->H}, fw[3] = {a->W / 4, a->W / 2, a->W}, fc[3] = {32, 16, 8};
+    for (int l = 0; l < 3; ++l) P->f[l] = take((size_t)n_img * fh[l] * fw[l] * (l == 2 && P->tex2 ? 12 : fc[l]));
+    P->featnet_ws_bytes = P->hip_feats ? enerf_feature_net_workspace_bytes((int)n_img, a->H, a->W) : 0;
+    P->featnet_ws = take(P->featnet_ws_bytes / sizeof(float));
+    P->costreg_ws_bytes = 0;
+    for (int i = 0; i < c.num; ++i) {
+        LevelPlan& L = P->L[i];
+        memset(&L, 0, sizeof(L));
+        L.D = c.volume_planes[i];
+        L.h = scaled(a->H, c.volume_scale[i]);
+        L.w = scaled(a->W, c.volume_scale[i]);
+        REQUIRE(i < 3, "forward: level %d has no feature map (FeatureNet has three scales)", i);
+        L.C = fc[i]; L.Hs = fh[i]; L.Ws = fw[i];
+        REQUIRE(!(i == 2 && P->tex2), "forward: level_2 texels cannot feed a cost volume");
+        REQUIRE(L.D > 0 && L.h > 0 && L.w > 0, "forward: level %d volume is empty", i);
+        if (i > 0) REQUIRE(c.depth_inv[i - 1], "forward: cascade levels after a depth-space level are undefined in the "
+                                               "reference (utils.py:130)");
+        REQUIRE(a->cost_reg_packed[i], "forward: cost_reg_packed[%d] missing", i);
+        const long long nv = (long long)a->B * L.D * L.h * L.w;
+        L.proj = take((size_t)a->B * a->S * 12);
+        L.dv = take((size_t)nv);
+        L.nf = take((size_t)a->B * 2 * L.h * L.w);
+        L.vol = take((size_t)nv * L.C);
+        L.feat3d = take((size_t)nv * 8);
+        L.prob = take((size_t)nv);
+        L.depth = take((size_t)a->B * L.h * L.w);
+        L.std = take((size_t)a->B * L.h * L.w);
+        L.dmvs = take((size_t)a->B * L.h * L.w);
+        const size_t cw = enerf_cost_reg_workspace_bytes(i != 0, a->B, L.D, L.h, L.w);
+        if (cw > P->costreg_ws_bytes) P->costreg_ws_bytes = cw;
+        L.render = c.render_if[i] != 0;
+        if (!L.render) continue;
+        L.Hr = scaled(a->H, c.render_scale[i]);
+        L.Wr = scaled(a->W, c.render_scale[i]);
+        L.Ns = c.num_samples[i];
+        L.F = c.nerf_model_feat_ch[i] + 3;
+        REQUIRE(L.Hr > 1 && L.Wr > 1, "forward: level %d render extent too small", i);
+        REQUIRE(a->nerf_packed[i], "forward: nerf_packed[%d] missing", i);
+        REQUIRE(a->rgb[i] && a->depth[i] && a->weights[i] && a->depth_mvs[i] && a->std[i], "forward: level %d output missing", i);
+        const int fl = c.render_im_feat_level[i];
+        REQUIRE(fl >= 0 && fl <= 2 && fc[fl] == c.nerf_model_feat_ch[i],
+                "forward: render_im_feat_level[%d]=%d does not have nerf_model_feat_ch=%d channels", i, fl, c.nerf_model_feat_ch[i]);
+        if (P->hip_feats)
+            REQUIRE(fh[fl] == L.Hr && fw[fl] == L.Wr, "forward: level %d renders at %dx%d but feature level_%d is %dx%d "
+                    "(the HIP FeatureNet path needs render_scale == im_ibr_scale)", i, L.Hr, L.Wr, fl, fh[fl], fw[fl]);
+        else {
+            const double up = c.render_scale[i] / c.im_ibr_scale[i];
+            REQUIRE(scaled(fh[fl], up) == L.Hr && scaled(fw[fl], up) == L.Wr,
+                    "forward: im_feat resolution inconsistent with render_scale / im_ibr_scale at level %d", i);
+        }
+        if (!(fl == 2 && P->tex2)) L.tex = take((size_t)n_img * L.Hr * L.Wr * 4 * ((L.F + 3) / 4));
+        if (a->rays[i] != nullptr) {
+            REQUIRE(a->n_rays[i] >= 0, "forward: n_rays[%d] negative", i);
+            L.n_rays = a->n_rays[i];
+        } else {
+            L.n_rays = (long long)L.Hr * L.Wr;
+            L.rays = take((size_t)a->B * L.n_rays * 8);
+        }
+        L.masked = a->mask_at_box != nullptr && i == c.num - 1;
+        if (L.masked) {
+            REQUIRE(a->B == 1, "forward: mask_at_box needs B == 1 (network_human.py:91 reshapes the mask to (1,-1))");
+            REQUIRE(L.n_rays == (long long)a->H * a->W, "forward: mask_at_box has H*W=%lld elements but level %d has %lld rays",
+                    (long long)a->H * a->W, i, L.n_rays);
+            REQUIRE(a->mask_elem_bytes == 1 || a->mask_elem_bytes == 2 || a->mask_elem_bytes == 4 || a->mask_elem_bytes == 8,
+                    "forward: mask_elem_bytes=%d unsupported", a->mask_elem_bytes);
+            REQUIRE((a->ray_index != nullptr) == (a->ray_count != nullptr), "forward: pass both ray_index and ray_count or neither");
+            REQUIRE(!a->ray_index_ready || a->ray_index, "forward: ray_index_ready without ray_index");
+            if (!a->ray_index) { P->ray_index = take((size_t)L.n_rays); P->ray_count = take(64); }
+            if (!a->ray_index_ready) P->mask_ws = take(mask_compact_workspace_bytes(L.n_rays) / sizeof(int) + 1);
+        }
+    }
+    P->costreg_ws = take(P->costreg_ws_bytes / sizeof(float));
+    P->total_floats = off;
+    return ENERF_OK;
+}
+}  // namespace
+}  // namespace enerf
+
+extern "C" {
+
+size_t enerf_mask_compact_workspace_bytes(long long n) { return mask_compact_workspace_bytes(n); }
+int enerf_mask_compact(const void* mask, int elem_bytes, long long n, int* index, int* count, void* workspace,
+                       size_t workspace_bytes, enerf_stream_t stream) {
+    REQUIRE(mask && index && count && workspace && n > 0, "mask_compact: bad arguments");
+    REQUIRE(n < (1LL << 31), "mask_compact: more than 2^31 elements");
+    REQUIRE(elem_bytes == 1 || elem_bytes == 2 || elem_bytes == 4 || elem_bytes == 8, "mask_compact: elem_bytes=%d unsupported", elem_bytes);
+    if (workspace_bytes < mask_compact_workspace_bytes(n)) return fail(ENERF_EWORKSPACE, "mask_compact: workspace too small");
+    launch_mask_compact(mask, elem_bytes, n, index, count, workspace, (hipStream_t)stream);
+    return check_launch("mask_compact");
+}
+
+size_t enerf_forward_workspace_bytes(const enerf_frame_args_t* a) {
+    FramePlan P;
+    if (make_plan(a, &P) != ENERF_OK) return 0;
+    return P.total_floats * sizeof(float);
+}
+
+int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
+    FramePlan P;
+    int rc = make_plan(a, &P);
+    if (rc != ENERF_OK) return rc;
+    REQUIRE(a->workspace, "forward: null workspace");
+    if (a->workspace_bytes < P.total_floats * sizeof(float))
+        return fail(ENERF_EWORKSPACE, "forward: workspace too small (%zu < %zu bytes)", a->workspace_bytes,
+                    P.total_floats * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)a->workspace;
+    const enerf_cascade_t& c = a->cas;
+    const int n_img = a->B * a->S;
+    auto mark = [&](int slot) {
+#ifndef ENERF_EMU
+        if (a->stage_events != nullptr && a->stage_events[slot] != nullptr) hipEventRecord((hipEvent_t)a->stage_events[slot], st);
+#else
+        (void)slot;
+#endif
+    };
+    mark(ENERF_STAGE_BEGIN);
+    // a caller-independent early start for the mask compaction: it only depends on the batch
+    int *ray_index = a->ray_index, *ray_count = a->ray_count;
+    const LevelPlan& last = P.L[c.num - 1];
+    if (last.render && last.masked) {
+        if (!ray_index) { ray_index = (int*)(ws + P.ray_index); ray_count = (int*)(ws + P.ray_count); }
+        if (!a->ray_index_ready)
+            launch_mask_compact(a->mask_at_box, a->mask_elem_bytes, last.n_rays, ray_index, ray_count, ws + P.mask_ws, st);
+    }
+
+    // ---- FeatureNet (feature_net.py:27-36) -> channels-last maps; level_2 straight to render texels when it can ----
+    float* f[3] = {ws + P.f[0], ws + P.f[1], ws + P.f[2]};
+    const int fh[3] = {a->H / 4, a->H / 2, a->H}, fw[3] = {a->W / 4, a->W / 2, a->W}, fc[3] = {32, 16, 8};
+    if (P.hip_feats) {
+        rc = enerf_feature_net(a->feature_net_packed, a->src_inps, n_img, a->H, a->W, f[0], f[1], f[2], P.tex2 ? 12 : 8,
+                               ws + P.featnet_ws, P.featnet_ws_bytes, a->options, stream);
+        if (rc != ENERF_OK) return rc;
+    } else {
+        for (int l = 0; l < c.num; ++l)   // the levels that feed a cost volume (texels are packed from NCHW below)
+            launch_channels_last(a->feats_nchw[l], f[l], n_img, fc[l], (long long)fh[l] * fw[l], fc[l], st);
+    }
+    mark(ENERF_STAGE_FEATURE_NET);
+
+    const float *pdepth = nullptr, *pstd = nullptr, *pnf = nullptr;
+    int hp = 0, wp = 0;
+    for (int i = 0; i < c.num; ++i) {
+        const LevelPlan& L = P.L[i];
+        float *proj = ws + L.proj, *dv = ws + L.dv, *nf = ws + L.nf, *vol = ws + L.vol, *feat3d = ws + L.feat3d;
+        float *prob = ws + L.prob, *depth = ws + L.depth;
+        float* std = L.render ? a->std[i] : ws + L.std;
+        float* dmvs = L.render ? a->depth_mvs[i] : nullptr;
+        rc = enerf_level_prep(a->src_ixts, a->src_exts, a->tar_ixt, a->tar_ext, a->B, a->S, (float)c.im_feat_scale[i],
+                              (float)c.volume_scale[i], proj, a->near_far, pdepth, pstd, pnf, L.D, L.h, L.w, hp, wp,
+                              c.depth_inv[i], dv, nf, stream);
+        if (rc != ENERF_OK) return rc;
+        mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_PREP));
+        rc = enerf_build_feature_volume(f[i], proj, dv, a->B, a->S, L.C, L.Hs, L.Ws, L.D, L.h, L.w, vol, stream);
+        if (rc != ENERF_OK) return rc;
+        mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_VOLUME));
+        rc = enerf_cost_reg(a->cost_reg_packed[i], L.C, i != 0, vol, a->B, L.D, L.h, L.w, feat3d, prob, ws + P.costreg_ws,
+                            P.costreg_ws_bytes, a->options, stream);
+        if (rc != ENERF_OK) return rc;
+        mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_COST_REG));
+        launch_depth_regression(prob, dv, a->B, L.D, L.h, L.w, c.depth_inv[i], depth, std, dmvs, st);
+        mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_DEPTH_REG));
+        pdepth = depth; pstd = std; pnf = nf; hp = L.h; wp = L.w;
+        if (!L.render) continue;
+
+        // ---- texels: unpreprocess + cat (network.py:28-34) as the channels-last gather source ----
+        const int fl = c.render_im_feat_level[i];
+        const int TEX = 4 * ((L.F + 3) / 4);
+        const float* tex;
+        if (fl == 2 && P.tex2) tex = f[2];
+        else {
+            float* t = ws + L.tex;
+            if (P.hip_feats)
+                rc = enerf_pack_texels_cl(f[fl], fc[fl], a->src_inps, a->H, a->W, L.Hr, L.Wr, TEX, n_img, t, stream);
+            else
+                rc = enerf_pack_img_feat_rgb(a->feats_nchw[fl], fc[fl], fh[fl], fw[fl], a->src_inps, a->H, a->W, L.Hr, L.Wr,
+                                             TEX, n_img, t, stream);
+            if (rc != ENERF_OK) return rc;
+            tex = t;
+        }
+        mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_TEXELS));
+
+        // ---- rays: the batch's, or the full image generated here (enerf_utils.py:61-71) ----
+        const float* rays8 = a->rays[i];
+        if (rays8 == nullptr) {
+            float* r = ws + L.rays;
+            rc = enerf_gen_rays(a->tar_ext, a->tar_ixt, a->B, L.Hr, L.Wr, (float)c.render_scale[i], r, stream);
+            if (rc != ENERF_OK) return rc;
+            rays8 = r;
+        }
+        // ---- build_rays + render_rays (utils.py:390-420, network.py:24-43), one launch ----
+        enerf_render_args_t ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.tex = tex; ra.vol = feat3d; ra.src_exts = a->src_exts; ra.src_ixts = a->src_ixts; ra.tar_ext = a->tar_ext;
+        ra.packed = a->nerf_packed[i];
+        ra.rgb = a->rgb[i]; ra.depth = a->depth[i]; ra.weights = a->weights[i];
+        ra.B = a->B; ra.N = (int)L.n_rays; ra.S = a->S; ra.n_samples = L.Ns; ra.depth_inv = c.depth_inv[i];
+        ra.Hr = L.Hr; ra.Wr = L.Wr; ra.F = L.F; ra.D = L.D; ra.h = L.h; ra.w = L.w; ra.white_bkgd = c.white_bkgd;
+        ra.render_scale = (float)c.render_scale[i];
+        ra.rays8 = rays8; ra.depth_map = depth; ra.std_map = std; ra.nf_map = nf; ra.map_h = L.h; ra.map_w = L.w;
+        ra.options = a->options;
+        if (L.masked) {
+            ra.ray_index = ray_index; ra.ray_count = ray_count; ra.scatter_rgb = 1;
+            hipMemsetAsync(a->rgb[i], 0, (size_t)L.n_rays * 3 * sizeof(float), st);      // torch.zeros_like(...), network_human.py:103
+        }
+        rc = enerf_render_rays(&ra, stream);
+        if (rc != ENERF_OK) return rc;
+        mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_RENDER));
+    }
+    return check_launch("forward");
+}
+
+}  // extern "C"

@@ -325,7 +325,8 @@ __device__ __forceinline__ void depth_moments_regs(const float* pr, const float*
 }
 __global__ __launch_bounds__(256) void k_depth_regression(const float* __restrict__ prob, const float* __restrict__ dv,
                                                           int B, int D, int h, int w, int depth_inv,
-                                                          float* __restrict__ depth, float* __restrict__ std) {
+                                                          float* __restrict__ depth, float* __restrict__ std,
+                                                          float* __restrict__ depth_mvs) {
     const int lane = threadIdx.x & 63, sl = lane >> 4;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int hw = h * w;
@@ -366,12 +367,14 @@ __global__ __launch_bounds__(256) void k_depth_regression(const float* __restric
     if (ok && sl == 0) {
         depth[i] = mu;
         std[i] = sqrtf(clamp_min(var, 1e-10f));
+        if (depth_mvs != nullptr) depth_mvs[i] = depth_inv ? 1.f / mu : mu;      // network.py:105-108
     }
 }
 void launch_depth_regression(const float* prob, const float* dv, int B, int D, int h, int w, int depth_inv,
-                             float* depth, float* std, hipStream_t st) {
+                             float* depth, float* std, float* depth_mvs, hipStream_t st) {
     long long waves = cdivl((long long)B * h * w, 16);
-    ENERF_LAUNCH(k_depth_regression, (unsigned)cdivl(waves, 4), 256, 0, st, prob, dv, B, D, h, w, depth_inv, depth, std);
+    ENERF_LAUNCH(k_depth_regression, (unsigned)cdivl(waves, 4), 256, 0, st, prob, dv, B, D, h, w, depth_inv, depth, std,
+                 depth_mvs);
 }
 
 // -------------------------------------------------------------------------------------------------

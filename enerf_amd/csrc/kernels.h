@@ -9,6 +9,12 @@ namespace enerf {
 // Explicit kernel-variant choices (include/enerf_hip.h: enerf_options_t); a NULL pointer at the C ABI means all zero.
 using Options = enerf_options_t;
 inline Options resolve_options(const enerf_options_t* o) { return o ? *o : Options{}; }
+// error reporting shared by the C-ABI translation units (capi.hip, frame.hip): thread-local message + code
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+const char* last_error();
+#define REQUIRE(cond, ...) \
+    do { if (!(cond)) return ::enerf::fail(ENERF_EINVAL, __VA_ARGS__); } while (0)
 // number of compute units of the current device (queried once per device; 256 on MI355X)
 int device_cu_count();
 
@@ -25,8 +31,9 @@ void launch_level_prep(const float* src_ixts, const float* src_exts, const float
                        float src_scale, float tar_scale, float* proj, const float* near_far, const float* pdepth,
                        const float* pstd, const float* pnf, int B, int D, int h, int w, int hp, int wp, int depth_inv,
                        float* dv, float* nf_out, hipStream_t st);     // proj_mats + depth_values in one launch
+// depth_mvs (optional): 1/depth for disparity-space levels, depth otherwise (network.py:105-108)
 void launch_depth_regression(const float* prob, const float* dv, int B, int D, int h, int w, int depth_inv,
-                             float* depth, float* std, hipStream_t st);
+                             float* depth, float* std, float* depth_mvs, hipStream_t st);
 void launch_build_rays(const float* rays8, const float* depth, const float* std, const float* nf, int B, int N, int h,
                        int w, int Hr, int Wr, int depth_inv, float* rays12, hipStream_t st);
 
@@ -104,6 +111,11 @@ void launch_gen_rays(const float* tar_ext, const float* tar_ixt, int B, int Hr, 
 void launch_pack_rgb8(const float* rgb, int H, int W, int flip, unsigned char* out, hipStream_t st);
 void launch_eval_stats(const float* pred_rgb, const float* gt_rgb, const int* mask, long long n_rgb,
                        const float* pred_depth, const float* gt_depth, long long n_depth, double* acc, hipStream_t st);
+
+// ---- frame.hip (mask_at_box compaction; the whole-frame driver enerf_forward lives there too) ---------
+size_t mask_compact_workspace_bytes(long long n);
+void launch_mask_compact(const void* mask, int elem_bytes, long long n, int* index, int* count, void* workspace,
+                         hipStream_t st);
 
 // ---- render.hip ---------------------------------------------------------------------------------
 using NerfRaw = enerf_nerf_raw_t;     // torch-layout parameter pointers of one NeRF (nerf.py:6-89)

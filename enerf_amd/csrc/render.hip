@@ -182,8 +182,10 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
 
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int wave_in_block = threadIdx.x >> 6, waves_per_block = blockDim.x >> 6;
-    const long long nrays = (long long)a.B * a.N;
+    // device-side ray selection (network_human.py:90-93): the number of rays is read here, not known to the host
+    const long long nrays = a.ray_index != nullptr ? (long long)a.ray_count[0] : (long long)a.B * a.N;
     const long long ntiles = cdivl(nrays, 16);
+    const bool scatter = a.ray_index != nullptr && a.scatter_rgb != 0;
     const int Ns = a.n_samples;
     const int TEX = 4 * R;
     const float* wlane = wl + lane;
@@ -193,7 +195,8 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
          tile += (long long)gridDim.x * waves_per_block) {
         long long ray = tile * 16 + j;
         const bool rok = ray < nrays;
-        const long long rr = rok ? ray : nrays - 1;
+        const long long rc = rok ? ray : nrays - 1;
+        const long long rr = a.ray_index != nullptr ? (long long)a.ray_index[rc] : rc;     // position in the ray list
         const int b = (int)(rr / a.N);
         float ox, oy, oz, dx, dy, dz, ru, rv, rn, rf, vn, vf;
         if (a.rays8 != nullptr) {      // fused build_rays (uniform branch): 8-float ray + the level's depth/std/near_far maps
@@ -499,7 +502,8 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
                 if (c >= 0 && c < 3) {
                     float v = rgbacc[r];
                     if (a.white_bkgd) v += 1.f - accw;              // utils.py:599-601
-                    a.rgb[ray * 3 + c] = v;
+                    if (!scatter) a.rgb[ray * 3 + c] = v;
+                    else if (nrays > 1) a.rgb[rr * 3 + c] = v;      // network_human.py:105-106: rgb[mask] = ..., if mask.sum() > 1
                 }
             }
             if (g == 0) {

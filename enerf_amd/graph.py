@@ -18,8 +18,8 @@ class GraphedFrame:
     def __init__(self, net, batch: Dict[str, torch.Tensor], warmup: int = 2):
         if net.training:
             raise RuntimeError("GraphedFrame: call net.eval() first")
-        if getattr(net, "overlap", False):
-            raise RuntimeError("GraphedFrame: capture needs the single-stream path (overlap=False)")
+        if getattr(net, "human", False) and not net.static_shapes:
+            raise RuntimeError("GraphedFrame: the human variant needs static_shapes=True (no count readback inside a graph)")
         self.net = net
         self.static_in = {k: v.clone() if torch.is_tensor(v) else v for k, v in batch.items()}
         with torch.no_grad():
@@ -35,7 +35,7 @@ class GraphedFrame:
         # the graph holds raw addresses of the packed weight images and the FeatureNet scratch, which live OUTSIDE the
         # graph's private pool: keep them alive here and refuse to replay once the network has replaced them
         self._held = {k: v[0] for k, v in net._packed.items()}
-        self._held_ws = dict(net._feat_ws_by_stream)
+        self._held_ws = {k: v["ws"] for k, v in net._frames.items()}     # the frame workspaces
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         for k, t in self._held.items():

@@ -65,7 +65,50 @@ class RenderArgs(C.Structure):
                                      "white_bkgd")]
                 + [("render_scale", _fl)]
                 + [(n, _f) for n in ("rays8", "depth_map", "std_map", "nf_map")] + [("map_h", _i), ("map_w", _i)]
-                + [("options", C.POINTER(Options))])
+                + [("options", C.POINTER(Options)), ("ray_index", C.c_void_p), ("ray_count", C.c_void_p),
+                   ("scatter_rgb", _i)])
+
+
+MAX_LEVELS = 3
+STAGE_COUNT = 2 + 6 * MAX_LEVELS
+STAGE_NAMES = ["begin", "feature_net"] + [f"{n}_{i}" for i in range(MAX_LEVELS)
+                                          for n in ("prep", "volume", "cost_reg", "depth_reg", "texels", "render")]
+_dL, _iL, _fL = C.c_double * MAX_LEVELS, C.c_int * MAX_LEVELS, C.c_void_p * MAX_LEVELS
+
+
+class Cascade(C.Structure):
+    """``enerf_cascade_t`` (cfg.enerf.cas_config)."""
+    _fields_ = [("num", _i), ("depth_inv", _iL), ("volume_scale", _dL), ("volume_planes", _iL), ("im_feat_scale", _dL),
+                ("im_ibr_scale", _dL), ("render_scale", _dL), ("render_im_feat_level", _iL), ("nerf_model_feat_ch", _iL),
+                ("render_if", _iL), ("num_samples", _iL), ("white_bkgd", _i)]
+
+
+class FrameArgs(C.Structure):
+    """``enerf_frame_args_t``."""
+    _fields_ = ([(n, _f) for n in ("src_inps", "src_exts", "src_ixts", "tar_ext", "tar_ixt", "near_far")]
+                + [("rays", _fL), ("n_rays", _iL), ("mask_at_box", C.c_void_p), ("mask_elem_bytes", _i)]
+                + [(n, _i) for n in ("B", "S", "H", "W")] + [("cas", Cascade)]
+                + [("feature_net_packed", _f), ("cost_reg_packed", _fL), ("nerf_packed", _fL), ("feats_nchw", C.c_void_p * 3)]
+                + [(n, _fL) for n in ("rgb", "depth", "weights", "depth_mvs", "std")]
+                + [("ray_index", C.c_void_p), ("ray_count", C.c_void_p), ("ray_index_ready", _i),
+                   ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("options", C.POINTER(Options)),
+                   ("stage_events", C.POINTER(C.c_void_p))])
+
+
+def cascade_struct(cfg) -> Cascade:
+    """EnerfConfig -> enerf_cascade_t."""
+    cas = cfg.cas
+    if cas.num > MAX_LEVELS:
+        raise EnerfError(f"cas_config.num={cas.num} > {MAX_LEVELS}")
+    c = Cascade(num=cas.num, white_bkgd=int(cfg.white_bkgd))
+    for i in range(cas.num):
+        c.depth_inv[i] = int(cas.depth_inv[i]); c.volume_scale[i] = float(cas.volume_scale[i])
+        c.volume_planes[i] = int(cas.volume_planes[i]); c.im_feat_scale[i] = float(cas.im_feat_scale[i])
+        c.im_ibr_scale[i] = float(cas.im_ibr_scale[i]); c.render_scale[i] = float(cas.render_scale[i])
+        c.render_im_feat_level[i] = int(cas.render_im_feat_level[i])
+        c.nerf_model_feat_ch[i] = int(cas.nerf_model_feat_ch[i]); c.render_if[i] = int(cas.render_if[i])
+        c.num_samples[i] = int(cas.num_samples[i])
+    return c
 
 
 _SIGNATURES = {
@@ -93,6 +136,10 @@ _SIGNATURES = {
     "enerf_nerf_packed_floats": (_ll, [_i]),
     "enerf_nerf_pack": (_i, [C.POINTER(NerfRaw), _i, _i, _f, _f]),
     "enerf_render_rays": (_i, [C.POINTER(RenderArgs), _f]),
+    "enerf_mask_compact_workspace_bytes": (C.c_size_t, [_ll]),
+    "enerf_mask_compact": (_i, [C.c_void_p, _i, _ll, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, _f]),
+    "enerf_forward_workspace_bytes": (C.c_size_t, [C.POINTER(FrameArgs)]),
+    "enerf_forward": (_i, [C.POINTER(FrameArgs), _f]),
     "enerf_gen_rays": (_i, [_f, _f, _i, _i, _i, _fl, _f, _f]),
     "enerf_pack_rgb8": (_i, [_f, _i, _i, _i, _f, _f]),
     "enerf_eval_stats": (_i, [_f, _f, _f, _ll, _f, _f, _ll, _f, _f]),
@@ -330,6 +377,32 @@ class EnerfLib:
         self._check(self.dll.enerf_render_rays(C.byref(a), self.stream_of(rays12)), "render_rays")
         return rgb, depth, weights
 
+
+    # -- whole frame / mask compaction -------------------------------------------------------------
+    def mask_compact(self, mask: torch.Tensor, workspace=None):
+        """network_human.py:90-93 on device: (index int32 (n), count int32 (1)) of the non-zero mask elements."""
+        if not mask.is_contiguous():
+            raise EnerfError("mask must be contiguous")
+        n = mask.numel()
+        dev = mask.device
+        need = self.dll.enerf_mask_compact_workspace_bytes(n)
+        if workspace is None or workspace.numel() * 4 < need:
+            workspace = torch.empty(((need + 3) // 4,), dtype=torch.int32, device=dev)
+        index = torch.empty((n,), dtype=torch.int32, device=dev)
+        count = torch.empty((1,), dtype=torch.int32, device=dev)
+        self._check(self.dll.enerf_mask_compact(mask.data_ptr(), mask.element_size(), n, index.data_ptr(), count.data_ptr(),
+                                                workspace.data_ptr(), workspace.numel() * 4, self.stream_of(mask)),
+                    "mask_compact")
+        return index, count
+
+    def forward_workspace_bytes(self, args: "FrameArgs") -> int:
+        n = self.dll.enerf_forward_workspace_bytes(C.byref(args))
+        if n == 0:
+            raise EnerfError(f"forward: {self.dll.enerf_last_error().decode()}")
+        return n
+
+    def forward(self, args: "FrameArgs", stream):
+        self._check(self.dll.enerf_forward(C.byref(args), stream), "forward")
 
     # -- the steps before / after the path (SURVEY.md 8f rows 3, 4) ---------------------------------
     def gen_rays(self, tar_ext, tar_ixt, Hr, Wr, scale):

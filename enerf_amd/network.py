@@ -17,6 +17,7 @@ Training (autograd through the HIP path) is the first "next" row of SURVEY.md §
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Dict, Optional
 
 import torch
@@ -24,7 +25,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .config import EnerfConfig
-from .lib import ConvBn, CostRegRaw, EnerfLib, FeatNetRaw, NerfRaw, Options, get_lib
+from .lib import (STAGE_COUNT, STAGE_NAMES, ConvBn, CostRegRaw, EnerfLib, FeatNetRaw, FrameArgs, NerfRaw, Options,
+                  cascade_struct, get_lib)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -214,24 +216,19 @@ class Network(nn.Module):
     """
 
     def __init__(self, cfg: Optional[EnerfConfig] = None, human: bool = False, lib: Optional[EnerfLib] = None,
-                 check_nan: bool = False, feature_backend: str = "hip", overlap: bool = False):
+                 check_nan: bool = False, feature_backend: str = "hip", static_shapes: bool = False):
         super().__init__()
         if feature_backend not in ("hip", "torch"):
             raise ValueError("feature_backend must be 'hip' or 'torch'")
-        # overlap=True (HIP FeatureNet on a GPU only): the level-0 cost volume needs feature level_0 only, so the
-        # rest of the FPN (level_1, level_2/texels: 0.19 of the 1.09 ms frame) is enqueued on a second HIP stream
-        # next to the level-0 cost regularisation; events order the consumers.  Same kernels, bit-identical
-        # results.  Measured on MI355X: the kernels do overlap in time but each slows down by what the other
-        # takes (the fused smooth0 blocks hold 141 of the 160 KB of LDS per CU, so the conv3d blocks queue for
-        # LDS): 927 -> 931 FPS.  Off by default — one stream keeps the frame graph-capturable.
-        self.overlap = overlap
-        self.fuse_build_rays = True         # forward(): build_rays in the render kernel's prologue (same bits)
-        self._side_stream = None
-        self._feat_events = {}
         # "torch": FeatureNet in PyTorch-ROCm/MIOpen (north_star's split); "hip": enerf_feature_net on the
         # matrix cores, channels-last outputs (SURVEY.md §8f row 2 — MIOpen was 49 % of the frame).
         self.feature_backend = feature_backend
-        self._feat_ws_by_stream = {}        # FeatureNet scratch, one per HIP stream (frames may be in flight on several)
+        # human variant only: the reference returns depth/weights with mask_at_box.sum() rows (network_human.py:93), a
+        # data-dependent shape the host can only build after reading the count back (a wait for three tiny kernels).
+        # static_shapes=True returns the full-size buffers (selected rays first) plus the device-side count
+        # ``num_rays_level{i}`` instead: no host sync at all, so the frame can be graph-captured / pipelined.
+        self.static_shapes = static_shapes
+        self._frames = {}                   # per HIP stream: frame args struct, workspace, plan signature
         self.cfg = cfg or EnerfConfig()
         self.cfg.cas.validate()
         self.human = human
@@ -245,11 +242,7 @@ class Network(nn.Module):
         self._packed: Dict[str, tuple] = {}           # name -> (packed image, ready event or None, stream id)
         self.options: Optional[Options] = None        # enerf_options_t for every launch of forward(); None = defaults
         self._tex_cache = None
-        self._timer = None                  # optional stage timer (bench.py): .begin()/.mark(name)/.end()
-
-    def _mark(self, name):
-        if self._timer is not None:
-            self._timer.mark(name)
+        self._timer = None                  # optional stage timer (bench.py StageTimer): .new_events(n) / .frame(list)
 
     # -- weight images ---------------------------------------------------------------------------
     @property
@@ -300,7 +293,7 @@ class Network(nn.Module):
 
     def prepare(self):
         """Pack every weight image now, on the current stream (e.g. before opening a FramePipeline or capturing a graph)."""
-        names = ["feature_net"] if self.feature_backend == "hip" else []
+        names = ["feature_net"] if self.feature_backend == "hip" else []      # torch backend: MIOpen owns those weights
         for i in range(self.cfg.cas.num):
             names += [f"cost_reg_{i}", f"nerf_{i}"]
         for n in names:
@@ -309,64 +302,19 @@ class Network(nn.Module):
 
     # -- reference surface -----------------------------------------------------------------------
     def forward_feat(self, x):
-        """network.py:58-67."""
+        """network.py:58-67 (FeatureNet in PyTorch-ROCm: ``feature_backend="torch"``, north_star's split)."""
         B, S, C, H, W = x.shape
         f2, f1, f0 = self.feature_net(x.view(B * S, C, H, W))
         return {"level_2": f0.reshape(B, S, f0.shape[1], H, W),
                 "level_1": f1.reshape(B, S, f1.shape[1], H // 2, W // 2),
                 "level_0": f2.reshape(B, S, f2.shape[1], H // 4, W // 4)}
 
-    @property
-    def _feat_ws(self):
-        return self._feat_ws_by_stream.get(torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
-
-    @_feat_ws.setter
-    def _feat_ws(self, ws):
-        self._feat_ws_by_stream[torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0] = ws
-
-    def _forward_feat_hip(self, x, texel_level2: bool, options=None):
-        """HIP FeatureNet: channels-last (B,S,h,w,C) maps tagged ``_enerf_cl``; level_2 optionally comes
-        out as ready render texels (tagged ``_enerf_tex``) when it is only used for the full-res render."""
-        B, S, C, H, W = x.shape
-        lib, packed = self.lib, self._packed_weights("feature_net")
-        src = x.reshape(B * S, C, H, W).contiguous()
-        stride = 12 if texel_level2 else 8
-        self._feat_events = {}
-        if self.overlap and x.is_cuda:
-            bufs = lib.feature_net_alloc(src, stride, self._feat_ws)
-            f0, f1, f2, self._feat_ws = bufs
-            lib.feature_net_stage(packed, src, bufs, lib.FEAT_TRUNK, stride, options)          # -> level_0, caller's stream
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=x.device)
-            main, side = torch.cuda.current_stream(x.device), self._side_stream
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                lib.feature_net_stage(packed, src, bufs, lib.FEAT_LEVEL1, stride, options)     # -> level_1
-                self._feat_events[1] = side.record_event()
-                lib.feature_net_stage(packed, src, bufs, lib.FEAT_LEVEL2, stride, options)     # -> level_2 / texels
-                self._feat_events[2] = side.record_event()
-            # the buffers were allocated on `main`; every consumer (and so every later reuse by the caching
-            # allocator) is ordered after these events through _wait_feat
-        else:
-            f0, f1, f2, self._feat_ws = lib.feature_net(packed, src, stride, self._feat_ws, options)
-        feats = {"level_0": f0.view(B, S, H // 4, W // 4, 32), "level_1": f1.view(B, S, H // 2, W // 2, 16),
-                 "level_2": f2.view(B, S, H, W, f2.shape[-1])}
-        for k, v in feats.items():
-            v._enerf_cl = True
-        if texel_level2:
-            feats["level_2"]._enerf_tex = True
-        return feats
-
-    def _wait_feat(self, feat_level: int):
-        """Order the current stream after the side-stream stage that produces feature ``level_{feat_level}``."""
-        for lv, ev in list(self._feat_events.items()):
-            if lv <= feat_level:
-                torch.cuda.current_stream().wait_event(ev)
-                del self._feat_events[lv]
+    @staticmethod
+    def _stream_key(t: torch.Tensor) -> int:
+        return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
 
     def _texels(self, level, batch, im_feat):
         """unpreprocess + cat as the channels-last gather source (network.py:28-34); cached per frame."""
-        self._wait_feat(2)
         if getattr(im_feat, "_enerf_tex", False):
             return im_feat
         key = (level, im_feat.data_ptr(), batch["src_inps"].data_ptr())
@@ -406,7 +354,6 @@ class Network(nn.Module):
         if nerf is not None and nerf is not getattr(self, name):
             raise RuntimeError("render_rays: nerf_model must be this network's nerf_{level}")
         tex = self._texels(level, batch, im_feat)
-        self._mark(f"texels_{level}")
         # internal fast path of forward(): 8-float rays + the level's (depth, std, near_far) maps — build_rays
         # (utils.py:390-420) then runs in the render kernel's prologue instead of as its own launch
         maps = kwargs.get("_build_rays_maps", None)
@@ -416,7 +363,6 @@ class Network(nn.Module):
             depth_inv=cas.depth_inv[level], F=cas.nerf_model_feat_ch[level] + 3,
             render_scale=cas.render_scale[level], white_bkgd=self.cfg.white_bkgd, maps=maps,
             options=kwargs.get("_options", self.options))
-        self._mark(f"render_{level}")
         return {"rgb": rgb, "depth": depth, "weights": weights}
 
     def batchify_rays(self, rays, **kwargs):
@@ -428,8 +374,16 @@ class Network(nn.Module):
         return {k: torch.cat([p[k] for p in parts], dim=1) for k in parts[0]}
 
     def forward(self, batch):
-        """network.py:76-113 / network_human.py:69-119."""
+        """network.py:76-113 / network_human.py:69-119 — one ``enerf_forward`` C call (enerf_amd/csrc/frame.hip)."""
         return self._forward(batch, self.options)
+
+    def _frame_state(self, key):
+        st = self._frames.get(key)
+        if st is None:
+            st = {"args": FrameArgs(), "ws": None, "need": None, "sig": None, "pin": None}
+            st["args"].cas = cascade_struct(self.cfg)
+            self._frames[key] = st
+        return st
 
     def _forward(self, batch, options):
         if self.training:
@@ -439,84 +393,114 @@ class Network(nn.Module):
         self._tex_cache = None
         src = batch["src_inps"]
         B, S, _, H, W = src.shape
-        if self._timer is not None:
-            self._timer.begin()
+        dev = src.device
+        st = self._frame_state(self._stream_key(src))
+        a = st["args"]
+        keep = []                                             # tensors whose addresses the call uses
+
+        def ptr(t):
+            t = t.contiguous()
+            if t.dtype != torch.float32:
+                raise RuntimeError(f"expected float32, got {t.dtype}")
+            keep.append(t)
+            return t.data_ptr()
+
         with torch.no_grad():
-            hip_feats = self.feature_backend == "hip"
-            if hip_feats:
-                # level_2 is only ever the im_feat of a full-resolution render: emit it as texels directly
-                uses = [i for i in range(cas.num) if cas.render_if[i] and cas.render_im_feat_level[i] == 2]
-                tex2 = bool(uses) and all(cas.render_scale[i] == 1.0 and cas.im_ibr_scale[i] == 1.0 for i in uses) \
-                    and all(cas.nerf_model_feat_ch[i] == 8 for i in uses) and cas.num <= 2   # level_2 never feeds a cost volume
-                feats = self._forward_feat_hip(src, tex2, options)
+            a.src_inps, a.src_exts, a.src_ixts = ptr(src), ptr(batch["src_exts"]), ptr(batch["src_ixts"])
+            a.tar_ext, a.tar_ixt, a.near_far = ptr(batch["tar_ext"]), ptr(batch["tar_ixt"]), ptr(batch["near_far"])
+            a.B, a.S, a.H, a.W = B, S, H, W
+            if self.feature_backend == "hip":
+                a.feature_net_packed = self._packed_weights("feature_net").data_ptr()
+                for l in range(3):
+                    a.feats_nchw[l] = None
             else:
                 feats = self.forward_feat(src)
-            self._mark("feature_net")
-            ret = {}
-            prev = None
+                a.feature_net_packed = None
+                for l in range(3):
+                    a.feats_nchw[l] = ptr(feats[f"level_{l}"])
+            masked = self.human and "mask_at_box" in batch
+            ret, sig = {}, [B, S, H, W, self.feature_backend, masked]
             for i in range(cas.num):
-                D = cas.volume_planes[i]
-                h, w = int(H * cas.volume_scale[i]), int(W * cas.volume_scale[i])
-                f = feats[f"level_{i}"]
-                if hip_feats:
-                    self._wait_feat(i)
-                    feat_cl = f                                   # already (B,S,Hs,Ws,C)
-                    Hs, Ws, C = f.shape[2:]
-                    if i == 2 and C != 8:
-                        raise RuntimeError("level_2 texels cannot feed a cost volume")
-                else:
-                    C, Hs, Ws = f.shape[2:]
-                    feat_cl = lib.channels_last(f.reshape(B * S, C, Hs * Ws), B * S, C, Hs * Ws).view(B, S, Hs, Ws, C)
-                if prev is not None and not cas.depth_inv[i - 1]:
-                    raise RuntimeError("cascade levels after a depth-space level are undefined in the "
-                                       "reference (utils.py:130)")
-                # get_proj_mats + get_depth_values of the level, one launch
-                proj, dv, near_far = lib.level_prep(batch["src_ixts"].contiguous(), batch["src_exts"].contiguous(),
-                                                    batch["tar_ixt"].contiguous(), batch["tar_ext"].contiguous(),
-                                                    cas.im_feat_scale[i], cas.volume_scale[i],
-                                                    batch["near_far"].contiguous(), prev, D, h, w, cas.depth_inv[i])
-                self._mark(f"prep_{i}")
-                vol = lib.build_feature_volume(feat_cl, proj, dv, C)
-                self._mark(f"volume_{i}")
-                name = f"cost_reg_{i}"
-                m = getattr(self, name)
-                feat3d, prob = lib.cost_reg(self._packed_weights(name), m.in_channels, m.full, vol, options=options)
-                feat3d._enerf_channels_last = True      # (B,D,h,w,8); render_rays also accepts (B,8,D,h,w)
-                self._mark(f"cost_reg_{i}")
-                depth, std = lib.depth_regression(prob, dv, cas.depth_inv[i])
-                self._mark(f"depth_reg_{i}")
-                prev = (depth, std, near_far)
+                a.cost_reg_packed[i] = self._packed_weights(f"cost_reg_{i}").data_ptr()
                 if not cas.render_if[i]:
+                    a.rays[i], a.n_rays[i], a.nerf_packed[i] = None, 0, None
+                    sig.append(-1)
                     continue
-                Hr, Wr = int(H * cas.render_scale[i]), int(W * cas.render_scale[i])
-                masked = self.human and "mask_at_box" in batch and i == cas.num - 1
-                rays8 = batch[f"rays_{i}"].contiguous()
-                extra = {}
-                if self.fuse_build_rays and not masked and rays8.shape[1] <= int(self.cfg.chunk_size):
-                    rays = rays8                                     # build_rays runs inside the render launch
-                    extra["_build_rays_maps"] = (depth, std, near_far)
+                a.nerf_packed[i] = self._packed_weights(f"nerf_{i}").data_ptr()
+                h, w = int(H * cas.volume_scale[i]), int(W * cas.volume_scale[i])
+                rays = batch.get(f"rays_{i}")
+                if rays is None:                              # full image, generated on the device (enerf_utils.py:61-71)
+                    N = int(H * cas.render_scale[i]) * int(W * cas.render_scale[i])
+                    a.rays[i] = None
                 else:
-                    rays = lib.build_rays(rays8, depth, std, near_far, Hr, Wr, cas.depth_inv[i])
-                    self._mark(f"build_rays_{i}")
-                if masked:
-                    mask = batch["mask_at_box"].bool().reshape(1, -1)
-                    rays = rays[mask][None]
-                ret_i = self.batchify_rays(rays=rays, feature_volume=feat3d, batch=batch,
-                                           im_feat=feats[f"level_{cas.render_im_feat_level[i]}"],
-                                           nerf_model=getattr(self, f"nerf_{i}"), level=i, _options=options, **extra)
-                if masked:
-                    rgb = torch.zeros((1, mask.shape[1], 3), dtype=torch.float32, device=src.device)
-                    if int(mask.sum()) > 1:
-                        rgb[mask] = ret_i["rgb"][0]
-                    ret_i["rgb"] = rgb
-                ret_i["depth_mvs"] = 1.0 / depth if cas.depth_inv[i] else depth
-                ret_i["std"] = std
-                if self.check_nan and bool(ret_i["rgb"].isnan().any()):
-                    raise RuntimeError(f"NaN in rgb_level{i}")
-                ret.update({f"{k}_level{i}": v for k, v in ret_i.items()})
-            self._wait_feat(2)              # never leave side-stream work un-joined (e.g. no level rendered level_2)
-        if self._timer is not None:
-            self._timer.end()
+                    N = rays.shape[1]
+                    a.rays[i] = ptr(rays)
+                a.n_rays[i] = N
+                sig.append(N if rays is not None else -2)
+                rgb = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+                depth = torch.empty((B, N), dtype=torch.float32, device=dev)
+                weights = torch.empty((B, N, cas.num_samples[i]), dtype=torch.float32, device=dev)
+                dmvs = torch.empty((B, h, w), dtype=torch.float32, device=dev)
+                std = torch.empty((B, h, w), dtype=torch.float32, device=dev)
+                a.rgb[i], a.depth[i], a.weights[i] = rgb.data_ptr(), depth.data_ptr(), weights.data_ptr()
+                a.depth_mvs[i], a.std[i] = dmvs.data_ptr(), std.data_ptr()
+                ret.update({f"rgb_level{i}": rgb, f"depth_level{i}": depth, f"weights_level{i}": weights,
+                            f"depth_mvs_level{i}": dmvs, f"std_level{i}": std})
+            count_ready = None
+            last = cas.num - 1
+            if masked and cas.render_if[last]:
+                mask = batch["mask_at_box"].contiguous()
+                keep.append(mask)
+                a.mask_at_box, a.mask_elem_bytes = mask.data_ptr(), mask.element_size()
+                # compaction first, on its own: its count can then reach the host (for the reference's data-dependent
+                # output shapes) after waiting for these three tiny kernels only, not for the frame
+                index, count = lib.mask_compact(mask.reshape(-1))
+                keep += [index, count]
+                a.ray_index, a.ray_count, a.ray_index_ready = index.data_ptr(), count.data_ptr(), 1
+                if not self.static_shapes:
+                    if count.is_cuda:
+                        if st["pin"] is None:
+                            st["pin"] = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+                        st["pin"].copy_(count, non_blocking=True)
+                        count_ready = torch.cuda.current_stream(dev).record_event()
+                    else:
+                        st["pin"] = count
+            else:
+                a.mask_at_box, a.ray_index, a.ray_count, a.ray_index_ready = None, None, None, 0
+            a.options = None if options is None else C.pointer(options)
+            timer = self._timer
+            if timer is not None and src.is_cuda:
+                evs = timer.new_events(STAGE_COUNT)
+                arr = (C.c_void_p * STAGE_COUNT)(*[e.cuda_event for e in evs])
+                a.stage_events = C.cast(arr, C.POINTER(C.c_void_p))
+            else:
+                a.stage_events = None
+            sig = tuple(sig)
+            if st["sig"] != sig:                                 # shapes changed: re-plan the workspace
+                a.workspace, a.workspace_bytes = None, 0
+                st["need"], st["sig"] = lib.forward_workspace_bytes(a), sig
+            if st["ws"] is None or st["ws"].numel() * 4 < st["need"]:
+                st["ws"] = torch.empty(((st["need"] + 3) // 4,), dtype=torch.float32, device=dev)
+            a.workspace, a.workspace_bytes = st["ws"].data_ptr(), st["ws"].numel() * 4
+            lib.forward(a, EnerfLib.stream_of(src))
+            if timer is not None and src.is_cuda:
+                used = [0, 1]
+                for i in range(cas.num):
+                    used += [2 + 6 * i + k for k in range(6 if cas.render_if[i] else 4)]
+                timer.frame([(STAGE_NAMES[k], evs[k]) for k in used])
+            if masked and cas.render_if[last]:
+                if self.static_shapes:                           # no host sync: full-size buffers + the count on the device
+                    ret[f"num_rays_level{last}"] = count
+                else:                                            # network_human.py:93: depth / weights have mask.sum() rows
+                    if count_ready is not None:
+                        count_ready.synchronize()
+                    m = int(st["pin"][0])
+                    ret[f"depth_level{last}"] = ret[f"depth_level{last}"][:, :m]
+                    ret[f"weights_level{last}"] = ret[f"weights_level{last}"][:, :m]
+            if self.check_nan:
+                for i in range(cas.num):
+                    if cas.render_if[i] and bool(ret[f"rgb_level{i}"].isnan().any()):
+                        raise RuntimeError(f"NaN in rgb_level{i}")
         return ret
 
 

@@ -33,8 +33,6 @@ class FramePipeline:
     def __init__(self, net, depth: int = 2, throughput_tuning: bool = False, options: Optional[Options] = None):
         if depth < 1:
             raise ValueError("depth must be >= 1")
-        if getattr(net, "overlap", False):
-            raise RuntimeError("FramePipeline: use overlap=False (each frame already owns a stream)")
         self.net = net
         self.options = options if options is not None else (throughput_options() if throughput_tuning else net.options)
         # weight images are packed lazily by device kernels: do it now on the caller's stream, then let every pipeline

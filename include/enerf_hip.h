@@ -188,8 +188,92 @@ typedef struct {
     const float *depth_map, *std_map, *nf_map;
     int map_h, map_w;
     const enerf_options_t* options; /* NULL = defaults (ABI >= 3) */
+    /* Optional device-side ray selection (network_human.py:90-93,102-107; ABI >= 3, B must be 1): when ray_index != NULL
+     * the kernel renders rays ray_index[0 .. *ray_count) of the (N) ray list — *ray_count is read ON THE DEVICE, so a
+     * data-dependent mask never forces a host sync — writes depth/weights compacted (row r <- ray ray_index[r], rows
+     * >= *ray_count untouched) and, with scatter_rgb != 0, writes rgb to row ray_index[r] of the (N,3) buffer the caller
+     * zeroed (only if *ray_count > 1: the reference's `mask.sum() > 1` quirk), else compacted like depth. */
+    const int* ray_index;
+    const int* ray_count;
+    int scatter_rgb;
 } enerf_render_args_t;
 int enerf_render_rays(const enerf_render_args_t* args, enerf_stream_t stream);
+
+/* ---- mask_at_box -> ray index list (network_human.py:90-93: rays[mask_at_box]), stable order, no host sync.
+ * mask: n elements of elem_bytes in {1,2,4,8} (bool/uint8, int16, int32/float32, int64); an element selects its ray when
+ * any of its bytes is non-zero (.bool()).  index (n) int32: the first *count entries are the selected positions in
+ * ascending order; count (1) int32 on the device.  workspace: enerf_mask_compact_workspace_bytes(n). ---- */
+size_t enerf_mask_compact_workspace_bytes(long long n);
+int enerf_mask_compact(const void* mask, int elem_bytes, long long n, int* index, int* count, void* workspace,
+                       size_t workspace_bytes, enerf_stream_t stream);
+
+/* ---- Network.forward (network.py:76-113 / network_human.py:69-119): the WHOLE cascade in one call. ----
+ * FeatureNet -> for every level {get_proj_mats + get_depth_values, homo_warp + variance, cost regularisation,
+ * depth_regression, [build_rays + render_rays]} enqueued on `stream` from one C call (a non-Python host does not have to
+ * re-implement the cascade loop; the Python binding's forward() is this call).  All buffers are caller-owned; scratch
+ * comes from `workspace` (enerf_forward_workspace_bytes).  Nothing synchronises. */
+#define ENERF_MAX_LEVELS 3
+typedef struct {                               /* cfg.enerf.cas_config (configs/enerf/dtu_pretrain.yaml:27-43) */
+    int num;
+    int depth_inv[ENERF_MAX_LEVELS];
+    double volume_scale[ENERF_MAX_LEVELS];
+    int volume_planes[ENERF_MAX_LEVELS];
+    double im_feat_scale[ENERF_MAX_LEVELS];
+    double im_ibr_scale[ENERF_MAX_LEVELS];
+    double render_scale[ENERF_MAX_LEVELS];
+    int render_im_feat_level[ENERF_MAX_LEVELS];
+    int nerf_model_feat_ch[ENERF_MAX_LEVELS];
+    int render_if[ENERF_MAX_LEVELS];
+    int num_samples[ENERF_MAX_LEVELS];
+    int white_bkgd;                            /* cfg.enerf.white_bkgd (network.py:42) */
+} enerf_cascade_t;
+/* stage_events slots: after each stage of the frame the driver records the caller's hipEvent_t (if non-NULL) on `stream`
+ * — per-stage timings without leaving the single call.  Slot = ENERF_STAGE_FEATURE_NET, or
+ * ENERF_STAGE_LEVEL(level, ENERF_STAGE_{PREP,VOLUME,COST_REG,DEPTH_REG,TEXELS,RENDER}). */
+enum { ENERF_STAGE_BEGIN = 0, ENERF_STAGE_FEATURE_NET = 1, ENERF_STAGE_PREP = 0, ENERF_STAGE_VOLUME = 1,
+       ENERF_STAGE_COST_REG = 2, ENERF_STAGE_DEPTH_REG = 3, ENERF_STAGE_TEXELS = 4, ENERF_STAGE_RENDER = 5,
+       ENERF_STAGES_PER_LEVEL = 6, ENERF_STAGE_COUNT = 2 + 6 * ENERF_MAX_LEVELS };
+#define ENERF_STAGE_LEVEL(level, k) (2 + (level) * ENERF_STAGES_PER_LEVEL + (k))
+typedef struct {
+    /* the batch dict (lib/datasets/dtu/enerf.py:100-119) */
+    const float* src_inps;                     /* (B,S,3,H,W) in [-1,1] */
+    const float* src_exts;                     /* (B,S,4,4) world->camera */
+    const float* src_ixts;                     /* (B,S,3,3) */
+    const float* tar_ext;                      /* (B,4,4) */
+    const float* tar_ixt;                      /* (B,3,3) */
+    const float* near_far;                     /* (B,2) */
+    const float* rays[ENERF_MAX_LEVELS];       /* rays_{i} (B,n_rays[i],8); NULL for a rendered level = the full image at
+                                                  render_scale[i], generated on the device (enerf_utils.py:61-71) */
+    int n_rays[ENERF_MAX_LEVELS];
+    const void* mask_at_box;                   /* network_human.py:90-107 (last level, B == 1), (H*W) elements, or NULL */
+    int mask_elem_bytes;
+    int B, S, H, W;
+    enerf_cascade_t cas;
+    /* weight images (enerf_*_pack) */
+    const float* feature_net_packed;           /* may be NULL when feats_nchw is given */
+    const float* cost_reg_packed[ENERF_MAX_LEVELS];
+    const float* nerf_packed[ENERF_MAX_LEVELS];/* rendered levels only */
+    /* north_star's split: a FeatureNet run elsewhere (PyTorch-ROCm) hands over its NCHW maps
+     * feats_nchw[l] = feats['level_l'] (B*S,C_l,H_l,W_l), all three or none */
+    const float* feats_nchw[3];
+    /* outputs of every rendered level i (network.py:105-112); pointers of non-rendered levels are ignored */
+    float* rgb[ENERF_MAX_LEVELS];              /* (B,N_i,3); masked level: (1,H*W,3), zero outside the mask */
+    float* depth[ENERF_MAX_LEVELS];            /* (B,N_i);   masked level: first *ray_count rows */
+    float* weights[ENERF_MAX_LEVELS];          /* (B,N_i,num_samples[i]); masked level: first *ray_count rows */
+    float* depth_mvs[ENERF_MAX_LEVELS];        /* (B,h_i,w_i) */
+    float* std[ENERF_MAX_LEVELS];              /* (B,h_i,w_i) */
+    /* masked level: selected ray positions / their number, on the device.  If ray_index is NULL they are computed into
+     * the workspace; a caller that wants the count on the host passes its own buffers (see enerf_mask_compact). */
+    int* ray_index;                            /* (H*W) int32 or NULL */
+    int* ray_count;                            /* (1) int32 or NULL */
+    int ray_index_ready;                       /* 1: the caller already ran enerf_mask_compact into ray_index/ray_count */
+    void* workspace;
+    size_t workspace_bytes;
+    const enerf_options_t* options;
+    void* const* stage_events;                 /* ENERF_STAGE_COUNT hipEvent_t slots or NULL */
+} enerf_frame_args_t;
+size_t enerf_forward_workspace_bytes(const enerf_frame_args_t* args);   /* 0 + enerf_last_error() on invalid arguments */
+int enerf_forward(const enerf_frame_args_t* args, enerf_stream_t stream);
 
 /* ---- the steps before / after the path ----
  * enerf_gen_rays: full-image rays of lib/datasets/enerf_utils.py:61-71 on device.  tar_ext (B,4,4),

@@ -151,27 +151,6 @@ def test_full_size_dtu_eval_vs_oracle_and_properties():
     assert abs(O.psnr(rgb, gt) - O.psnr(ref["rgb_level1"], gt)) < 1e-3
 
 
-def test_two_stream_overlap_is_bit_identical_to_single_stream():
-    """Network(overlap=True) runs FPN levels 1-2 on a side stream under the level-0 cost volume; same kernels, so
-    the outputs must equal the single-stream run bit for bit — also back to back on changing inputs (a missing
-    event wait would show up as a race on the reused workspace / feature buffers)."""
-    cfg = EnerfConfig.dtu_eval()
-    net = _net(cfg)
-    batches = [_to({k: torch.from_numpy(v) for k, v in make_batch(256, 320, 3, cfg, seed=s, textured=True).items()})
-               for s in range(4)]
-    net.overlap = False
-    ref = [net(b) for b in batches]
-    torch.cuda.synchronize()
-    net.overlap = True
-    for _ in range(3):
-        outs = [net(b) for b in batches]               # no sync in between: frames queue up behind each other
-        torch.cuda.synchronize()
-        for o, r in zip(outs, ref):
-            for k in r:
-                assert torch.equal(o[k], r[k]), k
-    assert net._side_stream is not None and not net._feat_events
-
-
 def test_whole_frame_hip_graph_replay_matches_eager():
     """enerf_amd.graph.GraphedFrame: one captured forward replayed on new inputs == eager forward, bit for bit."""
     from enerf_amd.graph import GraphedFrame
