@@ -1,16 +1,21 @@
-"""bench.py — rendered frames/sec of the ENeRF path at 512x640, 3 source views (BASELINE.json metric).
+"""bench.py — rendered frames/sec of the MI355X-native ENeRF path (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 200 --warmup 20 [--workload dtu|lego|zju]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one ``Network.forward(batch)`` = one rendered frame (FeatureNet in PyTorch-ROCm + the HIP
-path), on the DTU eval configuration the reference quotes its 21.78 FPS on (README.md:113:
-``render_if False,True``, ``volume_planes 48,8``).  Inputs are synthetic, resident in
-HBM before the timed region; weights are random-init with randomised BN statistics.  Rendering is
-frame-parallel: every rank renders its own frames, no data-path collective (scaling = weak).
-Timing mirrors run.py:62-76 (sync both sides) with a barrier and max-over-ranks.
-Rank 0 prints ONE JSON line.
+A "step" is one ``Network.forward(batch)`` = one rendered frame: the HIP FeatureNet + the whole cascade through ONE
+``enerf_forward`` C call.  Default workload = BASELINE config 2, the configuration the reference quotes its 21.78 FPS on
+(README.md:113: DTU 512x640, 3 source views, ``render_if False,True``, ``volume_planes 48,8``); ``--workload lego`` /
+``zju`` are BASELINE configs 3 / 4 at their real shapes.  Inputs are synthetic, resident in HBM before
+the timed region; weights are random-init with randomised BN statistics.
+
+Protocol of ``value`` (SURVEY.md §8d = the reference's run.py:62-76): for each of the K timed frames
+``synchronize(); network(batch); synchronize()`` on one stream with the default kernel variants — so
+``value == 1 / latency_ms.mean`` — bracketed by a barrier + synchronize, MAX over ranks.  Rendering is frame-parallel
+(frame f -> rank f mod G, no data-path collective: scaling = weak; enerf_amd/frame_parallel.py).  Extra keys, never
+``value``: ``sequential_fps`` (same frames without the per-frame sync), ``pipelined_fps`` (frames in flight on several
+HIP streams with the throughput kernel options), ``sustained`` (>= 2000 frames).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -25,32 +30,25 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BASELINE_FPS_RTX3090 = 21.778975517304048      # BASELINE.md §1 / README.md:121
-PEAK_F32_MFMA_TFLOPS = 157.3                   # MI355X_MICROARCH.md
-FLOP_PER_SAMPLE_L1 = 50952                     # SURVEY.md §8a (a14+a15 derivation, S=3, F=11): reference dense count
-MFMA_TILES_PER_16 = 201                        # 16x16x4 fp32 MFMA tiles k_render_rays issues per 16 samples (render.hip header)
+BASELINE_FPS_RTX3090 = 21.778975517304048      # BASELINE.md §1 / README.md:121 (DTU eval config only)
+PEAK_F32_MFMA_TFLOPS = 157.3                   # MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32, 2.4 GHz)
+PEAK_HBM_GBS = 8000.0
 
 
 class StageTimer:
-    """Records a HIP event after every stage of Network.forward (same stream the kernels run on)."""
+    """Per-stage HIP events: enerf_forward records the events this object hands out (same stream as the kernels)."""
 
     def __init__(self):
         self.frames = []
-        self.cur = None
 
-    def begin(self):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        self.cur = [("begin", e)]
+    def new_events(self, n):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        for e in evs:
+            e.record()                                 # creates the underlying hipEvent_t; the C call re-records it
+        return evs
 
-    def mark(self, name):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        self.cur.append((name, e))
-
-    def end(self):
-        self.frames.append(self.cur)
-        self.cur = None
+    def frame(self, named_events):
+        self.frames.append(named_events)
 
     def summary(self):
         acc = {}
@@ -60,29 +58,62 @@ class StageTimer:
         return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
+# ---- algorithmic work --------------------------------------------------------------------------------
+def render_mfma_tiles_per_16(S, R):
+    """16x16x4 fp32 MFMA tiles k_render_rays issues per 16 samples (render.hip): view_fc, global_fc (shared + per view),
+    fc, lr0, color.0 (shared + per view)."""
+    TR = (R + 3) // 4
+    return S * TR + 4 * R + 2 * S * R + 8 + 24 + 88 + 4 * S * (R + 1)
+
+
+def render_dense_flop_per_sample(S, F):
+    """The reference's dense count of the same maths (SURVEY.md §8a derivation, nerf.py:29-89)."""
+    return 2 * 4 * F * S + 2 * 3 * F * 32 * S + 2 * 32 * S + 2 * 32 * 16 + 2 * 24 * 64 + 2 * 64 + (2 * (88 + F + 4) * 64 + 2 * 64) * S
+
+
+def cost_reg_gflop(C, full, D, h, w):
+    """Dense conv FLOPs of MinCostRegNet / CostRegNet (cost_reg_net.py) on a (C,D,h,w) volume."""
+    n0 = D * h * w
+    n1, n2, n3 = n0 // 8, n0 // 64, n0 // 512
+    f = 27 * 2 * (C * 8 * n0 + 8 * 16 * n1 + 16 * 16 * n1 + 16 * 32 * n2 + 32 * 32 * n2 + 32 * 16 * n2 + 16 * 8 * n1 + 8 * 9 * n0)
+    if full:
+        f += 27 * 2 * (32 * 64 * n3 + 64 * 64 * n3 + 64 * 32 * n3)
+    return f / 1e9
+
+
+def make_workload(name, rank):
+    from enerf_amd.config import EnerfConfig
+    from enerf_amd.synth import make_batch, make_lego_batch, make_zju_batch
+    if name == "dtu":
+        cfg = EnerfConfig.dtu_eval()
+        return cfg, make_batch(512, 640, 3, cfg, seed=rank, textured=True), False, \
+            "DTU generalizable eval (dtu_pretrain.yaml, render_if False,True, volume_planes 48,8), 512x640, 3 src views, one target view per step"
+    if name == "lego":
+        cfg = EnerfConfig()
+        return cfg, make_lego_batch(800, 800, 4, cfg, seed=rank), False, \
+            "NeRF-Synthetic lego (configs/enerf/nerf/lego.yaml: render_if True,True, volume_planes 64,8), 800x800, 4 src views"
+    if name == "zju":
+        cfg = EnerfConfig().with_cas(volume_planes=(32, 8), render_if=(False, True))
+        return cfg, make_zju_batch(1024, 1024, 4, cfg, seed=rank), True, \
+            "ZJU-MoCap CoreView_313 (zjumocap_eval.yaml at input_ratio 1.0: network_human, volume_planes 32,8, render_if False,True), 1024x1024, 4 src views, mask_at_box"
+    raise SystemExit(f"unknown workload {name}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", choices=["dtu", "lego", "zju"], default="dtu")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-stages", action="store_true")
-    ap.add_argument("--height", type=int, default=512)
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--views", type=int, default=3)
-    ap.add_argument("--miopen-benchmark", action="store_true", help="experiment: let MIOpen search conv algos")
-    ap.add_argument("--in-flight", type=int, default=6,
-                    help="frames in flight on separate HIP streams during the timed region (1 = sequential).  Measured on "
-                         "MI355X: 1 -> 1002, 2 -> 1141, 4 -> 1131-1218 (depends on how the streams land on the 4 hardware "
-                         "queues), 6 -> 1195, 7 -> 1203, 10 -> 1206 frames/s; default 6")
-    ap.add_argument("--no-throughput-tuning", action="store_true",
-                    help="keep the single-frame kernel choices inside the frame pipeline (enerf_amd/pipeline.py THROUGHPUT_KNOBS)")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay one captured HIP graph per frame (enerf_amd/graph.py) instead of enqueueing ~38 launches")
-    ap.add_argument("--overlap", action="store_true",
-                    help="enqueue FPN levels 1-2 on a second HIP stream next to the level-0 cost volume (default: one stream)")
+    ap.add_argument("--no-stages", action="store_true", help="skip everything after the timed region (profiling runs)")
+    ap.add_argument("--no-sync-per-frame", action="store_true",
+                    help="profiling runs: enqueue the timed frames back to back (value is then sequential_fps)")
+    ap.add_argument("--in-flight", type=int, default=6, help="frames in flight for the pipelined_fps extra")
+    ap.add_argument("--sustained-frames", type=int, default=2000)
+    ap.add_argument("--graph", action="store_true", help="time whole-frame HIP graph replays (enerf_amd/graph.py)")
     ap.add_argument("--feature-backend", choices=["hip", "torch"], default="hip",
-                    help="FeatureNet on the HIP matrix-core path (default) or in PyTorch-ROCm/MIOpen")
+                    help="FeatureNet on the HIP matrix-core path (default) or in PyTorch-ROCm/MIOpen (north_star's split)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -98,21 +129,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL
 
-    if args.miopen_benchmark:
-        torch.backends.cudnn.benchmark = True
     from __graft_entry__ import _seeded_network
-    from enerf_amd.config import EnerfConfig
-    from enerf_amd.synth import make_batch
+    from enerf_amd.frame_parallel import render_sharded
 
-    cfg = EnerfConfig.dtu_eval()
-    net = _seeded_network(cfg, dev, feature_backend=args.feature_backend)
-    net.overlap = bool(args.overlap)
-    H, W, S = args.height, args.width, args.views
-    batch_np = make_batch(H, W, S, cfg, seed=rank, textured=True)
+    cfg, batch_np, human, workload = make_workload(args.workload, rank)
+    cas = cfg.cas
+    net = _seeded_network(cfg, dev, human=human, feature_backend=args.feature_backend)
+    _, S, _, H, W = batch_np["src_inps"].shape
     batch = {k: torch.from_numpy(v).to(dev) for k, v in batch_np.items()}
+    last = cas.num - 1
 
-    if args.graph:                                      # whole-frame HIP graph replay instead of eager enqueue
+    if args.graph:
         from enerf_amd.graph import GraphedFrame
+        net.static_shapes = True
         frame = GraphedFrame(net, batch)
 
         def step():
@@ -121,77 +150,47 @@ def main():
         def step():
             return net(batch)
 
-    # Timed region: `steps` frames, each one full pass of the hot path, submitted round-robin to `in_flight` HIP streams
-    # (enerf_amd/pipeline.py; 1 = strictly one frame after the other on the current stream).  A frame is ~36 dependent
-    # launches, a third of them small cascade layers that leave most CUs idle: frames in flight fill those holes.
-    in_flight = 1 if (args.graph or args.overlap) else max(1, args.in_flight)
-    pipe = None
-    if in_flight > 1:
-        from enerf_amd.pipeline import FramePipeline
-        pipe = FramePipeline(net, depth=in_flight, throughput_tuning=not args.no_throughput_tuning)
+    out = None
 
-        def timed_step():
-            return pipe.submit(batch)[0]
-    else:
-        timed_step = step
+    def timed_frame(_f):                                # run.py:62-67: sync, network(batch), sync
+        nonlocal out
+        out = step()
+        if not args.no_sync_per_frame:
+            torch.cuda.synchronize()
+        return None
 
     for _ in range(args.warmup):
-        timed_step()
-    if pipe is not None:
-        pipe.join()
+        step()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = timed_step()
-    if pipe is not None:
-        pipe.join()
-    torch.cuda.synchronize()
-    if pipe is not None:
-        pipe.close()                                    # the measurements below use the default (latency) kernel choices
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert bool(torch.isfinite(out["rgb_level1"]).all()), "non-finite render"
+    # frame f -> rank f mod world: every rank renders `steps` frames; barrier + sync both sides, MAX over ranks
+    _, fps, elapsed = render_sharded(timed_frame, args.steps * world, rank, world, sync=torch.cuda.synchronize)
+    assert bool(torch.isfinite(out[f"rgb_level{last}"]).all()), "non-finite render"
 
     result = None
     if rank == 0:
-        fps = world * args.steps / elapsed
         result = {
-            "metric": "rendered frames/sec @512x640 3-src-view", "value": fps, "unit": "frames/s",
+            "metric": f"rendered frames/sec @{H}x{W} {S}-src-view", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": fps / BASELINE_FPS_RTX3090, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"DTU generalizable eval (dtu_pretrain.yaml, render_if False,True, "
-                                   f"volume_planes 48,8), {H}x{W}, {S} src views, one target view per step",
-                       "feature_net": args.feature_backend, "streams": 2 if (args.overlap and args.feature_backend == "hip") else 1, "hip_graph": bool(args.graph), "frames_in_flight": in_flight,
-                       "throughput_tuning": bool(pipe is not None and not args.no_throughput_tuning),
+            "vs_baseline": (fps / BASELINE_FPS_RTX3090) if args.workload == "dtu" else None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "feature_net": args.feature_backend, "hip_graph": bool(args.graph),
+                       "protocol": "per-frame synchronize (run.py:62-76), one stream, default kernel options"
+                                   if not args.no_sync_per_frame else "frames enqueued back to back on one stream",
                        "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world} (no collectives)"},
         }
+        if args.workload == "dtu":
+            result["vs_baseline_note"] = ("value / 21.78 FPS (README.md:121, one RTX 3090, the same per-frame-sync protocol); "
+                                          "for N > 1 the numerator is the whole-job aggregate")
 
-    # ---- per-stage HIP-event timings + roofline of the dominant kernel (rank 0, not in the timed region) ----
+    # ---- extras on rank 0 (not in the timed region) ----
     if rank == 0 and not args.no_stages and not args.graph:
         t0 = time.perf_counter()                      # host-side enqueue cost (no device sync inside)
-        for _ in range(20):
+        for _ in range(50):
             step()
-        result["host_enqueue_ms_per_step"] = round(1e3 * (time.perf_counter() - t0) / 20, 4)
+        result["host_enqueue_ms_per_step"] = round(1e3 * (time.perf_counter() - t0) / 50, 4)
         torch.cuda.synchronize()
-        timer = StageTimer()
-        net._timer = timer
-        for _ in range(20):
-            step()
-        torch.cuda.synchronize()
-        net._timer = None
-        stages = timer.summary()
-        result["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
-        # the reference's own protocol (run.py:62-76: synchronize, time network(batch), synchronize): per-frame latency
+        # the reference's protocol once more, as a distribution
         lat = []
         for _ in range(200):
             torch.cuda.synchronize()
@@ -202,83 +201,128 @@ def main():
         lat.sort()
         result["latency_ms"] = {"p50": round(lat[len(lat) // 2], 4), "p95": round(lat[int(len(lat) * 0.95)], 4),
                                 "mean": round(sum(lat) / len(lat), 4), "protocol": "sync per frame (run.py:62-76), 200 frames"}
-        # throughput when several target views share one forward (same API, batch dimension): not the headline
-        # (BASELINE's metric is one target view per step) — shows what the small cascade layers leave idle at B=1
-        try:
-            Bn = 4
-            bb = {k: torch.from_numpy(v).to(dev) for k, v in make_batch(H, W, S, cfg, seed=rank, textured=True, B=Bn).items()}
-            for _ in range(5):
-                net(bb)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(50):
-                net(bb)
-            torch.cuda.synchronize()
-            result["batched_throughput"] = {"target_views_per_forward": Bn,
-                                            "frames_per_s": round(Bn * 50 / (time.perf_counter() - t1), 1)}
-            del bb
-        except Exception as e:                                   # never let an extra break the contract line
-            result["batched_throughput"] = {"error": str(e)[:200]}
-        # the same frames strictly one after the other on one stream (what `value` was before frames were pipelined)
+        # the same frames strictly one after the other on one stream, no per-frame sync
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(200):
             step()
         torch.cuda.synchronize()
         result["sequential_fps"] = round(200 / (time.perf_counter() - t1), 1)
-        # per-stage rooflines (algorithmic FLOP or compulsory bytes of the 512x640/3-view frame)
-        if (H, W, S) == (512, 640, 3):
-            sr = {}
-            for name, gf in (("cost_reg_0", 5.63), ("cost_reg_1", 11.04)):
-                if stages.get(name):
-                    a = gf / stages[name]                               # GFLOP / ms = TFLOP/s
-                    sr[name] = {"bound": "mfma", "achieved": round(a, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(a / PEAK_F32_MFMA_TFLOPS, 4), "algorithmic_gflop": gf}
-            for name, mb in (("volume_0", 39.4), ("volume_1", 57.6)):
-                if stages.get(name):
-                    a = mb / stages[name]                               # MB / ms = GB/s
-                    sr[name] = {"bound": "hbm", "achieved": round(a, 1), "peak": 8000.0, "unit": "GB/s",
-                                "frac": round(a / 8000.0, 4), "algorithmic_mbytes": mb}
-            result["stage_roofline"] = sr
-        # dominant single kernel: the fused level-1 render launch (k_render_rays<3,3,*>): 2 samples x H*W rays
-        n_samples_total = H * W * cfg.cas.num_samples[1]
-        flops = FLOP_PER_SAMPLE_L1 * n_samples_total if (S == 3) else None
-        dur_ms = stages.get("render_1")
-        if flops and dur_ms:
-            # Algorithmic FLOPs per sample: the MLP after the exact factoring of the two
-            # view-shared linear layers = 201 MFMA tiles of 16x16x4 per 16 samples = 25,728 FLOP/sample on the
-            # matrix cores.  SURVEY.md 8a's 50,952 is the reference's dense count of the same arithmetic (369
-            # tiles); it is reported next to it, not used for `frac` (it would exceed the peak).
-            mfma_flops = MFMA_TILES_PER_16 * 2 * 16 * 16 * 4 / 16.0 * n_samples_total
-            ach = mfma_flops / (dur_ms * 1e-3) / 1e12
-            traffic, pmc_note, busy = None, None, None
-            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_render.json")     # separate rocprofv3 --pmc passes
-            if os.path.exists(pmc_path) and (H, W, S) == (512, 640, 3):
-                pmc = json.load(open(pmc_path))
-                traffic, pmc_note, busy = pmc["hbm_bytes_per_launch"], pmc["source"], pmc["mfma_busy_frac"]
-            result["roofline"] = {
-                "kernel": "k_render_rays<3,3> (level-1 fused render: sample placement + gathers + Agg/NeRF MLP + "
-                          "compositing)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                "algorithmic_flops_per_launch": mfma_flops, "avg_launch_ms": dur_ms,
-                "reference_dense_flops_per_launch": flops,
-                "reference_dense_tflops": flops / (dur_ms * 1e-3) / 1e12,
-                "note": "achieved = 25,728 FLOP/sample (201 fp32 16x16x4 MFMA tiles per 16 samples, the MLP with the "
-                        "view-independent halves of global_fc/color.0 evaluated once per point) x 655,360 samples / "
-                        "launch time; the reference's dense count of the same maths is 50,952 FLOP/sample (369 tiles)",
-                "mfma_pipe_busy_frac_pmc": busy, "traffic_source": pmc_note, "algorithmic_bytes_per_launch": 92.4e6}
+        # per-stage HIP events recorded inside enerf_forward
+        timer = StageTimer()
+        net._timer = timer
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        net._timer = None
+        stages = timer.summary()
+        result["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
 
-    # ---- CPU baseline: the oracle (torch CPU restatement of the reference) on this box's host cores ----
+        # sustained legs (>= 2000 frames: long enough for utilisation sampling) and the pipelined throughput
+        n_sus = max(0, args.sustained_frames)
+        if n_sus:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n_sus):
+                step()
+            torch.cuda.synchronize()
+            sus = {"frames": n_sus, "sequential_fps": round(n_sus / (time.perf_counter() - t1), 1)}
+            from enerf_amd.pipeline import FramePipeline
+            if human:
+                net.static_shapes = True              # no count readback: frames can be in flight
+            pipe = FramePipeline(net, depth=max(1, args.in_flight), throughput_tuning=True)
+            for _ in range(20):
+                pipe.submit(batch)
+            pipe.join()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n_sus):
+                pipe.submit(batch)
+            pipe.join()
+            torch.cuda.synchronize()
+            sus["pipelined_fps"] = round(n_sus / (time.perf_counter() - t1), 1)
+            pipe.close()
+            net.static_shapes = False
+            result["sustained"] = sus
+            result["pipelined_fps"] = {"value": sus["pipelined_fps"], "frames_in_flight": max(1, args.in_flight),
+                                       "options": "enerf_options_t{conv3d_pk8=2, render_blocks_per_cu=2}",
+                                       "note": "throughput of frames in flight on separate HIP streams; NOT the reference's "
+                                               "protocol, never `value`"}
+            if args.workload == "dtu":
+                result["vs_baseline_pipelined"] = round(sus["pipelined_fps"] / BASELINE_FPS_RTX3090, 2)
+
+        # ---- rooflines: per stage, and the dominant kernel as the contract's `roofline` object ----
+        sr = {}
+        for i in range(cas.num):
+            D, h, w = cas.volume_planes[i], int(H * cas.volume_scale[i]), int(W * cas.volume_scale[i])
+            C = 32 >> i
+            t = stages.get(f"cost_reg_{i}")
+            if t:
+                gf = cost_reg_gflop(C, i != 0, D, h, w)
+                sr[f"cost_reg_{i}"] = {"bound": "mfma", "achieved": round(gf / t, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": round(gf / t / PEAK_F32_MFMA_TFLOPS, 4),
+                                       "algorithmic_gflop": round(gf, 3)}
+            t = stages.get(f"volume_{i}")
+            if t:
+                Hs, Ws = H >> (2 - i), W >> (2 - i)
+                mb = (S * Hs * Ws * C + D * h * w * C + D * h * w) * 4 / 1e6       # features once + volume once + depth planes
+                sr[f"volume_{i}"] = {"bound": "hbm", "achieved": round(mb / t, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                     "frac": round(mb / t / PEAK_HBM_GBS, 4), "algorithmic_mbytes": round(mb, 2)}
+            t = stages.get(f"render_{i}")
+            if t and cas.render_if[i]:
+                F = cas.nerf_model_feat_ch[i] + 3
+                R = (F + 3) // 4
+                n_rays = int(out[f"depth_level{i}"].shape[1])
+                n_samples = n_rays * cas.num_samples[i]
+                tiles = render_mfma_tiles_per_16(S, R)
+                fl = tiles * 2 * 16 * 16 * 4 / 16.0 * n_samples
+                ach = fl / (t * 1e-3) / 1e12
+                sr[f"render_{i}"] = {"kernel": f"k_render_rays<{R},{S},{3 if R == 3 else 2}>", "bound": "mfma",
+                                     "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "avg_launch_ms": round(t, 4),
+                                     "mfma_tiles_per_16_samples": tiles, "samples": n_samples,
+                                     "algorithmic_flops_per_launch": fl,
+                                     "reference_dense_flops_per_launch": render_dense_flop_per_sample(S, F) * n_samples}
+        t = stages.get("feature_net")
+        if t and args.feature_backend == "hip":
+            gf = 14.64 * (S * H * W) / (3 * 512 * 640)                                  # SURVEY.md §2.2 probe, per pixel
+            sr["feature_net"] = {"bound": "mfma", "achieved": round(gf / t, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": round(gf / t / PEAK_F32_MFMA_TFLOPS, 4),
+                                 "algorithmic_gflop": round(gf, 3)}
+        result["stage_roofline"] = sr
+        dom = max((k for k in sr if k.startswith("render_")), key=lambda k: stages[k], default=None)
+        if dom is not None:
+            d = sr[dom]
+            traffic, pmc_note, busy = None, None, None
+            pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_render_{args.workload}.json")   # separate rocprofv3 --pmc passes
+            if os.path.exists(pmc_path):
+                pmc = json.load(open(pmc_path))
+                traffic, pmc_note, busy = pmc.get("hbm_bytes_per_launch"), pmc.get("source"), pmc.get("mfma_busy_frac")
+            result["roofline"] = {
+                "kernel": d["kernel"] + f" (level-{dom[-1]} fused render: sample placement + gathers + Agg/NeRF MLP + compositing)",
+                "bound": "mfma", "achieved": d["achieved"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": d["frac"], "traffic": traffic, "avg_launch_ms": d["avg_launch_ms"],
+                "avg_launch_ms_source": "HIP events recorded around the launch inside enerf_forward, on its stream, default "
+                                        "kernel options (the variant `value` is timed on)",
+                "algorithmic_flops_per_launch": d["algorithmic_flops_per_launch"],
+                "reference_dense_flops_per_launch": d["reference_dense_flops_per_launch"],
+                "note": f"achieved = {d['mfma_tiles_per_16_samples']} fp32 16x16x4 MFMA tiles per 16 samples (the MLP with the "
+                        "view-independent halves of global_fc/color.0 evaluated once per point) x samples / launch time",
+                "traffic_measured_live": False, "mfma_pipe_busy_frac_pmc": busy, "pmc_measured_live": False,
+                "traffic_source": pmc_note}
+
+    # ---- CPU baseline: the oracle (torch CPU restatement of the reference) on this box's host cores + parity ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import enerf_oracle as O
-        # torch CPU ops stop scaling (and regress) far below 256 threads: 8 threads rendered a frame in 8.2 s
-        # in the build container, 256 threads took 70 s on the GPU box.  Use at most 32 and say so.
+        from enerf_amd.synth import make_batch
+        # torch CPU ops stop scaling (and regress) far below 256 threads: 8 threads rendered a DTU frame in 8.2 s in the
+        # build container, 256 threads took 70 s on the GPU box.  Use at most 32 and say so.
         ncores = min(os.cpu_count() or 1, 32)
         torch.set_num_threads(ncores)
         sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
         cb = {k: torch.from_numpy(v) for k, v in batch_np.items()}
         with torch.no_grad():
-            small = {k: torch.from_numpy(v) for k, v in make_batch(64, 96, S, cfg, seed=0).items()}
+            small = {k: torch.from_numpy(v) for k, v in make_batch(64, 96, 3, cfg, seed=0).items()}
             O.forward(cfg, sd, small)                      # page-in / thread-pool warm-up (untimed)
             n_frames, t0 = 0, time.perf_counter()
             while n_frames < 1 or (time.perf_counter() - t0 < 10.0 and n_frames < 8):
@@ -286,11 +330,14 @@ def main():
                 n_frames += 1
             cpu_s = (time.perf_counter() - t0) / n_frames
         result["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": ncores, "kind": "port",
-                                  "sample": f"{n_frames} full {H}x{W} {S}-view frames through oracle/enerf_oracle.py "
-                                            f"(torch CPU, {ncores} of {os.cpu_count()} host threads), first small frame untimed"}
-        err = float((out["rgb_level1"].cpu() - ref["rgb_level1"]).abs().max())
-        result["parity_vs_oracle"] = {"rgb_level1_max_abs": err,
-                                      "psnr_db": O.psnr(out["rgb_level1"].cpu(), ref["rgb_level1"])}
+                                  "sample": f"{n_frames} full {H}x{W} {S}-view frame(s) of this workload through "
+                                            f"oracle/enerf_oracle.py (torch CPU, {ncores} of {os.cpu_count()} host threads), "
+                                            "first small frame untimed"}
+        net.static_shapes = False
+        o = net(batch)
+        key = f"rgb_level{last}"
+        err = float((o[key].cpu() - ref[key]).abs().max())
+        result["parity_vs_oracle"] = {f"{key}_max_abs": err, "psnr_db": O.psnr(o[key].cpu(), ref[key])}
 
     if rank == 0:
         print(json.dumps(result))

@@ -29,8 +29,11 @@ with open(out, "w", newline="") as fh:
     w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
     w.writeheader()
     w.writerows(rows)
-for r in rows:
-    if r["kernel"].startswith("k_render_rays"):
+# the dominant render kernel: the full-resolution level (R = 3 channels per lane group) when both levels render
+renders = [r for r in rows if r["kernel"].startswith("k_render_rays")]
+renders.sort(key=lambda r: 0 if r["kernel"].startswith("k_render_rays<3") else 1)
+for r in renders[:1]:
+    if True:
         js = {"kernel": r["kernel"], "source": f"rocprofv3 --pmc passes (tools/collect_profiles.sh), profiles/{tag}_pmc_per_kernel.csv",
               "fetch_size_kb": r.get("FETCH_SIZE"), "write_size_kb": r.get("WRITE_SIZE"),
               "hbm_bytes_per_launch": r["hbm_bytes_corrected"],
