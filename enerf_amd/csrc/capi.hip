@@ -411,15 +411,43 @@ int enerf_pack_rgb8(const float* rgb, int H, int W, int flip, unsigned char* out
     launch_pack_rgb8(rgb, H, W, flip, out, (hipStream_t)stream);
     return check_launch("pack_rgb8");
 }
-int enerf_eval_stats(const float* pred_rgb, const float* gt_rgb, const int* mask, long long n_rgb,
-                     const float* pred_depth, const float* gt_depth, long long n_depth, double* acc,
-                     enerf_stream_t stream) {
+int enerf_eval_stats(const float* pred_rgb, const float* gt_rgb, const void* mask, int mask_elem_bytes, long long n_rgb,
+                     int img_w, int img_h, int crop_h, int crop_w, const float* pred_depth, const float* gt_depth,
+                     long long n_depth, double* acc, enerf_stream_t stream) {
     REQUIRE(acc && n_rgb >= 0 && n_depth >= 0, "eval_stats: bad arguments");
     if (n_rgb > 0) REQUIRE(pred_rgb && gt_rgb, "eval_stats: rgb pointers missing");
     if (n_depth > 0) REQUIRE(pred_depth && gt_depth, "eval_stats: depth pointers missing");
+    if (mask) REQUIRE(mask_elem_bytes == 1 || mask_elem_bytes == 4, "eval_stats: mask must be uint8/bool or int32");
+    if (img_w > 0) REQUIRE(img_h > 0 && crop_h >= 0 && crop_w >= 0 && n_rgb % ((long long)img_w * img_h) == 0,
+                           "eval_stats: crop needs the image extent (n_rgb a multiple of img_w*img_h)");
     hipMemsetAsync(acc, 0, 6 * sizeof(double), (hipStream_t)stream);
     if (n_rgb + n_depth == 0) return ENERF_OK;
-    launch_eval_stats(pred_rgb, gt_rgb, mask, n_rgb, pred_depth, gt_depth, n_depth, acc, (hipStream_t)stream);
+    launch_eval_stats(pred_rgb, gt_rgb, mask, mask_elem_bytes, n_rgb, img_w, img_h, crop_h, crop_w, pred_depth, gt_depth,
+                      n_depth, acc, (hipStream_t)stream);
     return check_launch("eval_stats");
+}
+int enerf_gen_rays_at(const float* tar_ext, const float* tar_ixt, const int* xy, int B, int N, float scale, float* rays,
+                      enerf_stream_t stream) {
+    REQUIRE(tar_ext && tar_ixt && xy && rays && B > 0 && N >= 0 && scale > 0.f, "gen_rays_at: bad arguments");
+    if (N == 0) return ENERF_OK;
+    launch_gen_rays_at(tar_ext, tar_ixt, xy, B, N, scale, rays, (hipStream_t)stream);
+    return check_launch("gen_rays_at");
+}
+int enerf_rays_bbox_mask(const float* rays, const float* bounds, long long n, int* mask, enerf_stream_t stream) {
+    REQUIRE(rays && bounds && mask && n > 0, "rays_bbox_mask: bad arguments");
+    launch_rays_bbox_mask(rays, bounds, n, mask, (hipStream_t)stream);
+    return check_launch("rays_bbox_mask");
+}
+int enerf_select_views(const float* cam_points, int V, const float* c2w, int k, int* idx, enerf_stream_t stream) {
+    REQUIRE(cam_points && c2w && idx && V > 0 && V <= 1024 && k > 0 && k <= V, "select_views: bad arguments (V <= 1024, k <= V)");
+    launch_select_views(cam_points, V, c2w, k, idx, (hipStream_t)stream);
+    return check_launch("select_views");
+}
+int enerf_gather_views(const float* inps, const float* exts, const float* ixts, const int* idx, int k, int H, int W,
+                       float* src_inps, float* src_exts, float* src_ixts, enerf_stream_t stream) {
+    REQUIRE(inps && exts && ixts && idx && src_inps && src_exts && src_ixts && k > 0 && H > 0 && W > 0 &&
+                (long long)k * H * W >= 16LL * k, "gather_views: bad arguments");
+    launch_gather_views(inps, exts, ixts, idx, k, H, W, src_inps, src_exts, src_ixts, (hipStream_t)stream);
+    return check_launch("gather_views");
 }
 }  // extern "C"

@@ -109,8 +109,15 @@ void launch_pack_texels_cl(const float* feat_cl, int C, const float* src_inps, i
 void launch_gen_rays(const float* tar_ext, const float* tar_ixt, int B, int Hr, int Wr, float scale, float* rays,
                      hipStream_t st);
 void launch_pack_rgb8(const float* rgb, int H, int W, int flip, unsigned char* out, hipStream_t st);
-void launch_eval_stats(const float* pred_rgb, const float* gt_rgb, const int* mask, long long n_rgb,
-                       const float* pred_depth, const float* gt_depth, long long n_depth, double* acc, hipStream_t st);
+void launch_eval_stats(const float* pred_rgb, const float* gt_rgb, const void* mask, int mask_bytes, long long n_rgb,
+                       int img_w, int img_h, int crop_h, int crop_w, const float* pred_depth, const float* gt_depth,
+                       long long n_depth, double* acc, hipStream_t st);
+void launch_gen_rays_at(const float* tar_ext, const float* tar_ixt, const int* xy, int B, int N, float scale, float* rays,
+                        hipStream_t st);
+void launch_rays_bbox_mask(const float* rays, const float* bounds, long long n, int* mask, hipStream_t st);
+void launch_select_views(const float* cam_points, int V, const float* c2w, int k, int* idx, hipStream_t st);
+void launch_gather_views(const float* inps, const float* exts, const float* ixts, const int* idx, int k, int H, int W,
+                         float* src_inps, float* src_exts, float* src_ixts, hipStream_t st);
 
 // ---- frame.hip (mask_at_box compaction; the whole-frame driver enerf_forward lives there too) ---------
 size_t mask_compact_workspace_bytes(long long n);

@@ -142,7 +142,11 @@ _SIGNATURES = {
     "enerf_forward": (_i, [C.POINTER(FrameArgs), _f]),
     "enerf_gen_rays": (_i, [_f, _f, _i, _i, _i, _fl, _f, _f]),
     "enerf_pack_rgb8": (_i, [_f, _i, _i, _i, _f, _f]),
-    "enerf_eval_stats": (_i, [_f, _f, _f, _ll, _f, _f, _ll, _f, _f]),
+    "enerf_eval_stats": (_i, [_f, _f, C.c_void_p, _i, _ll, _i, _i, _i, _i, _f, _f, _ll, _f, _f]),
+    "enerf_gen_rays_at": (_i, [_f, _f, C.c_void_p, _i, _i, _fl, _f, _f]),
+    "enerf_rays_bbox_mask": (_i, [_f, _f, _ll, C.c_void_p, _f]),
+    "enerf_select_views": (_i, [_f, _i, _f, _i, C.c_void_p, _f]),
+    "enerf_gather_views": (_i, [_f, _f, _f, C.c_void_p, _i, _i, _i, _f, _f, _f, _f]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -420,22 +424,69 @@ class EnerfLib:
                     "pack_rgb8")
         return out
 
-    def eval_stats(self, pred_rgb, gt_rgb, mask=None, pred_depth=None, gt_depth=None):
-        """evaluators/enerf.py:67-71,88-103 on device -> dict(psnr, abs, acc_2, acc_10); one 48-byte D2H copy."""
+    def gen_rays_at(self, tar_ext, tar_ixt, xy, scale):
+        """lib/datasets/enerf_utils.py:45-56 (training branch) for the pixel list ``xy`` (B,N,2) int32 -> (B,N,8)."""
+        B, N = xy.shape[:2]
+        if xy.dtype != torch.int32 or not xy.is_contiguous():
+            raise EnerfError("xy must be a contiguous int32 tensor (B,N,2)")
+        rays = torch.empty((B, N, 8), dtype=torch.float32, device=tar_ext.device)
+        self._check(self.dll.enerf_gen_rays_at(_ptr(tar_ext), _ptr(tar_ixt), xy.data_ptr(), B, N, float(scale), _ptr(rays),
+                                               self.stream_of(rays)), "gen_rays_at")
+        return rays
+
+    def rays_bbox_mask(self, rays, bounds):
+        """lib/utils/net_utils.py:13-28 gen_rays_bbox: rays (N,8), bounds (2,3) -> int32 mask (N)."""
+        n = rays.shape[0]
+        mask = torch.empty((n,), dtype=torch.int32, device=rays.device)
+        self._check(self.dll.enerf_rays_bbox_mask(_ptr(rays), _ptr(bounds), n, mask.data_ptr(), self.stream_of(rays)),
+                    "rays_bbox_mask")
+        return mask
+
+    def select_views(self, cam_points, c2w, k):
+        """zjumocap/enerf_interactive.py:207-210: indices (k) int32 of the cameras nearest to the target camera."""
+        idx = torch.empty((k,), dtype=torch.int32, device=cam_points.device)
+        self._check(self.dll.enerf_select_views(_ptr(cam_points), cam_points.shape[0], _ptr(c2w), k, idx.data_ptr(),
+                                                self.stream_of(cam_points)), "select_views")
+        return idx
+
+    def gather_views(self, inps, exts, ixts, idx):
+        """:214-217: inps (V,H,W,3), exts (V,4,4), ixts (V,3,3) + idx (k) -> src_inps (k,3,H,W), src_exts, src_ixts."""
+        V, H, W, _ = inps.shape
+        k, dev = idx.numel(), inps.device
+        si = torch.empty((k, 3, H, W), dtype=torch.float32, device=dev)
+        se = torch.empty((k, 4, 4), dtype=torch.float32, device=dev)
+        sk = torch.empty((k, 3, 3), dtype=torch.float32, device=dev)
+        self._check(self.dll.enerf_gather_views(_ptr(inps), _ptr(exts), _ptr(ixts), idx.data_ptr(), k, H, W, _ptr(si),
+                                                _ptr(se), _ptr(sk), self.stream_of(inps)), "gather_views")
+        return si, se, sk
+
+    def eval_stats(self, pred_rgb, gt_rgb, mask=None, pred_depth=None, gt_depth=None, image_hw=None, crop=(0, 0),
+                   sync=True):
+        """evaluators/enerf.py:45-71,88-103 on device.  Returns dict(psnr[, abs, acc_2, acc_10]) after ONE 48-byte D2H
+        copy — or, with ``sync=False``, the 6-double device accumulator (see include/enerf_hip.h)."""
         acc = torch.empty((6,), dtype=torch.float64, device=pred_rgb.device)
         n_rgb = pred_rgb.numel() // 3
-        if mask is not None and (mask.dtype != torch.int32 or not mask.is_contiguous()):
-            raise EnerfError("mask must be a contiguous int32 tensor")
+        mb = 0
+        if mask is not None:
+            if mask.dtype not in (torch.int32, torch.uint8, torch.bool) or not mask.is_contiguous():
+                raise EnerfError("mask must be a contiguous int32 / uint8 / bool tensor")
+            mb = mask.element_size()
         n_d = 0 if pred_depth is None else pred_depth.numel()
-        self._check(self.dll.enerf_eval_stats(_ptr(pred_rgb), _ptr(gt_rgb), None if mask is None else mask.data_ptr(),
-                                              n_rgb, _ptr(pred_depth), _ptr(gt_depth), n_d, acc.data_ptr(),
-                                              self.stream_of(pred_rgb)), "eval_stats")
-        a = acc.cpu().tolist()
-        import math
-        out = {"psnr": 10.0 * math.log10(a[1] / a[0]) if a[0] > 0 else float("inf")}
-        if n_d and a[3] > 0:
-            out.update(abs=a[2] / a[3], acc_2=a[4] / a[3], acc_10=a[5] / a[3])
-        return out
+        h, w = image_hw if image_hw is not None else (0, 0)
+        self._check(self.dll.enerf_eval_stats(_ptr(pred_rgb), _ptr(gt_rgb), None if mask is None else mask.data_ptr(), mb,
+                                              n_rgb, int(w), int(h), int(crop[0]), int(crop[1]), _ptr(pred_depth),
+                                              _ptr(gt_depth), n_d, acc.data_ptr(), self.stream_of(pred_rgb)), "eval_stats")
+        if not sync:
+            return acc
+        return stats_from_acc(acc.cpu().tolist())
+
+
+def stats_from_acc(a) -> dict:
+    import math
+    out = {"psnr": 10.0 * math.log10(a[1] / a[0]) if a[0] > 0 else float("inf")}
+    if a[3] > 0:
+        out.update(abs=a[2] / a[3], acc_2=a[4] / a[3], acc_10=a[5] / a[3])
+    return out
 
 
 _LIB: Optional[EnerfLib] = None

@@ -276,18 +276,36 @@ size_t enerf_forward_workspace_bytes(const enerf_frame_args_t* args);   /* 0 + e
 int enerf_forward(const enerf_frame_args_t* args, enerf_stream_t stream);
 
 /* ---- the steps before / after the path ----
- * enerf_gen_rays: full-image rays of lib/datasets/enerf_utils.py:61-71 on device.  tar_ext (B,4,4),
- *   tar_ixt (B,3,3); rays (B,Hr*Wr,8) = [o, d, x, y] at intrinsics scaled by `scale`.
- * enerf_pack_rgb8: gui_human.py:88-91 (x255, uint8, optional vertical flip); rgb (H*W,3) -> out (H,W,3) bytes.
- * enerf_eval_stats: evaluators/enerf.py:67-71,88-103.  acc (6 doubles, zeroed by this call):
- *   {sum sq rgb err over mask==1 (x3 ch), its count, sum |depth-gt| over gt!=0, count, #(<2), #(<10)};
- *   mask may be NULL (all pixels); pass n_depth = 0 to skip the depth part. */
+ * Before (ray generation, view selection):
+ *   enerf_gen_rays        full-image rays of lib/datasets/enerf_utils.py:61-71: rays (B,Hr*Wr,8) = [o, d, x, y] at the
+ *                         intrinsics scaled by `scale`; tar_ext (B,4,4), tar_ixt (B,3,3).
+ *   enerf_gen_rays_at     the training branch (enerf_utils.py:33-56): rays of the pixel list xy (B,N,2) int32 = (X,Y) the
+ *                         host RNG picked (mask / patch sampling stays numpy, bit-compatible with the reference's seeds).
+ *   enerf_rays_bbox_mask  gen_rays_bbox (lib/utils/net_utils.py:13-28): mask (n) int32 = ray hits the box bounds (2,3);
+ *                         origin of the first ray, like the reference.  Bit-exact fp32 restatement.
+ *   enerf_select_views    zjumocap/enerf_interactive.py:207-210: idx (k) int32 = the k cameras of cam_points (V,3) nearest
+ *                         to the target camera centre c2w[:3,3] (c2w (4,4)), nearest first.
+ *   enerf_gather_views    :214-217: inps (V,H,W,3) -> src_inps (k,3,H,W); exts (V,4,4) / ixts (V,3,3) -> (k,...).
+ * After (presentation, evaluation):
+ *   enerf_pack_rgb8       gui_human.py:88-91 (x255, uint8, optional vertical flip); rgb (H*W,3) -> out (H,W,3) bytes;
+ *                         bit-exact on [0,1]; outside it saturates (the reference's cast is undefined there).
+ *   enerf_eval_stats      evaluators/enerf.py:45-71,88-103.  acc (6 doubles, zeroed by this call):
+ *     {sum sq rgb err over selected pixels (x3 ch, float64 like skimage), its count, sum |depth-gt| over gt!=0 (float32
+ *     differences like numpy), count, #(<2), #(<10)}; mask (n_rgb, uint8/bool or int32; selected = value >= 1) may be
+ *     NULL; img_w > 0 enables the eval_center crop [crop_h:-crop_h, crop_w:-crop_w] of (img_h,img_w) images
+ *     (n_rgb = B*img_h*img_w); pass n_depth = 0 to skip the depth part. */
 int enerf_gen_rays(const float* tar_ext, const float* tar_ixt, int B, int Hr, int Wr, float scale, float* rays,
                    enerf_stream_t stream);
+int enerf_gen_rays_at(const float* tar_ext, const float* tar_ixt, const int* xy, int B, int N, float scale, float* rays,
+                      enerf_stream_t stream);
+int enerf_rays_bbox_mask(const float* rays, const float* bounds, long long n, int* mask, enerf_stream_t stream);
+int enerf_select_views(const float* cam_points, int V, const float* c2w, int k, int* idx, enerf_stream_t stream);
+int enerf_gather_views(const float* inps, const float* exts, const float* ixts, const int* idx, int k, int H, int W,
+                       float* src_inps, float* src_exts, float* src_ixts, enerf_stream_t stream);
 int enerf_pack_rgb8(const float* rgb, int H, int W, int flip, unsigned char* out, enerf_stream_t stream);
-int enerf_eval_stats(const float* pred_rgb, const float* gt_rgb, const int* mask, long long n_rgb,
-                     const float* pred_depth, const float* gt_depth, long long n_depth, double* acc,
-                     enerf_stream_t stream);
+int enerf_eval_stats(const float* pred_rgb, const float* gt_rgb, const void* mask, int mask_elem_bytes, long long n_rgb,
+                     int img_w, int img_h, int crop_h, int crop_w, const float* pred_depth, const float* gt_depth,
+                     long long n_depth, double* acc, enerf_stream_t stream);
 
 #ifdef __cplusplus
 }
