@@ -99,6 +99,69 @@ def make_workload(name, rank):
     raise SystemExit(f"unknown workload {name}")
 
 
+def train_bench(args, rank, world, dev, dist):
+    """Config 5: trainer.py:56-63 on the drop-in network — forward (train mode, BN batch statistics),
+    the MSE part of losses/enerf.py:21-24, backward (DDP gradient all-reduce over RCCL when world > 1),
+    clip_grad_value_(40), Adam step.  Data-parallel: one sample per GPU per step (dtu_pretrain.yaml:60), weak scaling."""
+    import numpy as np
+    import torch.nn.functional as F
+    from __graft_entry__ import _seeded_network
+    from enerf_amd.config import EnerfConfig
+    from enerf_amd.synth import make_batch
+    cfg = EnerfConfig()                                                  # dtu_pretrain.yaml: planes 64,8, render_if True,True
+    net = _seeded_network(cfg, dev).train()
+    model = net
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        model = DDP(torch.nn.SyncBatchNorm.convert_sync_batchnorm(net), device_ids=[dev.index], output_device=dev.index,
+                    find_unused_parameters=True)                         # trainer.py:15-22
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    b = make_batch(512, 640, 3, cfg, seed=rank, textured=True)
+    rng = np.random.default_rng(rank)
+    for i in range(2):
+        b[f"rgb_{i}"] = rng.uniform(0, 1, size=(1, b[f"rays_{i}"].shape[1], 3)).astype(np.float32)
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+
+    def step():
+        out = model(batch)
+        loss = sum(w * F.mse_loss(batch[f"rgb_{i}"], out[f"rgb_level{i}"]) for i, w in enumerate((0.1, 1.0)))
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_value_(net.parameters(), 40)
+        opt.step()
+        return loss
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training samples/sec (dtu_pretrain, 512x640, 3 src views, full-image rays at both levels)",
+            "value": world * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "final_loss": float(loss),
+            "config": {"workload": "BASELINE config 5: DTU dtu_pretrain training, one sample per GPU per step, MSE loss "
+                                   "(losses/enerf.py:21-24; the VGG perceptual term needs downloaded weights), Adam, "
+                                   "clip_grad_value_ 40", "parallelism": f"DDP x{world} + SyncBatchNorm over RCCL" if world > 1 else "single GPU",
+                       "backward": "PyTorch-ROCm autograd (enerf_amd/train_path.py); HIP backward kernels not built yet"}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +175,9 @@ def main():
     ap.add_argument("--in-flight", type=int, default=6, help="frames in flight for the pipelined_fps extra")
     ap.add_argument("--sustained-frames", type=int, default=2000)
     ap.add_argument("--graph", action="store_true", help="time whole-frame HIP graph replays (enerf_amd/graph.py)")
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE config 5 instead of rendering: one step = forward + MSE loss + backward + Adam step of "
+                         "dtu_pretrain (512x640, 3 views, full-image rays at both levels, bs 1 per GPU), DDP over RCCL for N > 1")
     ap.add_argument("--feature-backend", choices=["hip", "torch"], default="hip",
                     help="FeatureNet on the HIP matrix-core path (default) or in PyTorch-ROCm/MIOpen (north_star's split)")
     args = ap.parse_args()
@@ -132,6 +198,8 @@ def main():
     from __graft_entry__ import _seeded_network
     from enerf_amd.frame_parallel import render_sharded
 
+    if args.train:
+        return train_bench(args, rank, world, dev, dist)
     cfg, batch_np, human, workload = make_workload(args.workload, rank)
     cas = cfg.cas
     net = _seeded_network(cfg, dev, human=human, feature_backend=args.feature_backend)

@@ -11,9 +11,8 @@ What runs where:
     (``enerf_amd/lib.py`` -> ``libenerf_hip.so``).  The ``cost_reg_*`` / ``nerf_*`` sub-modules here only
     OWN the parameters (so checkpoints, ``.cuda()``, ``SyncBatchNorm.convert_sync_batchnorm`` keep
     working); their weights are re-laid-out once per load into MFMA operand images by device kernels.
-There is no eager fallback: without the built library ``forward`` raises.
-Training (autograd through the HIP path) is the first "next" row of SURVEY.md §8f and not built yet:
-``forward`` raises in ``.train()`` mode instead of silently computing something else.
+There is no eager fallback for inference: without the built library ``forward`` raises in ``.eval()`` mode.
+In ``.train()`` mode ``forward`` is the differentiable path of ``enerf_amd/train_path.py``.
 """
 from __future__ import annotations
 
@@ -387,8 +386,11 @@ class Network(nn.Module):
 
     def _forward(self, batch, options):
         if self.training:
-            raise NotImplementedError("enerf_amd.Network: the HIP path is inference-only for now "
-                                      "(training backward is SURVEY.md §8f row 1); call .eval()")
+            # trainer.py:56-63 / losses/enerf.py:16-56: the differentiable path on this network's own parameter modules
+            # (BatchNorm batch statistics, autograd, DDP-ready) — enerf_amd/train_path.py
+            from .train_path import forward_train
+            self.invalidate_packed()                   # the optimizer is about to change what the packed images hold
+            return forward_train(self, batch)
         cas, lib = self.cfg.cas, self.lib
         self._tex_cache = None
         src = batch["src_inps"]

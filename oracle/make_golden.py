@@ -162,18 +162,83 @@ def run_case(name: str) -> None:
           f"max {rgb.max():.4f}; keys {sorted(out)}")
 
 
+TRAIN_CASE = dict(H=32, W=64, S=3, planes=(8, 8), render_if=(True, True), seed=7, loss_weight=(0.1, 1.0))
+
+
+def grad_digest(g: torch.Tensor) -> dict:
+    """Full gradient for small parameters; head + tail + norm + sum for the big ones (keeps the fixture small)."""
+    f = g.detach().reshape(-1)
+    if f.numel() <= 4096:
+        return {"full": f.numpy()}
+    return {"head": f[:2048].numpy(), "tail": f[-2048:].numpy(), "norm": np.array(float(f.double().norm())),
+            "sum": np.array(float(f.double().sum()))}
+
+
+def run_train_case() -> None:
+    """One training step of the UNMODIFIED reference network (``.train()``: BN batch statistics, autograd) under the MSE
+    part of lib/train/losses/enerf.py:21-24 (loss_weight from dtu_pretrain.yaml:43; the VGG perceptual term needs
+    downloaded torchvision weights and is left out).  Writes tests/golden/train_tiny.npz: loss, outputs, parameter
+    gradients (digests) and the updated BN running statistics."""
+    from oracle.ref_loader import load_reference
+    from enerf_amd.config import EnerfConfig
+    from enerf_amd.synth import make_batch
+
+    c = TRAIN_CASE
+    opts = ["enerf.cas_config.volume_planes", ",".join(map(str, c["planes"])),
+            "enerf.cas_config.render_if", ",".join(map(str, c["render_if"]))]
+    cfg, ref_network = load_reference("configs/enerf/dtu_pretrain.yaml", opts)
+    assert tuple(cfg.enerf.cas_config.loss_weight) == c["loss_weight"]
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    net = ref_network.Network()
+    net.load_state_dict(seeded_state_dict(net))
+    wnp = np.load(os.path.join(GOLDEN, "weights_seed0.npz"))
+    assert all(np.array_equal(wnp[k], v.numpy()) for k, v in net.state_dict().items() if k in wnp.files)
+    net.train()
+    ecfg = EnerfConfig.from_yacs(cfg)
+    b = make_batch(c["H"], c["W"], c["S"], ecfg, seed=c["seed"], textured=True)
+    rng = np.random.default_rng(c["seed"])
+    for i in range(2):
+        b[f"rgb_{i}"] = rng.uniform(0, 1, size=(1, b[f"rays_{i}"].shape[1], 3)).astype(np.float32)
+    batch = {k: torch.from_numpy(v) for k, v in b.items()}
+    out = net(batch)
+    loss = sum(c["loss_weight"][i] * torch.nn.functional.mse_loss(batch[f"rgb_{i}"], out[f"rgb_level{i}"]) for i in range(2))
+    loss.backward()
+    save = {"loss": np.array(float(loss))}
+    save.update({f"out/{k}": v.detach().numpy() for k, v in out.items()})
+    for i in range(2):
+        save[f"in/rgb_{i}"] = b[f"rgb_{i}"]
+    n_grad = 0
+    for name, p_ in net.named_parameters():
+        if p_.grad is None:
+            save[f"nograd/{name}"] = np.array(1)
+            continue
+        n_grad += 1
+        for k, v in grad_digest(p_.grad).items():
+            save[f"grad/{name}/{k}"] = v
+    for name, buf in net.named_buffers():
+        if name.endswith("running_mean") or name.endswith("running_var"):
+            save[f"buf/{name}"] = buf.numpy()
+    save["meta/torch_version"] = np.array(torch.__version__)
+    np.savez_compressed(os.path.join(GOLDEN, "train_tiny.npz"), **save)
+    print(f"[golden] train_tiny: loss {float(loss):.6f}; {n_grad} parameter gradients; {len(save)} arrays")
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--case", default=None)
     a = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
+    if a.case == "train_tiny":
+        run_train_case()
+        return
     if a.case:
         run_case(a.case)
         return
     wpath = os.path.join(GOLDEN, "weights_seed0.npz")
     if os.path.exists(wpath):
         os.remove(wpath)
-    for name in CASES:
+    for name in list(CASES) + ["train_tiny"]:
         subprocess.run([sys.executable, os.path.abspath(__file__), "--case", name], check=True, cwd=ROOT)
 
 

@@ -47,12 +47,6 @@ def test_state_dict_names_match_reference():
     net.load_state_dict(sd, strict=False)
 
 
-def test_training_mode_is_loud():
-    net = Network(EnerfConfig(), lib=emu_lib()).train()
-    with pytest.raises(NotImplementedError):
-        net(case_batch("tiny_s3"))
-
-
 def test_batch2_ragged_rays_and_white_bkgd():
     """B=2, a ray list whose length is not a multiple of the 16-ray tile, white_bkgd quirk, vs oracle."""
     cfg = EnerfConfig(white_bkgd=True).with_cas(volume_planes=(8, 8))

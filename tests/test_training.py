@@ -1,0 +1,180 @@
+"""Training path (BASELINE config 5): ``Network.train()`` + autograd + DDP.
+
+PINNED to the reference: tests/golden/train_tiny.npz holds one training step of the unmodified reference network
+(``.train()``: BatchNorm batch statistics) under the MSE part of lib/train/losses/enerf.py:21-24 — loss, outputs, the
+gradient of every parameter (digests) and the updated BN running statistics (oracle/make_golden.py --case train_tiny)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+from enerf_amd.config import EnerfConfig
+from enerf_amd.network import Network
+from enerf_amd.synth import make_batch
+from golden_cases import GOLDEN, load_weights
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LOSS_W = (0.1, 1.0)                                   # configs/enerf/dtu_pretrain.yaml:43
+
+
+def _train_batch(seed=7, H=32, W=64, S=3):
+    cfg = EnerfConfig().with_cas(volume_planes=(8, 8), render_if=(True, True))
+    b = make_batch(H, W, S, cfg, seed=seed, textured=True)
+    rng = np.random.default_rng(seed)
+    for i in range(2):
+        b[f"rgb_{i}"] = rng.uniform(0, 1, size=(1, b[f"rays_{i}"].shape[1], 3)).astype(np.float32)
+    return cfg, {k: torch.from_numpy(v) for k, v in b.items()}
+
+
+def _loss(out, batch):                                # losses/enerf.py:21-24
+    return sum(LOSS_W[i] * F.mse_loss(batch[f"rgb_{i}"], out[f"rgb_level{i}"]) for i in range(2))
+
+
+def _net(cfg):
+    net = Network(cfg)
+    net.load_state_dict(load_weights(), strict=False)
+    return net.train()
+
+
+def test_training_step_matches_reference_gradients():
+    g = np.load(os.path.join(GOLDEN, "train_tiny.npz"))
+    cfg, batch = _train_batch()
+    for i in range(2):
+        assert np.array_equal(batch[f"rgb_{i}"].numpy(), g[f"in/rgb_{i}"])
+    torch.set_num_threads(1)
+    net = _net(cfg)
+    out = net(batch)
+    loss = _loss(out, batch)
+    assert float(loss) == pytest.approx(float(g["loss"]), rel=1e-5)
+    for k in [k[4:] for k in g.files if k.startswith("out/")]:
+        np.testing.assert_allclose(out[k].detach().numpy(), g["out/" + k], rtol=2e-4, atol=2e-5, err_msg=k)
+    loss.backward()
+    checked = 0
+    for name, p in net.named_parameters():
+        if f"nograd/{name}" in g.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        f = p.grad.reshape(-1)
+        scale = max(float(f.abs().max()), 1e-12)
+        if f"grad/{name}/full" in g.files:
+            ref = g[f"grad/{name}/full"]
+            assert np.abs(f.numpy() - ref).max() <= 2e-4 * max(scale, np.abs(ref).max()) + 1e-9, name
+        else:
+            for part, sl in (("head", slice(0, 2048)), ("tail", slice(-2048, None))):
+                ref = g[f"grad/{name}/{part}"]
+                assert np.abs(f[sl].numpy() - ref).max() <= 2e-4 * max(scale, np.abs(ref).max()) + 1e-9, (name, part)
+            assert float(f.double().norm()) == pytest.approx(float(g[f"grad/{name}/norm"]), rel=2e-4)
+        checked += 1
+    assert checked >= 110
+    # BatchNorm running statistics were updated like the reference's (momentum 0.1, unbiased variance)
+    for name, buf in net.named_buffers():
+        if f"buf/{name}" in g.files:
+            np.testing.assert_allclose(buf.numpy(), g[f"buf/{name}"], rtol=1e-4, atol=1e-6, err_msg=name)
+
+
+def test_train_then_eval_repacks_weights():
+    """An optimizer step changes the parameters; the eval-mode HIP path must see the new ones (packed images rebuilt)."""
+    from emu_lib import emu_lib
+    cfg, batch = _train_batch()
+    net = Network(cfg, lib=emu_lib())
+    net.load_state_dict(load_weights(), strict=False)
+    net.eval()
+    with torch.no_grad():
+        before = net(batch)["rgb_level1"].clone()
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    loss = _loss(net(batch), batch)
+    opt.zero_grad()
+    loss.backward()
+    torch.nn.utils.clip_grad_value_(net.parameters(), 40)            # trainer.py:62
+    opt.step()
+    net.eval()
+    with torch.no_grad():
+        after = net(batch)["rgb_level1"]
+    from oracle import enerf_oracle as O
+    with torch.no_grad():
+        ref = O.forward(cfg, {k: v.detach() for k, v in net.state_dict().items()}, batch)["rgb_level1"]
+    assert float((after - before).abs().max()) > 1e-5                 # the step changed the image ...
+    assert float((after - ref).abs().max()) < 1e-4                    # ... and the HIP path renders the NEW weights
+
+
+def _ddp_worker(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    cfg, batch = _train_batch(seed=20 + rank)                          # DistributedSampler: a different sample per rank
+    net = DDP(_net(cfg), find_unused_parameters=True)                  # trainer.py:17-22
+    loss = _loss(net(batch), batch)
+    loss.backward()                                                    # gradient all-reduce (RCCL on GPUs, gloo here)
+    grads = {n: p.grad.clone() for n, p in net.module.named_parameters() if p.grad is not None}
+    q.put((rank, float(loss), {n: v.numpy() for n, v in grads.items()}))
+    dist.destroy_process_group()
+
+
+def test_two_rank_ddp_gradients_equal_mean_of_single_process_gradients():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    [p.join(60) for p in procs]
+    # both ranks hold the same (averaged) gradients
+    for n in res[0][2]:
+        np.testing.assert_allclose(res[0][2][n], res[1][2][n], rtol=1e-6, atol=1e-9, err_msg=n)
+    # = the mean of the two single-process gradients
+    torch.set_num_threads(1)
+    single = []
+    for rank in range(2):
+        cfg, batch = _train_batch(seed=20 + rank)
+        net = _net(cfg)
+        loss = _loss(net(batch), batch)
+        loss.backward()
+        assert float(loss) == pytest.approx(res[rank][1], rel=1e-5)
+        single.append({n: p.grad for n, p in net.named_parameters() if p.grad is not None})
+    for n, v in res[0][2].items():
+        mean = 0.5 * (single[0][n] + single[1][n]).numpy()
+        assert np.abs(v - mean).max() <= 2e-5 * max(np.abs(mean).max(), 1e-12) + 1e-10, n
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_training_step_on_gpu_matches_reference_gradients():
+    """The same reference-pinned step on the MI355X (PyTorch-ROCm autograd: MIOpen convolutions, atomics in the
+    grid_sample backward -> a looser tolerance than the CPU run), then an optimizer step and an eval-mode HIP frame."""
+    g = np.load(os.path.join(GOLDEN, "train_tiny.npz"))
+    dev = torch.device("cuda:0")
+    cfg, batch = _train_batch()
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    net = _net(cfg).to(dev)
+    out = net(batch)
+    loss = _loss(out, batch)
+    assert float(loss) == pytest.approx(float(g["loss"]), rel=1e-4)
+    loss.backward()
+    bad = []
+    for name, p in net.named_parameters():
+        if f"grad/{name}/norm" in g.files:
+            if abs(float(p.grad.double().norm()) - float(g[f"grad/{name}/norm"])) > 2e-3 * float(g[f"grad/{name}/norm"]) + 1e-9:
+                bad.append(name)
+        elif f"grad/{name}/full" in g.files:
+            ref = g[f"grad/{name}/full"]
+            if np.abs(p.grad.reshape(-1).cpu().numpy() - ref).max() > 2e-3 * np.abs(ref).max() + 1e-8:
+                bad.append(name)
+    assert not bad, bad
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    opt.step()
+    net.eval()
+    with torch.no_grad():
+        img = net(batch)["rgb_level1"]                                   # the HIP path, re-packed weights
+    from oracle import enerf_oracle as O
+    with torch.no_grad():
+        ref = O.forward(cfg, {k: v.detach().cpu() for k, v in net.state_dict().items()},
+                        {k: v.cpu() for k, v in batch.items()})["rgb_level1"]
+    assert float((img.cpu() - ref).abs().max()) < 1e-4
