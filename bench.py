@@ -313,7 +313,7 @@ def main():
             net.static_shapes = False
             result["sustained"] = sus
             result["pipelined_fps"] = {"value": sus["pipelined_fps"], "frames_in_flight": max(1, args.in_flight),
-                                       "options": "enerf_options_t{conv3d_pk8=2, render_blocks_per_cu=2}",
+                                       "options": "enerf_options_t{conv3d_pk8=2}",
                                        "note": "throughput of frames in flight on separate HIP streams; NOT the reference's "
                                                "protocol, never `value`"}
             if args.workload == "dtu":
@@ -345,7 +345,7 @@ def main():
                 tiles = render_mfma_tiles_per_16(S, R)
                 fl = tiles * 2 * 16 * 16 * 4 / 16.0 * n_samples
                 ach = fl / (t * 1e-3) / 1e12
-                sr[f"render_{i}"] = {"kernel": f"k_render_rays<{R},{S},{3 if R == 3 else 2}>", "bound": "mfma",
+                sr[f"render_{i}"] = {"kernel": f"k_render_rays<{R},{S},{'4,2' if R == 3 else '8,2'}>", "bound": "mfma",
                                      "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                      "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "avg_launch_ms": round(t, 4),
                                      "mfma_tiles_per_16_samples": tiles, "samples": n_samples,

@@ -29,6 +29,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace enerf {
 
+// Ordering point between LDS writes of some lanes of a wave and LDS reads of other lanes of the SAME wave.  The hardware
+// keeps a wave's LDS operations in order; this only stops the compiler (and, in the CPU lane emulator, lets every lane of
+// the wave reach this point before any continues).
+__device__ __forceinline__ void wave_sync() {
+#ifdef ENERF_EMU
+    emu::wave_exchange(0.f);
+#else
+    // no fence: a fence would also drain the outstanding GLOBAL loads (s_waitcnt vmcnt(0)); the LDS store -> load
+    // dependence through the same array is visible to the compiler, which waits on lgkmcnt only
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+
 // ReLU as ONE instruction.  fmaxf(x, 0.f) compiles to two (hipcc first canonicalises x with v_max_f32 x, x
 // because the kernels run in IEEE mode); on MFMA outputs that doubled the ~110 ReLUs per 16 points of the
 // render kernel.  v_med3_f32(x, 0, FLT_MAX) is the same function for finite x (NaN -> 0 like fmaxf; +inf ->
@@ -46,6 +59,56 @@ __device__ __forceinline__ float relu1(float x) {
 constexpr int kWave = 64;
 
 __host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// v + (v of the lane 16 away) + (32 away) + (48 away): the sum / max over the four lane groups (lanes j, j+16, j+32, j+48)
+// that share an MFMA column.  gfx950 swaps 16- and 32-lane halves between two registers in one VALU instruction
+// (v_permlane16_swap / v_permlane32_swap): 2 swaps + 2 adds, no LDS round trip (__shfl_xor lowers to ds_bpermute: an
+// LDS-latency stall on the critical path, 14 of them per 16 samples in the render kernel).
+#ifdef ENERF_EMU
+__device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16); }
+__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32); }
+#else
+__device__ __forceinline__ float xor32(float v) {      // value held by lane ^ 32
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    // r[0] = {lo, lo}, r[1] = {hi, hi} of v's halves: the "other" half is r[1] for lanes < 32 and r[0] for lanes >= 32;
+    // for commutative reductions use quad_reduce below — this form is the general one
+    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float xor16(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float((threadIdx.x & 16) ? r[0] : r[1]);
+}
+#endif
+__device__ __forceinline__ float group_sum4(float v) {
+#ifdef ENERF_EMU
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+#else
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);       // {lo,lo} and {hi,hi}: their sum is v + v^32
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    u = __float_as_uint(v);
+    r = __builtin_amdgcn_permlane16_swap(u, u, false, false);            // rows {0,0,2,2} and {1,1,3,3}
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#endif
+}
+__device__ __forceinline__ float group_max4(float v) {
+#ifdef ENERF_EMU
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+#else
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    u = __float_as_uint(v);
+    r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+#endif
+}
 
 // XCD-aware block order.  The dispatcher places block b on XCD b % 8 and every XCD has a private 4 MiB L2,
 // so with the natural order neighbouring blocks (which share gather footprints / halos) land on eight

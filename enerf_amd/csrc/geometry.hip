@@ -282,12 +282,8 @@ void launch_level_prep(const float* src_ixts, const float* src_exts, const float
 // chip idle behind a 48-step serial loop.  Slices are combined with two xor-shuffles.  prob/dv are
 // (B,D,h,w): each plane read is a contiguous 64-B run per slice.
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float slice_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
-__device__ __forceinline__ float slice_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
-    return v;
-}
+__device__ __forceinline__ float slice_sum(float v) { return group_sum4(v); }
+__device__ __forceinline__ float slice_max(float v) { return group_max4(v); }
 // Softmax moments of one pixel's D planes, register-resident: every plane value is loaded once (all loads in
 // flight together) and exp'd once; lane slice sl handles planes sl, sl+4, ...  The sums run in the same order as
 // the streaming form in k_depth_regression, so the results are bit-identical to it.

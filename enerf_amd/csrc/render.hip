@@ -4,23 +4,30 @@
 // 12-float rays and {rgb, depth, weights} ever touches HBM (the reference materialises ~118 MB of
 // gathered features plus every MLP activation).
 //
-// Mapping.  A wave owns 16 rays; lane l = (g = l>>4, j = l&15) works on ray j.  For every sample the
-// MLP runs on v_mfma_f32_16x16x4_f32 with the *weights* as the A operand (rows = output units) and the
-// 16 points as the B/D columns:
+// Mapping.  A wave owns 16 rays at a time; lane l = (g = l>>4, j = l&15).
+//   Gather phase (per sample): lane group g < S owns SOURCE VIEW g of point j — projection, bilinear taps, 16-byte gathers
+//   of the whole texel, blend, direction code — and writes a (view, point) record to LDS; every group also fetches its
+//   channel pair of the trilinear voxel feature.  All addresses are computed first, then all gathers are issued together
+//   (pinned with sched_barrier), then the arithmetic that does not depend on them, then the blends.
+//   MLP phase: the MLP runs on v_mfma_f32_16x16x4_f32 with the *weights* as the A operand (rows = output units) and the
+//   16 points as the B/D columns:
 //     A: lane holds W[row = j][k = g]      B: lane holds X[k = g][col = j]
 //     D: lane holds rows 4g+r (r = 0..3) of column j
-// A layer's D registers are therefore directly the next layer's B operands (k-step (tile,r) supplies
-// unit 16*tile+4g+r from lane group g); the packed weight image (nerf_pack) is permuted to that K
-// order, so activations never move between lanes.  Gathered per-view features use the same idea:
-// lane group g fetches channels [gR, gR+R) of the texel (R = ceil((C+3)/4)), register r is k-step r.
-// Width-1 heads (agg weight, sigma, colour logit) are in-lane dot products + a 2-step xor reduction over
-// the four lane groups.  Softmaxes over views and the compositing scan over samples are in-lane.
+//   A layer's D registers are therefore directly the next layer's B operands (k-step (tile,r) supplies unit 16*tile+4g+r
+//   from lane group g); the packed weight image (nerf_pack) is permuted to that K order, so activations never move between
+//   lanes.  Gathered features use the same idea: lane group g reads channels [gR, gR+R) of each view's LDS record
+//   (R = ceil((C+3)/4)), register r is k-step r.  Width-1 heads (agg weight, sigma, colour logit) are in-lane dot products +
+//   a sum over the four lane groups (v_permlane32_swap / v_permlane16_swap).  Softmaxes over views and the compositing scan
+//   over samples are in-lane.  A operands stream from LDS through a two-deep register ring one k-step ahead of the MFMAs.
 //
-// Algebra (fp re-association only): global_fc = W_a·a_s + W_vm·[var,mean] and
-// color.0 = W_p·[h,vox,agg] + W_v·[x_s,dir_s] — the view-independent halves are evaluated once per
-// point instead of once per view (201 instead of 369 MFMAs per 16 points at S=3, C=8).
+// Algebra (fp re-association only): global_fc = W_a·a_s + W_vm·[var,mean], color.0 = W_p·[h,vox,agg] + W_v·[x_s,dir_s] — the
+// view-independent halves are evaluated once per point instead of once per view (201 instead of 369 MFMAs per 16 points at
+// S=3, C=8) — and pix = (K'·E)·X + K'·t with the 3x4 product formed once per view in fp64.
 //
-// Roofline: MFMA-bound (fp32 157.3 TF).  Algorithmic FLOPs/point: SURVEY.md §8a (50,952 at level 1).
+// Roofline: fp32 MFMA (157.3 TF).  On gfx950 VALU and MFMA instructions of a SIMD do NOT overlap, within a wave or across
+// waves (tools/micro/mfma_valu_overlap.hip: 4.50 ms MFMA-only + 1.68 ms VALU-only = 6.5 ms interleaved in one wave, 5.7 ms
+// from two waves): the kernel's time is (201 MFMA x 32 cycles + ~700 VALU x ~3-4 cycles) per 16 samples plus what latency the
+// two waves per SIMD fail to hide.  Algorithmic FLOPs/point: SURVEY.md §8a (50,952 at level 1).
 #include "kernels.h"
 
 namespace enerf {
@@ -128,11 +135,7 @@ void launch_nerf_pack(const NerfRaw& raw, int F, int viewdir_agg, float* packed,
 }
 
 // ---- device helpers ----------------------------------------------------------------------------------
-__device__ __forceinline__ float group_sum(float v) {      // sum over the 4 lane groups (lanes j, j+16, j+32, j+48)
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
-}
+__device__ __forceinline__ float group_sum(float v) { return group_sum4(v); }   // sum over the 4 lane groups (lanes j, j+16, j+32, j+48)
 __device__ __forceinline__ f32x4 lds4(const float* p) {     // 16-byte aligned LDS/global read
     float4 t = *reinterpret_cast<const float4*>(p);
     return f32x4{t.x, t.y, t.z, t.w};
@@ -146,17 +149,59 @@ __device__ __forceinline__ float dot4(f32x4 a, f32x4 b, float acc) {
 }
 #define ENERF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// camera table in LDS, per (b,s): E[:3] (12) | K' (9) | centre (3) ; per b: target centre (3)
-constexpr int kCamStride = 24;
+// NV accumulators x NK k-steps of MFMAs whose A operands (one float per lane and tile) come from LDS: the A values of
+// k-step ks+1 are read while the MFMAs of k-step ks run (a two-deep register ring), pinned with sched_barrier — left
+// alone, hipcc emits `ds_read; s_waitcnt lgkmcnt(0); mfma; mfma` and exposes one LDS latency per MFMA pair.
+// A(e) = this lane's element of tile e = ks*NV + v; B(ks) = the k-step's B operand.
+template <int NK, int NV, class AF, class BF>
+__device__ __forceinline__ void mfma_chain(f32x4 (&acc)[NV], AF A, BF B) {
+    float ring[2][NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) ring[0][v] = A(v);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        if (ks + 1 < NK) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) ring[(ks + 1) & 1][v] = A((ks + 1) * NV + v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float b = B(ks);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = ENERF_MFMA(ring[ks & 1][v], b, acc[v]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 
-template <int R, int S, int OCC>   // OCC = resident 256-thread blocks per CU the register budget is sized for
-__global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
+// camera table in LDS, per (b,s): M = K'·E[:3,:3] (9) | v = K'·E[:3,3] (3) | camera centre (3) | pad ; per b: target centre
+constexpr int kCamStride = 16;
+
+// Staging stride (floats) of one (view, point) record in LDS: TEX blended texel channels + 4 direction-code values,
+// padded so that 16 consecutive points land on distinct 16-byte bank groups (20 = 4*5, 44 = 4*11: j*stride mod 64 hits
+// every multiple of 4 once) — conflict-free ds_write_b128 by the geometry lanes and ds_read_b32 by the MLP lanes.
+template <int R> struct Stage { static constexpr int kTex = 4 * R, kStride = 4 * R + 8; };
+
+// k_render_rays — one wave renders 16 rays ("points" per sample) at a time.
+//   Geometry phase, lane (g, j): lane group g < S owns SOURCE VIEW g of point j: projection, bilinear taps, the gather
+//     of ALL texel channels of its view (16-byte loads), the blend and the view's direction code, written to an LDS
+//     record; every lane group also fetches its channel pair of the trilinear voxel feature.  (Before: all four lane
+//     groups projected all S views — the same ~390 VALU instructions four times over, 552 of the 930 per tile.)
+//   MLP phase, lane (g, j): channels [gR, gR+R) of every view come back from the LDS records as MFMA B operands; the
+//     rest is the k-ordered MFMA chain described at the top of this file.
+// WPE = waves per SIMD the register budget is sized for (512 / WPE VGPRs): blocks per CU x WAVES / 4
+template <int R, int S, int WAVES, int WPE>
+__global__ __launch_bounds__(64 * WAVES)
+#ifndef ENERF_EMU
+__attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+#endif
+void k_render_rays(RenderArgs a) {
     constexpr int TR = (R + 3) / 4;
+    constexpr int TEX = Stage<R>::kTex, SST = Stage<R>::kStride;
     const NerfLayout L = nerf_layout(a.F);
     ENERF_DYN_SMEM(float, smem);
     float* wl = smem;                                    // packed weights
-    float* cam = smem + L.total;                         // B*S*24
-    float* tcen = cam + a.B * S * kCamStride;            // B*3
+    float* cam = smem + L.total;                         // B*S*16
+    float* tcen = cam + a.B * S * kCamStride;            // B*4
+    float* stage_all = tcen + ((a.B * 4 + 15) & ~15);    // WAVES * S * 16 * SST
 
     // ---- prologue: stage weights + camera table ----
     for (int i = threadIdx.x * 4; i < L.total; i += blockDim.x * 4)
@@ -170,29 +215,45 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
         float c0 = ok ? (float)inv[3] : NAN, c1 = ok ? (float)inv[7] : NAN, c2 = ok ? (float)inv[11] : NAN;
         if (s < S) {
             float* c = cam + ((long long)b * S + s) * kCamStride;
-            for (int k = 0; k < 12; ++k) c[k] = E[k];
             const float* K = a.src_ixts + ((long long)b * S + s) * 9;
-            for (int k = 0; k < 9; ++k) c[12 + k] = (k < 6) ? K[k] * a.render_scale : K[k];     // utils.py:700-701
-            c[21] = c0; c[22] = c1; c[23] = c2;
+            // pix = K'·(E·[X,1]) (utils.py:698-703) evaluated as (K'·E33)·X + K'·t with the 3x4 product formed in fp64
+            for (int r = 0; r < 3; ++r) {
+                double kr[3];
+                for (int q = 0; q < 3; ++q) kr[q] = (double)K[r * 3 + q] * (r < 2 ? (double)a.render_scale : 1.0);   // utils.py:700-701
+                for (int q = 0; q < 4; ++q) {
+                    const double v = kr[0] * m[q] + kr[1] * m[4 + q] + kr[2] * m[8 + q];
+                    if (q < 3) c[r * 3 + q] = (float)v; else c[9 + r] = (float)v;
+                }
+            }
+            c[12] = c0; c[13] = c1; c[14] = c2; c[15] = 0.f;
         } else {
-            tcen[b * 3 + 0] = c0; tcen[b * 3 + 1] = c1; tcen[b * 3 + 2] = c2;
+            tcen[b * 4 + 0] = c0; tcen[b * 4 + 1] = c1; tcen[b * 4 + 2] = c2; tcen[b * 4 + 3] = 0.f;
         }
     }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-    const int wave_in_block = threadIdx.x >> 6, waves_per_block = blockDim.x >> 6;
+    const int wave_in_block = threadIdx.x >> 6;
     // device-side ray selection (network_human.py:90-93): the number of rays is read here, not known to the host
     const long long nrays = a.ray_index != nullptr ? (long long)a.ray_count[0] : (long long)a.B * a.N;
     const long long ntiles = cdivl(nrays, 16);
     const bool scatter = a.ray_index != nullptr && a.scatter_rgb != 0;
     const int Ns = a.n_samples;
-    const int TEX = 4 * R;
     const float* wlane = wl + lane;
+#define A_VIEW(e) wlane[L.view + (e) * 64]
+#define A_GLOB(e) wlane[L.glob + (e) * 64]
+#define A_FC(e) wlane[L.fc + (e) * 64]
+#define A_LR0(e) wlane[L.lr0 + (e) * 64]
+#define A_C0P(e) wlane[L.c0p + (e) * 64]
+#define A_C0V(e) wlane[L.c0v + (e) * 64]
+    float* stage = stage_all + wave_in_block * (S * 16 * SST);
+    const int sv = g < S ? g : S - 1;                    // the source view this lane's geometry works on
+    float* my_rec = stage + (sv * 16 + j) * SST;         // record this lane writes (lane groups >= S write nothing)
+    const float* rd_rec = stage + j * SST + g * R;       // + s*16*SST: channels [gR, gR+R) of view s, point j
+    const float* rd_dir = stage + j * SST + TEX + g;     // + s*16*SST: direction-code component g of view s
 
     // natural (round-robin) tile order: handing each XCD a contiguous run of tiles measured ~3 % slower
-    for (long long tile = (long long)blockIdx.x * waves_per_block + wave_in_block; tile < ntiles;
-         tile += (long long)gridDim.x * waves_per_block) {
+    for (long long tile = (long long)blockIdx.x * WAVES + wave_in_block; tile < ntiles; tile += (long long)gridDim.x * WAVES) {
         long long ray = tile * 16 + j;
         const bool rok = ray < nrays;
         const long long rc = rok ? ray : nrays - 1;
@@ -214,16 +275,37 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
             ox = q0.x; oy = q0.y; oz = q0.z; dx = q0.w; dy = q1.x; dz = q1.y; ru = q1.z; rv = q1.w;
             rn = q2.x; rf = q2.y; vn = q2.z; vf = q2.w;
         }
-        // normalised (x,y) of the ray inside the feature volume: network.py:37 then utils.py:457
-        const float gxv = (ru / (float)(a.Wr - 1)) * 2.f - 1.f, gyv = (rv / (float)(a.Hr - 1)) * 2.f - 1.f;
-        // 32-bit element offsets from the (uniform) tensor bases: one saddr+voffset load per tap instead of a
-        // 64-bit pointer add per tap (the launcher checks both tensors hold < 2^32 floats)
+        // ---- per-ray part of the voxel fetch (network.py:37 then utils.py:457): the (x, y) taps do not depend on the sample
+        // 32-bit element offsets from the (uniform) tensor bases (the launcher checks both tensors hold < 2^32 floats)
         const unsigned voff = (unsigned)b * (unsigned)(a.D * a.h * a.w * 8) + 2u * g;
-        const unsigned toff = (unsigned)b * (unsigned)(S * a.Hr * a.Wr * TEX) + (unsigned)(g * R);
+        float wxy[4];
+        int oxy[4];
+        {
+            const float gxv = (ru / (float)(a.Wr - 1)) * 2.f - 1.f, gyv = (rv / (float)(a.Hr - 1)) * 2.f - 1.f;
+            float ix = gs_unnorm(gxv, a.w), iy = gs_unnorm(gyv, a.h);
+            ix = fabsf(ix) < 1e8f ? ix : -10.f;
+            iy = fabsf(iy) < 1e8f ? iy : -10.f;
+            const float fx = floorf(ix), fy = floorf(iy);
+            const int x0 = (int)fx, y0 = (int)fy;
+            float wx[2] = {(fx + 1.f) - ix, ix - fx}, wy[2] = {(fy + 1.f) - iy, iy - fy};
+            int xo[2], yo[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int xx = x0 + c, yy = y0 + c;
+                wx[c] = (unsigned)xx < (unsigned)a.w ? wx[c] : 0.f;      // zeros padding: weight 0 outside
+                wy[c] = (unsigned)yy < (unsigned)a.h ? wy[c] : 0.f;
+                xo[c] = min(max(xx, 0), a.w - 1);
+                yo[c] = mul24(min(max(yy, 0), a.h - 1), a.w);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { wxy[c] = wx[c & 1] * wy[c >> 1]; oxy[c] = yo[c >> 1] + xo[c & 1]; }   // (wx*wy)*wz: ATen's association
+        }
+        // ---- this lane's view: camera constants of (b, sv) ----
+        const float* cb = cam + ((long long)b * S + sv) * kCamStride;
+        const f32x4 cm0 = lds4(cb), cm1 = lds4(cb + 4), cm2 = lds4(cb + 8), cm3 = lds4(cb + 12);
+        const f32x4 tc4 = lds4(tcen + b * 4);
+        const unsigned toff = (unsigned)b * (unsigned)(S * a.Hr * a.Wr * TEX) + (unsigned)sv * (unsigned)(a.Hr * a.Wr * TEX);
         const float rcpW = fast_rcp((float)(a.Wr - 1)), rcpH = fast_rcp((float)(a.Hr - 1));
-        const int view_stride = a.Hr * a.Wr * TEX;     // < 2^31 floats (checked by the launcher)
-        const float* camb = cam + (long long)b * S * kCamStride;
-        const float tcx = tcen[b * 3], tcy = tcen[b * 3 + 1], tcz = tcen[b * 3 + 2];
 
         float Tacc = 1.f;                 // transmittance, raw2outputs utils.py:588-589
         float wk[8];                      // per-sample weights (Ns <= 8)
@@ -235,8 +317,8 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
 
 #pragma unroll 1
         for (int k = 0; k < Ns; ++k) {
-            // Keep the MFMA A operands (weights) in LDS: without this barrier LICM hoists all ~155 LDS reads
-            // out of the sample loop into registers and the kernel drops to 1 wave/SIMD with spills.
+            // Keep the MFMA A operands (weights) in LDS (measured: holding all 155 tiles in registers at one wave per SIMD,
+            // 512-entry budget, is 40 % slower — hipcc parks them in AGPRs and copies each back with v_accvgpr_read).
             asm volatile("" ::: "memory");
             // ---------- sample placement (utils.py:425-436) ----------
             float tk = (Ns == 1) ? 0.5f : linspace01(k, Ns);
@@ -246,98 +328,115 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
             float dn = a.depth_inv ? (vn - z) * fast_rcp(clamp_min(vn - vf, 1e-6f))
                                    : (z - vn) * fast_rcp(clamp_min(vf - vn, 1e-6f));
 
-            // ---------- voxel feature: trilinear, zeros padding (utils.py:457) ----------
-            // Per axis: two corner indices clamped for addressing, corner weights zeroed outside the volume
-            // (zeros padding); the 8 taps are products/sums of those.  Non-finite coordinates -> all-zero taps.
-            float vox[2] = {0.f, 0.f};
-            {
-                float ix = gs_unnorm(gxv, a.w), iy = gs_unnorm(gyv, a.h), iz = gs_unnorm(dn * 2.f - 1.f, a.D);
-                ix = fabsf(ix) < 1e8f ? ix : -10.f;
-                iy = fabsf(iy) < 1e8f ? iy : -10.f;
-                iz = fabsf(iz) < 1e8f ? iz : -10.f;
-                const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-                const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-                float wx[2] = {(fx + 1.f) - ix, ix - fx}, wy[2] = {(fy + 1.f) - iy, iy - fy}, wz[2] = {(fz + 1.f) - iz, iz - fz};
-                int xo[2], yo[2], zo[2];
+            // ---------- addresses first, then ALL gathers of the sample in flight together, then the arithmetic that does
+            // not need them, then the blends.  The sched_barriers pin that order: left alone, hipcc sinks every load to
+            // its first use under register pressure — eight voxel taps became eight serial memory round trips.
+            // this lane's view of the point: projection + bilinear taps, border padding (utils.py:698-706)
+            const float px = X * cm0[0] + Y * cm0[1] + Z * cm0[2] + cm2[1];
+            const float py = X * cm0[3] + Y * cm1[0] + Z * cm1[1] + cm2[2];
+            const float pz = X * cm1[2] + Y * cm1[3] + Z * cm2[0] + cm2[3];
+            const float rz = fast_rcp(clamp_min(pz, 1e-6f));
+            const float gx = ((px * rz) * rcpW) * 2.f - 1.f, gy = ((py * rz) * rcpH) * 2.f - 1.f;
+            const Taps2 t = gs_taps2<true>(gs_unnorm(gx, a.Wr), gs_unnorm(gy, a.Hr), a.Wr, a.Hr);
+            const int r0 = mul24(t.y0, a.Wr), r1 = mul24(t.y1, a.Wr);
+            const float* tp[4] = {a.tex + (toff + (unsigned)mul24(r0 + t.x0, TEX)), a.tex + (toff + (unsigned)mul24(r0 + t.x1, TEX)),
+                                  a.tex + (toff + (unsigned)mul24(r1 + t.x0, TEX)), a.tex + (toff + (unsigned)mul24(r1 + t.x1, TEX))};
+            const float tw[4] = {t.w00, t.w01, t.w10, t.w11};
+            // voxel feature: trilinear, zeros padding (utils.py:457); lane group g fetches channels 2g, 2g+1
+            float iz = gs_unnorm(dn * 2.f - 1.f, a.D);
+            iz = fabsf(iz) < 1e8f ? iz : -10.f;
+            const float fz = floorf(iz);
+            const int z0 = (int)fz;
+            float wz[2] = {(fz + 1.f) - iz, iz - fz};
+            int zo[2];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int xx = x0 + c, yy = y0 + c, zc = z0 + c;
-                    wx[c] = (unsigned)xx < (unsigned)a.w ? wx[c] : 0.f;
-                    wy[c] = (unsigned)yy < (unsigned)a.h ? wy[c] : 0.f;
-                    wz[c] = (unsigned)zc < (unsigned)a.D ? wz[c] : 0.f;
-                    xo[c] = min(max(xx, 0), a.w - 1);
-                    yo[c] = mul24(min(max(yy, 0), a.h - 1), a.w);
-                    zo[c] = mul24(min(max(zc, 0), a.D - 1), a.h * a.w);
+            for (int c = 0; c < 2; ++c) {
+                const int zc = z0 + c;
+                wz[c] = (unsigned)zc < (unsigned)a.D ? wz[c] : 0.f;
+                zo[c] = mul24(min(max(zc, 0), a.D - 1), a.h * a.w);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float2 vt[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)                 // order tnw,tne,tsw,tse,bnw,bne,bsw,bse
+                vt[c] = *reinterpret_cast<const float2*>(a.vol + ((unsigned)(zo[c >> 2] + oxy[c & 3]) * 8u + voff));
+            constexpr int QB = R <= 3 ? R : 3;          // texel channels are gathered QB float4 chunks at a time (R = 9: 3 rounds)
+            f32x4 blend[R];
+            f32x4 tq[4][QB];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int q = 0; q < QB; ++q) tq[c][q] = lds4(tp[c] + 4 * q);
+            __builtin_amdgcn_sched_barrier(0);
+            // direction code (utils.py:707-720) while the gathers are in flight
+            float tx = X - tc4[0], ty = Y - tc4[1], tz = Z - tc4[2];
+            float sx = X - cm3[0], sy = Y - cm3[1], sz = Z - cm3[2];
+            const float tir = fast_rcp(fast_sqrt(tx * tx + ty * ty + tz * tz) + 1e-6f);
+            const float sir = fast_rcp(fast_sqrt(sx * sx + sy * sy + sz * sz) + 1e-6f);
+            tx *= tir; ty *= tir; tz *= tir;
+            sx *= sir; sy *= sir; sz *= sir;
+            const float ex = tx - sx, ey = ty - sy, ez = tz - sz;
+            const float eir = fast_rcp(fmaxf(fast_sqrt(ex * ex + ey * ey + ez * ez), 1e-6f));
+            const f32x4 dirc = f32x4{ex * eir, ey * eir, ez * eir, tx * sx + ty * sy + tz * sz};
+            float vw[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) vw[c] = wxy[c & 3] * wz[c >> 2];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q0 = 0; q0 < R; q0 += QB) {
+#pragma unroll
+                for (int q = 0; q < QB; ++q) {
+                    f32x4 acc = tq[0][q] * tw[0];
+                    acc += tq[1][q] * tw[1];
+                    acc += tq[2][q] * tw[2];
+                    acc += tq[3][q] * tw[3];
+                    blend[q0 + q] = acc;
                 }
-                float wxy[4];                         // (wx*wy)*wz: ATen's association
+                if (q0 + QB < R) {                      // next round of chunks (R = 9 only)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) wxy[c] = wx[c & 1] * wy[c >> 1];
+                    for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {           // order tnw,tne,tsw,tse,bnw,bne,bsw,bse
-                    const float wgt = wxy[c & 3] * wz[c >> 2];
-                    const unsigned vo = (unsigned)(zo[c >> 2] + yo[(c >> 1) & 1] + xo[c & 1]) * 8u + voff;
-                    const float2 t = *reinterpret_cast<const float2*>(a.vol + vo);
-                    vox[0] += t.x * wgt;
-                    vox[1] += t.y * wgt;
+                        for (int q = 0; q < QB; ++q) tq[c][q] = lds4(tp[c] + 4 * (q0 + QB + q));
                 }
             }
-
-            // ---------- per-view image features + direction code (utils.py:698-720) ----------
+            if (g < S) {
+#pragma unroll
+                for (int q = 0; q < R; ++q) *reinterpret_cast<f32x4*>(my_rec + 4 * q) = blend[q];
+                *reinterpret_cast<f32x4*>(my_rec + TEX) = dirc;
+            }
+            float vox[2] = {0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                vox[0] += vt[c].x * vw[c];
+                vox[1] += vt[c].y * vw[c];
+            }
+            wave_sync();                              // the records of this tile are written: read them back as B operands
             float x[S][R], dsel[S];
-            // (Tried: each lane group projecting ONE view and handing taps/direction round with lane broadcasts —
-            // 170 fewer VALU per 16 points but 36 ds_bpermute on the critical path: 201 -> 215 us.  Not kept.)
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                const float* c = camb + s * kCamStride;
-                float cx = X * c[0] + Y * c[1] + Z * c[2] + c[3];
-                float cy = X * c[4] + Y * c[5] + Z * c[6] + c[7];
-                float cz = X * c[8] + Y * c[9] + Z * c[10] + c[11];
-                float px = cx * c[12] + cy * c[13] + cz * c[14];
-                float py = cx * c[15] + cy * c[16] + cz * c[17];
-                float pz = cx * c[18] + cy * c[19] + cz * c[20];
-                float rz = fast_rcp(clamp_min(pz, 1e-6f));
-                float gx = ((px * rz) * rcpW) * 2.f - 1.f, gy = ((py * rz) * rcpH) * 2.f - 1.f;
-                Taps2 t = gs_taps2<true>(gs_unnorm(gx, a.Wr), gs_unnorm(gy, a.Hr), a.Wr, a.Hr);
-                const unsigned tb = toff + (unsigned)(s * view_stride);
-                const int r0 = mul24(t.y0, a.Wr), r1 = mul24(t.y1, a.Wr);
-                const float* p00 = a.tex + (tb + (unsigned)mul24(r0 + t.x0, TEX));
-                const float* p01 = a.tex + (tb + (unsigned)mul24(r0 + t.x1, TEX));
-                const float* p10 = a.tex + (tb + (unsigned)mul24(r1 + t.x0, TEX));
-                const float* p11 = a.tex + (tb + (unsigned)mul24(r1 + t.x1, TEX));
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float acc = p00[r] * t.w00;
-                    acc += p01[r] * t.w01;
-                    acc += p10[r] * t.w10;
-                    acc += p11[r] * t.w11;
-                    x[s][r] = acc;
-                }
-                // direction code
-                float tx = X - tcx, ty = Y - tcy, tz = Z - tcz;
-                float sx = X - c[21], sy = Y - c[22], sz = Z - c[23];
-                float tir = fast_rcp(fast_sqrt(tx * tx + ty * ty + tz * tz) + 1e-6f);
-                float sir = fast_rcp(fast_sqrt(sx * sx + sy * sy + sz * sz) + 1e-6f);
-                tx *= tir; ty *= tir; tz *= tir;
-                sx *= sir; sy *= sir; sz *= sir;
-                float ex = tx - sx, ey = ty - sy, ez = tz - sz;
-                float eir = fast_rcp(fmaxf(fast_sqrt(ex * ex + ey * ey + ez * ez), 1e-6f));
-                float dot = tx * sx + ty * sy + tz * sz;
-                dsel[s] = g == 0 ? ex * eir : (g == 1 ? ey * eir : (g == 2 ? ez * eir : dot));
+                for (int r = 0; r < R; ++r) x[s][r] = rd_rec[s * 16 * SST + r];
+                dsel[s] = rd_dir[s * 16 * SST];
             }
-
+            wave_sync();                              // ... before the next sample overwrites them
 
             // ---------- Agg (nerf.py:74-89) ----------
             float av[S][R];
+            {
+                float aview[TR];
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                f32x4 va[TR];
+                for (int t = 0; t < TR; ++t) aview[t] = A_VIEW(t);
+                f32x4 vb[TR];
 #pragma unroll
-                for (int t = 0; t < TR; ++t) {
-                    va[t] = lds4(wl + L.viewb + t * 16 + 4 * g);
-                    va[t] = ENERF_MFMA(wlane[L.view + t * 64], dsel[s], va[t]);
+                for (int t = 0; t < TR; ++t) vb[t] = lds4(wl + L.viewb + t * 16 + 4 * g);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    f32x4 va[TR];
+#pragma unroll
+                    for (int t = 0; t < TR; ++t) va[t] = ENERF_MFMA(aview[t], dsel[s], vb[t]);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) av[s][r] = x[s][r] + relu1(va[r >> 2][r & 3]);
                 }
-#pragma unroll
-                for (int r = 0; r < R; ++r) av[s][r] = x[s][r] + relu1(va[r >> 2][r & 3]);
             }
             float var[R], mean[R];
 #pragma unroll
@@ -355,28 +454,32 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
             f32x4 P[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) P[u] = lds4(wl + L.globb + u * 16 + 4 * g);
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    P[u] = ENERF_MFMA(wlane[L.glob + (((1 * R + r) * 2 + u) << 6)], var[r], P[u]);
-                    P[u] = ENERF_MFMA(wlane[L.glob + (((2 * R + r) * 2 + u) << 6)], mean[r], P[u]);
-                }
+            // k-steps 0..R-1: variance slots, R..2R-1: mean slots (tiles (1*R + r)*2 + u and (2*R + r)*2 + u)
+            mfma_chain<2 * R, 2>(P, [&](int e) { return A_GLOB(2 * R + e); },
+                                 [&](int ks) { return ks < R ? var[ks < R ? ks : 0] : mean[ks >= R ? ks - R : 0]; });
             f32x4 gf[S][2];
             float aw[S];
             const f32x4 aggw0 = lds4(wl + L.aggw + 4 * g), aggw1 = lds4(wl + L.aggw + 16 + 4 * g);
             const float aggb = wl[L.aggw + 32];
+            {
+                float ag[R * 2];                          // the per-view tiles are the same for every view: read them once
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                gf[s][0] = P[0]; gf[s][1] = P[1];
+                for (int e = 0; e < R * 2; ++e) ag[e] = A_GLOB(e);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < R; ++r)
+                for (int s = 0; s < S; ++s) {
+                    gf[s][0] = P[0]; gf[s][1] = P[1];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
-                        gf[s][u] = ENERF_MFMA(wlane[L.glob + (((0 * R + r) * 2 + u) << 6)], av[s][r], gf[s][u]);
-                gf[s][0] = relu4(gf[s][0]); gf[s][1] = relu4(gf[s][1]);
-                float part = dot4(gf[s][1], aggw1, dot4(gf[s][0], aggw0, 0.f));
-                aw[s] = relu1(group_sum(part) + aggb);
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) gf[s][u] = ENERF_MFMA(ag[r * 2 + u], av[s][r], gf[s][u]);
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    gf[s][0] = relu4(gf[s][0]); gf[s][1] = relu4(gf[s][1]);
+                    float part = dot4(gf[s][1], aggw1, dot4(gf[s][0], aggw0, 0.f));
+                    aw[s] = relu1(group_sum(part) + aggb);
+                }
             }
             {   // softmax over views
                 float m = aw[0];
@@ -396,23 +499,22 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
 #pragma unroll
                 for (int s = 1; s < S; ++s) G[u] += gf[s][u] * aw[s];
             }
-            f32x4 agg = lds4(wl + L.fcb + 4 * g);
+            f32x4 aggv[1] = {lds4(wl + L.fcb + 4 * g)};
+            {
+                float afc[8];                             // one accumulator, eight dependent k-steps: all A values up front
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+                for (int e = 0; e < 8; ++e) afc[e] = A_FC(e);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) agg = ENERF_MFMA(wlane[L.fc + ((u * 4 + r) << 6)], G[u][r], agg);
-            agg = relu4(agg);
+                for (int e = 0; e < 8; ++e) aggv[0] = ENERF_MFMA(afc[e], G[e >> 2][e & 3], aggv[0]);
+            }
+            const f32x4 agg = relu4(aggv[0]);
 
             // ---------- NeRF trunk (nerf.py:33-37) ----------
             f32x4 hid[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) hid[v] = lds4(wl + L.lr0b + v * 16 + 4 * g);
-#pragma unroll
-            for (int ks = 0; ks < 6; ++ks) {
-                float bop = ks < 2 ? vox[ks] : agg[ks - 2];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) hid[v] = ENERF_MFMA(wlane[L.lr0 + ((ks * 4 + v) << 6)], bop, hid[v]);
-            }
+            mfma_chain<6, 4>(hid, [&](int e) { return A_LR0(e); }, [&](int ks) { return ks < 2 ? vox[ks < 2 ? ks : 0] : agg[ks >= 2 ? ks - 2 : 0]; });
             float sig = 0.f;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -426,29 +528,35 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
             f32x4 P2[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) P2[v] = lds4(wl + L.c0b + v * 16 + 4 * g);
-#pragma unroll
-            for (int ks = 0; ks < 22; ++ks) {
-                float bop = ks < 16 ? hid[ks >> 2][ks & 3] : (ks < 18 ? vox[ks - 16] : agg[ks - 18]);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) P2[v] = ENERF_MFMA(wlane[L.c0p + ((ks * 4 + v) << 6)], bop, P2[v]);
-            }
+            mfma_chain<22, 4>(P2, [&](int e) { return A_C0P(e); },
+                              [&](int ks) { return ks < 16 ? hid[(ks < 16 ? ks : 0) >> 2][ks & 3]
+                                                           : (ks < 18 ? vox[ks < 18 ? ks - 16 : 0] : agg[ks >= 18 ? ks - 18 : 0]); });
             float cl[S];
             const float c2b = wl[L.col2 + 64];
+            {
+                float acv[(R + 1) * 4];                   // the per-view tiles of color.0, shared by the S views
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                f32x4 cc[4];
+                for (int e = 0; e < (R + 1) * 4; ++e) acv[e] = A_C0V(e);
+                f32x4 c2w[4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) cc[v] = P2[v];
+                for (int v = 0; v < 4; ++v) c2w[v] = lds4(wl + L.col2 + v * 16 + 4 * g);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ks = 0; ks <= R; ++ks) {
-                    float bop = ks < R ? x[s][ks < R ? ks : 0] : dsel[s];
+                for (int s = 0; s < S; ++s) {
+                    f32x4 cc[4];
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) cc[v] = ENERF_MFMA(wlane[L.c0v + ((ks * 4 + v) << 6)], bop, cc[v]);
+                    for (int v = 0; v < 4; ++v) cc[v] = P2[v];
+#pragma unroll
+                    for (int ks = 0; ks <= R; ++ks) {
+                        float bop = ks < R ? x[s][ks < R ? ks : 0] : dsel[s];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) cc[v] = ENERF_MFMA(acv[ks * 4 + v], bop, cc[v]);
+                    }
+                    float part = 0.f;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) part = dot4(relu4(cc[v]), c2w[v], part);
+                    cl[s] = relu1(group_sum(part) + c2b);
                 }
-                float part = 0.f;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) part = dot4(relu4(cc[v]), lds4(wl + L.col2 + v * 16 + 4 * g), part);
-                cl[s] = relu1(group_sum(part) + c2b);
             }
             {   // softmax over views (nerf.py:41)
                 float m = cl[0];
@@ -515,37 +623,58 @@ __global__ __launch_bounds__(256, OCC) void k_render_rays(RenderArgs a) {
     }
 }
 
-template <int R, int OCC>
+template <int R, int WAVES, int OCC>
 static int dispatch_s(const RenderArgs& a, unsigned grid, size_t shmem, hipStream_t st) {
+    constexpr int WPE = (WAVES * OCC + 3) / 4;
     switch (a.S) {
-        case 2: ENERF_LAUNCH((k_render_rays<R, 2, OCC>), grid, 256, shmem, st, a); return 0;
-        case 3: ENERF_LAUNCH((k_render_rays<R, 3, OCC>), grid, 256, shmem, st, a); return 0;
-        case 4: ENERF_LAUNCH((k_render_rays<R, 4, OCC>), grid, 256, shmem, st, a); return 0;
+        case 2: ENERF_LAUNCH((k_render_rays<R, 2, WAVES, WPE>), grid, 64 * WAVES, shmem, st, a); return 0;
+        case 3: ENERF_LAUNCH((k_render_rays<R, 3, WAVES, WPE>), grid, 64 * WAVES, shmem, st, a); return 0;
+        case 4: ENERF_LAUNCH((k_render_rays<R, 4, WAVES, WPE>), grid, 64 * WAVES, shmem, st, a); return 0;
         default: return -3;
     }
+}
+template <int R, int WAVES>
+static size_t render_shmem(const RenderArgs& a) {
+    return ((size_t)nerf_layout(a.F).total + (size_t)a.B * a.S * kCamStride + (size_t)((a.B * 4 + 15) & ~15) +
+            (size_t)WAVES * a.S * 16 * Stage<R>::kStride) * sizeof(float);
 }
 int launch_render_rays(const RenderArgs& a, hipStream_t st) {
     if (a.n_samples < 1 || a.n_samples > 8) return -1;
     const int R = (a.F + 3) / 4;
-    size_t shmem = ((size_t)nerf_layout(a.F).total + (size_t)a.B * a.S * kCamStride + (size_t)a.B * 3) * sizeof(float);
-    if (shmem > 64 * 1024) return -2;
     // 32-bit element offsets and 24-bit index multiplies inside the kernel
     if ((long long)a.B * a.S * a.Hr * a.Wr * 4 * R >= (1LL << 32) || (long long)a.B * a.D * a.h * a.w * 8 >= (1LL << 32) ||
         (long long)a.Hr * a.Wr >= (1LL << 23) || (long long)a.h * a.w >= (1LL << 23) || a.D >= (1 << 23))
         return -5;
-    long long ntiles = cdivl((long long)a.B * a.N, 16);
-    long long blocks = cdivl(ntiles, 4);
-    // Persistent waves: the weight image (40-56 KB) is staged into LDS once per block, so launch only as
-    // many blocks as are co-resident (OCC per CU x 256 CUs) and let each wave stride over ray tiles.
-    // enerf_options_t.render_blocks_per_cu: 3 blocks/CU (168 VGPR, 12 spilled) measured 4 % faster than 2 for one frame
-    // at a time; 2 (no spills) wins when several frames share the matrix pipes.
-    const Options o = resolve_options(a.options);
-    const int occ = o.render_blocks_per_cu == 2 ? 2 : 3;
-    const long long resident = (long long)device_cu_count() * occ;
-    unsigned grid = (unsigned)(blocks < resident ? blocks : resident);
-    if (grid == 0) return 0;
-    if (R == 3) return occ == 3 ? dispatch_s<3, 3>(a, grid, shmem, st) : dispatch_s<3, 2>(a, grid, shmem, st);   // C = 8
-    if (R == 9) return dispatch_s<9, 2>(a, grid, shmem, st);                                                   // C = 32
+    const long long ntiles = cdivl((long long)a.B * a.N, 16);
+    // Persistent waves: the weight image (41-56 KB) is staged into LDS once per block, so launch only as many blocks as
+    // are co-resident (blocks per CU x CUs) and let each wave stride over ray tiles.
+    // Measured on MI355X (512x640, S = 3): 4-wave blocks x 2 per CU (2 waves per SIMD, 187 VGPRs) 210 us; 12-wave blocks
+    // (3 per SIMD, 168 VGPRs + spills) 215 us; 16-wave blocks (4 per SIMD) 247 us; 1 wave per SIMD 350 us.
+    const int cus = device_cu_count();
+    auto grid_for = [&](int waves, int occ) {
+        const long long blocks = cdivl(ntiles, waves), resident = (long long)cus * occ;
+        return (unsigned)(blocks < resident ? blocks : resident);
+    };
+#ifndef ENERF_RENDER_WAVES
+#define ENERF_RENDER_WAVES 4
+#endif
+#ifndef ENERF_RENDER_OCC
+#define ENERF_RENDER_OCC 2
+#endif
+    if (R == 3) {                                                                                              // C = 8
+        const size_t shmem = render_shmem<3, ENERF_RENDER_WAVES>(a);
+        if (shmem > 160 * 1024 / ENERF_RENDER_OCC) return -2;
+        const unsigned grid = grid_for(ENERF_RENDER_WAVES, ENERF_RENDER_OCC);
+        if (grid == 0) return 0;
+        return dispatch_s<3, ENERF_RENDER_WAVES, ENERF_RENDER_OCC>(a, grid, shmem, st);
+    }
+    if (R == 9) {                                                                   // C = 32: one 8-wave block per CU
+        const size_t shmem = render_shmem<9, 8>(a);
+        if (shmem > 160 * 1024) return -2;
+        const unsigned grid = grid_for(8, 1);
+        if (grid == 0) return 0;
+        return dispatch_s<9, 8, 1>(a, grid, shmem, st);
+    }
     return -4;
 }
 

@@ -43,7 +43,7 @@ class NerfRaw(C.Structure):
 class Options(C.Structure):
     """``enerf_options_t``: explicit kernel-variant choices, passed per call (all zero = defaults)."""
     _fields_ = [("conv3d_global_only", _i), ("conv3d_lds_min_voxels", _ll), ("conv3d_pk8", _i),
-                ("featnet_unfused", _i), ("featnet_smooth0_plain", _i), ("render_blocks_per_cu", _i)]
+                ("featnet_unfused", _i), ("featnet_smooth0_plain", _i)]
 
     def __repr__(self):
         return "Options(" + ", ".join(f"{n}={getattr(self, n)}" for n, _ in self._fields_ if getattr(self, n)) + ")"
@@ -51,7 +51,7 @@ class Options(C.Structure):
 
 # what "most frames per second" prefers over "one frame as fast as possible" (enerf_amd/pipeline.py)
 def throughput_options() -> "Options":
-    return Options(conv3d_pk8=2, render_blocks_per_cu=2)
+    return Options(conv3d_pk8=2)
 
 
 def _opt(o):

@@ -24,7 +24,7 @@ from .lib import Options, throughput_options
 # several frames in flight the matrix pipes are shared, so variants that issue fewer MFMAs win even where they are
 # slower in isolation (measured on MI355X, 6 frames in flight: 1216 -> 1234 -> 1244 frames/s; one frame at a time the
 # same switches cost 2 %).  They are an explicit ``enerf_options_t`` (lib.throughput_options(): tap-packed conv3d for
-# every Cout=8 layer, render kernel at 2 blocks/CU) handed to every launch of the frames submitted HERE — nothing
+# every Cout=8 layer) handed to every launch of the frames submitted HERE — nothing
 # process-global is touched, other users of the same Network keep its own ``net.options``.  Results change at the
 # 1e-6 level (different summation order), not bit for bit.
 

@@ -44,7 +44,6 @@ typedef struct {
                                         1 = never, 2 = every Cout=8(+1) layer (fewest MFMAs: throughput mode) */
     int featnet_unfused;             /* 1: one launch per FeatureNet layer (no conv0/toplayer/lat0 fusions) */
     int featnet_smooth0_plain;       /* 1: plain 8x32 tiling in the fused smooth0 kernel instead of tap packing */
-    int render_blocks_per_cu;        /* 0 = auto (3); 2 or 3 resident 256-thread blocks per CU in k_render_rays */
 } enerf_options_t;
 
 /* ---- layout adapters at the PyTorch boundary (FeatureNet output is NCHW, network.py:58-67) ---- */
