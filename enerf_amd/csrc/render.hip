@@ -360,13 +360,17 @@ void k_render_rays(RenderArgs a) {
 #pragma unroll
             for (int c = 0; c < 8; ++c)                 // order tnw,tne,tsw,tse,bnw,bne,bsw,bse
                 vt[c] = *reinterpret_cast<const float2*>(a.vol + ((unsigned)(zo[c >> 2] + oxy[c & 3]) * 8u + voff));
-            constexpr int QB = R <= 3 ? R : 3;          // texel channels are gathered QB float4 chunks at a time (R = 9: 3 rounds)
+            // texel channels are gathered QB float4 chunks per tap at a time; R = 9 takes three rounds, two of them in flight
+            constexpr int QB = R <= 3 ? R : 3, NRND = R / QB, NBUF = NRND > 1 ? 2 : 1;
+            static_assert(R % QB == 0, "texel chunk rounds");
             f32x4 blend[R];
-            f32x4 tq[4][QB];
+            f32x4 tq[NBUF][4][QB];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int rd = 0; rd < NBUF; ++rd)
 #pragma unroll
-                for (int q = 0; q < QB; ++q) tq[c][q] = lds4(tp[c] + 4 * q);
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int q = 0; q < QB; ++q) tq[rd][c][q] = lds4(tp[c] + 4 * (rd * QB + q));
             __builtin_amdgcn_sched_barrier(0);
             // direction code (utils.py:707-720) while the gathers are in flight
             float tx = X - tc4[0], ty = Y - tc4[1], tz = Z - tc4[2];
@@ -383,20 +387,22 @@ void k_render_rays(RenderArgs a) {
             for (int c = 0; c < 8; ++c) vw[c] = wxy[c & 3] * wz[c >> 2];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q0 = 0; q0 < R; q0 += QB) {
+            for (int rd = 0; rd < NRND; ++rd) {
 #pragma unroll
                 for (int q = 0; q < QB; ++q) {
-                    f32x4 acc = tq[0][q] * tw[0];
-                    acc += tq[1][q] * tw[1];
-                    acc += tq[2][q] * tw[2];
-                    acc += tq[3][q] * tw[3];
-                    blend[q0 + q] = acc;
+                    f32x4 acc = tq[rd % NBUF][0][q] * tw[0];
+                    acc += tq[rd % NBUF][1][q] * tw[1];
+                    acc += tq[rd % NBUF][2][q] * tw[2];
+                    acc += tq[rd % NBUF][3][q] * tw[3];
+                    blend[rd * QB + q] = acc;
                 }
-                if (q0 + QB < R) {                      // next round of chunks (R = 9 only)
+                if (rd + NBUF < NRND) {                 // refill the buffer just consumed (R = 9 only)
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
 #pragma unroll
-                        for (int q = 0; q < QB; ++q) tq[c][q] = lds4(tp[c] + 4 * (q0 + QB + q));
+                        for (int q = 0; q < QB; ++q) tq[rd % NBUF][c][q] = lds4(tp[c] + 4 * ((rd + NBUF) * QB + q));
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (g < S) {
