@@ -1,0 +1,304 @@
+// backward.hip — hand-written backward kernels of the training path, first batch: the stages
+// around the dense layers whose PyTorch backward materialises large intermediates or runs as dozens of tiny launches:
+//   * homo_warp + variance (utils.py:57-95, 322-349): gradient w.r.t. the source feature maps (scatter-add of the four
+//     bilinear taps) AND w.r.t. the depth hypotheses (through the warp grid — this is how level 1 back-propagates into
+//     level 0's depth/std).  The forward never materialises the S warped volumes, neither does this.
+//   * depth_regression (utils.py:658-667): softmax over D, mean, std -> gradients of prob and depth_values.
+//   * raw2outputs (utils.py:571-603): alpha compositing forward and backward (cumprod, the softmaxed weights quirk).
+// All fp32, one thread (group) per voxel / pixel / ray, atomics only for the feature scatter.  Gradients follow torch
+// autograd's formulas (grid_sampler_2d_backward, clamp_min, softmax, cumprod) and are checked against them and against
+// the reference's own parameter gradients (tests/test_training.py).
+#include "kernels.h"
+
+namespace enerf {
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+#ifdef ENERF_EMU
+    atomicAdd(p, v);
+#else
+    unsafeAtomicAdd(p, v);          // global_atomic_add_f32 (hipMalloc memory is coarse-grained)
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// build_feature_volume backward.  CQ = C/4 lanes own one voxel (one float4 of channels each), as in the forward.
+//   var[c] = mean_s f_s[c]^2 - (mean_s f_s[c])^2          =>   d f_s[c] = (2/S) g[c] (f_s[c] - mean[c])
+//   f_s = bilinear(feat_s, u, v) (zeros padding)          =>   d feat_s[tap] += w_tap d f_s ;  d u, d v from the tap values
+//   (u, v) = p.xy / max(p.z, 1e-6), p = R [x,y,1] + T / d =>   d d = -(T . d p) / d^2
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CQ>
+__global__ __launch_bounds__(256) void k_feature_volume_bwd(const float* __restrict__ feat, const float* __restrict__ proj,
+                                                            const float* __restrict__ dv, const float* __restrict__ gvol,
+                                                            int B, int S, int Hs, int Ws, int D, int h, int w,
+                                                            float* __restrict__ gfeat, float* __restrict__ gdv) {
+    constexpr int C = CQ * 4;
+    const long long nvox = (long long)B * D * h * w;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long vraw = t / CQ;
+    const int cq = (int)(t - vraw * CQ);
+    const bool live = vraw < nvox;
+    const long long vox = live ? vraw : nvox - 1;
+    const int x = (int)(vox % w), y = (int)((vox / w) % h);
+    const int b = (int)(vox / ((long long)D * h * w));
+    const float depth = dv[vox];
+    const float fx = (float)x, fy = (float)y;
+    const float4 g = *reinterpret_cast<const float4*>(gvol + vox * C + cq * 4);
+    const long long img = (long long)Hs * Ws * C;
+    // pass 1: mean over views of the warped features
+    float4 mean = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < S; ++s) {
+        const float* P = proj + (b * S + s) * 12;
+        const float px = P[0] * fx + P[1] * fy + P[2] + P[3] / depth;
+        const float py = P[4] * fx + P[5] * fy + P[6] + P[7] / depth;
+        const float pz = P[8] * fx + P[9] * fy + P[10] + P[11] / depth;
+        const float z = clamp_min(pz, 1e-6f);
+        const Taps2 tp = gs_taps2<false>(px / z, py / z, Ws, Hs);
+        const float* base = feat + (long long)(b * S + s) * img + cq * 4;
+        const float4 v00 = *reinterpret_cast<const float4*>(base + ((long long)tp.y0 * Ws + tp.x0) * C);
+        const float4 v01 = *reinterpret_cast<const float4*>(base + ((long long)tp.y0 * Ws + tp.x1) * C);
+        const float4 v10 = *reinterpret_cast<const float4*>(base + ((long long)tp.y1 * Ws + tp.x0) * C);
+        const float4 v11 = *reinterpret_cast<const float4*>(base + ((long long)tp.y1 * Ws + tp.x1) * C);
+        mean.x += v00.x * tp.w00 + v01.x * tp.w01 + v10.x * tp.w10 + v11.x * tp.w11;
+        mean.y += v00.y * tp.w00 + v01.y * tp.w01 + v10.y * tp.w10 + v11.y * tp.w11;
+        mean.z += v00.z * tp.w00 + v01.z * tp.w01 + v10.z * tp.w10 + v11.z * tp.w11;
+        mean.w += v00.w * tp.w00 + v01.w * tp.w01 + v10.w * tp.w10 + v11.w * tp.w11;
+    }
+    const float inv_s = 1.f / (float)S;
+    mean.x *= inv_s; mean.y *= inv_s; mean.z *= inv_s; mean.w *= inv_s;
+    // pass 2: per view, d f_s -> scatter to the four taps, and the grid gradient -> d depth
+    float gd = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float* P = proj + (b * S + s) * 12;
+        const float px = P[0] * fx + P[1] * fy + P[2] + P[3] / depth;
+        const float py = P[4] * fx + P[5] * fy + P[6] + P[7] / depth;
+        const float pz = P[8] * fx + P[9] * fy + P[10] + P[11] / depth;
+        const float z = clamp_min(pz, 1e-6f);
+        const float u = px / z, v = py / z;
+        const Taps2 tp = gs_taps2<false>(u, v, Ws, Hs);
+        const long long vb = (long long)(b * S + s) * img + cq * 4;
+        const long long o00 = vb + ((long long)tp.y0 * Ws + tp.x0) * C, o01 = vb + ((long long)tp.y0 * Ws + tp.x1) * C;
+        const long long o10 = vb + ((long long)tp.y1 * Ws + tp.x0) * C, o11 = vb + ((long long)tp.y1 * Ws + tp.x1) * C;
+        const float4 v00 = *reinterpret_cast<const float4*>(feat + o00), v01 = *reinterpret_cast<const float4*>(feat + o01);
+        const float4 v10 = *reinterpret_cast<const float4*>(feat + o10), v11 = *reinterpret_cast<const float4*>(feat + o11);
+        float f[4] = {v00.x * tp.w00 + v01.x * tp.w01 + v10.x * tp.w10 + v11.x * tp.w11,
+                      v00.y * tp.w00 + v01.y * tp.w01 + v10.y * tp.w10 + v11.y * tp.w11,
+                      v00.z * tp.w00 + v01.z * tp.w01 + v10.z * tp.w10 + v11.z * tp.w11,
+                      v00.w * tp.w00 + v01.w * tp.w01 + v10.w * tp.w10 + v11.w * tp.w11};
+        const float gg[4] = {g.x, g.y, g.z, g.w}, mm[4] = {mean.x, mean.y, mean.z, mean.w};
+        const float a00[4] = {v00.x, v00.y, v00.z, v00.w}, a01[4] = {v01.x, v01.y, v01.z, v01.w};
+        const float a10[4] = {v10.x, v10.y, v10.z, v10.w}, a11[4] = {v11.x, v11.y, v11.z, v11.w};
+        // validity of the taps (zeros padding): a weight of exactly 0 marks an out-of-image tap or a zero-area one
+        const float fxu = floorf(u), fyv = floorf(v);
+        const bool fin = (u > -1e8f) && (u < 1e8f) && (v > -1e8f) && (v < 1e8f);
+        const float tx1 = u - fxu, ty1 = v - fyv, tx0 = 1.f - tx1, ty0 = 1.f - ty1;
+        const int x0 = (int)fxu, y0 = (int)fyv;
+        const bool vx0 = fin && x0 >= 0 && x0 < Ws, vx1 = fin && x0 + 1 >= 0 && x0 + 1 < Ws;
+        const bool vy0 = fin && y0 >= 0 && y0 < Hs, vy1 = fin && y0 + 1 >= 0 && y0 + 1 < Hs;
+        float gu = 0.f, gv = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float df = live ? (2.f * inv_s) * gg[c] * (f[c] - mm[c]) : 0.f;
+            if (vx0 && vy0) { atomic_add_f32(gfeat + o00 + c, tp.w00 * df); gu -= a00[c] * ty0 * df; gv -= a00[c] * tx0 * df; }
+            if (vx1 && vy0) { atomic_add_f32(gfeat + o01 + c, tp.w01 * df); gu += a01[c] * ty0 * df; gv -= a01[c] * tx1 * df; }
+            if (vx0 && vy1) { atomic_add_f32(gfeat + o10 + c, tp.w10 * df); gu -= a10[c] * ty1 * df; gv += a10[c] * tx0 * df; }
+            if (vx1 && vy1) { atomic_add_f32(gfeat + o11 + c, tp.w11 * df); gu += a11[c] * ty1 * df; gv += a11[c] * tx1 * df; }
+        }
+        // (u, v) = p.xy / z ; z = max(p.z, 1e-6)
+        const float gpx = gu / z, gpy = gv / z;
+        const float gpz = pz >= 1e-6f ? -(gu * px + gv * py) / (z * z) : 0.f;
+        gd -= (P[3] * gpx + P[7] * gpy + P[11] * gpz) / (depth * depth);
+    }
+    // sum over the CQ channel lanes of the voxel
+    for (int m = CQ >> 1; m >= 1; m >>= 1) gd += __shfl_xor(gd, m);
+    if (live && cq == 0) gdv[vox] = gd;
+}
+bool launch_feature_volume_bwd(const float* feat, const float* proj, const float* dv, const float* gvol, int B, int S, int C,
+                               int Hs, int Ws, int D, int h, int w, float* gfeat, float* gdv, hipStream_t st) {
+    const long long threads = (long long)B * D * h * w * (C / 4);
+    const unsigned grid = (unsigned)cdivl(threads, 256);
+    switch (C) {
+        case 32: ENERF_LAUNCH(k_feature_volume_bwd<8>, grid, 256, 0, st, feat, proj, dv, gvol, B, S, Hs, Ws, D, h, w, gfeat, gdv); return true;
+        case 16: ENERF_LAUNCH(k_feature_volume_bwd<4>, grid, 256, 0, st, feat, proj, dv, gvol, B, S, Hs, Ws, D, h, w, gfeat, gdv); return true;
+        case 8: ENERF_LAUNCH(k_feature_volume_bwd<2>, grid, 256, 0, st, feat, proj, dv, gvol, B, S, Hs, Ws, D, h, w, gfeat, gdv); return true;
+        default: return false;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// depth_regression backward: p = softmax_D(prob), v = depth_inv ? 1/max(dv,1e-6) : dv, mu = sum p v,
+// var = sum p (v - mu)^2, std = sqrt(max(var, 1e-10)).  One thread per pixel (D <= 64 in every config).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_depth_regression_bwd(const float* __restrict__ prob, const float* __restrict__ dv,
+                                                              const float* __restrict__ g_depth, const float* __restrict__ g_std,
+                                                              int B, int D, int h, int w, int depth_inv,
+                                                              float* __restrict__ g_prob, float* __restrict__ g_dv) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long hw = (long long)h * w;
+    if (i >= (long long)B * hw) return;
+    const long long b = i / hw, p = i - b * hw;
+    const float* pr = prob + b * D * hw + p;
+    const float* dp = dv + b * D * hw + p;
+    float m = -INFINITY;
+    for (int k = 0; k < D; ++k) m = fmaxf(m, pr[k * hw]);
+    float se = 0.f;
+    for (int k = 0; k < D; ++k) se += expf(pr[k * hw] - m);
+    float mu = 0.f;
+    for (int k = 0; k < D; ++k) {
+        const float d = dp[k * hw], v = depth_inv ? 1.f / clamp_min(d, 1e-6f) : d;
+        mu += (expf(pr[k * hw] - m) / se) * v;
+    }
+    float var = 0.f, s1 = 0.f;                          // s1 = sum p (v - mu): d var / d mu = -2 s1
+    for (int k = 0; k < D; ++k) {
+        const float d = dp[k * hw], v = depth_inv ? 1.f / clamp_min(d, 1e-6f) : d;
+        const float pk = expf(pr[k * hw] - m) / se;
+        var += pk * (v - mu) * (v - mu);
+        s1 += pk * (v - mu);
+    }
+    const float gvar = var >= 1e-10f ? g_std[i] * 0.5f / sqrtf(var) : 0.f;         // clamp_min + sqrt
+    const float gmu = g_depth[i] + gvar * (-2.f * s1);
+    float dot = 0.f;                                    // sum_j p_j dL/dp_j (softmax backward)
+    for (int k = 0; k < D; ++k) {
+        const float d = dp[k * hw], v = depth_inv ? 1.f / clamp_min(d, 1e-6f) : d;
+        const float pk = expf(pr[k * hw] - m) / se;
+        dot += pk * (gmu * v + gvar * (v - mu) * (v - mu));
+    }
+    for (int k = 0; k < D; ++k) {
+        const float d = dp[k * hw], v = depth_inv ? 1.f / clamp_min(d, 1e-6f) : d;
+        const float pk = expf(pr[k * hw] - m) / se;
+        const float gp = gmu * v + gvar * (v - mu) * (v - mu);
+        g_prob[b * D * hw + k * hw + p] = pk * (gp - dot);
+        const float gvk = gmu * pk + gvar * 2.f * pk * (v - mu);
+        g_dv[b * D * hw + k * hw + p] = depth_inv ? (d >= 1e-6f ? -gvk / (d * d) : 0.f) : gvk;
+    }
+}
+void launch_depth_regression_bwd(const float* prob, const float* dv, const float* g_depth, const float* g_std, int B, int D,
+                                 int h, int w, int depth_inv, float* g_prob, float* g_dv, hipStream_t st) {
+    ENERF_LAUNCH_SIMPLE(k_depth_regression_bwd, (unsigned)cdivl((long long)B * h * w, 256), 256, 0, st, prob, dv, g_depth, g_std, B,
+                        D, h, w, depth_inv, g_prob, g_dv);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// raw2outputs (utils.py:571-603) forward / backward, one thread per ray (Ns <= 8).  raw (n,Ns,4) = [rgb, sigma], z (n,Ns).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_composite_fwd(const float* __restrict__ raw, const float* __restrict__ z, long long n,
+                                                       int Ns, int white_bkgd, float* __restrict__ rgb,
+                                                       float* __restrict__ depth, float* __restrict__ weights) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float wt[8], T = 1.f, c[3] = {0.f, 0.f, 0.f}, m = -INFINITY;
+    for (int k = 0; k < Ns; ++k) {
+        const float* r = raw + (i * Ns + k) * 4;
+        const float alpha = 1.f - expf(-r[3]);
+        wt[k] = alpha * T;
+        T *= (1.f - alpha + 1e-10f);
+        c[0] += wt[k] * r[0]; c[1] += wt[k] * r[1]; c[2] += wt[k] * r[2];
+        m = fmaxf(m, wt[k]);
+    }
+    float se = 0.f;
+    for (int k = 0; k < Ns; ++k) { wt[k] = expf(wt[k] - m); se += wt[k]; }
+    float d = 0.f, acc = 0.f;
+    for (int k = 0; k < Ns; ++k) {
+        const float wk = wt[k] / se;
+        weights[i * Ns + k] = wk;
+        d += wk * z[i * Ns + k];
+        acc += wk;
+    }
+    depth[i] = d;
+    for (int q = 0; q < 3; ++q) rgb[i * 3 + q] = c[q] + (white_bkgd ? 1.f - acc : 0.f);
+}
+__global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__ raw, const float* __restrict__ z,
+                                                       const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
+                                                       const float* __restrict__ g_weights, long long n, int Ns,
+                                                       float* __restrict__ g_raw, float* __restrict__ g_z) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float alpha[8], tt[8], Tk[8], wt[8], ws[8];
+    float T = 1.f, m = -INFINITY;
+    for (int k = 0; k < Ns; ++k) {
+        alpha[k] = 1.f - expf(-raw[(i * Ns + k) * 4 + 3]);
+        tt[k] = 1.f - alpha[k] + 1e-10f;
+        Tk[k] = T;
+        wt[k] = alpha[k] * T;
+        T *= tt[k];
+        m = fmaxf(m, wt[k]);
+    }
+    float se = 0.f;
+    for (int k = 0; k < Ns; ++k) { ws[k] = expf(wt[k] - m); se += ws[k]; }
+    const float gr[3] = {g_rgb[i * 3], g_rgb[i * 3 + 1], g_rgb[i * 3 + 2]};
+    const float gd = g_depth[i];
+    float gws[8], dot = 0.f;                            // gradient w.r.t. the softmaxed weights (white_bkgd adds 1 - sum = const)
+    for (int k = 0; k < Ns; ++k) {
+        ws[k] /= se;
+        gws[k] = g_weights[i * Ns + k] + gd * z[i * Ns + k];
+        g_z[i * Ns + k] = gd * ws[k];
+        dot += ws[k] * gws[k];
+    }
+    float gT[8], galpha[8];
+    for (int k = 0; k < Ns; ++k) {
+        const float* r = raw + (i * Ns + k) * 4;
+        const float gwt = ws[k] * (gws[k] - dot) + gr[0] * r[0] + gr[1] * r[1] + gr[2] * r[2];
+        for (int q = 0; q < 3; ++q) g_raw[(i * Ns + k) * 4 + q] = wt[k] * gr[q];
+        galpha[k] = gwt * Tk[k];
+        gT[k] = gwt * alpha[k];
+    }
+    // T_k = prod_{j<k} t_j :  d t_j = sum_{k>j} gT_k T_k / t_j   (torch cumprod backward, no zeros: t >= 1e-10)
+    float run = 0.f;
+    for (int j = Ns - 1; j >= 0; --j) {
+        const float gt = run / tt[j];
+        galpha[j] -= gt;                                // t_j = 1 - alpha_j + 1e-10
+        run += gT[j] * Tk[j];
+        g_raw[(i * Ns + j) * 4 + 3] = galpha[j] * expf(-raw[(i * Ns + j) * 4 + 3]);   // alpha = 1 - exp(-sigma)
+    }
+}
+void launch_composite_fwd(const float* raw, const float* z, long long n, int Ns, int white_bkgd, float* rgb, float* depth,
+                          float* weights, hipStream_t st) {
+    ENERF_LAUNCH_SIMPLE(k_composite_fwd, (unsigned)cdivl(n, 256), 256, 0, st, raw, z, n, Ns, white_bkgd, rgb, depth, weights);
+}
+void launch_composite_bwd(const float* raw, const float* z, const float* g_rgb, const float* g_depth, const float* g_weights,
+                          long long n, int Ns, float* g_raw, float* g_z, hipStream_t st) {
+    ENERF_LAUNCH_SIMPLE(k_composite_bwd, (unsigned)cdivl(n, 256), 256, 0, st, raw, z, g_rgb, g_depth, g_weights, n, Ns, g_raw, g_z);
+}
+
+}  // namespace enerf
+
+using namespace enerf;
+extern "C" {
+
+int enerf_build_feature_volume_bwd(const float* feat, const float* proj, const float* depth_values, const float* grad_vol, int B,
+                                   int S, int C, int Hs, int Ws, int D, int h, int w, float* grad_feat, float* grad_depth_values,
+                                   enerf_stream_t stream) {
+    REQUIRE(feat && proj && depth_values && grad_vol && grad_feat && grad_depth_values, "build_feature_volume_bwd: null pointer");
+    REQUIRE(C == 8 || C == 16 || C == 32, "build_feature_volume_bwd: C=%d unsupported (8/16/32)", C);
+    REQUIRE(B > 0 && S > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0, "build_feature_volume_bwd: bad shape");
+    hipMemsetAsync(grad_feat, 0, (size_t)B * S * Hs * Ws * C * sizeof(float), (hipStream_t)stream);
+    launch_feature_volume_bwd(feat, proj, depth_values, grad_vol, B, S, C, Hs, Ws, D, h, w, grad_feat, grad_depth_values,
+                              (hipStream_t)stream);
+    return check_launch("build_feature_volume_bwd");
+}
+int enerf_depth_regression_bwd(const float* prob, const float* depth_values, const float* grad_depth, const float* grad_std, int B,
+                               int D, int h, int w, int depth_inv, float* grad_prob, float* grad_depth_values,
+                               enerf_stream_t stream) {
+    REQUIRE(prob && depth_values && grad_depth && grad_std && grad_prob && grad_depth_values && B > 0 && D > 0 && h > 0 && w > 0,
+            "depth_regression_bwd: bad arguments");
+    launch_depth_regression_bwd(prob, depth_values, grad_depth, grad_std, B, D, h, w, depth_inv, grad_prob, grad_depth_values,
+                                (hipStream_t)stream);
+    return check_launch("depth_regression_bwd");
+}
+int enerf_composite(const float* raw, const float* z, long long n, int n_samples, int white_bkgd, float* rgb, float* depth,
+                    float* weights, enerf_stream_t stream) {
+    REQUIRE(n >= 0 && n_samples >= 1 && n_samples <= 8, "composite: n_samples must be in [1,8]");
+    if (n == 0) return ENERF_OK;
+    REQUIRE(raw && z && rgb && depth && weights, "composite: null pointer");
+    launch_composite_fwd(raw, z, n, n_samples, white_bkgd, rgb, depth, weights, (hipStream_t)stream);
+    return check_launch("composite");
+}
+int enerf_composite_bwd(const float* raw, const float* z, const float* grad_rgb, const float* grad_depth, const float* grad_weights,
+                        long long n, int n_samples, float* grad_raw, float* grad_z, enerf_stream_t stream) {
+    REQUIRE(n >= 0 && n_samples >= 1 && n_samples <= 8, "composite_bwd: n_samples must be in [1,8]");
+    if (n == 0) return ENERF_OK;
+    REQUIRE(raw && z && grad_rgb && grad_depth && grad_weights && grad_raw && grad_z, "composite_bwd: null pointer");
+    launch_composite_bwd(raw, z, grad_rgb, grad_depth, grad_weights, n, n_samples, grad_raw, grad_z, (hipStream_t)stream);
+    return check_launch("composite_bwd");
+}
+
+}  // extern "C"

@@ -140,6 +140,10 @@ _SIGNATURES = {
     "enerf_mask_compact": (_i, [C.c_void_p, _i, _ll, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, _f]),
     "enerf_forward_workspace_bytes": (C.c_size_t, [C.POINTER(FrameArgs)]),
     "enerf_forward": (_i, [C.POINTER(FrameArgs), _f]),
+    "enerf_build_feature_volume_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f]),
+    "enerf_depth_regression_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f]),
+    "enerf_composite": (_i, [_f, _f, _ll, _i, _i, _f, _f, _f, _f]),
+    "enerf_composite_bwd": (_i, [_f, _f, _f, _f, _f, _ll, _i, _f, _f, _f]),
     "enerf_gen_rays": (_i, [_f, _f, _i, _i, _i, _fl, _f, _f]),
     "enerf_pack_rgb8": (_i, [_f, _i, _i, _i, _f, _f]),
     "enerf_eval_stats": (_i, [_f, _f, C.c_void_p, _i, _ll, _i, _i, _i, _i, _f, _f, _ll, _f, _f]),
@@ -381,6 +385,41 @@ class EnerfLib:
         self._check(self.dll.enerf_render_rays(C.byref(a), self.stream_of(rays12)), "render_rays")
         return rgb, depth, weights
 
+
+    # -- backward kernels (training path; wrapped by enerf_amd/autograd.py) -----------------------------
+    def build_feature_volume_bwd(self, feat_cl, proj, dv, grad_vol):
+        B, S, Hs, Ws, Cc = feat_cl.shape
+        _, D, h, w = dv.shape
+        gfeat = torch.empty_like(feat_cl)
+        gdv = torch.empty_like(dv)
+        self._check(self.dll.enerf_build_feature_volume_bwd(_ptr(feat_cl), _ptr(proj), _ptr(dv), _ptr(grad_vol), B, S, Cc, Hs, Ws,
+                                                            D, h, w, _ptr(gfeat), _ptr(gdv), self.stream_of(dv)),
+                    "build_feature_volume_bwd")
+        return gfeat, gdv
+
+    def depth_regression_bwd(self, prob, dv, g_depth, g_std, depth_inv):
+        B, D, h, w = prob.shape
+        gp, gdv = torch.empty_like(prob), torch.empty_like(dv)
+        self._check(self.dll.enerf_depth_regression_bwd(_ptr(prob), _ptr(dv), _ptr(g_depth), _ptr(g_std), B, D, h, w,
+                                                        int(depth_inv), _ptr(gp), _ptr(gdv), self.stream_of(prob)),
+                    "depth_regression_bwd")
+        return gp, gdv
+
+    def composite(self, raw, z, white_bkgd=False):
+        n, Ns = z.shape
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=raw.device)
+        depth = torch.empty((n,), dtype=torch.float32, device=raw.device)
+        weights = torch.empty((n, Ns), dtype=torch.float32, device=raw.device)
+        self._check(self.dll.enerf_composite(_ptr(raw), _ptr(z), n, Ns, int(white_bkgd), _ptr(rgb), _ptr(depth), _ptr(weights),
+                                             self.stream_of(raw)), "composite")
+        return rgb, depth, weights
+
+    def composite_bwd(self, raw, z, g_rgb, g_depth, g_weights):
+        n, Ns = z.shape
+        g_raw, g_z = torch.empty_like(raw), torch.empty_like(z)
+        self._check(self.dll.enerf_composite_bwd(_ptr(raw), _ptr(z), _ptr(g_rgb), _ptr(g_depth), _ptr(g_weights), n, Ns,
+                                                 _ptr(g_raw), _ptr(g_z), self.stream_of(raw)), "composite_bwd")
+        return g_raw, g_z
 
     # -- whole frame / mask compaction -------------------------------------------------------------
     def mask_compact(self, mask: torch.Tensor, workspace=None):

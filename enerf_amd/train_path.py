@@ -8,11 +8,15 @@ What runs where in training (state of this round, stated plainly):
   * every stage is expressed on the network's OWN parameter modules (``feature_net``, ``cost_reg_i.conv*.{conv,bn}``,
     ``nerf_i.*``), so BatchNorm uses batch statistics (and becomes SyncBatchNorm under the reference trainer), the
     running statistics are updated exactly like the reference's, and autograd sees every parameter;
-  * forward AND backward of the training step execute as PyTorch-ROCm ops (MIOpen / rocBLAS / ATen grid_sample) with
-    autograd — the hand-written HIP kernels serve the inference path; their backward counterparts (render MLP +
-    compositing, gather scatter-adds, conv3d dgrad/wgrad, BN-train) are the next step of this row and are NOT built yet.
+  * three stages run on hand-written HIP kernels in BOTH directions (``enerf_amd/autograd.py`` over
+    ``csrc/backward.hip``): the cost-volume warp + variance (gradients w.r.t. the feature maps and, through the warp grid,
+    w.r.t. the depth hypotheses), depth regression, and alpha compositing;
+  * the dense layers (2-D / 3-D convolutions + BatchNorm, the Agg/NeRF MLP) and the render-side gathers execute as
+    PyTorch-ROCm ops (MIOpen / rocBLAS / ATen grid_sample) with autograd; their HIP backward (MLP, gather scatter-adds,
+    conv3d dgrad/wgrad, BN-train) is the next step of this row and is NOT built yet.
     This is GPU code (no CPU fallback, nothing from ``oracle/``), checked against the reference's own gradients
-    (tests/test_training.py, tests/golden/train_tiny.npz: every parameter gradient of one reference training step).
+    (tests/test_training.py, tests/golden/train_tiny.npz: every parameter gradient of one reference training step), with
+    the HIP stages switched on and off.
 The inference path (eval mode) never comes here: it is the single ``enerf_forward`` C call.
 
 Semantics follow the reference line by line where gradients are concerned: the in-place masked clamps of
@@ -253,7 +257,7 @@ def raw2outputs(raw, z, white_bkgd=False):
     return {"rgb": rgb, "depth": depth, "weights": w}
 
 
-def render_rays(net, rays, level, batch, im_feat, feat_vol):
+def render_rays(net, rays, level, batch, im_feat, feat_vol, lib=None):
     """Network.render_rays (network.py:24-43), differentiable: rays (B,N,12), im_feat (B,S,C,Hf,Wf), feat_vol (B,8,D,h,w)."""
     cas = net.cfg.cas
     Ns = cas.num_samples[level]
@@ -275,12 +279,29 @@ def render_rays(net, rays, level, batch, im_feat, feat_vol):
     vox = F.grid_sample(feat_vol, g, align_corners=True)[:, :, 0, 0].permute(0, 2, 1)        # get_vox_feat utils.py:456-458
     x = img_feat(cas, xyz, tex, batch, level)
     raw = nerf_forward(getattr(net, f"nerf_{level}"), vox, x).reshape(B, N, Ns, 4)
+    if lib is not None:
+        from .autograd import CompositeFn
+        rgb, depth, weights = CompositeFn.apply(lib, raw, z, bool(net.cfg.white_bkgd))
+        return {"rgb": rgb, "depth": depth, "weights": weights}
     return raw2outputs(raw, z, net.cfg.white_bkgd)
+
+
+def _hip_lib(net, t: torch.Tensor):
+    """The library whose kernels can run on ``t``'s memory: the GPU build for CUDA tensors, a CPU lane-emulator build only
+    when a test injected one (``Network(lib=...)``); None -> the stage runs as torch ops."""
+    if not getattr(net, "hip_backward", True):
+        return None
+    if t.is_cuda:
+        return net.lib
+    lib = net._lib
+    return lib if (lib is not None and "emu" in lib.path) else None
 
 
 def forward_train(net, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Network.forward (network.py:76-113 / network_human.py:69-119) with autograd, on the network's own modules."""
+    from .autograd import CompositeFn, DepthRegressionFn, FeatureVolumeFn
     cas = net.cfg.cas
+    lib = _hip_lib(net, batch["src_inps"])
     feats = net.forward_feat(batch["src_inps"])
     ret: Dict[str, torch.Tensor] = {}
     depth: Optional[torch.Tensor] = None
@@ -288,14 +309,15 @@ def forward_train(net, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor
     for i in range(cas.num):
         dv, near_far = depth_values(cas, batch, i, cas.volume_planes[i], depth, std, near_far)
         P = proj_mats(batch, cas.im_feat_scale[i], cas.volume_scale[i])
-        vol = feature_volume(feats[f"level_{i}"], P, dv)
+        vol = FeatureVolumeFn.apply(lib, feats[f"level_{i}"], P, dv) if lib is not None else feature_volume(feats[f"level_{i}"], P, dv)
         feat3d, prob = cost_reg_forward(getattr(net, f"cost_reg_{i}"), vol)
-        depth, std = depth_regression(cas, prob, dv, i)
+        depth, std = DepthRegressionFn.apply(lib, prob, dv, bool(cas.depth_inv[i])) if lib is not None \
+            else depth_regression(cas, prob, dv, i)
         if not cas.render_if[i]:
             continue
         rays = build_rays(cas, depth, std, batch[f"rays_{i}"], near_far, i)
         # network_human.py:90 only compacts rays in eval mode (`not self.training`): training renders every ray
-        out = render_rays(net, rays, i, batch, feats[f"level_{cas.render_im_feat_level[i]}"], feat3d)
+        out = render_rays(net, rays, i, batch, feats[f"level_{cas.render_im_feat_level[i]}"], feat3d, lib)
         out["depth_mvs"] = 1.0 / depth if cas.depth_inv[i] else depth
         out["std"] = std
         ret.update({f"{k}_level{i}": v for k, v in out.items()})

@@ -274,6 +274,24 @@ typedef struct {
 size_t enerf_forward_workspace_bytes(const enerf_frame_args_t* args);   /* 0 + enerf_last_error() on invalid arguments */
 int enerf_forward(const enerf_frame_args_t* args, enerf_stream_t stream);
 
+/* ---- backward kernels of the training path (enerf_amd/autograd.py wraps them as
+ * torch.autograd.Functions).  First batch: the stages around the dense layers.
+ *   enerf_build_feature_volume_bwd  homo_warp + variance (utils.py:57-95,322-349): grad_vol (B,D,h,w,C) ->
+ *       grad_feat (B,S,Hs,Ws,C) (zeroed here, then scatter-added) and grad_depth_values (B,D,h,w) (through the warp grid).
+ *   enerf_depth_regression_bwd      utils.py:658-667: grad_depth, grad_std (B,h,w) -> grad_prob, grad_depth_values (B,D,h,w).
+ *   enerf_composite / _bwd          raw2outputs (utils.py:571-603): raw (n,Ns,4) = [rgb, sigma], z (n,Ns) ->
+ *       rgb (n,3), depth (n), weights (n,Ns); backward -> grad_raw (n,Ns,4), grad_z (n,Ns). ---- */
+int enerf_build_feature_volume_bwd(const float* feat, const float* proj, const float* depth_values, const float* grad_vol, int B,
+                                   int S, int C, int Hs, int Ws, int D, int h, int w, float* grad_feat, float* grad_depth_values,
+                                   enerf_stream_t stream);
+int enerf_depth_regression_bwd(const float* prob, const float* depth_values, const float* grad_depth, const float* grad_std, int B,
+                               int D, int h, int w, int depth_inv, float* grad_prob, float* grad_depth_values,
+                               enerf_stream_t stream);
+int enerf_composite(const float* raw, const float* z, long long n, int n_samples, int white_bkgd, float* rgb, float* depth,
+                    float* weights, enerf_stream_t stream);
+int enerf_composite_bwd(const float* raw, const float* z, const float* grad_rgb, const float* grad_depth, const float* grad_weights,
+                        long long n, int n_samples, float* grad_raw, float* grad_z, enerf_stream_t stream);
+
 /* ---- the steps before / after the path ----
  * Before (ray generation, view selection):
  *   enerf_gen_rays        full-image rays of lib/datasets/enerf_utils.py:61-71: rays (B,Hr*Wr,8) = [o, d, x, y] at the

@@ -279,6 +279,15 @@ inline double atomicAdd(double* p, double v) {          // blocks run on several
     return od;
 }
 
+inline float atomicAdd(float* p, float v) {            // blocks run on several OS threads: real atomic
+    uint32_t* u = reinterpret_cast<uint32_t*>(p);
+    uint32_t old = __atomic_load_n(u, __ATOMIC_RELAXED), neu;
+    float of;
+    do { memcpy(&of, &old, 4); float nf = of + v; memcpy(&neu, &nf, 4);
+    } while (!__atomic_compare_exchange_n(u, &old, neu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    return of;
+}
+
 #define ENERF_LAUNCH(kern, grid, block, shmem, stream, ...) \
     emu::launch(true, dim3(grid), dim3(block), (size_t)(shmem), [&]() { kern(__VA_ARGS__); })
 #define ENERF_LAUNCH_SIMPLE(kern, grid, block, shmem, stream, ...) \

@@ -77,6 +77,92 @@ def test_training_step_matches_reference_gradients():
             np.testing.assert_allclose(buf.numpy(), g[f"buf/{name}"], rtol=1e-4, atol=1e-6, err_msg=name)
 
 
+def _check_hip_backward_stages(lib, dev):
+    """Every autograd.Function of enerf_amd/autograd.py (HIP forward + HIP backward through the C ABI) against the same
+    stage in torch ops (enerf_amd/train_path.py), values and gradients."""
+    from enerf_amd import train_path as T
+    from enerf_amd.autograd import CompositeFn, DepthRegressionFn, FeatureVolumeFn
+    cfg, batch = _train_batch()
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    cas = cfg.cas
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    # --- warp + variance, both levels (C = 32 at 8x16 / C = 16 at 16x32 source maps) ---
+    for level, (C, Hs, Ws, D) in enumerate(((32, 8, 16, 8), (16, 16, 32, 8))):
+        feats = rnd(1, 3, C, Hs, Ws).requires_grad_(True)
+        h, w = int(32 * cas.volume_scale[level]), int(64 * cas.volume_scale[level])
+        dv0 = (torch.linspace(500.0, 800.0, D).view(1, D, 1, 1).expand(1, D, h, w) + 3.0 * torch.randn(1, D, h, w, generator=g)).to(dev)
+        dv = dv0.clone().requires_grad_(True)
+        P = T.proj_mats(batch, cas.im_feat_scale[level], cas.volume_scale[level])
+        gout = rnd(1, C, D, h, w)
+        ref = T.feature_volume(feats, P, dv)
+        ref.backward(gout)
+        gf_ref, gd_ref = feats.grad.clone(), dv.grad.clone()
+        feats.grad = dv.grad = None
+        out = FeatureVolumeFn.apply(lib, feats, P, dv)
+        out.backward(gout)
+        assert float((out - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+        assert float((feats.grad - gf_ref).abs().max()) <= 1e-4 * float(gf_ref.abs().max()), level
+        assert float((dv.grad - gd_ref).abs().max()) <= 2e-3 * float(gd_ref.abs().max()), level      # sums of +- terms
+    # --- depth regression, disparity- and depth-space ---
+    for level, inv in enumerate((True, False)):
+        prob = rnd(1, 8, 6, 10).requires_grad_(True)
+        dv = (500 + 300 * torch.rand(1, 8, 6, 10, generator=g)).to(dev).requires_grad_(True)
+        gd, gs = rnd(1, 6, 10), rnd(1, 6, 10)
+        c2 = cfg.with_cas(depth_inv=(inv, inv)).cas
+        d_ref, s_ref = T.depth_regression(c2, prob, dv, 0)
+        (d_ref * gd + s_ref * gs).sum().backward()
+        gp_ref, gv_ref = prob.grad.clone(), dv.grad.clone()
+        prob.grad = dv.grad = None
+        d, s_ = DepthRegressionFn.apply(lib, prob, dv, inv)
+        (d * gd + s_ * gs).sum().backward()
+        assert float((d - d_ref).abs().max()) <= 1e-5 * float(d_ref.abs().max())
+        assert float((prob.grad - gp_ref).abs().max()) <= 1e-4 * float(gp_ref.abs().max()), inv
+        assert float((dv.grad - gv_ref).abs().max()) <= 1e-4 * float(gv_ref.abs().max()), inv
+    # --- compositing ---
+    for Ns in (2, 8):
+        raw = torch.cat([torch.rand(2, 37, Ns, 3, generator=g), 2 * torch.rand(2, 37, Ns, 1, generator=g)], -1).to(dev).requires_grad_(True)
+        z = (400 + 500 * torch.rand(2, 37, Ns, generator=g)).to(dev).requires_grad_(True)
+        gr, gdp, gw = rnd(2, 37, 3), rnd(2, 37) * 1e-2, rnd(2, 37, Ns)
+        ref = T.raw2outputs(raw, z)
+        (ref["rgb"] * gr).sum().add((ref["depth"] * gdp).sum()).add((ref["weights"] * gw).sum()).backward()
+        gr_ref, gz_ref = raw.grad.clone(), z.grad.clone()
+        raw.grad = z.grad = None
+        rgb, depth, wts = CompositeFn.apply(lib, raw, z, False)
+        ((rgb * gr).sum() + (depth * gdp).sum() + (wts * gw).sum()).backward()
+        assert float((rgb - ref["rgb"]).abs().max()) < 1e-5 and float((wts - ref["weights"]).abs().max()) < 1e-5
+        assert float((raw.grad - gr_ref).abs().max()) <= 1e-4 * float(gr_ref.abs().max()), Ns
+        assert float((z.grad - gz_ref).abs().max()) <= 1e-4 * float(gz_ref.abs().max()), Ns
+
+
+def test_hip_backward_stages_emulated():
+    from emu_lib import emu_lib
+    _check_hip_backward_stages(emu_lib(), torch.device("cpu"))
+
+
+def test_training_step_with_hip_stages_matches_reference_gradients():
+    """The reference-pinned training step again, now with the three HIP forward+backward stages switched on (CPU lane
+    emulator here, the real kernels in the gpu test below)."""
+    from emu_lib import emu_lib
+    g = np.load(os.path.join(GOLDEN, "train_tiny.npz"))
+    cfg, batch = _train_batch()
+    torch.set_num_threads(1)
+    net = Network(cfg, lib=emu_lib())
+    net.load_state_dict(load_weights(), strict=False)
+    net.train()
+    from enerf_amd import train_path as T
+    assert T._hip_lib(net, batch["src_inps"]) is not None
+    loss = _loss(net(batch), batch)
+    assert float(loss) == pytest.approx(float(g["loss"]), rel=1e-5)
+    loss.backward()
+    for name, p in net.named_parameters():
+        if f"grad/{name}/norm" in g.files:
+            assert float(p.grad.double().norm()) == pytest.approx(float(g[f"grad/{name}/norm"]), rel=5e-4), name
+        elif f"grad/{name}/full" in g.files:
+            ref = g[f"grad/{name}/full"]
+            assert np.abs(p.grad.reshape(-1).numpy() - ref).max() <= 5e-4 * np.abs(ref).max() + 1e-9, name
+
+
 def test_train_then_eval_repacks_weights():
     """An optimizer step changes the parameters; the eval-mode HIP path must see the new ones (packed images rebuilt)."""
     from emu_lib import emu_lib
@@ -151,9 +237,13 @@ def test_training_step_on_gpu_matches_reference_gradients():
     grid_sample backward -> a looser tolerance than the CPU run), then an optimizer step and an eval-mode HIP frame."""
     g = np.load(os.path.join(GOLDEN, "train_tiny.npz"))
     dev = torch.device("cuda:0")
+    from enerf_amd.lib import get_lib
+    _check_hip_backward_stages(get_lib(), dev)           # each HIP forward+backward stage vs its torch-op twin
     cfg, batch = _train_batch()
     batch = {k: v.to(dev) for k, v in batch.items()}
     net = _net(cfg).to(dev)
+    from enerf_amd import train_path as T
+    assert T._hip_lib(net, batch["src_inps"]) is get_lib()   # the HIP stages are on
     out = net(batch)
     loss = _loss(out, batch)
     assert float(loss) == pytest.approx(float(g["loss"]), rel=1e-4)
