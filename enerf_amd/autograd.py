@@ -4,7 +4,8 @@ Each Function's forward is the SAME kernel the inference path uses (or its train
 hand-written HIP kernel (enerf_amd/csrc/backward.hip) — no torch ops in between, raw pointers through the C ABI.
 ``enerf_amd/train_path.py`` routes a stage through here when the library is available for the tensors' device (the GPU
 build, or the CPU lane-emulator build in tests); otherwise the stage runs as the equivalent torch ops.  Built so far:
-the cost-volume warp + variance, depth regression, alpha compositing.  Not yet: render MLP, conv3d/BN.
+the cost-volume warp + variance, depth regression, alpha compositing, and the WEIGHT gradient of every convolution
+(the library GEMM MIOpen picks for it took 89 % of a training step).  Not yet: render MLP, conv dgrad / BN-train.
 """
 from __future__ import annotations
 
@@ -76,3 +77,48 @@ class CompositeFn(torch.autograd.Function):
         g_raw, g_z = ctx.lib.composite_bwd(raw2, z2, _c(g_rgb).reshape(B * N, 3), _c(g_depth).reshape(B * N),
                                            _c(g_weights).reshape(B * N, Ns))
         return None, g_raw.view(B, N, Ns, 4), g_z.view(B, N, Ns), None
+
+
+class ConvFn(torch.autograd.Function):
+    """A bias-free Conv2d / Conv3d / ConvTranspose3d(k3,s2,p1,op1) whose WEIGHT gradient runs on the matrix cores
+    (enerf_conv_wgrad).  Forward and the input gradient stay on the library convolution (MIOpen) for now."""
+
+    @staticmethod
+    def forward(ctx, lib: EnerfLib, x, w, stride: int, padding: int, transposed: bool):
+        nd = x.dim() - 2
+        if transposed:
+            y = torch.nn.functional.conv_transpose3d(x, w, None, stride=stride, padding=padding, output_padding=stride - 1)
+        elif nd == 3:
+            y = torch.nn.functional.conv3d(x, w, None, stride, padding)
+        else:
+            y = torch.nn.functional.conv2d(x, w, None, stride, padding)
+        ctx.lib, ctx.cfg = lib, (stride, padding, transposed, nd)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, padding, transposed, nd = ctx.cfg
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[1]:
+            if transposed:                              # dgrad of a transposed conv = the plain strided conv
+                gx = torch.nn.functional.conv3d(gy, w, None, stride, padding)
+            elif nd == 3:
+                gx = torch.nn.grad.conv3d_input(x.shape, w, gy, stride, padding)
+            else:
+                gx = torch.nn.grad.conv2d_input(x.shape, w, gy, stride, padding)
+        if ctx.needs_input_grad[2]:
+            k, pad = tuple(w.shape[2:]), (padding,) * nd
+            gw = ctx.lib.conv_wgrad(x, gy, k, stride, pad) if transposed else ctx.lib.conv_wgrad(gy, x, k, stride, pad)
+        return None, gx, gw, None, None, None
+
+
+def conv_module(lib, m, x):
+    """Apply an nn.Conv2d / nn.Conv3d / nn.ConvTranspose3d of the network through ConvFn (bias added outside)."""
+    transposed = isinstance(m, torch.nn.ConvTranspose3d)
+    y = ConvFn.apply(lib, x, m.weight, int(m.stride[0]), int(m.padding[0]), transposed)
+    if m.bias is not None:
+        y = y + m.bias.view(1, -1, *([1] * (x.dim() - 2)))
+    return y

@@ -142,6 +142,7 @@ _SIGNATURES = {
     "enerf_forward": (_i, [C.POINTER(FrameArgs), _f]),
     "enerf_build_feature_volume_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f]),
     "enerf_depth_regression_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f]),
+    "enerf_conv_wgrad": (_i, [_f, _f] + [_i] * 16 + [_f, _f]),
     "enerf_composite": (_i, [_f, _f, _ll, _i, _i, _f, _f, _f, _f]),
     "enerf_composite_bwd": (_i, [_f, _f, _f, _f, _f, _ll, _i, _f, _f, _f]),
     "enerf_gen_rays": (_i, [_f, _f, _i, _i, _i, _fl, _f, _f]),
@@ -404,6 +405,24 @@ class EnerfLib:
                                                         int(depth_inv), _ptr(gp), _ptr(gdv), self.stream_of(prob)),
                     "depth_regression_bwd")
         return gp, gdv
+
+    def conv_wgrad(self, a, b, kernel, stride, padding):
+        """Weight gradient on the matrix cores (enerf_conv_wgrad).  ``a`` (n,Ca,*grid_a), ``b`` (n,Cb,*grid_b) in torch's
+        channels-first layout (converted to channels-last here by the library's own adapter kernel); 2-D or 3-D.
+        Returns (Ca, Cb, *kernel)."""
+        nd = a.dim() - 2
+        ga, gb = list(a.shape[2:]), list(b.shape[2:])
+        if nd == 2:
+            ga, gb, kernel, padding = [1] + ga, [1] + gb, (1,) + tuple(kernel), (0,) + tuple(padding)
+        n, Ca, Cb = a.shape[0], a.shape[1], b.shape[1]
+        pa, pb = ga[0] * ga[1] * ga[2], gb[0] * gb[1] * gb[2]
+        a_cl = self.channels_last(a.contiguous().reshape(n, Ca, pa), n, Ca, pa)
+        b_cl = self.channels_last(b.contiguous().reshape(n, Cb, pb), n, Cb, pb)
+        gw = torch.empty((Ca, Cb) + tuple(kernel), dtype=torch.float32, device=a.device)
+        self._check(self.dll.enerf_conv_wgrad(_ptr(a_cl), _ptr(b_cl), n, ga[0], ga[1], ga[2], Ca, gb[0], gb[1], gb[2], Cb,
+                                              kernel[0], kernel[1], kernel[2], int(stride), padding[0], padding[1], padding[2],
+                                              _ptr(gw), self.stream_of(a)), "conv_wgrad")
+        return gw if nd == 3 else gw.reshape(Ca, Cb, kernel[1], kernel[2])
 
     def composite(self, raw, z, white_bkgd=False):
         n, Ns = z.shape

@@ -11,9 +11,11 @@ What runs where in training (state of this round, stated plainly):
   * three stages run on hand-written HIP kernels in BOTH directions (``enerf_amd/autograd.py`` over
     ``csrc/backward.hip``): the cost-volume warp + variance (gradients w.r.t. the feature maps and, through the warp grid,
     w.r.t. the depth hypotheses), depth regression, and alpha compositing;
-  * the dense layers (2-D / 3-D convolutions + BatchNorm, the Agg/NeRF MLP) and the render-side gathers execute as
+  * the WEIGHT gradient of all 32 convolutions (FeatureNet and both cost-reg nets) runs on the matrix cores
+    (``csrc/wgrad.hip``): the library GEMM MIOpen picks for these shapes took 511 of the 573 ms of a training step;
+  * the convolutions' forward / input gradient, BatchNorm, the Agg/NeRF MLP and the render-side gathers still execute as
     PyTorch-ROCm ops (MIOpen / rocBLAS / ATen grid_sample) with autograd; their HIP backward (MLP, gather scatter-adds,
-    conv3d dgrad/wgrad, BN-train) is the next step of this row and is NOT built yet.
+    conv dgrad through the existing MFMA kernels, BN-train) is the next step of this row and is NOT built yet.
     This is GPU code (no CPU fallback, nothing from ``oracle/``), checked against the reference's own gradients
     (tests/test_training.py, tests/golden/train_tiny.npz: every parameter gradient of one reference training step), with
     the HIP stages switched on and off.
@@ -41,13 +43,34 @@ def _resize_ac(x, scale, recompute=None):
 # ---------------------------------------------------------------------------------------------------------------------
 # parameter-module forwards (train or eval mode: whatever the modules are in)
 # ---------------------------------------------------------------------------------------------------------------------
-def cost_reg_forward(m, x):
+def _conv(lib, m, t):
+    """A convolution module of the network; with the HIP library its weight gradient runs on the matrix cores."""
+    if lib is None:
+        return m(t)
+    from .autograd import conv_module
+    return conv_module(lib, m, t)
+
+
+def feature_net_forward(m, x, lib=None):
+    """FeatureNet.forward (feature_net.py:27-36) on the ``FeatureNet`` parameter module, convolutions through ``_conv``."""
+    def cbr(blk, t):
+        return F.relu(blk.bn(_conv(lib, blk.conv, t)), inplace=True)
+    c0 = cbr(m.conv0[1], cbr(m.conv0[0], x))
+    c1 = cbr(m.conv1[1], cbr(m.conv1[0], c0))
+    c2 = cbr(m.conv2[1], cbr(m.conv2[0], c1))
+    f2 = _conv(lib, m.toplayer, c2)
+    f1 = m._up2(f2) + _conv(lib, m.lat1, c1)
+    f0 = m._up2(f1) + _conv(lib, m.lat0, c0)
+    return f2, _conv(lib, m.smooth1, f1), _conv(lib, m.smooth0, f0)
+
+
+def cost_reg_forward(m, x, lib=None):
     """MinCostRegNet / CostRegNet (cost_reg_net.py:35-48, 75-86) on ``CostRegParams``: x (B,C,D,h,w) -> feat, prob."""
     def cbr(blk, t):
-        return F.relu(blk.bn(blk.conv(t)), inplace=True)
+        return F.relu(blk.bn(_conv(lib, blk.conv, t)), inplace=True)
 
     def up(seq, t):
-        return seq[1](seq[0](t))
+        return seq[1](_conv(lib, seq[0], t))
     c0 = cbr(m.conv0, x)
     c2 = cbr(m.conv2, cbr(m.conv1, c0))
     c4 = cbr(m.conv4, cbr(m.conv3, c2))
@@ -57,7 +80,7 @@ def cost_reg_forward(m, x):
         y = c4 + up(m.conv7, y)
     y = c2 + up(m.conv9, y)
     y = c0 + up(m.conv11, y)
-    return m.feat_conv(y), m.depth_conv(y).squeeze(1)
+    return _conv(lib, m.feat_conv[0], y), _conv(lib, m.depth_conv[0], y).squeeze(1)
 
 
 def agg_forward(m, x):
@@ -302,7 +325,11 @@ def forward_train(net, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor
     from .autograd import CompositeFn, DepthRegressionFn, FeatureVolumeFn
     cas = net.cfg.cas
     lib = _hip_lib(net, batch["src_inps"])
-    feats = net.forward_feat(batch["src_inps"])
+    src = batch["src_inps"]
+    B, S, _, H, W = src.shape
+    f2, f1, f0 = feature_net_forward(net.feature_net, src.view(B * S, 3, H, W), lib)          # network.py:58-67
+    feats = {"level_2": f0.reshape(B, S, f0.shape[1], H, W), "level_1": f1.reshape(B, S, f1.shape[1], H // 2, W // 2),
+             "level_0": f2.reshape(B, S, f2.shape[1], H // 4, W // 4)}
     ret: Dict[str, torch.Tensor] = {}
     depth: Optional[torch.Tensor] = None
     std = near_far = None
@@ -310,7 +337,7 @@ def forward_train(net, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor
         dv, near_far = depth_values(cas, batch, i, cas.volume_planes[i], depth, std, near_far)
         P = proj_mats(batch, cas.im_feat_scale[i], cas.volume_scale[i])
         vol = FeatureVolumeFn.apply(lib, feats[f"level_{i}"], P, dv) if lib is not None else feature_volume(feats[f"level_{i}"], P, dv)
-        feat3d, prob = cost_reg_forward(getattr(net, f"cost_reg_{i}"), vol)
+        feat3d, prob = cost_reg_forward(getattr(net, f"cost_reg_{i}"), vol, lib)
         depth, std = DepthRegressionFn.apply(lib, prob, dv, bool(cas.depth_inv[i])) if lib is not None \
             else depth_regression(cas, prob, dv, i)
         if not cas.render_if[i]:

@@ -281,6 +281,13 @@ int enerf_forward(const enerf_frame_args_t* args, enerf_stream_t stream);
  *   enerf_depth_regression_bwd      utils.py:658-667: grad_depth, grad_std (B,h,w) -> grad_prob, grad_depth_values (B,D,h,w).
  *   enerf_composite / _bwd          raw2outputs (utils.py:571-603): raw (n,Ns,4) = [rgb, sigma], z (n,Ns) ->
  *       rgb (n,3), depth (n), weights (n,Ns); backward -> grad_raw (n,Ns,4), grad_z (n,Ns). ---- */
+/*   enerf_conv_wgrad  weight gradient of every convolution of the path on the matrix cores:
+ *       grad_w[a][b][kd][kh][kw] = sum over positions o of the A grid of A[a][o] * B[b][o*stride + k - pad]
+ *       a_cl (n, Da*Ha*Wa, Ca) and b_cl (n, Db*Hb*Wb, Cb) channels-last.  Conv{2,3}d: A = grad_output, B = input ->
+ *       (Cout,Cin,k..); ConvTranspose3d(k3,s2,p1,op1): A = input, B = grad_output -> (Cin,Cout,k..).  2-D layers pass
+ *       Da = Db = kd = 1.  Kernels 3x3x3, 1x3x3, 1x5x5, 1x1x1.  grad_w is zeroed here (fp32 atomics accumulate into it). */
+int enerf_conv_wgrad(const float* a_cl, const float* b_cl, int n, int Da, int Ha, int Wa, int Ca, int Db, int Hb, int Wb, int Cb,
+                     int kd, int kh, int kw, int stride, int pad_d, int pad_h, int pad_w, float* grad_w, enerf_stream_t stream);
 int enerf_build_feature_volume_bwd(const float* feat, const float* proj, const float* depth_values, const float* grad_vol, int B,
                                    int S, int C, int Hs, int Ws, int D, int h, int w, float* grad_feat, float* grad_depth_values,
                                    enerf_stream_t stream);

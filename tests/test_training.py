@@ -135,6 +135,44 @@ def _check_hip_backward_stages(lib, dev):
         assert float((z.grad - gz_ref).abs().max()) <= 1e-4 * float(gz_ref.abs().max()), Ns
 
 
+def _check_conv_wgrad(lib, dev):
+    """enerf_conv_wgrad against torch's own weight gradients for every convolution shape of the path (FeatureNet 2-D
+    layers incl. the 5x5 stride-2 ones, the 3-D stride-1 / stride-2 / transposed layers, the width-1 depth head)."""
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    cases2d = [(3, 8, 3, 1, 1), (8, 16, 5, 2, 2), (16, 32, 5, 2, 2), (32, 32, 1, 1, 0), (32, 8, 3, 1, 1), (16, 16, 3, 1, 1)]
+    for cin, cout, k, st, pad in cases2d:
+        x = rnd(2, cin, 12, 20)
+        w = rnd(cout, cin, k, k).requires_grad_(True)
+        y = F.conv2d(x, w, None, st, pad)
+        gy = rnd(*y.shape)
+        (ref,) = torch.autograd.grad(y, w, gy)
+        got = lib.conv_wgrad(gy, x, (k, k), st, (pad, pad))
+        assert got.shape == ref.shape
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (cin, cout, k, st)
+    for cin, cout, st in [(32, 8, 1), (8, 16, 2), (16, 32, 2), (64, 64, 1), (8, 1, 1), (8, 8, 1)]:
+        x = rnd(1, cin, 4, 6, 10)
+        w = rnd(cout, cin, 3, 3, 3).requires_grad_(True)
+        y = F.conv3d(x, w, None, st, 1)
+        gy = rnd(*y.shape)
+        (ref,) = torch.autograd.grad(y, w, gy)
+        got = lib.conv_wgrad(gy, x, (3, 3, 3), st, (1, 1, 1))
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (cin, cout, st)
+    for cin, cout in [(64, 32), (16, 8)]:                                   # ConvTranspose3d(k3, s2, p1, op1)
+        x = rnd(1, cin, 2, 3, 5)
+        w = rnd(cin, cout, 3, 3, 3).requires_grad_(True)
+        y = F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1)
+        gy = rnd(*y.shape)
+        (ref,) = torch.autograd.grad(y, w, gy)
+        got = lib.conv_wgrad(x, gy, (3, 3, 3), 2, (1, 1, 1))
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (cin, cout)
+
+
+def test_conv_wgrad_emulated():
+    from emu_lib import emu_lib
+    _check_conv_wgrad(emu_lib(), torch.device("cpu"))
+
+
 def test_hip_backward_stages_emulated():
     from emu_lib import emu_lib
     _check_hip_backward_stages(emu_lib(), torch.device("cpu"))
@@ -239,6 +277,7 @@ def test_training_step_on_gpu_matches_reference_gradients():
     dev = torch.device("cuda:0")
     from enerf_amd.lib import get_lib
     _check_hip_backward_stages(get_lib(), dev)           # each HIP forward+backward stage vs its torch-op twin
+    _check_conv_wgrad(get_lib(), dev)                    # MFMA weight gradients vs torch's
     cfg, batch = _train_batch()
     batch = {k: v.to(dev) for k, v in batch.items()}
     net = _net(cfg).to(dev)

@@ -1,0 +1,25 @@
+import sys, os, time, torch, numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch.nn.functional as F
+from __graft_entry__ import _seeded_network
+from enerf_amd.config import EnerfConfig
+from enerf_amd.synth import make_batch
+dev = torch.device("cuda:0")
+cfg = EnerfConfig()
+net = _seeded_network(cfg, dev).train()
+opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+b = make_batch(512, 640, 3, cfg, seed=0, textured=True)
+rng = np.random.default_rng(0)
+for i in range(2):
+    b[f"rgb_{i}"] = rng.uniform(0, 1, size=(1, b[f"rays_{i}"].shape[1], 3)).astype(np.float32)
+batch = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+def step():
+    out = net(batch)
+    loss = sum(w * F.mse_loss(batch[f"rgb_{i}"], out[f"rgb_level{i}"]) for i, w in enumerate((0.1, 1.0)))
+    opt.zero_grad(); loss.backward(); opt.step()
+for _ in range(3): step()
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+    step(); torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=28, max_name_column_width=60))
