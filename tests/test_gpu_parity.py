@@ -245,3 +245,52 @@ def test_full_size_zju_1024_4views_masked_vs_oracle():
     assert out["rgb_level1"].shape == (1, 1024 * 1024, 3)
     assert float(out["rgb_level1"][0].cpu()[~m].abs().max()) == 0.0              # outside the box: exact zeros
     assert out["depth_level1"].shape == (1, int(m.sum()))                          # compacted, like the reference
+
+
+def test_human_path_has_no_implicit_host_sync_and_runs_under_graph_and_pipeline():
+    """network_human.py:90-107 on the device (index-list compaction + scatter): under
+    ``torch.cuda.set_sync_debug_mode("error")`` any implicit synchronisation (``.item()``, boolean-mask indexing,
+    pageable copies) raises.  static_shapes=True must be clean at the tiny golden size and at 1024x1024; the default
+    (reference shapes) reads the count back through a pinned non-blocking copy + an explicit event wait on three tiny
+    kernels, which the debug mode accepts as well.  The static mode is then captured in a HIP graph and pipelined."""
+    from enerf_amd.graph import GraphedFrame
+    from enerf_amd.pipeline import FramePipeline
+    from enerf_amd.synth import make_zju_batch
+    name = "tiny_s4_mask"
+    cfg, gold = case_config(name), load_golden(name)
+    net = _net(cfg, human=True)
+    batch = _to(case_batch(name))
+    ref = {k: v.clone() for k, v in net(batch).items()}
+    cfg2 = EnerfConfig().with_cas(volume_planes=(32, 8), render_if=(False, True))
+    big = _to({k: torch.from_numpy(v) for k, v in make_zju_batch(1024, 1024, 4, cfg2, seed=6).items()})   # uploads sync
+    net2 = _net(cfg2, human=True)
+    net2.static_shapes = True
+    net2.prepare()
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        out = net(batch)                                   # reference shapes: explicit event wait only
+        net.static_shapes = True
+        outs = net(batch)
+        obig = net2(big)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    m = int(batch["mask_at_box"].sum())
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k
+    assert int(outs["num_rays_level1"][0]) == m and torch.equal(outs["depth_level1"][:, :m], ref["depth_level1"])
+    assert torch.equal(outs["rgb_level1"], ref["rgb_level1"])
+    assert _rel(ref["rgb_level1"].cpu(), gold["out/rgb_level1"]) < REL_TOL
+    assert int(obig["num_rays_level1"][0]) == int(big["mask_at_box"].sum()) and bool(torch.isfinite(obig["rgb_level1"]).all())
+    # graph capture + frames in flight (impossible with the host-side boolean-mask indexing of round 1)
+    frame = GraphedFrame(net, batch)
+    g = frame(batch)
+    torch.cuda.synchronize()
+    assert torch.equal(g["rgb_level1"], ref["rgb_level1"])
+    pipe = FramePipeline(net, depth=3)
+    res = [pipe.submit(batch)[0] for _ in range(6)]
+    pipe.close()
+    torch.cuda.synchronize()
+    for r in res:
+        assert torch.equal(r["rgb_level1"], ref["rgb_level1"])
