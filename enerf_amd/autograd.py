@@ -122,3 +122,184 @@ def conv_module(lib, m, x):
     if m.bias is not None:
         y = y + m.bias.view(1, -1, *([1] * (x.dim() - 2)))
     return y
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MinCostRegNet / CostRegNet (cost_reg_net.py:4-86) in TRAINING mode, forward and backward on the HIP kernels:
+# convolutions and their input gradients on the inference path's MFMA kernels (enerf_conv3d_layer), weight gradients on
+# the matrix cores (enerf_conv_wgrad), BatchNorm batch statistics / normalise+ReLU+skip / backward on the two channel
+# kernels of train.hip.  Everything between the cost volume and (feat, prob) stays channels-last on the device; only
+# C-sized vectors (means, scales, d gamma, d beta) are touched by torch ops.
+# ---------------------------------------------------------------------------------------------------------------------
+_S1, _S2, _T2 = 0, 1, 2
+
+
+def _sync_sums(bn, s1, s2, n, count_is_global=False):
+    """SyncBatchNorm (trainer.py:16): batch statistics over all ranks — one small all-reduce per layer and direction.
+    ``n`` is this rank's position count (summed over ranks here) unless ``count_is_global``."""
+    import torch.distributed as dist
+    if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        buf = torch.cat([s1, s2, torch.tensor([0.0 if count_is_global else float(n)], dtype=torch.float64, device=s1.device)])
+        dist.all_reduce(buf)
+        c = s1.numel()
+        return buf[:c], buf[c:2 * c], (float(n) if count_is_global else float(buf[-1]))   # host-side count for the divisions
+    return s1, s2, float(n)
+
+
+class _Block:
+    """One Conv3d/ConvTranspose3d + BatchNorm3d (+ ReLU) (+ skip add) in training mode."""
+
+    def __init__(self, lib, w, bn, kind, relu):
+        self.lib, self.w, self.bn, self.kind, self.relu = lib, w, bn, kind, relu
+        if kind == _T2:
+            self.cin, self.cout = w.shape[0], w.shape[1]
+        else:
+            self.cout, self.cin = w.shape[0], w.shape[1]
+
+    def forward(self, x, residual=None):
+        lib, bn = self.lib, self.bn
+        self.x = x
+        packed = lib.conv3d_layer_pack(self.w.detach().contiguous(), self.cin, self.cout, self.kind)
+        z = lib.conv3d_layer(packed, self.cin, self.cout, self.kind, x)
+        s1, s2 = lib.channel_sums(z, z)
+        s1, s2, n = _sync_sums(bn, s1, s2, z.numel() // self.cout)
+        mean = s1 / n
+        var = (s2 / n - mean * mean).clamp_min(0.0)                                  # biased (normalisation)
+        invstd = torch.rsqrt(var + bn.eps)
+        scale = (bn.weight.detach().double() * invstd).float()
+        shift = (bn.bias.detach().double() - mean * bn.weight.detach().double() * invstd).float()
+        with torch.no_grad():                                                        # running statistics, like nn.BatchNorm3d
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            bn.running_mean.mul_(1 - mom).add_(mean.float(), alpha=mom)
+            bn.running_var.mul_(1 - mom).add_((var * (n / max(n - 1.0, 1.0))).float(), alpha=mom)
+            bn.num_batches_tracked.add_(1)
+        self.z, self.n, self.mean, self.invstd, self.scale, self.shift = z, n, mean, invstd, scale, shift
+        return lib.channel_affine(z, scale, shift, residual=residual, relu=self.relu)
+
+    def backward(self, g):
+        """g = gradient w.r.t. the block's output (the skip branch's share is the same tensor).  Returns
+        (grad_input, grad_weight, grad_bn_weight, grad_bn_bias)."""
+        lib, bn, z = self.lib, self.bn, self.z
+        mask = dict(z_mask=z, mask_scale=self.scale, mask_shift=self.shift) if self.relu else {}
+        sg, sgz = lib.channel_sums(g, z, **mask)                                     # sum gm, sum gm*z over this rank
+        dbeta = sg                                                                   # parameter gradients stay LOCAL (DDP
+        dgamma = self.invstd * (sgz - self.mean * sg)                                # averages them), like torch's SyncBatchNorm
+        sg, sgz, n = _sync_sums(bn, sg, sgz, self.n, count_is_global=True)           # the input gradient needs the global sums
+        sc = self.scale.double()
+        k2 = -sc * self.invstd * (self.invstd * (sgz - self.mean * sg)) / n
+        k3 = -sc * sg / n - k2 * self.mean
+        dz = lib.channel_affine(g, self.scale, k3.float(), b=z, q=k2.float(), **mask)
+        w = self.w.detach()
+        if self.kind == _S1:                                                         # dgrad: flipped, channel-transposed
+            wd = w.flip(2, 3, 4).transpose(0, 1).contiguous()
+            pk = lib.conv3d_layer_pack(wd, self.cout, self.cin, _S1)
+            gx = lib.conv3d_layer(pk, self.cout, self.cin, _S1, dz)
+            gw = lib.conv_wgrad_cl(dz, self.x, 1)
+        elif self.kind == _S2:                                                       # dgrad of a stride-2 conv = transposed conv on w
+            pk = lib.conv3d_layer_pack(w.contiguous(), self.cout, self.cin, _T2)
+            gx = lib.conv3d_layer(pk, self.cout, self.cin, _T2, dz)
+            gw = lib.conv_wgrad_cl(dz, self.x, 2)
+        else:                                                                        # dgrad of a transposed conv = stride-2 conv on w
+            pk = lib.conv3d_layer_pack(w.contiguous(), self.cout, self.cin, _S2)
+            gx = lib.conv3d_layer(pk, self.cout, self.cin, _S2, dz)
+            gw = lib.conv_wgrad_cl(self.x, dz, 2)
+        return gx, gw, dgamma.float(), dbeta.float()
+
+
+class CostRegTrainFn(torch.autograd.Function):
+    """vol (B,C,D,h,w) -> feat (B,8,D,h,w), prob (B,D,h,w) through ``CostRegParams`` ``m`` in training mode."""
+
+    @staticmethod
+    def forward(ctx, lib: EnerfLib, m, vol, *params):
+        x = vol.permute(0, 2, 3, 4, 1).contiguous()                                   # channels-last (a view of FeatureVolumeFn's output)
+        blk = {}
+
+        def cbr(i, kind):
+            mod = getattr(m, f"conv{i}")
+            blk[i] = _Block(lib, mod.conv.weight, mod.bn, kind, True)
+            return blk[i]
+
+        def up(i):
+            mod = getattr(m, f"conv{i}")
+            blk[i] = _Block(lib, mod[0].weight, mod[1], _T2, False)
+            return blk[i]
+        c0 = cbr(0, _S1).forward(x)
+        c2 = cbr(2, _S1).forward(cbr(1, _S2).forward(c0))
+        c4 = cbr(4, _S1).forward(cbr(3, _S2).forward(c2))
+        y = c4
+        if m.full:
+            c6 = cbr(6, _S1).forward(cbr(5, _S2).forward(c4))
+            y = up(7).forward(c6, residual=c4)
+        y = up(9).forward(y, residual=c2)
+        y = up(11).forward(y, residual=c0)
+        # heads: feat_conv (8 -> 8) ++ depth_conv (8 -> 1) as one 8 -> 16 layer (rows 9..15 zero)
+        wf, wd = m.feat_conv[0].weight.detach(), m.depth_conv[0].weight.detach()
+        w16 = torch.cat([wf, wd, wf.new_zeros(7, 8, 3, 3, 3)], 0).contiguous()
+        heads = lib.conv3d_layer(lib.conv3d_layer_pack(w16, 8, 16, _S1), 8, 16, _S1, y)
+        ctx.lib, ctx.m, ctx.blk, ctx.y, ctx.w16 = lib, m, blk, y, w16
+        feat = heads[..., :8].permute(0, 4, 1, 2, 3)
+        prob = heads[..., 8]
+        return feat, prob
+
+    @staticmethod
+    def backward(ctx, g_feat, g_prob):
+        lib, m, blk, y = ctx.lib, ctx.m, ctx.blk, ctx.y
+        B, D, h, w, _ = y.shape
+        g16 = torch.zeros((B, D, h, w, 16), dtype=torch.float32, device=y.device)
+        g16[..., :8] = g_feat.permute(0, 2, 3, 4, 1)
+        g16[..., 8] = g_prob
+        wd = ctx.w16.flip(2, 3, 4).transpose(0, 1).contiguous()
+        g = lib.conv3d_layer(lib.conv3d_layer_pack(wd, 16, 8, _S1), 16, 8, _S1, g16)     # d y11
+        gw16 = lib.conv_wgrad_cl(g16, y, 1)
+        grads = {"feat": gw16[:8], "depth": gw16[8:9]}
+
+        def back(i, gi):
+            gx, gw, dg, db = blk[i].backward(gi)
+            grads[i] = (gw, dg, db)
+            return gx
+        g_c0 = g
+        g = back(11, g)                                           # -> d y9 ; skip share of y11 goes to c0
+        g_c2 = g
+        g = back(9, g)                                            # -> d y7
+        if m.full:
+            g_c4 = g
+            g = back(5, back(6, back(7, g)))
+            g_c4 = g_c4 + g
+        else:
+            g_c4 = g
+        g = back(3, back(4, g_c4))
+        g_c2 = g_c2 + g
+        g = back(1, back(2, g_c2))
+        g_c0 = g_c0 + g
+        g_x = back(0, g_c0)
+        out = []
+        for i in ctx.order:
+            if i == "feat":
+                out.append(grads["feat"])
+            elif i == "depth":
+                out.append(grads["depth"])
+            else:
+                out.extend(grads[i])
+        return (None, None, g_x.permute(0, 4, 1, 2, 3)) + tuple(out)
+
+
+def cost_reg_train(lib, m, vol):
+    """Apply CostRegTrainFn with the module's parameters as differentiable inputs (fixed order)."""
+    order = [0, 1, 2, 3, 4] + ([5, 6, 7] if m.full else []) + [9, 11, "feat", "depth"]
+    params = []
+    for i in order:
+        if i == "feat":
+            params.append(m.feat_conv[0].weight)
+        elif i == "depth":
+            params.append(m.depth_conv[0].weight)
+        else:
+            mod = getattr(m, f"conv{i}")
+            conv, bn = (mod[0], mod[1]) if i in (7, 9, 11) else (mod.conv, mod.bn)
+            params += [conv.weight, bn.weight, bn.bias]
+
+    class _Fn(CostRegTrainFn):
+        @staticmethod
+        def forward(ctx, *a):
+            ctx.order = order
+            return CostRegTrainFn.forward(ctx, *a)
+    return _Fn.apply(lib, m, vol, *params)

@@ -1,0 +1,134 @@
+// train.hip — per-layer building blocks of the TRAINING-mode cost-regularisation networks:
+//   * one 3x3x3 convolution layer on the inference path's MFMA kernels with an identity epilogue (enerf_conv3d_layer) —
+//     in training the BatchNorm cannot be folded (batch statistics), and the same kernels serve the INPUT gradients:
+//     the dgrad of a stride-2 conv is the transposed-conv kernel on the same weight tensor, the dgrad of a transposed conv
+//     is the stride-2 conv kernel, the dgrad of a stride-1 conv is the stride-1 kernel on the flipped/transposed weights;
+//   * BatchNorm3d in training mode (ConvBnReLU3D utils.py:22-33; cost_reg_net.py:25-31 without ReLU): per-channel sums
+//     (enerf_channel_sums) and a per-channel affine map with optional ReLU mask / residual (enerf_channel_affine) — the two
+//     kernels cover the forward (statistics, normalise+ReLU+skip add) and the backward (d gamma / d beta sums, d input).
+// Tensors are channels-last (n positions, C channels), C a multiple of 4.  HBM-bound elementwise / reduction work.
+#include "kernels.h"
+
+namespace enerf {
+
+// sums[c] = sum_p a[p][c]*m ;  sums[C + c] = sum_p a[p][c]*m*b[p][c] ;  m = (zm[p][c]*ms[c] + mh[c] > 0) or 1
+__global__ __launch_bounds__(256) void k_channel_sums(const float* __restrict__ a, const float* __restrict__ b,
+                                                      const float* __restrict__ zm, const float* __restrict__ ms,
+                                                      const float* __restrict__ mh, long long n, int C,
+                                                      double* __restrict__ sums) {
+    __shared__ double red[2][256][4];
+    const int CQ = C >> 2;                                 // float4 channel groups
+    const int cq = threadIdx.x % CQ, lane_p = threadIdx.x / CQ, ppb = 256 / CQ;   // positions per block step
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {1.f, 1.f, 1.f, 1.f};
+    if (zm != nullptr)
+        for (int k = 0; k < 4; ++k) { sc[k] = ms[cq * 4 + k]; sh[k] = mh[cq * 4 + k]; }
+    for (long long p = (long long)blockIdx.x * ppb + lane_p; p < n; p += (long long)gridDim.x * ppb) {
+        const float4 av = *reinterpret_cast<const float4*>(a + p * C + cq * 4);
+        const float4 bv = *reinterpret_cast<const float4*>(b + p * C + cq * 4);
+        float am[4] = {av.x, av.y, av.z, av.w};
+        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+        if (zm != nullptr) {
+            const float4 zv = *reinterpret_cast<const float4*>(zm + p * C + cq * 4);
+            const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+            for (int k = 0; k < 4; ++k) am[k] = (zz[k] * sc[k] + sh[k] > 0.f) ? am[k] : 0.f;
+        }
+        for (int k = 0; k < 4; ++k) { s1[k] += (double)am[k]; s2[k] += (double)am[k] * (double)bb[k]; }
+    }
+    for (int k = 0; k < 4; ++k) { red[0][threadIdx.x][k] = s1[k]; red[1][threadIdx.x][k] = s2[k]; }
+    __syncthreads();
+    if (threadIdx.x < CQ) {                                // thread cq sums the ppb position lanes of its channel group
+        for (int k = 0; k < 4; ++k) {
+            double t1 = 0, t2 = 0;
+            for (int q = 0; q < ppb; ++q) { t1 += red[0][q * CQ + cq][k]; t2 += red[1][q * CQ + cq][k]; }
+            atomicAdd(sums + cq * 4 + k, t1);
+            atomicAdd(sums + C + cq * 4 + k, t2);
+        }
+    }
+}
+
+// out[p][c] = f( a[p][c]*m*pp[c] + (b ? b[p][c]*qq[c] : 0) + rr[c] ) (+ residual[p][c]);  f = ReLU if relu;  m as above
+__global__ __launch_bounds__(256) void k_channel_affine(const float* __restrict__ a, const float* __restrict__ b,
+                                                        const float* __restrict__ pp, const float* __restrict__ qq,
+                                                        const float* __restrict__ rr, const float* __restrict__ zm,
+                                                        const float* __restrict__ ms, const float* __restrict__ mh,
+                                                        const float* __restrict__ residual, int relu, long long n4, int CQ,
+                                                        float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 of channels
+    if (i >= n4) return;
+    const int c0 = (int)(i % CQ) * 4;
+    const float4 av = *reinterpret_cast<const float4*>(a + i * 4);
+    float x[4] = {av.x, av.y, av.z, av.w};
+    if (zm != nullptr) {
+        const float4 zv = *reinterpret_cast<const float4*>(zm + i * 4);
+        const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+        for (int k = 0; k < 4; ++k) x[k] = (zz[k] * ms[c0 + k] + mh[c0 + k] > 0.f) ? x[k] : 0.f;
+    }
+    float y[4];
+    for (int k = 0; k < 4; ++k) y[k] = x[k] * pp[c0 + k] + rr[c0 + k];
+    if (b != nullptr) {
+        const float4 bv = *reinterpret_cast<const float4*>(b + i * 4);
+        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+        for (int k = 0; k < 4; ++k) y[k] += bb[k] * qq[c0 + k];
+    }
+    if (relu) for (int k = 0; k < 4; ++k) y[k] = fmaxf(y[k], 0.f);
+    if (residual != nullptr) {
+        const float4 rv = *reinterpret_cast<const float4*>(residual + i * 4);
+        y[0] += rv.x; y[1] += rv.y; y[2] += rv.z; y[3] += rv.w;
+    }
+    *reinterpret_cast<float4*>(out + i * 4) = make_float4(y[0], y[1], y[2], y[3]);
+}
+
+}  // namespace enerf
+
+using namespace enerf;
+extern "C" {
+
+long long enerf_conv3d_layer_packed_floats(int cin, int cout, int kind) {
+    return conv3d_packed_floats(cin, cout, kind) + 2 * cdiv(cout, 16) * 16;
+}
+int enerf_conv3d_layer_pack(const float* w, int cin, int cout, int kind, float* packed, enerf_stream_t stream) {
+    REQUIRE(w && packed, "conv3d_layer_pack: null pointer");
+    REQUIRE((cin == 8 || cin == 16 || cin == 32 || cin == 64) && cout >= 1 && cout <= 64 && kind >= kConvS1 && kind <= kConvT2,
+            "conv3d_layer_pack: unsupported layer %d -> %d kind %d", cin, cout, kind);
+    const long long wf = conv3d_packed_floats(cin, cout, kind);
+    const int cp = cdiv(cout, 16) * 16;
+    launch_conv3d_pack(w, nullptr, cout, nullptr, nullptr, nullptr, nullptr, 1e-5f, cin, cout, kind, packed, packed + wf,
+                       packed + wf + cp, (hipStream_t)stream);
+    return check_launch("conv3d_layer_pack");
+}
+int enerf_conv3d_layer(const float* packed, int cin, int cout, int kind, const float* in, const float* residual, float* out, int B,
+                       int Di, int Hi, int Wi, const enerf_options_t* options, enerf_stream_t stream) {
+    REQUIRE(packed && in && out && B > 0 && Di > 0 && Hi > 0 && Wi > 0, "conv3d_layer: bad arguments");
+    const long long wf = conv3d_packed_floats(cin, cout, kind);
+    const int cp = cdiv(cout, 16) * 16;
+    Conv3dDesc d = {packed, packed + wf, packed + wf + cp, cin, cout, kind, 0, nullptr};
+    if (!launch_conv3d(d, in, residual, out, nullptr, B, Di, Hi, Wi, resolve_options(options), (hipStream_t)stream))
+        return fail(ENERF_EINVAL, "conv3d_layer: no kernel for %d -> %d kind %d", cin, cout, kind);
+    return check_launch("conv3d_layer");
+}
+int enerf_channel_sums(const float* a, const float* b, const float* z_mask, const float* mask_scale, const float* mask_shift,
+                       long long n, int C, double* sums, enerf_stream_t stream) {
+    REQUIRE(a && b && sums && n > 0 && C >= 4 && C <= 64 && C % 4 == 0 && (256 % (C / 4)) == 0, "channel_sums: bad arguments (C in 4..64, power-of-two quads)");
+    if (z_mask) REQUIRE(mask_scale && mask_shift, "channel_sums: mask needs its scale/shift");
+    hipMemsetAsync(sums, 0, (size_t)2 * C * sizeof(double), (hipStream_t)stream);
+    const int ppb = 256 / (C / 4);
+    long long blocks = cdivl(n, (long long)ppb * 16);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    ENERF_LAUNCH(k_channel_sums, (unsigned)blocks, 256, 0, (hipStream_t)stream, a, b, z_mask, mask_scale, mask_shift, n, C, sums);
+    return check_launch("channel_sums");
+}
+int enerf_channel_affine(const float* a, const float* b, const float* p, const float* q, const float* r, const float* z_mask,
+                         const float* mask_scale, const float* mask_shift, const float* residual, int relu, long long n, int C,
+                         float* out, enerf_stream_t stream) {
+    REQUIRE(a && p && r && out && n > 0 && C >= 4 && C % 4 == 0, "channel_affine: bad arguments");
+    if (b) REQUIRE(q, "channel_affine: b needs q");
+    if (z_mask) REQUIRE(mask_scale && mask_shift, "channel_affine: mask needs its scale/shift");
+    const long long n4 = n * (C / 4);
+    ENERF_LAUNCH_SIMPLE(k_channel_affine, (unsigned)cdivl(n4, 256), 256, 0, (hipStream_t)stream, a, b, p, q, r, z_mask, mask_scale,
+                        mask_shift, residual, relu, n4, C / 4, out);
+    return check_launch("channel_affine");
+}
+
+}  // extern "C"

@@ -143,6 +143,11 @@ _SIGNATURES = {
     "enerf_build_feature_volume_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f]),
     "enerf_depth_regression_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f]),
     "enerf_conv_wgrad": (_i, [_f, _f] + [_i] * 16 + [_f, _f]),
+    "enerf_conv3d_layer_packed_floats": (_ll, [_i, _i, _i]),
+    "enerf_conv3d_layer_pack": (_i, [_f, _i, _i, _i, _f, _f]),
+    "enerf_conv3d_layer": (_i, [_f, _i, _i, _i, _f, _f, _f, _i, _i, _i, _i, C.POINTER(Options), _f]),
+    "enerf_channel_sums": (_i, [_f, _f, _f, _f, _f, _ll, _i, C.c_void_p, _f]),
+    "enerf_channel_affine": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _ll, _i, _f, _f]),
     "enerf_composite": (_i, [_f, _f, _ll, _i, _i, _f, _f, _f, _f]),
     "enerf_composite_bwd": (_i, [_f, _f, _f, _f, _f, _ll, _i, _f, _f, _f]),
     "enerf_gen_rays": (_i, [_f, _f, _i, _i, _i, _fl, _f, _f]),
@@ -405,6 +410,51 @@ class EnerfLib:
                                                         int(depth_inv), _ptr(gp), _ptr(gdv), self.stream_of(prob)),
                     "depth_regression_bwd")
         return gp, gdv
+
+    # training-mode 3-D conv layers / BatchNorm pieces (train.hip); kind: 0 stride 1, 1 stride 2, 2 transposed stride 2
+    def conv3d_layer_pack(self, w, cin, cout, kind):
+        packed = torch.empty((self.dll.enerf_conv3d_layer_packed_floats(cin, cout, kind),), dtype=torch.float32, device=w.device)
+        self._check(self.dll.enerf_conv3d_layer_pack(_ptr(w), cin, cout, kind, _ptr(packed), self.stream_of(w)), "conv3d_layer_pack")
+        return packed
+
+    def conv3d_layer(self, packed, cin, cout, kind, x_cl, residual=None, options=None):
+        """x_cl (B,D,h,w,cin) channels-last -> (B,D',h',w',cout); D' = D (kind 0), ceil(D/2) (kind 1), 2D (kind 2)."""
+        B, D, h, w, _ = x_cl.shape
+        if kind == 1:
+            Do, Ho, Wo = (D - 1) // 2 + 1, (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        elif kind == 2:
+            Do, Ho, Wo = 2 * D, 2 * h, 2 * w
+        else:
+            Do, Ho, Wo = D, h, w
+        out = torch.empty((B, Do, Ho, Wo, cout), dtype=torch.float32, device=x_cl.device)
+        self._check(self.dll.enerf_conv3d_layer(_ptr(packed), cin, cout, kind, _ptr(x_cl), _ptr(residual), _ptr(out), B, D, h, w,
+                                                _opt(options), self.stream_of(x_cl)), "conv3d_layer")
+        return out
+
+    def channel_sums(self, a, b, z_mask=None, mask_scale=None, mask_shift=None):
+        """(sum_p a*m, sum_p a*m*b) per channel in fp64; tensors channels-last (..., C)."""
+        Cc = a.shape[-1]
+        sums = torch.empty((2, Cc), dtype=torch.float64, device=a.device)
+        self._check(self.dll.enerf_channel_sums(_ptr(a), _ptr(b), _ptr(z_mask), _ptr(mask_scale), _ptr(mask_shift),
+                                                a.numel() // Cc, Cc, sums.data_ptr(), self.stream_of(a)), "channel_sums")
+        return sums[0], sums[1]
+
+    def channel_affine(self, a, p, r, b=None, q=None, z_mask=None, mask_scale=None, mask_shift=None, residual=None, relu=False):
+        Cc = a.shape[-1]
+        out = torch.empty_like(a)
+        self._check(self.dll.enerf_channel_affine(_ptr(a), _ptr(b), _ptr(p), _ptr(q), _ptr(r), _ptr(z_mask), _ptr(mask_scale),
+                                                  _ptr(mask_shift), _ptr(residual), int(relu), a.numel() // Cc, Cc, _ptr(out),
+                                                  self.stream_of(a)), "channel_affine")
+        return out
+
+    def conv_wgrad_cl(self, a_cl, b_cl, stride):
+        """3x3x3 weight gradient from channels-last tensors a (n,Da,Ha,Wa,Ca), b (n,Db,Hb,Wb,Cb) -> (Ca,Cb,3,3,3)."""
+        n, Da, Ha, Wa, Ca = a_cl.shape
+        _, Db, Hb, Wb, Cb = b_cl.shape
+        gw = torch.empty((Ca, Cb, 3, 3, 3), dtype=torch.float32, device=a_cl.device)
+        self._check(self.dll.enerf_conv_wgrad(_ptr(a_cl), _ptr(b_cl), n, Da, Ha, Wa, Ca, Db, Hb, Wb, Cb, 3, 3, 3, int(stride),
+                                              1, 1, 1, _ptr(gw), self.stream_of(a_cl)), "conv_wgrad")
+        return gw
 
     def conv_wgrad(self, a, b, kernel, stride, padding):
         """Weight gradient on the matrix cores (enerf_conv_wgrad).  ``a`` (n,Ca,*grid_a), ``b`` (n,Cb,*grid_b) in torch's

@@ -337,7 +337,11 @@ def forward_train(net, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor
         dv, near_far = depth_values(cas, batch, i, cas.volume_planes[i], depth, std, near_far)
         P = proj_mats(batch, cas.im_feat_scale[i], cas.volume_scale[i])
         vol = FeatureVolumeFn.apply(lib, feats[f"level_{i}"], P, dv) if lib is not None else feature_volume(feats[f"level_{i}"], P, dv)
-        feat3d, prob = cost_reg_forward(getattr(net, f"cost_reg_{i}"), vol, lib)
+        if lib is not None and getattr(net, "hip_cost_reg_train", True):
+            from .autograd import cost_reg_train
+            feat3d, prob = cost_reg_train(lib, getattr(net, f"cost_reg_{i}"), vol)     # conv/BN forward + backward on HIP kernels
+        else:
+            feat3d, prob = cost_reg_forward(getattr(net, f"cost_reg_{i}"), vol, lib)
         depth, std = DepthRegressionFn.apply(lib, prob, dv, bool(cas.depth_inv[i])) if lib is not None \
             else depth_regression(cas, prob, dv, i)
         if not cas.render_if[i]:

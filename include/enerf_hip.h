@@ -288,6 +288,25 @@ int enerf_forward(const enerf_frame_args_t* args, enerf_stream_t stream);
  *       Da = Db = kd = 1.  Kernels 3x3x3, 1x3x3, 1x5x5, 1x1x1.  grad_w is zeroed here (fp32 atomics accumulate into it). */
 int enerf_conv_wgrad(const float* a_cl, const float* b_cl, int n, int Da, int Ha, int Wa, int Ca, int Db, int Hb, int Wb, int Cb,
                      int kd, int kh, int kw, int stride, int pad_d, int pad_h, int pad_w, float* grad_w, enerf_stream_t stream);
+/*   Training-mode cost-regularisation layers (ConvBnReLU3D utils.py:22-33, cost_reg_net.py) — BatchNorm uses batch
+ *   statistics, so it cannot be folded into the convolution:
+ *   enerf_conv3d_layer[_pack]  one bias-free 3x3x3 layer on the inference path's MFMA kernels, identity epilogue (+ optional
+ *       residual).  kind 0 = stride 1, 1 = stride 2 (weights (cout,cin,3,3,3)), 2 = transposed stride 2 (weights
+ *       (cin,cout,3,3,3), output 2x).  The same entry computes INPUT gradients: dgrad(stride-2 conv, w) = kind 2 on w,
+ *       dgrad(transposed, w) = kind 1 on w, dgrad(stride-1, w) = kind 0 on w flipped and channel-transposed.
+ *   enerf_channel_sums    sums[c] = sum_p a*m, sums[C+c] = sum_p a*m*b  (fp64), m = (z_mask*mask_scale[c]+mask_shift[c] > 0)
+ *       or 1: BN batch statistics (a = b = z) and the d beta / d gamma reductions of its backward (a = grad, b = z).
+ *   enerf_channel_affine  out = f(a*m*p[c] + b*q[c] + r[c]) (+ residual), f = ReLU if relu: BN normalise + ReLU + skip add,
+ *       and the input gradient of BN.  All tensors channels-last (n, C). */
+long long enerf_conv3d_layer_packed_floats(int cin, int cout, int kind);
+int enerf_conv3d_layer_pack(const float* w, int cin, int cout, int kind, float* packed, enerf_stream_t stream);
+int enerf_conv3d_layer(const float* packed, int cin, int cout, int kind, const float* in, const float* residual, float* out, int B,
+                       int Di, int Hi, int Wi, const enerf_options_t* options, enerf_stream_t stream);
+int enerf_channel_sums(const float* a, const float* b, const float* z_mask, const float* mask_scale, const float* mask_shift,
+                       long long n, int C, double* sums, enerf_stream_t stream);
+int enerf_channel_affine(const float* a, const float* b, const float* p, const float* q, const float* r, const float* z_mask,
+                         const float* mask_scale, const float* mask_shift, const float* residual, int relu, long long n, int C,
+                         float* out, enerf_stream_t stream);
 int enerf_build_feature_volume_bwd(const float* feat, const float* proj, const float* depth_values, const float* grad_vol, int B,
                                    int S, int C, int Hs, int Ws, int D, int h, int w, float* grad_feat, float* grad_depth_values,
                                    enerf_stream_t stream);

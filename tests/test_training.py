@@ -189,16 +189,38 @@ def test_training_step_with_hip_stages_matches_reference_gradients():
     net.load_state_dict(load_weights(), strict=False)
     net.train()
     from enerf_amd import train_path as T
+    from enerf_amd import autograd as AG
     assert T._hip_lib(net, batch["src_inps"]) is not None
-    loss = _loss(net(batch), batch)
+    calls = {"cost_reg": 0, "conv": 0}
+    orig_cr, orig_conv = AG.cost_reg_train, AG.conv_module
+    AG.cost_reg_train = lambda *a: (calls.__setitem__("cost_reg", calls["cost_reg"] + 1), orig_cr(*a))[1]
+    AG.conv_module = lambda *a: (calls.__setitem__("conv", calls["conv"] + 1), orig_conv(*a))[1]
+    try:
+        loss = _loss(net(batch), batch)
+    finally:
+        AG.cost_reg_train, AG.conv_module = orig_cr, orig_conv
+    assert calls == {"cost_reg": 2, "conv": 11}          # both cost-reg nets whole on HIP; the 11 FeatureNet convs via ConvFn
     assert float(loss) == pytest.approx(float(g["loss"]), rel=1e-5)
     loss.backward()
     for name, p in net.named_parameters():
+        assert p.grad is not None or f"nograd/{name}" in g.files, name
         if f"grad/{name}/norm" in g.files:
             assert float(p.grad.double().norm()) == pytest.approx(float(g[f"grad/{name}/norm"]), rel=5e-4), name
         elif f"grad/{name}/full" in g.files:
             ref = g[f"grad/{name}/full"]
             assert np.abs(p.grad.reshape(-1).numpy() - ref).max() <= 5e-4 * np.abs(ref).max() + 1e-9, name
+    for name, buf in net.named_buffers():                # BatchNorm running statistics updated by the HIP path as well
+        if f"buf/{name}" in g.files:
+            np.testing.assert_allclose(buf.numpy(), g[f"buf/{name}"], rtol=2e-4, atol=2e-6, err_msg=name)
+    # the same step with the whole-net HIP function off (per-layer ConvFn only) gives the same gradients
+    net2 = Network(cfg, lib=emu_lib())
+    net2.load_state_dict(load_weights(), strict=False)
+    net2.train()
+    net2.hip_cost_reg_train = False
+    _loss(net2(batch), batch).backward()
+    for (n1, p1), (_, p2) in zip(net.named_parameters(), net2.named_parameters()):
+        if p1.grad is not None:
+            assert float((p1.grad - p2.grad).abs().max()) <= 5e-4 * float(p2.grad.abs().max()) + 1e-9, n1
 
 
 def test_train_then_eval_repacks_weights():
@@ -240,6 +262,74 @@ def _ddp_worker(rank, world, port, q):
     grads = {n: p.grad.clone() for n, p in net.module.named_parameters() if p.grad is not None}
     q.put((rank, float(loss), {n: v.numpy() for n, v in grads.items()}))
     dist.destroy_process_group()
+
+
+def _batch2():
+    """A two-sample batch (B = 2) and its per-sample slices."""
+    cfg = EnerfConfig().with_cas(volume_planes=(8, 8), render_if=(True, True))
+    b = make_batch(32, 64, 3, cfg, seed=31, B=2, textured=True)
+    rng = np.random.default_rng(31)
+    for i in range(2):
+        b[f"rgb_{i}"] = rng.uniform(0, 1, size=(2, b[f"rays_{i}"].shape[1], 3)).astype(np.float32)
+    full = {k: torch.from_numpy(v) for k, v in b.items()}
+    return cfg, full, [{k: v[r:r + 1].contiguous() for k, v in full.items()} for r in range(2)]
+
+
+def _syncbn_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, HERE)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ENERF_EMU_THREADS="2")
+        torch.set_num_threads(1)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from emu_lib import emu_lib
+        cfg, _, parts = _batch2()
+        net = Network(cfg, lib=emu_lib())                                  # HIP training stages on (lane emulator)
+        net.load_state_dict(load_weights(), strict=False)
+        net.train()
+        net.feature_net.eval()            # torch's SyncBatchNorm refuses CPU tensors: keep the 2-D FPN out of the batch coupling
+        for i in range(2):                # trainer.py:16 on the cost-reg nets, whose BatchNorm runs inside CostRegTrainFn
+            setattr(net, f"cost_reg_{i}", torch.nn.SyncBatchNorm.convert_sync_batchnorm(getattr(net, f"cost_reg_{i}")))
+        loss = _loss(net(parts[rank]), parts[rank])
+        loss.backward()
+        grads = {}
+        for n, p in net.named_parameters():                                # what DDP does: average over ranks
+            if p.grad is not None:
+                dist.all_reduce(p.grad)
+                grads[n] = (p.grad / world).numpy()
+        q.put((rank, grads, {n: b.numpy().copy() for n, b in net.named_buffers() if n.endswith("running_var") and "cost_reg" in n}))
+        dist.destroy_process_group()
+    except Exception as e:                                                 # never leave the parent waiting
+        import traceback
+        q.put((rank, "ERROR: " + traceback.format_exc(), None))
+
+
+def test_two_rank_syncbn_on_hip_training_path_equals_one_process_with_batch_two():
+    """trainer.py:15-22 on the HIP training path: SyncBatchNorm statistics all-reduced inside CostRegTrainFn (one small
+    all-reduce per BN layer and direction) + gradient averaging == one process with both samples in one batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    [p.join(60) for p in procs]
+    for r in res:
+        assert not isinstance(r[1], str), r[1]
+    torch.set_num_threads(1)
+    cfg, full, _ = _batch2()
+    net = _net(cfg)                                                    # torch-op path, plain BatchNorm, B = 2
+    net.feature_net.eval()
+    _loss(net(full), full).backward()
+    ref = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    checked = 0
+    for n, v in res[0][1].items():
+        assert np.allclose(v, res[1][1][n], rtol=1e-5, atol=1e-9), n   # both ranks hold the averaged gradients
+        r = ref[n].numpy()
+        assert np.abs(v - r).max() <= 5e-3 * max(np.abs(r).max(), 1e-12) + 1e-9, (n, float(np.abs(v - r).max() / max(np.abs(r).max(), 1e-12)))
+        checked += 1
+    assert checked > 80
+    for n, v in res[0][2].items():                                     # running_var from the global statistics
+        assert np.allclose(v, dict(net.named_buffers())[n].numpy(), rtol=1e-3, atol=1e-6), n
 
 
 def test_two_rank_ddp_gradients_equal_mean_of_single_process_gradients():
