@@ -303,3 +303,131 @@ def cost_reg_train(lib, m, vol):
             ctx.order = order
             return CostRegTrainFn.forward(ctx, *a)
     return _Fn.apply(lib, m, vol, *params)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Agg + NeRF MLP (nerf.py:29-89): fused HIP backward (mlp_train.hip) + weight gradients as position-reductions on the
+# matrix cores (enerf_gemm_wgrad).
+# ---------------------------------------------------------------------------------------------------------------------
+def _tile_image(Wt, row_idx, k_idx):
+    """One MFMA A-operand tile set for a TRANSPOSED product: image[e, lane = 16 g + j] = W[k_idx[e, g], row_idx[e, j]]
+    (0 where an index is -1).  W (out, in); row_idx (E,16) input indices, k_idx (E,4) output indices."""
+    E = row_idx.shape[0]
+    rows = row_idx[:, None, :].expand(E, 4, 16)                    # [e, g, j]
+    ks = k_idx[:, :, None].expand(E, 4, 16)
+    valid = (rows >= 0) & (ks >= 0)
+    vals = Wt[ks.clamp_min(0), rows.clamp_min(0)]
+    return torch.where(valid, vals, torch.zeros_like(vals)).reshape(E * 64)
+
+
+def mlp_backward_images(m, S):
+    """Transposed-weight MFMA images of one ``NerfParams`` for enerf_nerf_mlp_bwd, in the kernel's unit / slot layouts
+    (mlp_train.hip header).  Returns (flat image tensor, the 8 offsets b1, b2, b3, b4, b5, b6v, b6m, b7)."""
+    F = m.feat_ch
+    R = (F + 3) // 4
+    TR, TX = (R + 3) // 4, (R + 1 + 3) // 4
+    dev = m.lr0[0].weight.device
+    j = torch.arange(16, device=dev)
+    g4 = torch.arange(4, device=dev)
+
+    def unit_rows(t, base=0, n=None):                              # row j -> input index base + 16 t + j
+        idx = base + 16 * t + j
+        return idx if n is None else torch.where(16 * t + j < n, idx, -torch.ones_like(idx))
+
+    def slot_rows(t, with_dir, base=0):                            # row j -> slot (g' = j>>2, r' = 4t + (j&3))
+        gp, rp = j >> 2, 4 * t + (j & 3)
+        ch = gp * R + rp
+        idx = torch.where((rp < R) & (ch < F), base + ch, -torch.ones_like(ch))
+        if with_dir:
+            idx = torch.where(rp == R, base + F + gp, idx)
+        return idx
+
+    vox_rows = lambda base: torch.where((j & 3) < 2, base + 2 * (j >> 2) + (j & 3), -torch.ones_like(j))
+    unit_k = lambda kk: 16 * (kk >> 2) + 4 * g4 + (kk & 3)         # k-step kk = (tile, r): lane group g -> unit
+    def slot_k(r):                                                 # k-step r over slot-layout outputs: group g -> channel gR + r
+        ch = g4 * R + r
+        return torch.where(ch < F, ch, -torch.ones_like(ch))
+
+    def build(W, row_sets, k_sets):
+        rows = torch.stack([rs for rs in row_sets for _ in k_sets])
+        ks = torch.stack([k for _ in row_sets for k in k_sets])
+        return _tile_image(W, rows, ks)
+    col0 = m.color[0].weight.detach()
+    glob = m.agg.global_fc[0].weight.detach()
+    k16 = [unit_k(kk) for kk in range(16)]
+    imgs = [
+        build(col0[:, 88:], [slot_rows(t, True) for t in range(TX)], k16),                                        # b1
+        build(col0[:, :88], [unit_rows(t) for t in range(4)] + [vox_rows(64), unit_rows(0, 72)], k16),            # b2
+        build(m.lr0[0].weight.detach(), [vox_rows(0), unit_rows(0, 8)], k16),                                     # b3
+        build(m.agg.fc[0].weight.detach(), [unit_rows(0), unit_rows(1)], [unit_k(kk) for kk in range(4)]),        # b4
+        build(glob[:, :F], [slot_rows(t, False) for t in range(TR)], [unit_k(kk) for kk in range(8)]),            # b5
+        build(glob[:, F:2 * F], [slot_rows(t, False) for t in range(TR)], [unit_k(kk) for kk in range(8)]),       # b6 var
+        build(glob[:, 2 * F:], [slot_rows(t, False) for t in range(TR)], [unit_k(kk) for kk in range(8)]),        # b6 mean
+    ]
+    if hasattr(m.agg, "view_fc"):
+        vw = m.agg.view_fc[0].weight.detach()                                                                      # (F, 4)
+        dir_rows = lambda t: torch.where(4 * t + (j & 3) == R, j >> 2, -torch.ones_like(j))
+        imgs.append(build(vw, [dir_rows(t) for t in range(TX)], [slot_k(r) for r in range(R)]))                   # b7
+    else:
+        imgs.append(torch.zeros(TX * R * 64, device=dev))
+    offs, o = [], 0
+    for im in imgs:
+        offs.append(o)
+        o += im.numel()
+    return torch.cat(imgs).contiguous(), offs
+
+
+class NerfMlpFn(torch.autograd.Function):
+    """raw (P,4) = NeRF(vox (P,8), x (P,S,F+4)) with the fused HIP backward.  The forward runs the module's own layers
+    (PyTorch-ROCm, no graph kept); the backward recomputes it inside enerf_nerf_mlp_bwd."""
+
+    @staticmethod
+    def forward(ctx, lib: EnerfLib, m, forward_fn, vox, x, *params):
+        with torch.no_grad():
+            raw = forward_fn(m, vox.unsqueeze(0), x.unsqueeze(0))[0]
+        ctx.lib, ctx.m = lib, m
+        ctx.save_for_backward(vox, x)
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        lib, m = ctx.lib, ctx.m
+        vox, x = ctx.saved_tensors
+        P, S, XW = x.shape
+        F = XW - 4
+        from .network import NerfParams  # noqa: F401  (layout of the parameter module)
+        packed = lib.nerf_pack(m.raw(), F, m.viewdir_agg, vox.device)
+        bimg, offs = mlp_backward_images(m, S)
+        g_vox, g_x, sv = lib.nerf_mlp_bwd(vox.contiguous(), x.contiguous(), g_raw.contiguous(), packed, bimg, offs, S, F)
+        hv, G, q, gs, a_, vm, d_c, d_q, d_p2, d_s, d_h, d_agg, d_u, d_g, d_gsum, d_v = sv
+        PS = P * S
+        x2 = x.reshape(PS, XW)
+        gw = {}
+        # color.2 (1,64) / color.0 (64, 88+F+4) / sigma (1,64) / lr0 (64,24) / fc (16,32) / agg_w (1,32) / global_fc (32,3F) / view_fc (F,4)
+        gw["color.2.weight"] = lib.gemm_wgrad(d_c.reshape(PS, 1), q.reshape(PS, 64))
+        gw["color.2.bias"] = d_c.sum().reshape(1)
+        gw["color.0.weight"] = torch.cat([lib.gemm_wgrad(d_p2, hv), lib.gemm_wgrad(d_q.reshape(PS, 64), x2)], 1)
+        gw["color.0.bias"] = d_p2.sum(0)
+        gw["sigma.0.weight"] = lib.gemm_wgrad(d_s.reshape(P, 1), hv, Cb=64)
+        gw["sigma.0.bias"] = d_s.sum().reshape(1)
+        gw["lr0.0.weight"] = lib.gemm_wgrad(d_h, hv[:, 64:])
+        gw["lr0.0.bias"] = d_h.sum(0)
+        gw["agg.fc.0.weight"] = lib.gemm_wgrad(d_agg, G)
+        gw["agg.fc.0.bias"] = d_agg.sum(0)
+        gw["agg.agg_w_fc.0.weight"] = lib.gemm_wgrad(d_u.reshape(PS, 1), gs.reshape(PS, 32))
+        gw["agg.agg_w_fc.0.bias"] = d_u.sum().reshape(1)
+        gw["agg.global_fc.0.weight"] = torch.cat([lib.gemm_wgrad(d_g.reshape(PS, 32), a_.reshape(PS, F)), lib.gemm_wgrad(d_gsum, vm)], 1)
+        gw["agg.global_fc.0.bias"] = d_gsum.sum(0)
+        if m.viewdir_agg:
+            gw["agg.view_fc.0.weight"] = lib.gemm_wgrad(d_v.reshape(PS, F), x2[:, F:])
+            gw["agg.view_fc.0.bias"] = d_v.reshape(PS, F).sum(0)
+        grads = [gw.get(n) for n, _ in m.named_parameters()]
+        return (None, None, None, g_vox, g_x) + tuple(grads)
+
+
+def nerf_mlp(lib, m, forward_fn, vox, x):
+    """vox (B,P,8), x (B,P,S,F+4) -> raw (B,P,4) through NerfMlpFn (all points of the batch as one row list)."""
+    B, P = vox.shape[:2]
+    params = [p for _, p in m.named_parameters()]
+    raw = NerfMlpFn.apply(lib, m, forward_fn, vox.reshape(B * P, 8), x.reshape(B * P, x.shape[2], x.shape[3]), *params)
+    return raw.reshape(B, P, 4)

@@ -1,0 +1,425 @@
+// mlp_train.hip — backward of the Agg + NeRF MLP (nerf.py:29-89) for training, fused per point.
+//
+// PyTorch's backward of this MLP materialises every per-(point, view) activation (up to 103 floats x 2 M rows per layer) and is
+// memory-bound: 21 ms of `aten::mm` + 7 ms of reductions per training step at 512x640.  Here a wave takes 16 points,
+// RECOMPUTES the forward in registers exactly like the render kernel (same packed weight image, same MFMA operand chaining)
+// and back-propagates through it with the TRANSPOSED weights as MFMA A operands: a layer's output gradient sits in the D
+// layout (rows 4g+r of column j), which is the B layout of the transposed product, so gradients never move between lanes
+// either.  It writes (i) the gradients of the inputs (voxel feature, per-view texel features + direction code) and (ii), per
+// layer, the pre-activation gradient and the layer input as channels-last rows — the weight gradients are then plain
+// position-reductions on the matrix cores (enerf_gemm_wgrad, the 1x1 case of wgrad.hip).
+//
+// Activation layouts inside a wave (lane l = (g = l>>4, j = l&15), point j):
+//   "unit" layout: f32x4 tile t holds units 16t + 4g + r;   "slot" layout: register r of lane group g holds channel g*R + r
+//   (r < R) and the direction-code component g (r == R) — one 16-row tile t covers slots 4t..4t+3.
+// The transposed weight images (built on the host, enerf_amd/autograd.py:mlp_backward_images) follow those two layouts.
+#include "nerf_layout.h"
+
+namespace enerf {
+
+struct MlpBwdArgs {
+    const float *vox, *x, *g_raw;        // (P,8), (P,S,F+4), (P,4)
+    const float *packed, *bimg;          // forward weight image (nerf_pack), backward images
+    float *g_vox, *g_x;                  // (P,8), (P,S,F+4)
+    // saved layer inputs / pre-activation gradients (channels-last rows)
+    float *sv_hv, *sv_G, *sv_q, *sv_g, *sv_a, *sv_vm;                       // (P,88) (P,32) (P,S,64) (P,S,32) (P,S,F) (P,2F)
+    float *d_cpre, *d_qpre, *d_p2, *d_spre, *d_hpre, *d_aggpre, *d_upre, *d_gpre, *d_gsum, *d_vpre;
+    long long P;
+    int F;
+    int o_b1, o_b2, o_b3, o_b4, o_b5, o_b6v, o_b6m, o_b7;                  // float offsets of the backward images
+};
+
+template <int R, int S>
+__global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
+    constexpr int TR = (R + 3) / 4;             // slot tiles of the F channels
+    constexpr int TX = (R + 1 + 3) / 4;         // slot tiles of [channels | direction code]
+    const int F = a.F, XW = F + 4;
+    const NerfLayout L = nerf_layout(F);
+    ENERF_DYN_SMEM(float, smem);
+    float* wl = smem;
+    for (int i = threadIdx.x * 4; i < L.total; i += blockDim.x * 4)
+        *reinterpret_cast<float4*>(wl + i) = *reinterpret_cast<const float4*>(a.packed + i);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const float* wlane = wl + lane;
+    const float* bl = a.bimg + lane;
+    const long long ntiles = cdivl(a.P, 16);
+    const int waves = blockDim.x >> 6;
+    for (long long tile = (long long)blockIdx.x * waves + (threadIdx.x >> 6); tile < ntiles; tile += (long long)gridDim.x * waves) {
+        const long long pr = tile * 16 + j;
+        const bool ok = pr < a.P;
+        const long long p = ok ? pr : a.P - 1;
+        // ---------------- inputs ----------------
+        float vox[2], x[S][R], dsel[S];
+        vox[0] = a.vox[p * 8 + 2 * g]; vox[1] = a.vox[p * 8 + 2 * g + 1];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float* xp = a.x + (p * S + s) * XW;
+#pragma unroll
+            for (int r = 0; r < R; ++r) x[s][r] = (g * R + r < F) ? xp[g * R + r] : 0.f;
+            dsel[s] = xp[F + g];
+        }
+        // ---------------- forward recompute (the render kernel's MLP phase) ----------------
+        float aview[TR];
+        f32x4 vb[TR];
+#pragma unroll
+        for (int t = 0; t < TR; ++t) { aview[t] = wlane[L.view + t * 64]; vb[t] = lds4(wl + L.viewb + t * 16 + 4 * g); }
+        float av[S][R];
+        bool vmask[S][R];                                   // view_fc pre-activation > 0
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            f32x4 va[TR];
+#pragma unroll
+            for (int t = 0; t < TR; ++t) va[t] = ENERF_MFMA(aview[t], dsel[s], vb[t]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const float v = va[r >> 2][r & 3]; vmask[s][r] = v > 0.f; av[s][r] = x[s][r] + relu1(v); }
+        }
+        float var[R], mean[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float m = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) m += av[s][r];
+            m *= (1.f / (float)S);
+            float q = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { float d = av[s][r] - m; q += d * d; }
+            mean[r] = m;
+            var[r] = q * (1.f / (float)(S - 1));
+        }
+        f32x4 Pg[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) Pg[u] = lds4(wl + L.globb + u * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                Pg[u] = ENERF_MFMA(wlane[L.glob + ((1 * R + r) * 2 + u) * 64], var[r], Pg[u]);
+                Pg[u] = ENERF_MFMA(wlane[L.glob + ((2 * R + r) * 2 + u) * 64], mean[r], Pg[u]);
+            }
+        f32x4 gf[S][2];
+        float upre[S], aw[S];
+        const f32x4 aggw0 = lds4(wl + L.aggw + 4 * g), aggw1 = lds4(wl + L.aggw + 16 + 4 * g);
+        const float aggb = wl[L.aggw + 32];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            gf[s][0] = Pg[0]; gf[s][1] = Pg[1];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) gf[s][u] = ENERF_MFMA(wlane[L.glob + ((0 * R + r) * 2 + u) * 64], av[s][r], gf[s][u]);
+            gf[s][0] = relu4(gf[s][0]); gf[s][1] = relu4(gf[s][1]);
+            upre[s] = group_sum(dot4(gf[s][1], aggw1, dot4(gf[s][0], aggw0, 0.f))) + aggb;
+            aw[s] = relu1(upre[s]);
+        }
+        {
+            float m = aw[0];
+#pragma unroll
+            for (int s = 1; s < S; ++s) m = fmaxf(m, aw[s]);
+            float se = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { aw[s] = expf(aw[s] - m); se += aw[s]; }
+#pragma unroll
+            for (int s = 0; s < S; ++s) aw[s] /= se;
+        }
+        f32x4 G[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            G[u] = gf[0][u] * aw[0];
+#pragma unroll
+            for (int s = 1; s < S; ++s) G[u] += gf[s][u] * aw[s];
+        }
+        f32x4 aggv = lds4(wl + L.fcb + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) aggv = ENERF_MFMA(wlane[L.fc + e * 64], G[e >> 2][e & 3], aggv);
+        const f32x4 agg = relu4(aggv);
+        f32x4 hid[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) hid[v] = lds4(wl + L.lr0b + v * 16 + 4 * g);
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const float bop = ks < 2 ? vox[ks < 2 ? ks : 0] : agg[ks >= 2 ? ks - 2 : 0];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) hid[v] = ENERF_MFMA(wlane[L.lr0 + (ks * 4 + v) * 64], bop, hid[v]);
+        }
+        f32x4 sigw[4];
+        float spre = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            hid[v] = relu4(hid[v]);
+            sigw[v] = lds4(wl + L.sigma + v * 16 + 4 * g);
+            spre = dot4(hid[v], sigw[v], spre);
+        }
+        spre = group_sum(spre) + wl[L.sigma + 64];
+        f32x4 P2[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) P2[v] = lds4(wl + L.c0b + v * 16 + 4 * g);
+#pragma unroll
+        for (int ks = 0; ks < 22; ++ks) {
+            const float bop = ks < 16 ? hid[(ks < 16 ? ks : 0) >> 2][ks & 3] : (ks < 18 ? vox[ks < 18 ? ks - 16 : 0] : agg[ks >= 18 ? ks - 18 : 0]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) P2[v] = ENERF_MFMA(wlane[L.c0p + (ks * 4 + v) * 64], bop, P2[v]);
+        }
+        f32x4 c2w[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) c2w[v] = lds4(wl + L.col2 + v * 16 + 4 * g);
+        const float c2b = wl[L.col2 + 64];
+        // colour logits of every view (needed before any view's gradient: softmax over views)
+        float cpre[S], cl[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            f32x4 cc[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) cc[v] = P2[v];
+#pragma unroll
+            for (int ks = 0; ks <= R; ++ks) {
+                const float bop = ks < R ? x[s][ks < R ? ks : 0] : dsel[s];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) cc[v] = ENERF_MFMA(wlane[L.c0v + (ks * 4 + v) * 64], bop, cc[v]);
+            }
+            float part = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) part = dot4(relu4(cc[v]), c2w[v], part);
+            cpre[s] = group_sum(part) + c2b;
+            cl[s] = relu1(cpre[s]);
+        }
+        {
+            float m = cl[0];
+#pragma unroll
+            for (int s = 1; s < S; ++s) m = fmaxf(m, cl[s]);
+            float se = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { cl[s] = expf(cl[s] - m); se += cl[s]; }
+#pragma unroll
+            for (int s = 0; s < S; ++s) cl[s] /= se;
+        }
+        // ---------------- save the layer inputs ----------------
+        if (ok) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(a.sv_hv + p * 88 + 16 * v + 4 * g) = hid[v];
+            a.sv_hv[p * 88 + 64 + 2 * g] = vox[0]; a.sv_hv[p * 88 + 64 + 2 * g + 1] = vox[1];
+            *reinterpret_cast<f32x4*>(a.sv_hv + p * 88 + 72 + 4 * g) = agg;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) *reinterpret_cast<f32x4*>(a.sv_G + p * 32 + 16 * u + 4 * g) = G[u];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) *reinterpret_cast<f32x4*>(a.sv_g + (p * S + s) * 32 + 16 * u + 4 * g) = gf[s][u];
+#pragma unroll
+                for (int r = 0; r < R; ++r) if (g * R + r < F) a.sv_a[(p * S + s) * F + g * R + r] = av[s][r];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (g * R + r < F) { a.sv_vm[p * 2 * F + g * R + r] = var[r]; a.sv_vm[p * 2 * F + F + g * R + r] = mean[r]; }
+        }
+        // ---------------- backward ----------------
+        const float4 graw = *reinterpret_cast<const float4*>(a.g_raw + p * 4);
+        const float gcol[3] = {graw.x, graw.y, graw.z};
+        const float gsig = ok ? graw.w : 0.f;
+        // col = sum_s cw_s rgb_s (rgb_s = channels F-3..F-1 of x_s): d cw_s, softmax over views, ReLU of the logit
+        float gcw[S], gcpre[S];
+        float dotc = 0.f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            float part = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int c = g * R + r - (F - 3);
+                if (c >= 0 && c < 3) part += gcol[c] * x[s][r];
+            }
+            gcw[s] = group_sum(part);
+            dotc += cl[s] * gcw[s];
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float gc = cl[s] * (gcw[s] - dotc);
+            gcpre[s] = (ok && cpre[s] > 0.f) ? gc : 0.f;
+        }
+        f32x4 dP2[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+        f32x4 dxd[S][TX];                                   // gradient of [x_s | dir_s] in slot layout
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            // recompute q_s = relu(P2 + W_v [x_s, dir_s])
+            f32x4 cc[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) cc[v] = P2[v];
+#pragma unroll
+            for (int ks = 0; ks <= R; ++ks) {
+                const float bop = ks < R ? x[s][ks < R ? ks : 0] : dsel[s];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) cc[v] = ENERF_MFMA(wlane[L.c0v + (ks * 4 + v) * 64], bop, cc[v]);
+            }
+            f32x4 gq[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gq[v][r] = cc[v][r] > 0.f ? c2w[v][r] * gcpre[s] : 0.f;
+                dP2[v] += gq[v];
+                if (ok) {
+                    *reinterpret_cast<f32x4*>(a.sv_q + (p * S + s) * 64 + 16 * v + 4 * g) = relu4(cc[v]);
+                    *reinterpret_cast<f32x4*>(a.d_qpre + (p * S + s) * 64 + 16 * v + 4 * g) = gq[v];
+                }
+            }
+            if (ok && g == 0) a.d_cpre[p * S + s] = gcpre[s];
+            // B1: d [x_s | dir_s] = W_v^T gq
+#pragma unroll
+            for (int t = 0; t < TX; ++t) {
+                f32x4 acc = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) acc = ENERF_MFMA(bl[a.o_b1 + (t * 16 + kk) * 64], gq[kk >> 2][kk & 3], acc);
+                dxd[s][t] = acc;
+            }
+        }
+        // B2: d [h | vox | agg] = W_p^T dP2
+        f32x4 dh[4], dvox = f32x4{0, 0, 0, 0}, dagg = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            f32x4 acc = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc = ENERF_MFMA(bl[a.o_b2 + (t * 16 + kk) * 64], dP2[kk >> 2][kk & 3], acc);
+            if (t < 4) dh[t] = acc; else if (t == 4) dvox = acc; else dagg = acc;
+        }
+        if (ok) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(a.d_p2 + p * 64 + 16 * v + 4 * g) = dP2[v];
+        }
+        // sigma = softplus(spre) (beta 1, threshold 20)
+        const float gspre = gsig * (spre > 20.f ? 1.f : 1.f / (1.f + expf(-spre)));
+        if (ok && g == 0) a.d_spre[p] = gspre;
+        f32x4 ghpre[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ghpre[v][r] = hid[v][r] > 0.f ? dh[v][r] + sigw[v][r] * gspre : 0.f;
+            if (ok) *reinterpret_cast<f32x4*>(a.d_hpre + p * 64 + 16 * v + 4 * g) = ghpre[v];
+        }
+        // B3: d [vox | agg] += W_0^T ghpre
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 acc = t == 0 ? dvox : dagg;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc = ENERF_MFMA(bl[a.o_b3 + (t * 16 + kk) * 64], ghpre[kk >> 2][kk & 3], acc);
+            if (t == 0) dvox = acc; else dagg = acc;
+        }
+        f32x4 gaggpre;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gaggpre[r] = agg[r] > 0.f ? dagg[r] : 0.f;
+        if (ok) *reinterpret_cast<f32x4*>(a.d_aggpre + p * 16 + 4 * g) = gaggpre;
+        // B4: dG = W_f^T gaggpre
+        f32x4 dG[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 acc = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = ENERF_MFMA(bl[a.o_b4 + (u * 4 + kk) * 64], gaggpre[kk], acc);
+            dG[u] = acc;
+        }
+        // G = sum_s w_s g_s ; w = softmax_s(relu(upre))
+        float daw[S], dot2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            daw[s] = group_sum(dot4(dG[1], gf[s][1], dot4(dG[0], gf[s][0], 0.f)));
+            dot2 += aw[s] * daw[s];
+        }
+        f32x4 dgsum[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+        f32x4 dgp[S][2];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float du = aw[s] * (daw[s] - dot2);
+            const float dup = (ok && upre[s] > 0.f) ? du : 0.f;
+            if (ok && g == 0) a.d_upre[p * S + s] = dup;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const f32x4 wv = u == 0 ? aggw0 : aggw1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dgp[s][u][r] = gf[s][u][r] > 0.f ? aw[s] * dG[u][r] + wv[r] * dup : 0.f;
+                dgsum[u] += dgp[s][u];
+                if (ok) *reinterpret_cast<f32x4*>(a.d_gpre + (p * S + s) * 32 + 16 * u + 4 * g) = dgp[s][u];
+            }
+        }
+        if (ok) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) *reinterpret_cast<f32x4*>(a.d_gsum + p * 32 + 16 * u + 4 * g) = dgsum[u];
+        }
+        // B6: d var, d mean (slot layout) = W_var^T dgsum, W_mean^T dgsum ; B5: d a_s = W_a^T dgp_s
+        f32x4 dvar[TR], dmean[TR];
+#pragma unroll
+        for (int t = 0; t < TR; ++t) {
+            f32x4 a1 = f32x4{0, 0, 0, 0}, a2 = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                a1 = ENERF_MFMA(bl[a.o_b6v + (t * 8 + kk) * 64], dgsum[kk >> 2][kk & 3], a1);
+                a2 = ENERF_MFMA(bl[a.o_b6m + (t * 8 + kk) * 64], dgsum[kk >> 2][kk & 3], a2);
+            }
+            dvar[t] = a1; dmean[t] = a2;
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            f32x4 da[TR];
+#pragma unroll
+            for (int t = 0; t < TR; ++t) {
+                f32x4 acc = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) acc = ENERF_MFMA(bl[a.o_b5 + (t * 8 + kk) * 64], dgp[s][kk >> 2][kk & 3], acc);
+                da[t] = acc;
+            }
+            float dvp[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float d = da[r >> 2][r & 3] + dmean[r >> 2][r & 3] * (1.f / (float)S) +
+                                dvar[r >> 2][r & 3] * (2.f / (float)(S - 1)) * (av[s][r] - mean[r]);
+                dxd[s][r >> 2][r & 3] += d;                                  // a_s = x_s + relu(view_fc(dir_s))
+                dvp[r] = vmask[s][r] ? d : 0.f;
+                if (ok && g * R + r < F) a.d_vpre[(p * S + s) * F + g * R + r] = dvp[r];
+                // the rgb channels also feed the colour blend directly: col = sum_s cw_s rgb_s
+                const int c = g * R + r - (F - 3);
+                if (c >= 0 && c < 3) dxd[s][r >> 2][r & 3] += cl[s] * gcol[c];
+            }
+            // B7: d dir_s += W_view^T dvp  (k-steps over the view_fc outputs in slot layout)
+#pragma unroll
+            for (int t = 0; t < TX; ++t)
+#pragma unroll
+                for (int r = 0; r < R; ++r) dxd[s][t] = ENERF_MFMA(bl[a.o_b7 + (t * R + r) * 64], dvp[r], dxd[s][t]);
+            if (ok) {
+                float* gx = a.g_x + (p * S + s) * XW;
+#pragma unroll
+                for (int r = 0; r < R; ++r) if (g * R + r < F) gx[g * R + r] = dxd[s][r >> 2][r & 3];
+                gx[F + g] = dxd[s][R >> 2][R & 3];
+            }
+        }
+        if (ok) { a.g_vox[p * 8 + 2 * g] = dvox[0]; a.g_vox[p * 8 + 2 * g + 1] = dvox[1]; }
+    }
+}
+
+}  // namespace enerf
+
+using namespace enerf;
+extern "C" int enerf_nerf_mlp_bwd(const enerf_mlp_bwd_args_t* u, enerf_stream_t stream) {
+    REQUIRE(u, "nerf_mlp_bwd: null args");
+    REQUIRE(u->F == 11 || u->F == 35, "nerf_mlp_bwd: F=%d unsupported (11 or 35)", u->F);
+    REQUIRE(u->S >= 2 && u->S <= 4 && u->P >= 0, "nerf_mlp_bwd: bad shape");
+    if (u->P == 0) return ENERF_OK;
+    REQUIRE(u->vox && u->x && u->g_raw && u->packed && u->bimg && u->g_vox && u->g_x, "nerf_mlp_bwd: null pointer");
+    for (int i = 0; i < 16; ++i) REQUIRE(u->save[i], "nerf_mlp_bwd: save buffer %d missing", i);
+    MlpBwdArgs a;
+    a.vox = u->vox; a.x = u->x; a.g_raw = u->g_raw; a.packed = u->packed; a.bimg = u->bimg; a.g_vox = u->g_vox; a.g_x = u->g_x;
+    a.sv_hv = u->save[0]; a.sv_G = u->save[1]; a.sv_q = u->save[2]; a.sv_g = u->save[3]; a.sv_a = u->save[4]; a.sv_vm = u->save[5];
+    a.d_cpre = u->save[6]; a.d_qpre = u->save[7]; a.d_p2 = u->save[8]; a.d_spre = u->save[9]; a.d_hpre = u->save[10];
+    a.d_aggpre = u->save[11]; a.d_upre = u->save[12]; a.d_gpre = u->save[13]; a.d_gsum = u->save[14]; a.d_vpre = u->save[15];
+    a.P = u->P; a.F = u->F;
+    a.o_b1 = u->image_offsets[0]; a.o_b2 = u->image_offsets[1]; a.o_b3 = u->image_offsets[2]; a.o_b4 = u->image_offsets[3];
+    a.o_b5 = u->image_offsets[4]; a.o_b6v = u->image_offsets[5]; a.o_b6m = u->image_offsets[6]; a.o_b7 = u->image_offsets[7];
+    const size_t shmem = (size_t)nerf_layout(u->F).total * sizeof(float);
+    const long long ntiles = cdivl(u->P, 16);
+    long long blocks = cdivl(ntiles, 4);
+    const long long resident = (long long)device_cu_count() * 2;
+    if (blocks > resident) blocks = resident;
+    const unsigned grid = (unsigned)blocks;
+    hipStream_t st = (hipStream_t)stream;
+    const int R = (u->F + 3) / 4;
+#define ENERF_MLPB(RR, SS) ENERF_LAUNCH((k_mlp_bwd<RR, SS>), grid, 256, shmem, st, a)
+    if (R == 3) { if (u->S == 2) ENERF_MLPB(3, 2); else if (u->S == 3) ENERF_MLPB(3, 3); else ENERF_MLPB(3, 4); }
+    else { if (u->S == 2) ENERF_MLPB(9, 2); else if (u->S == 3) ENERF_MLPB(9, 3); else ENERF_MLPB(9, 4); }
+#undef ENERF_MLPB
+    return check_launch("nerf_mlp_bwd");
+}

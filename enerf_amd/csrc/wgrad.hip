@@ -30,6 +30,7 @@ struct WgradGeom {
     int stride, pad_d, pad_h, pad_w;
     int tiles_a, tiles_b;        // ceil(C/16)
     int chunks;                  // position chunks (blocks per tile pair)
+    int lda, ldb;                // floats between consecutive positions of A / B (>= Ca / Cb: column slices of wider rows)
     long long npos;              // n * Da * Ha * Wa
 };
 
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ A,
         const unsigned r2 = r1 / (unsigned)q.Ha;
         const int oh = (int)(r1 - r2 * (unsigned)q.Ha);
         const int b = (int)(r2 / (unsigned)q.Da), od = (int)(r2 - (unsigned)b * (unsigned)q.Da);
-        const float av = (pv && ca_ok) ? A[(long long)pc * q.Ca + ca] : 0.f;
+        const float av = (pv && ca_ok) ? A[(long long)pc * q.lda + ca] : 0.f;
         const int id0 = od * q.stride - q.pad_d, ih0 = oh * q.stride - q.pad_h, iw0 = ow * q.stride - q.pad_w;
         const long long bbase = (long long)b * q.Db;
         float bv[NT];
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ A,
             const int id = id0 + kd, ih = ih0 + kh, iw = iw0 + kw;
             const bool ok = pv && cb_ok && (unsigned)id < (unsigned)q.Db && (unsigned)ih < (unsigned)q.Hb && (unsigned)iw < (unsigned)q.Wb;
             const long long bi = ((bbase + (ok ? id : 0)) * q.Hb + (ok ? ih : 0)) * q.Wb + (ok ? iw : 0);
-            bv[t] = ok ? Bt[bi * q.Cb + cb] : 0.f;
+            bv[t] = ok ? Bt[bi * q.ldb + cb] : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = ENERF_MFMA_W(av, bv[t], acc[t]);
@@ -117,8 +118,10 @@ static void launch_wgrad_k(const float* A, const float* Bt, const WgradGeom& q, 
 }
 
 bool launch_conv_wgrad(const float* A, const float* Bt, int n, int Da, int Ha, int Wa, int Ca, int Db, int Hb, int Wb, int Cb,
-                       int kd, int kh, int kw, int stride, int pad_d, int pad_h, int pad_w, float* dW, hipStream_t st) {
+                       int kd, int kh, int kw, int stride, int pad_d, int pad_h, int pad_w, float* dW, hipStream_t st, int lda = 0,
+                       int ldb = 0) {
     WgradGeom q;
+    q.lda = lda > 0 ? lda : Ca; q.ldb = ldb > 0 ? ldb : Cb;
     q.n = n; q.Da = Da; q.Ha = Ha; q.Wa = Wa; q.Ca = Ca; q.Db = Db; q.Hb = Hb; q.Wb = Wb; q.Cb = Cb;
     q.stride = stride; q.pad_d = pad_d; q.pad_h = pad_h; q.pad_w = pad_w;
     q.tiles_a = cdiv(Ca, 16); q.tiles_b = cdiv(Cb, 16);
@@ -151,4 +154,15 @@ extern "C" int enerf_conv_wgrad(const float* a_cl, const float* b_cl, int n, int
                            (hipStream_t)stream))
         return fail(ENERF_EINVAL, "conv_wgrad: kernel %dx%dx%d unsupported (3x3x3, 1x3x3, 1x5x5, 1x1x1)", kd, kh, kw);
     return check_launch("conv_wgrad");
+}
+
+// Plain position-reduction GEMM: grad_w[a][b] = sum_p A[p][a] * B[p][b] — the weight gradient of a Linear layer from its
+// pre-activation gradient A (P rows, Ca used columns of rows lda floats wide) and its input B (P x Cb, rows ldb wide).
+extern "C" int enerf_gemm_wgrad(const float* a, int lda, int Ca, const float* b, int ldb, int Cb, long long P, float* grad_w,
+                                enerf_stream_t stream) {
+    REQUIRE(a && b && grad_w && Ca > 0 && Cb > 0 && lda >= Ca && ldb >= Cb, "gemm_wgrad: bad arguments");
+    REQUIRE(P > 0 && P < (1LL << 31), "gemm_wgrad: P out of range");
+    hipMemsetAsync(grad_w, 0, (size_t)Ca * Cb * sizeof(float), (hipStream_t)stream);
+    launch_conv_wgrad(a, b, 1, 1, 1, (int)P, Ca, 1, 1, (int)P, Cb, 1, 1, 1, 1, 0, 0, 0, grad_w, (hipStream_t)stream, lda, ldb);
+    return check_launch("gemm_wgrad");
 }

@@ -58,6 +58,12 @@ def _opt(o):
     return None if o is None else C.byref(o)
 
 
+class MlpBwdArgs(C.Structure):
+    """``enerf_mlp_bwd_args_t``."""
+    _fields_ = ([(n, _f) for n in ("vox", "x", "g_raw", "packed", "bimg", "g_vox", "g_x")] + [("save", C.c_void_p * 16),
+                ("P", _ll), ("F", _i), ("S", _i), ("image_offsets", _i * 8)])
+
+
 class RenderArgs(C.Structure):
     _fields_ = ([(n, _f) for n in ("rays12", "tex", "vol", "src_exts", "src_ixts", "tar_ext", "packed", "rgb",
                                    "depth", "weights")]
@@ -143,6 +149,8 @@ _SIGNATURES = {
     "enerf_build_feature_volume_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f]),
     "enerf_depth_regression_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f]),
     "enerf_conv_wgrad": (_i, [_f, _f] + [_i] * 16 + [_f, _f]),
+    "enerf_nerf_mlp_bwd": (_i, [C.POINTER(MlpBwdArgs), _f]),
+    "enerf_gemm_wgrad": (_i, [_f, _i, _i, _f, _i, _i, _ll, _f, _f]),
     "enerf_conv3d_layer_packed_floats": (_ll, [_i, _i, _i]),
     "enerf_conv3d_layer_pack": (_i, [_f, _i, _i, _i, _f, _f]),
     "enerf_conv3d_layer": (_i, [_f, _i, _i, _i, _f, _f, _f, _i, _i, _i, _i, C.POINTER(Options), _f]),
@@ -446,6 +454,34 @@ class EnerfLib:
                                                   _ptr(mask_shift), _ptr(residual), int(relu), a.numel() // Cc, Cc, _ptr(out),
                                                   self.stream_of(a)), "channel_affine")
         return out
+
+    def gemm_wgrad(self, a, b, Ca=None, Cb=None):
+        """grad_w (Ca,Cb) = sum over rows p of a[p,:Ca]^T b[p,:Cb]; a, b 2-D row-major (possibly column slices: a view whose
+        rows are wider than Ca is passed by its base pointer + row stride)."""
+        P = a.shape[0]
+        Ca, Cb = Ca or a.shape[1], Cb or b.shape[1]
+        if a.stride(1) != 1 or b.stride(1) != 1:
+            raise EnerfError("gemm_wgrad: rows must be contiguous")
+        gw = torch.empty((Ca, Cb), dtype=torch.float32, device=a.device)
+        self._check(self.dll.enerf_gemm_wgrad(a.data_ptr(), a.stride(0), Ca, b.data_ptr(), b.stride(0), Cb, P, _ptr(gw),
+                                              self.stream_of(a)), "gemm_wgrad")
+        return gw
+
+    def nerf_mlp_bwd(self, vox, x, g_raw, packed, bimg, offsets, S, F):
+        """Fused MLP backward (enerf_nerf_mlp_bwd) -> (g_vox, g_x, saves: list of 16 tensors)."""
+        P, dev = vox.shape[0], vox.device
+        E = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        g_vox, g_x = E(P, 8), E(P, S, F + 4)
+        saves = [E(P, 88), E(P, 32), E(P, S, 64), E(P, S, 32), E(P, S, F), E(P, 2 * F),
+                 E(P, S), E(P, S, 64), E(P, 64), E(P), E(P, 64), E(P, 16), E(P, S), E(P, S, 32), E(P, 32), E(P, S, F)]
+        a = MlpBwdArgs(_ptr(vox), _ptr(x), _ptr(g_raw), _ptr(packed), _ptr(bimg), _ptr(g_vox), _ptr(g_x))
+        for i, t in enumerate(saves):
+            a.save[i] = t.data_ptr()
+        a.P, a.F, a.S = P, F, S
+        for i, o in enumerate(offsets):
+            a.image_offsets[i] = int(o)
+        self._check(self.dll.enerf_nerf_mlp_bwd(C.byref(a), self.stream_of(vox)), "nerf_mlp_bwd")
+        return g_vox, g_x, saves
 
     def conv_wgrad_cl(self, a_cl, b_cl, stride):
         """3x3x3 weight gradient from channels-last tensors a (n,Da,Ha,Wa,Ca), b (n,Db,Hb,Wb,Cb) -> (Ca,Cb,3,3,3)."""

@@ -301,7 +301,11 @@ def render_rays(net, rays, level, batch, im_feat, feat_vol, lib=None):
     g = nd.reshape(B, 1, 1, N * Ns, 3) * 2.0 - 1.0
     vox = F.grid_sample(feat_vol, g, align_corners=True)[:, :, 0, 0].permute(0, 2, 1)        # get_vox_feat utils.py:456-458
     x = img_feat(cas, xyz, tex, batch, level)
-    raw = nerf_forward(getattr(net, f"nerf_{level}"), vox, x).reshape(B, N, Ns, 4)
+    if lib is not None and getattr(net, "hip_mlp_backward", True):
+        from .autograd import nerf_mlp
+        raw = nerf_mlp(lib, getattr(net, f"nerf_{level}"), nerf_forward, vox, x).reshape(B, N, Ns, 4)   # fused HIP backward
+    else:
+        raw = nerf_forward(getattr(net, f"nerf_{level}"), vox, x).reshape(B, N, Ns, 4)
     if lib is not None:
         from .autograd import CompositeFn
         rgb, depth, weights = CompositeFn.apply(lib, raw, z, bool(net.cfg.white_bkgd))

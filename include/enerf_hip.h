@@ -307,6 +307,25 @@ int enerf_channel_sums(const float* a, const float* b, const float* z_mask, cons
 int enerf_channel_affine(const float* a, const float* b, const float* p, const float* q, const float* r, const float* z_mask,
                          const float* mask_scale, const float* mask_shift, const float* residual, int relu, long long n, int C,
                          float* out, enerf_stream_t stream);
+/*   Agg + NeRF MLP backward (nerf.py:29-89), fused per point: recomputes the forward in registers (same weight image and MFMA
+ *   operand chaining as enerf_render_rays) and back-propagates with the transposed weights as MFMA A operands.  Writes the
+ *   input gradients and, per layer, {pre-activation gradient, layer input} as channels-last rows; enerf_gemm_wgrad
+ *   (grad_w[a][b] = sum_p A[p][a] B[p][b] on the matrix cores) turns those into the weight gradients.
+ *   vox (P,8), x (P,S,F+4) = [features F | direction code 4], g_raw (P,4) = d loss / d [rgb, sigma]; packed = enerf_nerf_pack
+ *   image; bimg + image_offsets = the transposed-weight images (enerf_amd/autograd.py: mlp_backward_images);
+ *   save[16] = hv (P,88) G (P,32) q (P,S,64) g (P,S,32) a (P,S,F) varmean (P,2F) | d_cpre (P,S) d_qpre (P,S,64) d_p2 (P,64)
+ *   d_spre (P) d_hpre (P,64) d_aggpre (P,16) d_upre (P,S) d_gpre (P,S,32) d_gsum (P,32) d_vpre (P,S,F). */
+typedef struct {
+    const float *vox, *x, *g_raw, *packed, *bimg;
+    float *g_vox, *g_x;
+    float* save[16];
+    long long P;
+    int F, S;
+    int image_offsets[8];
+} enerf_mlp_bwd_args_t;
+int enerf_nerf_mlp_bwd(const enerf_mlp_bwd_args_t* args, enerf_stream_t stream);
+int enerf_gemm_wgrad(const float* a, int lda, int Ca, const float* b, int ldb, int Cb, long long P, float* grad_w,
+                     enerf_stream_t stream);
 int enerf_build_feature_volume_bwd(const float* feat, const float* proj, const float* depth_values, const float* grad_vol, int B,
                                    int S, int C, int Hs, int Ws, int D, int h, int w, float* grad_feat, float* grad_depth_values,
                                    enerf_stream_t stream);

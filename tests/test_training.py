@@ -368,6 +368,7 @@ def test_training_step_on_gpu_matches_reference_gradients():
     from enerf_amd.lib import get_lib
     _check_hip_backward_stages(get_lib(), dev)           # each HIP forward+backward stage vs its torch-op twin
     _check_conv_wgrad(get_lib(), dev)                    # MFMA weight gradients vs torch's
+    _check_mlp_backward(get_lib(), dev)                  # fused MLP backward vs torch autograd
     cfg, batch = _train_batch()
     batch = {k: v.to(dev) for k, v in batch.items()}
     net = _net(cfg).to(dev)
@@ -397,3 +398,43 @@ def test_training_step_on_gpu_matches_reference_gradients():
         ref = O.forward(cfg, {k: v.detach().cpu() for k, v in net.state_dict().items()},
                         {k: v.cpu() for k, v in batch.items()})["rgb_level1"]
     assert float((img.cpu() - ref).abs().max()) < 1e-4
+
+
+def _check_mlp_backward(lib, dev):
+    """enerf_nerf_mlp_bwd + enerf_gemm_wgrad (NerfMlpFn) against torch autograd through the module's own layers, for both
+    MLP widths (F = 11: level 1, F = 35: level 0) and S = 2, 3, 4 views; ragged point counts."""
+    from enerf_amd import train_path as T
+    from enerf_amd.autograd import nerf_mlp
+    from enerf_amd.network import NerfParams
+    g = torch.Generator().manual_seed(11)
+    torch.manual_seed(11)                                   # NerfParams draws its kaiming init from the global generator
+    for F, S, P in ((11, 3, 37), (11, 4, 16), (35, 2, 21), (35, 4, 33)):
+        m = NerfParams(F, True).to(dev)
+        with torch.no_grad():
+            for p in m.parameters():
+                if p.dim() == 1:
+                    p.copy_(torch.randn(p.shape, generator=g).to(dev) * 0.1)
+        vox = torch.randn(1, P, 8, generator=g).to(dev).requires_grad_(True)
+        x = torch.randn(1, P, S, F + 4, generator=g).to(dev).requires_grad_(True)
+        gout = torch.randn(1, P, 4, generator=g).to(dev)
+        ref = T.nerf_forward(m, vox, x)
+        ref.backward(gout)
+        want = {n: p.grad.clone() for n, p in m.named_parameters()}
+        gv, gx = vox.grad.clone(), x.grad.clone()
+        for p in m.parameters():
+            p.grad = None
+        vox.grad = x.grad = None
+        out = nerf_mlp(lib, m, T.nerf_forward, vox, x)
+        assert float((out - ref.detach()).abs().max()) <= 1e-6 * float(ref.abs().max())
+        out.backward(gout)
+        tol = lambda r: 5e-4 * float(r.abs().max()) + 1e-6
+        assert float((vox.grad - gv).abs().max()) <= tol(gv), (F, S, "vox")
+        assert float((x.grad - gx).abs().max()) <= tol(gx), (F, S, "x")
+        for n, p in m.named_parameters():
+            assert p.grad is not None, n
+            assert float((p.grad - want[n]).abs().max()) <= tol(want[n]), (F, S, n)
+
+
+def test_mlp_backward_emulated():
+    from emu_lib import emu_lib
+    _check_mlp_backward(emu_lib(), torch.device("cpu"))
