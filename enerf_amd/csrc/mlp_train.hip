@@ -269,6 +269,14 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
                 for (int kk = 0; kk < 16; ++kk) acc = ENERF_MFMA(bl[a.o_b1 + (t * 16 + kk) * 64], gq[kk >> 2][kk & 3], acc);
                 dxd[s][t] = acc;
             }
+            // park the slot-layout gradient in g_x (this lane's own entries) instead of holding S x TX accumulators
+            // across the rest of the backward pass
+            if (ok) {
+                float* gx = a.g_x + (p * S + s) * XW;
+#pragma unroll
+                for (int r = 0; r < R; ++r) if (g * R + r < F) gx[g * R + r] = dxd[s][r >> 2][r & 3];
+                gx[F + g] = dxd[s][R >> 2][R & 3];
+            }
         }
         // B2: d [h | vox | agg] = W_p^T dP2
         f32x4 dh[4], dvox = f32x4{0, 0, 0, 0}, dagg = f32x4{0, 0, 0, 0};
@@ -364,27 +372,30 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
                 da[t] = acc;
             }
             float dvp[R];
+            f32x4 dx2[TX];
+#pragma unroll
+            for (int t = 0; t < TX; ++t) dx2[t] = f32x4{0, 0, 0, 0};
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float d = da[r >> 2][r & 3] + dmean[r >> 2][r & 3] * (1.f / (float)S) +
                                 dvar[r >> 2][r & 3] * (2.f / (float)(S - 1)) * (av[s][r] - mean[r]);
-                dxd[s][r >> 2][r & 3] += d;                                  // a_s = x_s + relu(view_fc(dir_s))
+                dx2[r >> 2][r & 3] += d;                                     // a_s = x_s + relu(view_fc(dir_s))
                 dvp[r] = vmask[s][r] ? d : 0.f;
                 if (ok && g * R + r < F) a.d_vpre[(p * S + s) * F + g * R + r] = dvp[r];
                 // the rgb channels also feed the colour blend directly: col = sum_s cw_s rgb_s
                 const int c = g * R + r - (F - 3);
-                if (c >= 0 && c < 3) dxd[s][r >> 2][r & 3] += cl[s] * gcol[c];
+                if (c >= 0 && c < 3) dx2[r >> 2][r & 3] += cl[s] * gcol[c];
             }
             // B7: d dir_s += W_view^T dvp  (k-steps over the view_fc outputs in slot layout)
 #pragma unroll
             for (int t = 0; t < TX; ++t)
 #pragma unroll
-                for (int r = 0; r < R; ++r) dxd[s][t] = ENERF_MFMA(bl[a.o_b7 + (t * R + r) * 64], dvp[r], dxd[s][t]);
+                for (int r = 0; r < R; ++r) dx2[t] = ENERF_MFMA(bl[a.o_b7 + (t * R + r) * 64], dvp[r], dx2[t]);
             if (ok) {
                 float* gx = a.g_x + (p * S + s) * XW;
 #pragma unroll
-                for (int r = 0; r < R; ++r) if (g * R + r < F) gx[g * R + r] = dxd[s][r >> 2][r & 3];
-                gx[F + g] = dxd[s][R >> 2][R & 3];
+                for (int r = 0; r < R; ++r) if (g * R + r < F) gx[g * R + r] += dx2[r >> 2][r & 3];
+                gx[F + g] += dx2[R >> 2][R & 3];
             }
         }
         if (ok) { a.g_vox[p * 8 + 2 * g] = dvox[0]; a.g_vox[p * 8 + 2 * g + 1] = dvox[1]; }
