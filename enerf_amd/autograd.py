@@ -378,14 +378,16 @@ def mlp_backward_images(m, S):
 
 
 class NerfMlpFn(torch.autograd.Function):
-    """raw (P,4) = NeRF(vox (P,8), x (P,S,F+4)) with the fused HIP backward.  The forward runs the module's own layers
-    (PyTorch-ROCm, no graph kept); the backward recomputes it inside enerf_nerf_mlp_bwd."""
+    """raw (P,4) = NeRF(vox (P,8), x (P,S,F+4)), forward and backward fused on the HIP kernels (enerf_nerf_mlp_fwd /
+    enerf_nerf_mlp_bwd): nothing but the inputs is kept for the backward, which recomputes the forward in registers."""
 
     @staticmethod
     def forward(ctx, lib: EnerfLib, m, forward_fn, vox, x, *params):
-        with torch.no_grad():
-            raw = forward_fn(m, vox.unsqueeze(0), x.unsqueeze(0))[0]
-        ctx.lib, ctx.m = lib, m
+        vox, x = vox.contiguous(), x.contiguous()
+        P, S, XW = x.shape
+        packed = lib.nerf_pack(m.raw(), XW - 4, m.viewdir_agg, vox.device)
+        raw = lib.nerf_mlp_fwd(vox, x, packed, S, XW - 4)
+        ctx.lib, ctx.m, ctx.packed = lib, m, packed
         ctx.save_for_backward(vox, x)
         return raw
 
@@ -395,8 +397,7 @@ class NerfMlpFn(torch.autograd.Function):
         vox, x = ctx.saved_tensors
         P, S, XW = x.shape
         F = XW - 4
-        from .network import NerfParams  # noqa: F401  (layout of the parameter module)
-        packed = lib.nerf_pack(m.raw(), F, m.viewdir_agg, vox.device)
+        packed = ctx.packed
         bimg, offs = mlp_backward_images(m, S)
         g_vox, g_x, sv = lib.nerf_mlp_bwd(vox.contiguous(), x.contiguous(), g_raw.contiguous(), packed, bimg, offs, S, F)
         hv, G, q, gs, a_, vm, d_c, d_q, d_p2, d_s, d_h, d_agg, d_u, d_g, d_gsum, d_v = sv

@@ -402,6 +402,191 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
     }
 }
 
+
+// Forward only (training-mode forward of NerfMlpFn): raw (P,4) = [sum_s softmax_s(c_s) rgb_s | softplus(sigma)] — the same
+// register-resident evaluation as the first half of k_mlp_bwd / the render kernel's MLP phase, nothing materialised.
+template <int R, int S>
+__global__ __launch_bounds__(256) void k_mlp_fwd(const float* __restrict__ voxp, const float* __restrict__ xin,
+                                                 const float* __restrict__ packed, long long P, int Fin, float* __restrict__ raw) {
+    constexpr int TR = (R + 3) / 4;
+    struct { const float *vox, *x; long long P; int F; } a = {voxp, xin, P, Fin};
+    const int F = a.F, XW = F + 4;
+    const NerfLayout L = nerf_layout(F);
+    ENERF_DYN_SMEM(float, smem);
+    float* wl = smem;
+    for (int i = threadIdx.x * 4; i < L.total; i += blockDim.x * 4)
+        *reinterpret_cast<float4*>(wl + i) = *reinterpret_cast<const float4*>(packed + i);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const float* wlane = wl + lane;
+    const long long ntiles = cdivl(a.P, 16);
+    const int waves = blockDim.x >> 6;
+    for (long long tile = (long long)blockIdx.x * waves + (threadIdx.x >> 6); tile < ntiles; tile += (long long)gridDim.x * waves) {
+        const long long pr = tile * 16 + j;
+        const bool ok = pr < a.P;
+        const long long p = ok ? pr : a.P - 1;
+        // ---------------- inputs ----------------
+        float vox[2], x[S][R], dsel[S];
+        vox[0] = a.vox[p * 8 + 2 * g]; vox[1] = a.vox[p * 8 + 2 * g + 1];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float* xp = a.x + (p * S + s) * XW;
+#pragma unroll
+            for (int r = 0; r < R; ++r) x[s][r] = (g * R + r < F) ? xp[g * R + r] : 0.f;
+            dsel[s] = xp[F + g];
+        }
+        // ---------------- forward recompute (the render kernel's MLP phase) ----------------
+        float aview[TR];
+        f32x4 vb[TR];
+#pragma unroll
+        for (int t = 0; t < TR; ++t) { aview[t] = wlane[L.view + t * 64]; vb[t] = lds4(wl + L.viewb + t * 16 + 4 * g); }
+        float av[S][R];
+        bool vmask[S][R];                                   // view_fc pre-activation > 0
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            f32x4 va[TR];
+#pragma unroll
+            for (int t = 0; t < TR; ++t) va[t] = ENERF_MFMA(aview[t], dsel[s], vb[t]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const float v = va[r >> 2][r & 3]; vmask[s][r] = v > 0.f; av[s][r] = x[s][r] + relu1(v); }
+        }
+        float var[R], mean[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float m = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) m += av[s][r];
+            m *= (1.f / (float)S);
+            float q = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { float d = av[s][r] - m; q += d * d; }
+            mean[r] = m;
+            var[r] = q * (1.f / (float)(S - 1));
+        }
+        f32x4 Pg[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) Pg[u] = lds4(wl + L.globb + u * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                Pg[u] = ENERF_MFMA(wlane[L.glob + ((1 * R + r) * 2 + u) * 64], var[r], Pg[u]);
+                Pg[u] = ENERF_MFMA(wlane[L.glob + ((2 * R + r) * 2 + u) * 64], mean[r], Pg[u]);
+            }
+        f32x4 gf[S][2];
+        float upre[S], aw[S];
+        const f32x4 aggw0 = lds4(wl + L.aggw + 4 * g), aggw1 = lds4(wl + L.aggw + 16 + 4 * g);
+        const float aggb = wl[L.aggw + 32];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            gf[s][0] = Pg[0]; gf[s][1] = Pg[1];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) gf[s][u] = ENERF_MFMA(wlane[L.glob + ((0 * R + r) * 2 + u) * 64], av[s][r], gf[s][u]);
+            gf[s][0] = relu4(gf[s][0]); gf[s][1] = relu4(gf[s][1]);
+            upre[s] = group_sum(dot4(gf[s][1], aggw1, dot4(gf[s][0], aggw0, 0.f))) + aggb;
+            aw[s] = relu1(upre[s]);
+        }
+        {
+            float m = aw[0];
+#pragma unroll
+            for (int s = 1; s < S; ++s) m = fmaxf(m, aw[s]);
+            float se = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { aw[s] = expf(aw[s] - m); se += aw[s]; }
+#pragma unroll
+            for (int s = 0; s < S; ++s) aw[s] /= se;
+        }
+        f32x4 G[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            G[u] = gf[0][u] * aw[0];
+#pragma unroll
+            for (int s = 1; s < S; ++s) G[u] += gf[s][u] * aw[s];
+        }
+        f32x4 aggv = lds4(wl + L.fcb + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) aggv = ENERF_MFMA(wlane[L.fc + e * 64], G[e >> 2][e & 3], aggv);
+        const f32x4 agg = relu4(aggv);
+        f32x4 hid[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) hid[v] = lds4(wl + L.lr0b + v * 16 + 4 * g);
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const float bop = ks < 2 ? vox[ks < 2 ? ks : 0] : agg[ks >= 2 ? ks - 2 : 0];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) hid[v] = ENERF_MFMA(wlane[L.lr0 + (ks * 4 + v) * 64], bop, hid[v]);
+        }
+        f32x4 sigw[4];
+        float spre = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            hid[v] = relu4(hid[v]);
+            sigw[v] = lds4(wl + L.sigma + v * 16 + 4 * g);
+            spre = dot4(hid[v], sigw[v], spre);
+        }
+        spre = group_sum(spre) + wl[L.sigma + 64];
+        f32x4 P2[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) P2[v] = lds4(wl + L.c0b + v * 16 + 4 * g);
+#pragma unroll
+        for (int ks = 0; ks < 22; ++ks) {
+            const float bop = ks < 16 ? hid[(ks < 16 ? ks : 0) >> 2][ks & 3] : (ks < 18 ? vox[ks < 18 ? ks - 16 : 0] : agg[ks >= 18 ? ks - 18 : 0]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) P2[v] = ENERF_MFMA(wlane[L.c0p + (ks * 4 + v) * 64], bop, P2[v]);
+        }
+        f32x4 c2w[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) c2w[v] = lds4(wl + L.col2 + v * 16 + 4 * g);
+        const float c2b = wl[L.col2 + 64];
+        // colour logits of every view (needed before any view's gradient: softmax over views)
+        float cpre[S], cl[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            f32x4 cc[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) cc[v] = P2[v];
+#pragma unroll
+            for (int ks = 0; ks <= R; ++ks) {
+                const float bop = ks < R ? x[s][ks < R ? ks : 0] : dsel[s];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) cc[v] = ENERF_MFMA(wlane[L.c0v + (ks * 4 + v) * 64], bop, cc[v]);
+            }
+            float part = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) part = dot4(relu4(cc[v]), c2w[v], part);
+            cpre[s] = group_sum(part) + c2b;
+            cl[s] = relu1(cpre[s]);
+        }
+        {
+            float m = cl[0];
+#pragma unroll
+            for (int s = 1; s < S; ++s) m = fmaxf(m, cl[s]);
+            float se = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { cl[s] = expf(cl[s] - m); se += cl[s]; }
+#pragma unroll
+            for (int s = 0; s < S; ++s) cl[s] /= se;
+        }
+        const float sig = spre > 20.f ? spre : log1pf(expf(spre));             // nn.Softplus(beta=1, threshold=20)
+        if (ok) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int c = g * R + r - (F - 3);
+                if (c >= 0 && c < 3) {
+                    float col = x[0][r] * cl[0];
+#pragma unroll
+                    for (int s = 1; s < S; ++s) col += x[s][r] * cl[s];
+                    raw[p * 4 + c] = col;
+                }
+            }
+            if (g == 0) raw[p * 4 + 3] = sig;
+        }
+        (void)upre; (void)cpre; (void)vmask;
+    }
+}
+
 }  // namespace enerf
 
 using namespace enerf;
@@ -433,4 +618,24 @@ extern "C" int enerf_nerf_mlp_bwd(const enerf_mlp_bwd_args_t* u, enerf_stream_t 
     else { if (u->S == 2) ENERF_MLPB(9, 2); else if (u->S == 3) ENERF_MLPB(9, 3); else ENERF_MLPB(9, 4); }
 #undef ENERF_MLPB
     return check_launch("nerf_mlp_bwd");
+}
+
+extern "C" int enerf_nerf_mlp_fwd(const float* vox, const float* x, const float* packed, long long P, int S, int F, float* raw,
+                                  enerf_stream_t stream) {
+    REQUIRE(F == 11 || F == 35, "nerf_mlp_fwd: F=%d unsupported (11 or 35)", F);
+    REQUIRE(S >= 2 && S <= 4 && P >= 0, "nerf_mlp_fwd: bad shape");
+    if (P == 0) return ENERF_OK;
+    REQUIRE(vox && x && packed && raw, "nerf_mlp_fwd: null pointer");
+    const size_t shmem = (size_t)nerf_layout(F).total * sizeof(float);
+    long long blocks = cdivl(cdivl(P, 16), 4);
+    const long long resident = (long long)device_cu_count() * 2;
+    if (blocks > resident) blocks = resident;
+    const unsigned grid = (unsigned)blocks;
+    hipStream_t st = (hipStream_t)stream;
+    const int R = (F + 3) / 4;
+#define ENERF_MLPF(RR, SS) ENERF_LAUNCH((k_mlp_fwd<RR, SS>), grid, 256, shmem, st, vox, x, packed, P, F, raw)
+    if (R == 3) { if (S == 2) ENERF_MLPF(3, 2); else if (S == 3) ENERF_MLPF(3, 3); else ENERF_MLPF(3, 4); }
+    else { if (S == 2) ENERF_MLPF(9, 2); else if (S == 3) ENERF_MLPF(9, 3); else ENERF_MLPF(9, 4); }
+#undef ENERF_MLPF
+    return check_launch("nerf_mlp_fwd");
 }

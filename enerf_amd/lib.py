@@ -151,6 +151,7 @@ _SIGNATURES = {
     "enerf_conv_wgrad": (_i, [_f, _f] + [_i] * 16 + [_f, _f]),
     "enerf_nerf_mlp_bwd": (_i, [C.POINTER(MlpBwdArgs), _f]),
     "enerf_gemm_wgrad": (_i, [_f, _i, _i, _f, _i, _i, _ll, _f, _f]),
+    "enerf_nerf_mlp_fwd": (_i, [_f, _f, _f, _ll, _i, _i, _f, _f]),
     "enerf_conv3d_layer_packed_floats": (_ll, [_i, _i, _i]),
     "enerf_conv3d_layer_pack": (_i, [_f, _i, _i, _i, _f, _f]),
     "enerf_conv3d_layer": (_i, [_f, _i, _i, _i, _f, _f, _f, _i, _i, _i, _i, C.POINTER(Options), _f]),
@@ -466,6 +467,12 @@ class EnerfLib:
         self._check(self.dll.enerf_gemm_wgrad(a.data_ptr(), a.stride(0), Ca, b.data_ptr(), b.stride(0), Cb, P, _ptr(gw),
                                               self.stream_of(a)), "gemm_wgrad")
         return gw
+
+    def nerf_mlp_fwd(self, vox, x, packed, S, F):
+        raw = torch.empty((vox.shape[0], 4), dtype=torch.float32, device=vox.device)
+        self._check(self.dll.enerf_nerf_mlp_fwd(_ptr(vox), _ptr(x), _ptr(packed), vox.shape[0], S, F, _ptr(raw),
+                                                self.stream_of(vox)), "nerf_mlp_fwd")
+        return raw
 
     def nerf_mlp_bwd(self, vox, x, g_raw, packed, bimg, offsets, S, F):
         """Fused MLP backward (enerf_nerf_mlp_bwd) -> (g_vox, g_x, saves: list of 16 tensors)."""

@@ -324,6 +324,9 @@ typedef struct {
     int image_offsets[8];
 } enerf_mlp_bwd_args_t;
 int enerf_nerf_mlp_bwd(const enerf_mlp_bwd_args_t* args, enerf_stream_t stream);
+/* forward of the same MLP on materialised inputs (training): raw (P,4) = [rgb, sigma]; nothing else is written. */
+int enerf_nerf_mlp_fwd(const float* vox, const float* x, const float* packed, long long P, int S, int F, float* raw,
+                       enerf_stream_t stream);
 int enerf_gemm_wgrad(const float* a, int lda, int Ca, const float* b, int ldb, int Cb, long long P, float* grad_w,
                      enerf_stream_t stream);
 int enerf_build_feature_volume_bwd(const float* feat, const float* proj, const float* depth_values, const float* grad_vol, int B,

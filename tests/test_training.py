@@ -425,7 +425,7 @@ def _check_mlp_backward(lib, dev):
             p.grad = None
         vox.grad = x.grad = None
         out = nerf_mlp(lib, m, T.nerf_forward, vox, x)
-        assert float((out - ref.detach()).abs().max()) <= 1e-6 * float(ref.abs().max())
+        assert float((out - ref.detach()).abs().max()) <= 2e-5 * float(ref.abs().max())       # HIP forward (enerf_nerf_mlp_fwd)
         out.backward(gout)
         tol = lambda r: 5e-4 * float(r.abs().max()) + 1e-6
         assert float((vox.grad - gv).abs().max()) <= tol(gv), (F, S, "vox")
