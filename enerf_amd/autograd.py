@@ -309,20 +309,35 @@ def cost_reg_train(lib, m, vol):
 # Agg + NeRF MLP (nerf.py:29-89): fused HIP backward (mlp_train.hip) + weight gradients as position-reductions on the
 # matrix cores (enerf_gemm_wgrad).
 # ---------------------------------------------------------------------------------------------------------------------
-def _tile_image(Wt, row_idx, k_idx):
-    """One MFMA A-operand tile set for a TRANSPOSED product: image[e, lane = 16 g + j] = W[k_idx[e, g], row_idx[e, j]]
-    (0 where an index is -1).  W (out, in); row_idx (E,16) input indices, k_idx (E,4) output indices."""
-    E = row_idx.shape[0]
-    rows = row_idx[:, None, :].expand(E, 4, 16)                    # [e, g, j]
-    ks = k_idx[:, :, None].expand(E, 4, 16)
-    valid = (rows >= 0) & (ks >= 0)
-    vals = Wt[ks.clamp_min(0), rows.clamp_min(0)]
-    return torch.where(valid, vals, torch.zeros_like(vals)).reshape(E * 64)
+_IMAGE_INDEX_CACHE = {}
 
 
 def mlp_backward_images(m, S):
     """Transposed-weight MFMA images of one ``NerfParams`` for enerf_nerf_mlp_bwd, in the kernel's unit / slot layouts
-    (mlp_train.hip header).  Returns (flat image tensor, the 8 offsets b1, b2, b3, b4, b5, b6v, b6m, b7)."""
+    (mlp_train.hip header).  Returns (flat image tensor, the 8 offsets b1, b2, b3, b4, b5, b6v, b6m, b7).  The index maps
+    only depend on (F, device) and are cached; per step this is eight gathers and one concatenation."""
+    key = (m.feat_ch, str(m.lr0[0].weight.device), hasattr(m.agg, "view_fc"))
+    if key not in _IMAGE_INDEX_CACHE:
+        _IMAGE_INDEX_CACHE[key] = _mlp_image_indices(m)
+    specs = _IMAGE_INDEX_CACHE[key]
+    F = m.feat_ch
+    col0, glob = m.color[0].weight.detach(), m.agg.global_fc[0].weight.detach()
+    mats = [col0[:, 88:], col0[:, :88], m.lr0[0].weight.detach(), m.agg.fc[0].weight.detach(), glob[:, :F], glob[:, F:2 * F],
+            glob[:, 2 * F:], m.agg.view_fc[0].weight.detach() if hasattr(m.agg, "view_fc") else None]
+    imgs, offs, o = [], [], 0
+    for W, (rows, ks, valid) in zip(mats, specs):
+        if W is None:
+            im = torch.zeros(valid.numel(), device=valid.device)
+        else:
+            im = torch.where(valid, W[ks, rows], torch.zeros((), device=W.device)).reshape(-1)
+        offs.append(o)
+        o += im.numel()
+        imgs.append(im)
+    return torch.cat(imgs).contiguous(), offs
+
+
+def _mlp_image_indices(m):
+    """(row index, k index, validity) tensors of the eight backward tile sets (see mlp_backward_images)."""
     F = m.feat_ch
     R = (F + 3) // 4
     TR, TX = (R + 3) // 4, (R + 1 + 3) // 4
@@ -348,33 +363,27 @@ def mlp_backward_images(m, S):
         ch = g4 * R + r
         return torch.where(ch < F, ch, -torch.ones_like(ch))
 
-    def build(W, row_sets, k_sets):
+    def build(row_sets, k_sets):
+        """image[e, lane = 16 g + j] = W[k_idx[e, g], row_idx[e, j]]: index tensors (E,4,16) + validity."""
         rows = torch.stack([rs for rs in row_sets for _ in k_sets])
         ks = torch.stack([k for _ in row_sets for k in k_sets])
-        return _tile_image(W, rows, ks)
-    col0 = m.color[0].weight.detach()
-    glob = m.agg.global_fc[0].weight.detach()
+        E = rows.shape[0]
+        r3 = rows[:, None, :].expand(E, 4, 16)
+        k3 = ks[:, :, None].expand(E, 4, 16)
+        return r3.clamp_min(0).contiguous(), k3.clamp_min(0).contiguous(), ((r3 >= 0) & (k3 >= 0)).contiguous()
     k16 = [unit_k(kk) for kk in range(16)]
-    imgs = [
-        build(col0[:, 88:], [slot_rows(t, True) for t in range(TX)], k16),                                        # b1
-        build(col0[:, :88], [unit_rows(t) for t in range(4)] + [vox_rows(64), unit_rows(0, 72)], k16),            # b2
-        build(m.lr0[0].weight.detach(), [vox_rows(0), unit_rows(0, 8)], k16),                                     # b3
-        build(m.agg.fc[0].weight.detach(), [unit_rows(0), unit_rows(1)], [unit_k(kk) for kk in range(4)]),        # b4
-        build(glob[:, :F], [slot_rows(t, False) for t in range(TR)], [unit_k(kk) for kk in range(8)]),            # b5
-        build(glob[:, F:2 * F], [slot_rows(t, False) for t in range(TR)], [unit_k(kk) for kk in range(8)]),       # b6 var
-        build(glob[:, 2 * F:], [slot_rows(t, False) for t in range(TR)], [unit_k(kk) for kk in range(8)]),        # b6 mean
+    k8, k4 = [unit_k(kk) for kk in range(8)], [unit_k(kk) for kk in range(4)]
+    dir_rows = lambda t: torch.where(4 * t + (j & 3) == R, j >> 2, -torch.ones_like(j))
+    return [
+        build([slot_rows(t, True) for t in range(TX)], k16),                                        # b1: color.0, per-view columns
+        build([unit_rows(t) for t in range(4)] + [vox_rows(64), unit_rows(0, 72)], k16),            # b2: color.0, shared columns
+        build([vox_rows(0), unit_rows(0, 8)], k16),                                                 # b3: lr0
+        build([unit_rows(0), unit_rows(1)], k4),                                                    # b4: agg.fc
+        build([slot_rows(t, False) for t in range(TR)], k8),                                        # b5: global_fc, a columns
+        build([slot_rows(t, False) for t in range(TR)], k8),                                        # b6: var columns
+        build([slot_rows(t, False) for t in range(TR)], k8),                                        # b6: mean columns
+        build([dir_rows(t) for t in range(TX)], [slot_k(r) for r in range(R)]),                     # b7: view_fc
     ]
-    if hasattr(m.agg, "view_fc"):
-        vw = m.agg.view_fc[0].weight.detach()                                                                      # (F, 4)
-        dir_rows = lambda t: torch.where(4 * t + (j & 3) == R, j >> 2, -torch.ones_like(j))
-        imgs.append(build(vw, [dir_rows(t) for t in range(TX)], [slot_k(r) for r in range(R)]))                   # b7
-    else:
-        imgs.append(torch.zeros(TX * R * 64, device=dev))
-    offs, o = [], 0
-    for im in imgs:
-        offs.append(o)
-        o += im.numel()
-    return torch.cat(imgs).contiguous(), offs
 
 
 class NerfMlpFn(torch.autograd.Function):

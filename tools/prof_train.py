@@ -22,4 +22,10 @@ torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
     step(); torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=28, max_name_column_width=60))
+tab = prof.key_averages().table(sort_by="cuda_time_total", row_limit=28, max_name_column_width=60)
+print(tab)
+import time
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5): step()
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print(f"host enqueue per step {1e3*(t1-t0)/5:.1f} ms ; wall per step {1e3*(t2-t0)/5:.1f} ms")
