@@ -6,19 +6,17 @@ RCCL: the gradient all-reduce of the 436,012 parameters) work unchanged on the d
 
 What runs where in training (state of this round, stated plainly):
   * every stage is expressed on the network's OWN parameter modules (``feature_net``, ``cost_reg_i.conv*.{conv,bn}``,
-    ``nerf_i.*``), so BatchNorm uses batch statistics (and becomes SyncBatchNorm under the reference trainer), the
-    running statistics are updated exactly like the reference's, and autograd sees every parameter;
-  * three stages run on hand-written HIP kernels in BOTH directions (``enerf_amd/autograd.py`` over
-    ``csrc/backward.hip``): the cost-volume warp + variance (gradients w.r.t. the feature maps and, through the warp grid,
-    w.r.t. the depth hypotheses), depth regression, and alpha compositing;
-  * the WEIGHT gradient of all 32 convolutions (FeatureNet and both cost-reg nets) runs on the matrix cores
-    (``csrc/wgrad.hip``): the library GEMM MIOpen picks for these shapes took 511 of the 573 ms of a training step;
-  * the convolutions' forward / input gradient, BatchNorm, the Agg/NeRF MLP and the render-side gathers still execute as
-    PyTorch-ROCm ops (MIOpen / rocBLAS / ATen grid_sample) with autograd; their HIP backward (MLP, gather scatter-adds,
-    conv dgrad through the existing MFMA kernels, BN-train) is the next step of this row and is NOT built yet.
-    This is GPU code (no CPU fallback, nothing from ``oracle/``), checked against the reference's own gradients
-    (tests/test_training.py, tests/golden/train_tiny.npz: every parameter gradient of one reference training step), with
-    the HIP stages switched on and off.
+    ``nerf_i.*``), so BatchNorm uses batch statistics (SyncBatchNorm under the reference trainer), the running statistics
+    are updated exactly like the reference's, and autograd sees every parameter;
+  * HIP kernels in BOTH directions (``enerf_amd/autograd.py``): the cost-volume warp + variance (feature scatter-add and
+    the depth gradient through the warp grid), both cost-regularisation networks end to end (MFMA convolutions and input
+    gradients, BatchNorm-train kernels, MFMA weight gradients), depth regression, the Agg + NeRF MLP (fused forward, fused
+    recompute-backward, weight gradients as position reductions on the matrix cores), alpha compositing, and the weight
+    gradients of the FeatureNet convolutions;
+  * still PyTorch-ROCm ops under autograd: the FeatureNet's convolution forward / input gradient and BatchNorm2d (the
+    north_star keeps the 2-D FPN in PyTorch), the render-side gathers (grid_sample and its backward) and the per-ray
+    geometry glue.  This is GPU code (no CPU fallback, nothing from ``oracle/``), checked against the reference's own
+    gradients (tests/test_training.py, tests/golden/train_tiny.npz) with the HIP stages switched on and off.
 The inference path (eval mode) never comes here: it is the single ``enerf_forward`` C call.
 
 Semantics follow the reference line by line where gradients are concerned: the in-place masked clamps of
