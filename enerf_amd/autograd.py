@@ -79,6 +79,44 @@ class CompositeFn(torch.autograd.Function):
         return None, g_raw.view(B, N, Ns, 4), g_z.view(B, N, Ns), None
 
 
+def gather_cameras(batch, render_scale: float):
+    """The per-view constants of enerf_gather_*: cam (B,S,16) = K'E33 | K't | source centre | 0 and tcen (B,4), with
+    K' = K scaled to the level (utils.py:697-704); products in fp64, stored fp32 (as the inference kernel's table)."""
+    E = batch["src_exts"].double()
+    K = batch["src_ixts"].double().clone()
+    K[:, :, :2] *= render_scale
+    B, S = E.shape[:2]
+    M = K @ E[:, :, :3, :3]
+    v = (K @ E[:, :, :3, 3:4])[..., 0]
+    cs = torch.inverse(E)[:, :, :3, 3]
+    z1 = torch.zeros(B, S, 1, dtype=torch.float64, device=E.device)
+    cam = torch.cat([M.reshape(B, S, 9), v, cs, z1], -1).float().contiguous()
+    ct = torch.inverse(batch["tar_ext"].double())[:, :3, 3]
+    tcen = torch.cat([ct, z1[:, 0]], -1).float().contiguous()
+    return cam, tcen
+
+
+class GatherFn(torch.autograd.Function):
+    """get_img_feat + get_vox_feat (utils.py:689-722, 456-458) on the HIP kernels: xyz (B,P,3), dn (B,P), uv (B,P,2),
+    tex (B,S,F,Hr,Wr), feat_vol (B,8,D,h,w) -> x (B,P,S,F+4), vox (B,P,8).  Differentiable in xyz, dn, tex, feat_vol."""
+
+    @staticmethod
+    def forward(ctx, lib: EnerfLib, xyz, dn, uv, tex, feat_vol, cam, tcen):
+        xyz, dn, uv = _c(xyz), _c(dn), _c(uv)
+        tex_cl = tex.permute(0, 1, 3, 4, 2).contiguous()
+        vol_cl = feat_vol.permute(0, 2, 3, 4, 1).contiguous()
+        x, vox = lib.gather_fwd(xyz, dn, uv, tex_cl, vol_cl, cam, tcen)
+        ctx.lib = lib
+        ctx.save_for_backward(xyz, dn, uv, tex_cl, vol_cl, cam, tcen)
+        return x, vox
+
+    @staticmethod
+    def backward(ctx, g_x, g_vox):
+        xyz, dn, uv, tex_cl, vol_cl, cam, tcen = ctx.saved_tensors
+        g_tex, g_vol, g_xyz, g_dn = ctx.lib.gather_bwd(xyz, dn, uv, tex_cl, vol_cl, cam, tcen, _c(g_x), _c(g_vox))
+        return None, g_xyz, g_dn, None, g_tex.permute(0, 1, 4, 2, 3), g_vol.permute(0, 4, 1, 2, 3), None, None
+
+
 class ConvFn(torch.autograd.Function):
     """A bias-free Conv2d / Conv3d / ConvTranspose3d(k3,s2,p1,op1) whose WEIGHT gradient runs on the matrix cores
     (enerf_conv_wgrad).  Forward and the input gradient stay on the library convolution (MIOpen) for now."""

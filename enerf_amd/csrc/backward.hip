@@ -12,14 +12,6 @@
 
 namespace enerf {
 
-__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
-#ifdef ENERF_EMU
-    atomicAdd(p, v);
-#else
-    unsafeAtomicAdd(p, v);          // global_atomic_add_f32 (hipMalloc memory is coarse-grained)
-#endif
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // build_feature_volume backward.  CQ = C/4 lanes own one voxel (one float4 of channels each), as in the forward.
 //   var[c] = mean_s f_s[c]^2 - (mean_s f_s[c])^2          =>   d f_s[c] = (2/S) g[c] (f_s[c] - mean[c])

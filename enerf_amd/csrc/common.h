@@ -210,6 +210,14 @@ __host__ __device__ __forceinline__ Taps2 gs_taps2(float ix, float iy, int W, in
 
 __device__ __forceinline__ float clamp_min(float v, float lo) { return v < lo ? lo : v; }  // torch.clamp_min
 
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+#ifdef ENERF_EMU
+    atomicAdd(p, v);
+#else
+    unsafeAtomicAdd(p, v);          // global_atomic_add_f32 (hipMalloc memory is coarse-grained)
+#endif
+}
+
 // Hardware transcendental forms (v_rcp_f32 / v_sqrt_f32 / v_exp_f32, ~1 ulp) for the render kernel's
 // per-sample geometry and softmaxes: an IEEE-correct fp32 divide or sqrt expands to ~10 VALU
 // instructions and the sample loop had ~50 of them per 201 MFMAs.  The induced error (<=1e-6 relative)

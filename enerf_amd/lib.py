@@ -64,6 +64,13 @@ class MlpBwdArgs(C.Structure):
                 ("P", _ll), ("F", _i), ("S", _i), ("image_offsets", _i * 8)])
 
 
+class GatherArgs(C.Structure):
+    """``enerf_gather_args_t``."""
+    _fields_ = ([(n, _f) for n in ("xyz", "dn", "uv", "tex", "vol", "cam", "tcen", "x", "vox", "g_x", "g_vox", "g_tex",
+                                   "g_vol", "g_xyz", "g_dn")]
+                + [("P", _ll)] + [(n, _i) for n in ("B", "S", "F", "Hr", "Wr", "D", "h", "w")])
+
+
 class RenderArgs(C.Structure):
     _fields_ = ([(n, _f) for n in ("rays12", "tex", "vol", "src_exts", "src_ixts", "tar_ext", "packed", "rgb",
                                    "depth", "weights")]
@@ -152,6 +159,8 @@ _SIGNATURES = {
     "enerf_nerf_mlp_bwd": (_i, [C.POINTER(MlpBwdArgs), _f]),
     "enerf_gemm_wgrad": (_i, [_f, _i, _i, _f, _i, _i, _ll, _f, _f]),
     "enerf_nerf_mlp_fwd": (_i, [_f, _f, _f, _ll, _i, _i, _f, _f]),
+    "enerf_gather_fwd": (_i, [C.POINTER(GatherArgs), _f]),
+    "enerf_gather_bwd": (_i, [C.POINTER(GatherArgs), _f]),
     "enerf_conv3d_layer_packed_floats": (_ll, [_i, _i, _i]),
     "enerf_conv3d_layer_pack": (_i, [_f, _i, _i, _i, _f, _f]),
     "enerf_conv3d_layer": (_i, [_f, _i, _i, _i, _f, _f, _f, _i, _i, _i, _i, C.POINTER(Options), _f]),
@@ -489,6 +498,35 @@ class EnerfLib:
             a.image_offsets[i] = int(o)
         self._check(self.dll.enerf_nerf_mlp_bwd(C.byref(a), self.stream_of(vox)), "nerf_mlp_bwd")
         return g_vox, g_x, saves
+
+    def _gather_args(self, xyz, dn, uv, tex_cl, vol_cl, cam, tcen):
+        B, P = xyz.shape[0], xyz.shape[1]
+        a = GatherArgs(_ptr(xyz), _ptr(dn), _ptr(uv), _ptr(tex_cl), _ptr(vol_cl), _ptr(cam), _ptr(tcen))
+        a.P, a.B, a.S, a.F = P, B, tex_cl.shape[1], tex_cl.shape[4]
+        a.Hr, a.Wr = tex_cl.shape[2], tex_cl.shape[3]
+        a.D, a.h, a.w = vol_cl.shape[1], vol_cl.shape[2], vol_cl.shape[3]
+        assert vol_cl.shape[4] == 8 and cam.shape[-1] == 16 and tcen.shape[-1] == 4
+        return a
+
+    def gather_fwd(self, xyz, dn, uv, tex_cl, vol_cl, cam, tcen):
+        """Training-path feature fetch (enerf_gather_fwd): xyz (B,P,3), dn (B,P), uv (B,P,2), tex_cl (B,S,Hr,Wr,F),
+        vol_cl (B,D,h,w,8), cam (B,S,16), tcen (B,4) -> x (B,P,S,F+4), vox (B,P,8)."""
+        a = self._gather_args(xyz, dn, uv, tex_cl, vol_cl, cam, tcen)
+        x = torch.empty((a.B, a.P, a.S, a.F + 4), dtype=torch.float32, device=xyz.device)
+        vox = torch.empty((a.B, a.P, 8), dtype=torch.float32, device=xyz.device)
+        a.x, a.vox = _ptr(x), _ptr(vox)
+        self._check(self.dll.enerf_gather_fwd(C.byref(a), self.stream_of(xyz)), "gather_fwd")
+        return x, vox
+
+    def gather_bwd(self, xyz, dn, uv, tex_cl, vol_cl, cam, tcen, g_x, g_vox):
+        """-> (g_tex_cl, g_vol_cl, g_xyz, g_dn)."""
+        a = self._gather_args(xyz, dn, uv, tex_cl, vol_cl, cam, tcen)
+        E = lambda ref: torch.empty_like(ref)
+        g_tex, g_vol, g_xyz, g_dn = E(tex_cl), E(vol_cl), E(xyz), E(dn)
+        a.g_x, a.g_vox, a.g_tex, a.g_vol, a.g_xyz, a.g_dn = (_ptr(g_x), _ptr(g_vox), _ptr(g_tex), _ptr(g_vol), _ptr(g_xyz),
+                                                            _ptr(g_dn))
+        self._check(self.dll.enerf_gather_bwd(C.byref(a), self.stream_of(xyz)), "gather_bwd")
+        return g_tex, g_vol, g_xyz, g_dn
 
     def conv_wgrad_cl(self, a_cl, b_cl, stride):
         """3x3x3 weight gradient from channels-last tensors a (n,Da,Ha,Wa,Ca), b (n,Db,Hb,Wb,Cb) -> (Ca,Cb,3,3,3)."""

@@ -295,10 +295,16 @@ def render_rays(net, rays, level, batch, im_feat, feat_vol, lib=None):
         b, s, c, h, w = im_feat.shape
         im_feat = _resize_ac(im_feat.reshape(b * s, c, h, w), up).view(b, s, c, int(h * up), int(w * up))
     tex = torch.cat([im_feat, rgbs], 2)
-    nd = torch.stack([uvd[..., 0] / (Wr - 1), uvd[..., 1] / (Hr - 1), uvd[..., 2]], -1)      # network.py:36-38
-    g = nd.reshape(B, 1, 1, N * Ns, 3) * 2.0 - 1.0
-    vox = F.grid_sample(feat_vol, g, align_corners=True)[:, :, 0, 0].permute(0, 2, 1)        # get_vox_feat utils.py:456-458
-    x = img_feat(cas, xyz, tex, batch, level)
+    if lib is not None and getattr(net, "hip_gather", True):
+        from .autograd import GatherFn, gather_cameras
+        cam, tcen = gather_cameras(batch, rs)
+        x, vox = GatherFn.apply(lib, xyz.reshape(B, N * Ns, 3), uvd[..., 2].reshape(B, N * Ns),
+                                uvd[..., :2].reshape(B, N * Ns, 2), tex, feat_vol, cam, tcen)
+    else:
+        nd = torch.stack([uvd[..., 0] / (Wr - 1), uvd[..., 1] / (Hr - 1), uvd[..., 2]], -1)      # network.py:36-38
+        g = nd.reshape(B, 1, 1, N * Ns, 3) * 2.0 - 1.0
+        vox = F.grid_sample(feat_vol, g, align_corners=True)[:, :, 0, 0].permute(0, 2, 1)        # get_vox_feat utils.py:456-458
+        x = img_feat(cas, xyz, tex, batch, level)
     if lib is not None and getattr(net, "hip_mlp_backward", True):
         from .autograd import nerf_mlp
         raw = nerf_mlp(lib, getattr(net, f"nerf_{level}"), nerf_forward, vox, x).reshape(B, N, Ns, 4)   # fused HIP backward

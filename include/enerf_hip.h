@@ -327,6 +327,24 @@ int enerf_nerf_mlp_bwd(const enerf_mlp_bwd_args_t* args, enerf_stream_t stream);
 /* forward of the same MLP on materialised inputs (training): raw (P,4) = [rgb, sigma]; nothing else is written. */
 int enerf_nerf_mlp_fwd(const float* vox, const float* x, const float* packed, long long P, int S, int F, float* raw,
                        enerf_stream_t stream);
+/* Render-side feature fetches of the TRAINING path, forward and backward (utils.py:689-722 get_img_feat + utils.py:456-458
+ * get_vox_feat; inference does them inside enerf_render_rays).  Per batch element b and point p (P points each):
+ *   xyz (B,P,3) world position, dn (B,P) normalised depth coordinate, uv (B,P,2) ray pixel coordinates at the level's
+ *   resolution; tex (B,S,Hr,Wr,F) channels-last [features | rgb]; vol (B,D,h,w,8) channels-last feature volume;
+ *   cam (B,S,16) = K'E[:3,:3] (9, row-major) | K't (3) | source camera centre (3) | 0, with K' = K scaled to the level;
+ *   tcen (B,4) target camera centre.
+ * fwd writes x (B,P,S,F+4) = [bilinear(border) texel | direction code] and vox (B,P,8) = trilinear(zeros) volume sample.
+ * bwd reads g_x, g_vox and writes g_tex, g_vol (zeroed here, scatter-added), g_xyz (B,P,3) and g_dn (B,P). */
+typedef struct {
+    const float *xyz, *dn, *uv, *tex, *vol, *cam, *tcen;
+    float *x, *vox;
+    const float *g_x, *g_vox;
+    float *g_tex, *g_vol, *g_xyz, *g_dn;
+    long long P;
+    int B, S, F, Hr, Wr, D, h, w;
+} enerf_gather_args_t;
+int enerf_gather_fwd(const enerf_gather_args_t* args, enerf_stream_t stream);
+int enerf_gather_bwd(const enerf_gather_args_t* args, enerf_stream_t stream);
 int enerf_gemm_wgrad(const float* a, int lda, int Ca, const float* b, int ldb, int Cb, long long P, float* grad_w,
                      enerf_stream_t stream);
 int enerf_build_feature_volume_bwd(const float* feat, const float* proj, const float* depth_values, const float* grad_vol, int B,

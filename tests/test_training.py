@@ -134,6 +134,42 @@ def _check_hip_backward_stages(lib, dev):
         assert float((raw.grad - gr_ref).abs().max()) <= 1e-4 * float(gr_ref.abs().max()), Ns
         assert float((z.grad - gz_ref).abs().max()) <= 1e-4 * float(gz_ref.abs().max()), Ns
 
+    # --- render-side fetches: get_img_feat + get_vox_feat (points in front of the cameras, some outside the images) ---
+    from enerf_amd.autograd import GatherFn, gather_cameras
+    for level, (Fc, Ns) in enumerate(((35, 4), (11, 2))):
+        rs = cas.render_scale[level]
+        Hr, Wr = int(32 * rs), int(64 * rs)
+        rays = batch[f"rays_{level}"][:, :200]
+        N = rays.shape[1]
+        o, d = rays[..., :3], rays[..., 3:6]
+        t = (batch["near_far"].min() + (batch["near_far"].max() - batch["near_far"].min()) * torch.rand(1, N, Ns, generator=g).to(dev))
+        side = (0.0 + 120.0 * torch.randn(1, N, Ns, 3, generator=g)).to(dev) * (torch.rand(1, N, Ns, 1, generator=g).to(dev) < 0.3)
+        xyz = (o[:, :, None] + d[:, :, None] * t[..., None] + side).reshape(1, N * Ns, 3).requires_grad_(True)
+        dn = (torch.rand(1, N * Ns, generator=g) * 1.3 - 0.15).to(dev).requires_grad_(True)
+        uv = (torch.rand(1, N * Ns, 2, generator=g) * torch.tensor([Wr - 1.0, Hr - 1.0])).to(dev)
+        tex = rnd(1, 3, Fc, Hr, Wr).requires_grad_(True)
+        vol = rnd(1, 8, 8, int(32 * cas.volume_scale[level]), int(64 * cas.volume_scale[level])).requires_grad_(True)
+        gx, gv = rnd(1, N * Ns, 3, Fc + 4), rnd(1, N * Ns, 8)
+
+        def torch_twin():
+            nd = torch.stack([uv[..., 0] / (Wr - 1), uv[..., 1] / (Hr - 1), dn], -1)
+            gg = nd.reshape(1, 1, 1, N * Ns, 3) * 2.0 - 1.0
+            vox = F.grid_sample(vol, gg, align_corners=True)[:, :, 0, 0].permute(0, 2, 1)
+            return T.img_feat(cas, xyz.reshape(1, N, Ns, 3), tex, batch, level), vox
+        x_ref, v_ref = torch_twin()
+        ((x_ref * gx).sum() + (v_ref * gv).sum()).backward()
+        ref = [t_.grad.clone() for t_ in (xyz, dn, tex, vol)]
+        for t_ in (xyz, dn, tex, vol):
+            t_.grad = None
+        cam, tcen = gather_cameras(batch, rs)
+        x, vox = GatherFn.apply(lib, xyz, dn, uv, tex, vol, cam, tcen)
+        ((x * gx).sum() + (vox * gv).sum()).backward()
+        assert float((x - x_ref).abs().max()) <= 2e-4 * float(x_ref.abs().max()), level
+        assert float((vox - v_ref).abs().max()) <= 1e-5 * float(v_ref.abs().max()), level
+        for name, t_, r in zip(("xyz", "dn", "tex", "vol"), (xyz, dn, tex, vol), ref):
+            err, scale = float((t_.grad - r).abs().max()), float(r.abs().max())
+            assert err <= (2e-3 if name == "xyz" else 2e-4) * scale, (level, name, err, scale)
+
 
 def _check_conv_wgrad(lib, dev):
     """enerf_conv_wgrad against torch's own weight gradients for every convolution shape of the path (FeatureNet 2-D
