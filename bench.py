@@ -157,7 +157,7 @@ def train_bench(args, rank, world, dev, dist):
             "config": {"workload": "BASELINE config 5: DTU dtu_pretrain training, one sample per GPU per step, MSE loss "
                                    "(losses/enerf.py:21-24; the VGG perceptual term needs downloaded weights), Adam, "
                                    "clip_grad_value_ 40", "parallelism": f"DDP x{world} + SyncBatchNorm over RCCL" if world > 1 else "single GPU",
-                       "backward": "HIP forward+backward: cost-reg nets (MFMA conv/dgrad/wgrad, BN-train), Agg+NeRF MLP (fused), warp+variance, depth regression, compositing, FeatureNet conv wgrad; PyTorch-ROCm autograd: FeatureNet conv forward/dgrad + BN2d, grid_sample gathers, geometry glue"}}))
+                       "backward": "HIP forward+backward: cost-reg nets (MFMA conv/dgrad/wgrad, BN-train), Agg+NeRF MLP (fused), warp+variance, depth regression, compositing, render-side fetches (bilinear texel + trilinear volume gathers, direction code), FeatureNet conv wgrad; PyTorch-ROCm autograd: FeatureNet conv forward/dgrad + BN2d, geometry glue"}}))
     if dist is not None:
         dist.destroy_process_group()
 

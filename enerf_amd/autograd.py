@@ -454,21 +454,18 @@ class NerfMlpFn(torch.autograd.Function):
         # color.2 (1,64) / color.0 (64, 88+F+4) / sigma (1,64) / lr0 (64,24) / fc (16,32) / agg_w (1,32) / global_fc (32,3F) / view_fc (F,4)
         gw["color.2.weight"] = lib.gemm_wgrad(d_c.reshape(PS, 1), q.reshape(PS, 64))
         gw["color.2.bias"] = d_c.sum().reshape(1)
-        gw["color.0.weight"] = torch.cat([lib.gemm_wgrad(d_p2, hv), lib.gemm_wgrad(d_q.reshape(PS, 64), x2)], 1)
-        gw["color.0.bias"] = d_p2.sum(0)
+        w_hv, gw["color.0.bias"] = lib.gemm_wgrad(d_p2, hv, bias=True)
+        gw["color.0.weight"] = torch.cat([w_hv, lib.gemm_wgrad(d_q.reshape(PS, 64), x2)], 1)
         gw["sigma.0.weight"] = lib.gemm_wgrad(d_s.reshape(P, 1), hv, Cb=64)
         gw["sigma.0.bias"] = d_s.sum().reshape(1)
-        gw["lr0.0.weight"] = lib.gemm_wgrad(d_h, hv[:, 64:])
-        gw["lr0.0.bias"] = d_h.sum(0)
-        gw["agg.fc.0.weight"] = lib.gemm_wgrad(d_agg, G)
-        gw["agg.fc.0.bias"] = d_agg.sum(0)
+        gw["lr0.0.weight"], gw["lr0.0.bias"] = lib.gemm_wgrad(d_h, hv[:, 64:], bias=True)
+        gw["agg.fc.0.weight"], gw["agg.fc.0.bias"] = lib.gemm_wgrad(d_agg, G, bias=True)
         gw["agg.agg_w_fc.0.weight"] = lib.gemm_wgrad(d_u.reshape(PS, 1), gs.reshape(PS, 32))
         gw["agg.agg_w_fc.0.bias"] = d_u.sum().reshape(1)
-        gw["agg.global_fc.0.weight"] = torch.cat([lib.gemm_wgrad(d_g.reshape(PS, 32), a_.reshape(PS, F)), lib.gemm_wgrad(d_gsum, vm)], 1)
-        gw["agg.global_fc.0.bias"] = d_gsum.sum(0)
+        w_vm, gw["agg.global_fc.0.bias"] = lib.gemm_wgrad(d_gsum, vm, bias=True)
+        gw["agg.global_fc.0.weight"] = torch.cat([lib.gemm_wgrad(d_g.reshape(PS, 32), a_.reshape(PS, F)), w_vm], 1)
         if m.viewdir_agg:
-            gw["agg.view_fc.0.weight"] = lib.gemm_wgrad(d_v.reshape(PS, F), x2[:, F:])
-            gw["agg.view_fc.0.bias"] = d_v.reshape(PS, F).sum(0)
+            gw["agg.view_fc.0.weight"], gw["agg.view_fc.0.bias"] = lib.gemm_wgrad(d_v.reshape(PS, F), x2[:, F:], bias=True)
         grads = [gw.get(n) for n, _ in m.named_parameters()]
         return (None, None, None, g_vox, g_x) + tuple(grads)
 

@@ -31,12 +31,13 @@ struct WgradGeom {
     int tiles_a, tiles_b;        // ceil(C/16)
     int chunks;                  // position chunks (blocks per tile pair)
     int lda, ldb;                // floats between consecutive positions of A / B (>= Ca / Cb: column slices of wider rows)
+    int bias;                    // 1: B has a virtual column Cb of ones -> dbias[a] = sum_p A[a][p] (the layer's bias gradient)
     long long npos;              // n * Da * Ha * Wa
 };
 
 template <int KD, int KH, int KW>
 __global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ A, const float* __restrict__ Bt, WgradGeom q,
-                                                    float* __restrict__ dW) {
+                                                    float* __restrict__ dW, float* __restrict__ dbias) {
     constexpr int NT = KD * KH * KW;
     __shared__ float red[NT][256];                      // one wave's partial tiles at a time (27 KB at 27 taps)
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ A,
             const bool ok = pv && cb_ok && (unsigned)id < (unsigned)q.Db && (unsigned)ih < (unsigned)q.Hb && (unsigned)iw < (unsigned)q.Wb;
             const long long bi = ((bbase + (ok ? id : 0)) * q.Hb + (ok ? ih : 0)) * q.Wb + (ok ? iw : 0);
             bv[t] = ok ? Bt[bi * q.ldb + cb] : 0.f;
+            if (NT == 1 && q.bias && cb == q.Cb) bv[t] = pv ? 1.f : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = ENERF_MFMA_W(av, bv[t], acc[t]);
@@ -99,32 +101,28 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ A,
             for (int r = 0; r < 4; ++r) {
                 const float v = acc[t][r];
                 const int a_ch = ta * 16 + 4 * g + r, b_ch = tb * 16 + j;      // D layout: rows 4g+r of column j
-                if (a_ch < q.Ca && b_ch < q.Cb && v != 0.f) {
-#ifdef ENERF_EMU
-                    atomicAdd(dW + ((long long)a_ch * q.Cb + b_ch) * NT + t, v);
-#else
-                    unsafeAtomicAdd(dW + ((long long)a_ch * q.Cb + b_ch) * NT + t, v);
-#endif
-                }
+                if (a_ch < q.Ca && b_ch < q.Cb && v != 0.f) atomic_add_f32(dW + ((long long)a_ch * q.Cb + b_ch) * NT + t, v);
+                if (NT == 1 && q.bias && a_ch < q.Ca && b_ch == q.Cb && v != 0.f) atomic_add_f32(dbias + a_ch, v);
             }
         }
     }
 }
 
 template <int KD, int KH, int KW>
-static void launch_wgrad_k(const float* A, const float* Bt, const WgradGeom& q, float* dW, hipStream_t st) {
+static void launch_wgrad_k(const float* A, const float* Bt, const WgradGeom& q, float* dW, float* dbias, hipStream_t st) {
     const unsigned grid = (unsigned)(q.tiles_a * q.tiles_b * q.chunks);
-    ENERF_LAUNCH((k_conv_wgrad<KD, KH, KW>), grid, 256, 0, st, A, Bt, q, dW);
+    ENERF_LAUNCH((k_conv_wgrad<KD, KH, KW>), grid, 256, 0, st, A, Bt, q, dW, dbias);
 }
 
 bool launch_conv_wgrad(const float* A, const float* Bt, int n, int Da, int Ha, int Wa, int Ca, int Db, int Hb, int Wb, int Cb,
                        int kd, int kh, int kw, int stride, int pad_d, int pad_h, int pad_w, float* dW, hipStream_t st, int lda = 0,
-                       int ldb = 0) {
+                       int ldb = 0, float* dbias = nullptr) {
     WgradGeom q;
+    q.bias = dbias != nullptr;
     q.lda = lda > 0 ? lda : Ca; q.ldb = ldb > 0 ? ldb : Cb;
     q.n = n; q.Da = Da; q.Ha = Ha; q.Wa = Wa; q.Ca = Ca; q.Db = Db; q.Hb = Hb; q.Wb = Wb; q.Cb = Cb;
     q.stride = stride; q.pad_d = pad_d; q.pad_h = pad_h; q.pad_w = pad_w;
-    q.tiles_a = cdiv(Ca, 16); q.tiles_b = cdiv(Cb, 16);
+    q.tiles_a = cdiv(Ca, 16); q.tiles_b = cdiv(Cb + q.bias, 16);
     q.npos = (long long)n * Da * Ha * Wa;
     // enough blocks to fill the chip a few times over, few enough that the final atomics stay cheap
     const long long groups = cdivl(q.npos, 4);
@@ -132,10 +130,10 @@ bool launch_conv_wgrad(const float* A, const float* Bt, int n, int Da, int Ha, i
     if (want < 1) want = 1;
     const long long maxc = cdivl(groups, 4 * 8);                     // >= 8 position groups per wave
     q.chunks = (int)(want < maxc ? want : (maxc < 1 ? 1 : maxc));
-    if (kd == 3 && kh == 3 && kw == 3) { launch_wgrad_k<3, 3, 3>(A, Bt, q, dW, st); return true; }
-    if (kd == 1 && kh == 3 && kw == 3) { launch_wgrad_k<1, 3, 3>(A, Bt, q, dW, st); return true; }
-    if (kd == 1 && kh == 5 && kw == 5) { launch_wgrad_k<1, 5, 5>(A, Bt, q, dW, st); return true; }
-    if (kd == 1 && kh == 1 && kw == 1) { launch_wgrad_k<1, 1, 1>(A, Bt, q, dW, st); return true; }
+    if (kd == 3 && kh == 3 && kw == 3) { launch_wgrad_k<3, 3, 3>(A, Bt, q, dW, dbias, st); return true; }
+    if (kd == 1 && kh == 3 && kw == 3) { launch_wgrad_k<1, 3, 3>(A, Bt, q, dW, dbias, st); return true; }
+    if (kd == 1 && kh == 5 && kw == 5) { launch_wgrad_k<1, 5, 5>(A, Bt, q, dW, dbias, st); return true; }
+    if (kd == 1 && kh == 1 && kw == 1) { launch_wgrad_k<1, 1, 1>(A, Bt, q, dW, dbias, st); return true; }
     return false;
 }
 
@@ -158,11 +156,13 @@ extern "C" int enerf_conv_wgrad(const float* a_cl, const float* b_cl, int n, int
 
 // Plain position-reduction GEMM: grad_w[a][b] = sum_p A[p][a] * B[p][b] — the weight gradient of a Linear layer from its
 // pre-activation gradient A (P rows, Ca used columns of rows lda floats wide) and its input B (P x Cb, rows ldb wide).
+// grad_bias (nullable): the layer's bias gradient sum_p A[p][a], from the same pass (a virtual all-ones column of B).
 extern "C" int enerf_gemm_wgrad(const float* a, int lda, int Ca, const float* b, int ldb, int Cb, long long P, float* grad_w,
-                                enerf_stream_t stream) {
+                                float* grad_bias, enerf_stream_t stream) {
     REQUIRE(a && b && grad_w && Ca > 0 && Cb > 0 && lda >= Ca && ldb >= Cb, "gemm_wgrad: bad arguments");
     REQUIRE(P > 0 && P < (1LL << 31), "gemm_wgrad: P out of range");
     hipMemsetAsync(grad_w, 0, (size_t)Ca * Cb * sizeof(float), (hipStream_t)stream);
-    launch_conv_wgrad(a, b, 1, 1, 1, (int)P, Ca, 1, 1, (int)P, Cb, 1, 1, 1, 1, 0, 0, 0, grad_w, (hipStream_t)stream, lda, ldb);
+    if (grad_bias) hipMemsetAsync(grad_bias, 0, (size_t)Ca * sizeof(float), (hipStream_t)stream);
+    launch_conv_wgrad(a, b, 1, 1, 1, (int)P, Ca, 1, 1, (int)P, Cb, 1, 1, 1, 1, 0, 0, 0, grad_w, (hipStream_t)stream, lda, ldb, grad_bias);
     return check_launch("gemm_wgrad");
 }

@@ -157,7 +157,7 @@ _SIGNATURES = {
     "enerf_depth_regression_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f]),
     "enerf_conv_wgrad": (_i, [_f, _f] + [_i] * 16 + [_f, _f]),
     "enerf_nerf_mlp_bwd": (_i, [C.POINTER(MlpBwdArgs), _f]),
-    "enerf_gemm_wgrad": (_i, [_f, _i, _i, _f, _i, _i, _ll, _f, _f]),
+    "enerf_gemm_wgrad": (_i, [_f, _i, _i, _f, _i, _i, _ll, _f, _f, _f]),
     "enerf_nerf_mlp_fwd": (_i, [_f, _f, _f, _ll, _i, _i, _f, _f]),
     "enerf_gather_fwd": (_i, [C.POINTER(GatherArgs), _f]),
     "enerf_gather_bwd": (_i, [C.POINTER(GatherArgs), _f]),
@@ -465,17 +465,19 @@ class EnerfLib:
                                                   self.stream_of(a)), "channel_affine")
         return out
 
-    def gemm_wgrad(self, a, b, Ca=None, Cb=None):
+    def gemm_wgrad(self, a, b, Ca=None, Cb=None, bias=False):
         """grad_w (Ca,Cb) = sum over rows p of a[p,:Ca]^T b[p,:Cb]; a, b 2-D row-major (possibly column slices: a view whose
-        rows are wider than Ca is passed by its base pointer + row stride)."""
+        rows are wider than Ca is passed by its base pointer + row stride).  bias=True -> (grad_w, grad_bias (Ca) = column
+        sums of a) from the same pass."""
         P = a.shape[0]
         Ca, Cb = Ca or a.shape[1], Cb or b.shape[1]
         if a.stride(1) != 1 or b.stride(1) != 1:
             raise EnerfError("gemm_wgrad: rows must be contiguous")
         gw = torch.empty((Ca, Cb), dtype=torch.float32, device=a.device)
+        gb = torch.empty((Ca,), dtype=torch.float32, device=a.device) if bias else None
         self._check(self.dll.enerf_gemm_wgrad(a.data_ptr(), a.stride(0), Ca, b.data_ptr(), b.stride(0), Cb, P, _ptr(gw),
-                                              self.stream_of(a)), "gemm_wgrad")
-        return gw
+                                              _ptr(gb), self.stream_of(a)), "gemm_wgrad")
+        return (gw, gb) if bias else gw
 
     def nerf_mlp_fwd(self, vox, x, packed, S, F):
         raw = torch.empty((vox.shape[0], 4), dtype=torch.float32, device=vox.device)

@@ -346,7 +346,7 @@ typedef struct {
 int enerf_gather_fwd(const enerf_gather_args_t* args, enerf_stream_t stream);
 int enerf_gather_bwd(const enerf_gather_args_t* args, enerf_stream_t stream);
 int enerf_gemm_wgrad(const float* a, int lda, int Ca, const float* b, int ldb, int Cb, long long P, float* grad_w,
-                     enerf_stream_t stream);
+                     float* grad_bias /* nullable: (Ca) = sum_p a[p][:] from the same pass */, enerf_stream_t stream);
 int enerf_build_feature_volume_bwd(const float* feat, const float* proj, const float* depth_values, const float* grad_vol, int B,
                                    int S, int C, int Hs, int Ws, int D, int h, int w, float* grad_feat, float* grad_depth_values,
                                    enerf_stream_t stream);

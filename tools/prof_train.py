@@ -22,7 +22,7 @@ torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
     step(); torch.cuda.synchronize()
-tab = prof.key_averages().table(sort_by="cuda_time_total", row_limit=28, max_name_column_width=60)
+tab = prof.key_averages().table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=60)
 print(tab)
 import time
 torch.cuda.synchronize(); t0 = time.perf_counter()
