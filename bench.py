@@ -115,21 +115,36 @@ def train_bench(args, rank, world, dev, dist):
         from torch.nn.parallel import DistributedDataParallel as DDP
         model = DDP(torch.nn.SyncBatchNorm.convert_sync_batchnorm(net), device_ids=[dev.index], output_device=dev.index,
                     find_unused_parameters=True)                         # trainer.py:15-22
-    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    graphed = world == 1 and not args.train_eager                        # one hipGraph replay per step (train_graph.py)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4, capturable=graphed)
     b = make_batch(512, 640, 3, cfg, seed=rank, textured=True)
     rng = np.random.default_rng(rank)
     for i in range(2):
         b[f"rgb_{i}"] = rng.uniform(0, 1, size=(1, b[f"rays_{i}"].shape[1], 3)).astype(np.float32)
     batch = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
 
+    from enerf_amd.train_graph import GraphedTrainStep, GraphMismatch, mse_loss as tree_mse
+    mse = tree_mse if graphed else F.mse_loss          # same value; the tree form keeps memset nodes out of the graph
+
+    def loss_fn(out, bt):
+        return sum(w * mse(bt[f"rgb_{i}"], out[f"rgb_level{i}"]) for i, w in enumerate((0.1, 1.0)))
+
     def step():
         out = model(batch)
-        loss = sum(w * F.mse_loss(batch[f"rgb_{i}"], out[f"rgb_level{i}"]) for i, w in enumerate((0.1, 1.0)))
+        loss = loss_fn(out, batch)
         opt.zero_grad()
         loss.backward()
         torch.nn.utils.clip_grad_value_(net.parameters(), 40)
         opt.step()
         return loss
+    launch_note = "eager"
+    if graphed:
+        try:
+            gstep = GraphedTrainStep(net, opt, loss_fn, batch, clip_value=40.0)   # verifies replays against eager steps
+            step = lambda: gstep(batch)                                  # copies the batch in, camera tables, one replay
+            launch_note = "one hipGraph replay per step (enerf_amd/train_graph.py; replays verified against eager steps)"
+        except GraphMismatch as e:
+            launch_note = f"eager (graph replay failed verification: {str(e)[:200]})"
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -157,6 +172,7 @@ def train_bench(args, rank, world, dev, dist):
             "config": {"workload": "BASELINE config 5: DTU dtu_pretrain training, one sample per GPU per step, MSE loss "
                                    "(losses/enerf.py:21-24; the VGG perceptual term needs downloaded weights), Adam, "
                                    "clip_grad_value_ 40", "parallelism": f"DDP x{world} + SyncBatchNorm over RCCL" if world > 1 else "single GPU",
+                       "step_launch": launch_note,
                        "backward": "HIP forward+backward: cost-reg nets (MFMA conv/dgrad/wgrad, BN-train), Agg+NeRF MLP (fused), warp+variance, depth regression, compositing, render-side fetches (bilinear texel + trilinear volume gathers, direction code), FeatureNet conv wgrad; PyTorch-ROCm autograd: FeatureNet conv forward/dgrad + BN2d, geometry glue"}}))
     if dist is not None:
         dist.destroy_process_group()
@@ -178,6 +194,7 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 5 instead of rendering: one step = forward + MSE loss + backward + Adam step of "
                          "dtu_pretrain (512x640, 3 views, full-image rays at both levels, bs 1 per GPU), DDP over RCCL for N > 1")
+    ap.add_argument("--train-eager", action="store_true", help="--train: enqueue every step eagerly instead of one graph replay")
     ap.add_argument("--feature-backend", choices=["hip", "torch"], default="hip",
                     help="FeatureNet on the HIP matrix-core path (default) or in PyTorch-ROCm/MIOpen (north_star's split)")
     args = ap.parse_args()

@@ -118,18 +118,19 @@ class GatherFn(torch.autograd.Function):
 
 
 class ConvFn(torch.autograd.Function):
-    """A bias-free Conv2d / Conv3d / ConvTranspose3d(k3,s2,p1,op1) whose WEIGHT gradient runs on the matrix cores
-    (enerf_conv_wgrad).  Forward and the input gradient stay on the library convolution (MIOpen) for now."""
+    """A Conv2d / Conv3d / ConvTranspose3d(k3,s2,p1,op1) whose WEIGHT and BIAS gradients come from the HIP kernels
+    (enerf_conv_wgrad on the matrix cores; enerf_channel_sums).  Forward and the input gradient stay on the library
+    convolution (MIOpen) for now."""
 
     @staticmethod
-    def forward(ctx, lib: EnerfLib, x, w, stride: int, padding: int, transposed: bool):
+    def forward(ctx, lib: EnerfLib, x, w, bias, stride: int, padding: int, transposed: bool):
         nd = x.dim() - 2
         if transposed:
-            y = torch.nn.functional.conv_transpose3d(x, w, None, stride=stride, padding=padding, output_padding=stride - 1)
+            y = torch.nn.functional.conv_transpose3d(x, w, bias, stride=stride, padding=padding, output_padding=stride - 1)
         elif nd == 3:
-            y = torch.nn.functional.conv3d(x, w, None, stride, padding)
+            y = torch.nn.functional.conv3d(x, w, bias, stride, padding)
         else:
-            y = torch.nn.functional.conv2d(x, w, None, stride, padding)
+            y = torch.nn.functional.conv2d(x, w, bias, stride, padding)
         ctx.lib, ctx.cfg = lib, (stride, padding, transposed, nd)
         ctx.save_for_backward(x, w)
         return y
@@ -139,7 +140,7 @@ class ConvFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         stride, padding, transposed, nd = ctx.cfg
         gy = gy.contiguous()
-        gx = gw = None
+        gx = gw = gb = None
         if ctx.needs_input_grad[1]:
             if transposed:                              # dgrad of a transposed conv = the plain strided conv
                 gx = torch.nn.functional.conv3d(gy, w, None, stride, padding)
@@ -147,19 +148,22 @@ class ConvFn(torch.autograd.Function):
                 gx = torch.nn.grad.conv3d_input(x.shape, w, gy, stride, padding)
             else:
                 gx = torch.nn.grad.conv2d_input(x.shape, w, gy, stride, padding)
-        if ctx.needs_input_grad[2]:
+        want_b = ctx.needs_input_grad[3]
+        if ctx.needs_input_grad[2] or want_b:
             k, pad = tuple(w.shape[2:]), (padding,) * nd
-            gw = ctx.lib.conv_wgrad(x, gy, k, stride, pad) if transposed else ctx.lib.conv_wgrad(gy, x, k, stride, pad)
-        return None, gx, gw, None, None, None
+            if transposed:
+                gw = ctx.lib.conv_wgrad(x, gy, k, stride, pad)
+                if want_b:
+                    gb = gy.sum(dim=[0] + list(range(2, gy.dim())))
+            else:
+                gw, gb = ctx.lib.conv_wgrad(gy, x, k, stride, pad, bias=True) if want_b else (ctx.lib.conv_wgrad(gy, x, k, stride, pad), None)
+        return None, gx, gw, gb, None, None, None
 
 
 def conv_module(lib, m, x):
-    """Apply an nn.Conv2d / nn.Conv3d / nn.ConvTranspose3d of the network through ConvFn (bias added outside)."""
+    """Apply an nn.Conv2d / nn.Conv3d / nn.ConvTranspose3d of the network through ConvFn."""
     transposed = isinstance(m, torch.nn.ConvTranspose3d)
-    y = ConvFn.apply(lib, x, m.weight, int(m.stride[0]), int(m.padding[0]), transposed)
-    if m.bias is not None:
-        y = y + m.bias.view(1, -1, *([1] * (x.dim() - 2)))
-    return y
+    return ConvFn.apply(lib, x, m.weight, m.bias, int(m.stride[0]), int(m.padding[0]), transposed)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -452,16 +456,13 @@ class NerfMlpFn(torch.autograd.Function):
         x2 = x.reshape(PS, XW)
         gw = {}
         # color.2 (1,64) / color.0 (64, 88+F+4) / sigma (1,64) / lr0 (64,24) / fc (16,32) / agg_w (1,32) / global_fc (32,3F) / view_fc (F,4)
-        gw["color.2.weight"] = lib.gemm_wgrad(d_c.reshape(PS, 1), q.reshape(PS, 64))
-        gw["color.2.bias"] = d_c.sum().reshape(1)
+        gw["color.2.weight"], gw["color.2.bias"] = lib.gemm_wgrad(d_c.reshape(PS, 1), q.reshape(PS, 64), bias=True)
         w_hv, gw["color.0.bias"] = lib.gemm_wgrad(d_p2, hv, bias=True)
         gw["color.0.weight"] = torch.cat([w_hv, lib.gemm_wgrad(d_q.reshape(PS, 64), x2)], 1)
-        gw["sigma.0.weight"] = lib.gemm_wgrad(d_s.reshape(P, 1), hv, Cb=64)
-        gw["sigma.0.bias"] = d_s.sum().reshape(1)
+        gw["sigma.0.weight"], gw["sigma.0.bias"] = lib.gemm_wgrad(d_s.reshape(P, 1), hv, Cb=64, bias=True)
         gw["lr0.0.weight"], gw["lr0.0.bias"] = lib.gemm_wgrad(d_h, hv[:, 64:], bias=True)
         gw["agg.fc.0.weight"], gw["agg.fc.0.bias"] = lib.gemm_wgrad(d_agg, G, bias=True)
-        gw["agg.agg_w_fc.0.weight"] = lib.gemm_wgrad(d_u.reshape(PS, 1), gs.reshape(PS, 32))
-        gw["agg.agg_w_fc.0.bias"] = d_u.sum().reshape(1)
+        gw["agg.agg_w_fc.0.weight"], gw["agg.agg_w_fc.0.bias"] = lib.gemm_wgrad(d_u.reshape(PS, 1), gs.reshape(PS, 32), bias=True)
         w_vm, gw["agg.global_fc.0.bias"] = lib.gemm_wgrad(d_gsum, vm, bias=True)
         gw["agg.global_fc.0.weight"] = torch.cat([lib.gemm_wgrad(d_g.reshape(PS, 32), a_.reshape(PS, F)), w_vm], 1)
         if m.viewdir_agg:

@@ -262,7 +262,7 @@ int enerf_build_feature_volume_bwd(const float* feat, const float* proj, const f
     REQUIRE(feat && proj && depth_values && grad_vol && grad_feat && grad_depth_values, "build_feature_volume_bwd: null pointer");
     REQUIRE(C == 8 || C == 16 || C == 32, "build_feature_volume_bwd: C=%d unsupported (8/16/32)", C);
     REQUIRE(B > 0 && S > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0, "build_feature_volume_bwd: bad shape");
-    hipMemsetAsync(grad_feat, 0, (size_t)B * S * Hs * Ws * C * sizeof(float), (hipStream_t)stream);
+    zero_async(grad_feat, (size_t)B * S * Hs * Ws * C * sizeof(float), (hipStream_t)stream);
     launch_feature_volume_bwd(feat, proj, depth_values, grad_vol, B, S, C, Hs, Ws, D, h, w, grad_feat, grad_depth_values,
                               (hipStream_t)stream);
     return check_launch("build_feature_volume_bwd");

@@ -8,6 +8,16 @@
 using namespace enerf;
 
 namespace enerf {
+__global__ __launch_bounds__(256) void k_zero(unsigned* __restrict__ p, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0u;
+}
+void zero_async(void* p, size_t bytes, hipStream_t st) {
+    const long long n = (long long)(bytes / 4);
+    if (n <= 0) return;
+    long long blocks = cdivl(n, 256 * 4);
+    if (blocks > 4096) blocks = 4096;
+    ENERF_LAUNCH_SIMPLE(k_zero, (unsigned)blocks, 256, 0, st, (unsigned*)p, n);
+}
 int device_cu_count() {
 #ifdef ENERF_EMU
     return 256;
@@ -420,7 +430,7 @@ int enerf_eval_stats(const float* pred_rgb, const float* gt_rgb, const void* mas
     if (mask) REQUIRE(mask_elem_bytes == 1 || mask_elem_bytes == 4, "eval_stats: mask must be uint8/bool or int32");
     if (img_w > 0) REQUIRE(img_h > 0 && crop_h >= 0 && crop_w >= 0 && n_rgb % ((long long)img_w * img_h) == 0,
                            "eval_stats: crop needs the image extent (n_rgb a multiple of img_w*img_h)");
-    hipMemsetAsync(acc, 0, 6 * sizeof(double), (hipStream_t)stream);
+    zero_async(acc, 6 * sizeof(double), (hipStream_t)stream);
     if (n_rgb + n_depth == 0) return ENERF_OK;
     launch_eval_stats(pred_rgb, gt_rgb, mask, mask_elem_bytes, n_rgb, img_w, img_h, crop_h, crop_w, pred_depth, gt_depth,
                       n_depth, acc, (hipStream_t)stream);

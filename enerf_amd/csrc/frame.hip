@@ -334,7 +334,7 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
         ra.options = a->options;
         if (L.masked) {
             ra.ray_index = ray_index; ra.ray_count = ray_count; ra.scatter_rgb = 1;
-            hipMemsetAsync(a->rgb[i], 0, (size_t)L.n_rays * 3 * sizeof(float), st);      // torch.zeros_like(...), network_human.py:103
+            zero_async(a->rgb[i], (size_t)L.n_rays * 3 * sizeof(float), st);      // torch.zeros_like(...), network_human.py:103
         }
         rc = enerf_render_rays(&ra, stream);
         if (rc != ENERF_OK) return rc;

@@ -235,10 +235,10 @@ int enerf_gather_bwd(const enerf_gather_args_t* u, enerf_stream_t stream) {
     if (rc != ENERF_OK) return rc;
     REQUIRE(u->g_x && u->g_vox && u->g_tex && u->g_vol && u->g_xyz && u->g_dn, "gather_bwd: null gradient buffer");
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(a.g_tex, 0, (size_t)a.B * a.S * a.Hr * a.Wr * a.F * sizeof(float), st);
-    hipMemsetAsync(a.g_vol, 0, (size_t)a.B * a.D * a.h * a.w * 8 * sizeof(float), st);
+    zero_async(a.g_tex, (size_t)a.B * a.S * a.Hr * a.Wr * a.F * sizeof(float), st);
+    zero_async(a.g_vol, (size_t)a.B * a.D * a.h * a.w * 8 * sizeof(float), st);
     if (u->P == 0) return ENERF_OK;
-    hipMemsetAsync(a.g_xyz, 0, (size_t)a.B * a.P * 3 * sizeof(float), st);
+    zero_async(a.g_xyz, (size_t)a.B * a.P * 3 * sizeof(float), st);
     const long long total = (long long)a.B * a.P * a.S;
     ENERF_LAUNCH(k_gather_bwd, (unsigned)cdivl(total, 16), 256, 0, st, a);
     return check_launch("gather_bwd");

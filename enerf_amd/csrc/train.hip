@@ -111,7 +111,7 @@ int enerf_channel_sums(const float* a, const float* b, const float* z_mask, cons
                        long long n, int C, double* sums, enerf_stream_t stream) {
     REQUIRE(a && b && sums && n > 0 && C >= 4 && C <= 64 && C % 4 == 0 && (256 % (C / 4)) == 0, "channel_sums: bad arguments (C in 4..64, power-of-two quads)");
     if (z_mask) REQUIRE(mask_scale && mask_shift, "channel_sums: mask needs its scale/shift");
-    hipMemsetAsync(sums, 0, (size_t)2 * C * sizeof(double), (hipStream_t)stream);
+    zero_async(sums, (size_t)2 * C * sizeof(double), (hipStream_t)stream);
     const int ppb = 256 / (C / 4);
     long long blocks = cdivl(n, (long long)ppb * 16);
     if (blocks > 2048) blocks = 2048;

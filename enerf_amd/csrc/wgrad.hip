@@ -147,7 +147,7 @@ extern "C" int enerf_conv_wgrad(const float* a_cl, const float* b_cl, int n, int
     REQUIRE(n > 0 && Da > 0 && Ha > 0 && Wa > 0 && Ca > 0 && Db > 0 && Hb > 0 && Wb > 0 && Cb > 0 && stride >= 1,
             "conv_wgrad: bad shape");
     REQUIRE((long long)n * Da * Ha * Wa < (1LL << 31) && (long long)n * Db * Hb * Wb < (1LL << 31), "conv_wgrad: more than 2^31 positions");
-    hipMemsetAsync(grad_w, 0, (size_t)Ca * Cb * kd * kh * kw * sizeof(float), (hipStream_t)stream);
+    zero_async(grad_w, (size_t)Ca * Cb * kd * kh * kw * sizeof(float), (hipStream_t)stream);
     if (!launch_conv_wgrad(a_cl, b_cl, n, Da, Ha, Wa, Ca, Db, Hb, Wb, Cb, kd, kh, kw, stride, pad_d, pad_h, pad_w, grad_w,
                            (hipStream_t)stream))
         return fail(ENERF_EINVAL, "conv_wgrad: kernel %dx%dx%d unsupported (3x3x3, 1x3x3, 1x5x5, 1x1x1)", kd, kh, kw);
@@ -161,8 +161,8 @@ extern "C" int enerf_gemm_wgrad(const float* a, int lda, int Ca, const float* b,
                                 float* grad_bias, enerf_stream_t stream) {
     REQUIRE(a && b && grad_w && Ca > 0 && Cb > 0 && lda >= Ca && ldb >= Cb, "gemm_wgrad: bad arguments");
     REQUIRE(P > 0 && P < (1LL << 31), "gemm_wgrad: P out of range");
-    hipMemsetAsync(grad_w, 0, (size_t)Ca * Cb * sizeof(float), (hipStream_t)stream);
-    if (grad_bias) hipMemsetAsync(grad_bias, 0, (size_t)Ca * sizeof(float), (hipStream_t)stream);
+    zero_async(grad_w, (size_t)Ca * Cb * sizeof(float), (hipStream_t)stream);
+    if (grad_bias) zero_async(grad_bias, (size_t)Ca * sizeof(float), (hipStream_t)stream);
     launch_conv_wgrad(a, b, 1, 1, 1, (int)P, Ca, 1, 1, (int)P, Cb, 1, 1, 1, 1, 0, 0, 0, grad_w, (hipStream_t)stream, lda, ldb, grad_bias);
     return check_launch("gemm_wgrad");
 }

@@ -539,10 +539,10 @@ class EnerfLib:
                                               1, 1, 1, _ptr(gw), self.stream_of(a_cl)), "conv_wgrad")
         return gw
 
-    def conv_wgrad(self, a, b, kernel, stride, padding):
+    def conv_wgrad(self, a, b, kernel, stride, padding, bias=False):
         """Weight gradient on the matrix cores (enerf_conv_wgrad).  ``a`` (n,Ca,*grid_a), ``b`` (n,Cb,*grid_b) in torch's
         channels-first layout (converted to channels-last here by the library's own adapter kernel); 2-D or 3-D.
-        Returns (Ca, Cb, *kernel)."""
+        Returns (Ca, Cb, *kernel); with ``bias`` also the per-channel sums of ``a`` (the bias gradient when a = d y)."""
         nd = a.dim() - 2
         ga, gb = list(a.shape[2:]), list(b.shape[2:])
         if nd == 2:
@@ -555,7 +555,12 @@ class EnerfLib:
         self._check(self.dll.enerf_conv_wgrad(_ptr(a_cl), _ptr(b_cl), n, ga[0], ga[1], ga[2], Ca, gb[0], gb[1], gb[2], Cb,
                                               kernel[0], kernel[1], kernel[2], int(stride), padding[0], padding[1], padding[2],
                                               _ptr(gw), self.stream_of(a)), "conv_wgrad")
-        return gw if nd == 3 else gw.reshape(Ca, Cb, kernel[1], kernel[2])
+        gw = gw if nd == 3 else gw.reshape(Ca, Cb, kernel[1], kernel[2])
+        if not bias:
+            return gw
+        # the layer's bias gradient = per-channel sums of ``a`` (= d y), from the channels-last copy made above
+        gb = self.channel_sums(a_cl, a_cl)[0].float() if Ca % 4 == 0 else a.sum(dim=[0] + list(range(2, a.dim())))
+        return gw, gb
 
     def composite(self, raw, z, white_bkgd=False):
         n, Ns = z.shape

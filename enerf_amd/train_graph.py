@@ -1,0 +1,143 @@
+"""One training step as ONE hipGraph replay (trainer.py:56-63).
+
+A dtu_pretrain step is ~700 kernel launches (FeatureNet, two cost-volume networks, two fused render levels, their backward
+kernels, clip, Adam) whose GPU time (~35 ms) is no longer than the time Python + the dispatcher need to enqueue them
+(~34 ms): eager steps are host-bound.  Shapes are static over an epoch (fixed image size, fixed ray count), so the step is
+captured once — forward, loss, backward, gradient clip and optimizer update — and replayed with new batch contents copied
+into the captured input buffers.
+
+What stays outside the graph: the camera-only tables (train_path.camera_tables: 4x4 inverses — torch.inverse synchronises,
+which a capture does not allow); they are recomputed eagerly before every replay into the buffers the graph reads.
+
+Single-process only: under DDP the bucketed all-reduce hooks belong to the eager step (bench.py keeps it for N > 1).
+
+MEMSET NODES.  On this stack (ROCm 7.2 / PyTorch 2.10, MI355X) a hipMemsetAsync captured into a large graph does not replay
+reliably: tools/micro/graph_reduce_check.py captures nothing but torch reductions (whose multi-block kernels reset their
+semaphores with a memset) and gets wrong sums in about half of the replays.  Consequences here:
+  * the library zeroes its accumulators with a fill kernel (csrc/capi.hip zero_async), never with hipMemsetAsync;
+  * every large reduction of the step runs on the library's own kernels (bias gradients: enerf_channel_sums / the
+    enerf_gemm_wgrad pass; BatchNorm: enerf_channel_sums);
+  * a loss function should reduce with ``tree_sum`` / ``mse_loss`` below (single-block reductions: no semaphores);
+  * ``GraphedTrainStep(verify=True)`` (the default) replays a few steps against eager steps from the same state and
+    compares every gradient before the graph is trusted; a mismatch raises ``GraphMismatch`` (bench.py then runs eager).
+"""
+from typing import Callable, Dict
+
+import torch
+
+from .train_path import camera_tables
+
+
+class GraphMismatch(RuntimeError):
+    pass
+
+
+def tree_sum(x: torch.Tensor) -> torch.Tensor:
+    """Sum of all elements as a tree of 256-wide row sums: every stage is a one-block-per-output reduction, i.e. none of
+    torch's multi-block reduction kernels (semaphore memset) ends up in a captured graph.  Differentiable."""
+    x = x.reshape(-1)
+    while x.numel() > 256:
+        pad = (-x.numel()) % 256
+        if pad:
+            x = torch.cat([x, x.new_zeros(pad)])
+        x = x.view(-1, 256).sum(1)
+    return x.sum()
+
+
+def mse_loss(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """F.mse_loss(a, b) (mean reduction) on ``tree_sum``."""
+    d = a - b
+    return tree_sum(d * d) / d.numel()
+
+
+class GraphedTrainStep:
+    """``step = GraphedTrainStep(net, optimizer, loss_fn, example_batch); loss = step(batch)``.
+
+    ``loss_fn(outputs, batch) -> scalar``.  ``optimizer`` must be capture-safe (``torch.optim.Adam(..., capturable=True)``).
+    Every batch passed later must have the tensors (keys, shapes, dtypes) of ``example_batch``.  The returned loss tensor is
+    the graph's own output buffer: read it (``.item()``) before the next call."""
+
+    def __init__(self, net, optimizer, loss_fn: Callable, example_batch: Dict[str, torch.Tensor], clip_value: float = 40.0,
+                 warmup: int = 3, verify: bool = True, verify_steps: int = 4):
+        if not net.training:
+            raise ValueError("GraphedTrainStep captures a training step: call net.train() first")
+        if warmup < 1:
+            raise ValueError("at least one eager warm-up step: optimizer state must exist before the capture")
+        self.net, self.opt, self.loss_fn, self.clip = net, optimizer, loss_fn, clip_value
+        self.static = {k: v.clone() for k, v in example_batch.items() if torch.is_tensor(v)}
+        self.extra = {k: v for k, v in example_batch.items() if not torch.is_tensor(v)}
+        self.tables = {k: v.clone() for k, v in camera_tables(net.cfg.cas, self.static).items()}
+        self._params = [p for p in net.parameters() if p.requires_grad]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up on a side stream: lazy initialisation, caches, allocator
+            for _ in range(warmup):
+                self._eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.opt.zero_grad(set_to_none=True)               # gradients are (re)allocated inside the graph's memory pool
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._eager_step(zero=False)
+        net.invalidate_packed()
+        if verify:
+            self._verify(verify_steps)
+
+    # ---- replay-vs-eager check (see MEMSET NODES above) ----
+    def _snapshot(self):
+        opt_state = [(t, t.clone()) for st in self.opt.state.values() for t in st.values() if torch.is_tensor(t)]
+        return [(t, t.clone()) for t in self.net.state_dict().values()] + opt_state
+
+    @staticmethod
+    def _restore(snap):
+        for t, saved in snap:
+            t.copy_(saved)                                  # in place: the graph holds these addresses
+
+    def _verify(self, steps: int):
+        """From the same state: one replay vs one eager step, ``steps`` times; every parameter gradient must agree to
+        2e-3 of its largest element (fp32 atomics reorder; a broken replay is off by orders of magnitude)."""
+        for k in range(steps):
+            snap = self._snapshot()
+            self.graph.replay()
+            g_graph = {n: p.grad.clone() for n, p in self.net.named_parameters() if p.grad is not None}
+            loss_graph = float(self.loss)
+            self._restore(snap)
+            grads_kept = {n: p.grad for n, p in self.net.named_parameters()}      # the graph's own gradient buffers
+            loss_eager = float(self._eager_step())           # zero_grad(set_to_none) detaches the graph's buffers: put them back
+            bad = []
+            for n, p in self.net.named_parameters():
+                ge, gg = p.grad, g_graph.get(n)
+                if (ge is None) != (gg is None):
+                    bad.append((n, "missing"))
+                elif ge is not None:
+                    err, scale = float((ge - gg).abs().max()), float(ge.abs().max())
+                    if not (err <= 2e-3 * scale + 1e-9):
+                        bad.append((n, err, scale))
+                p.grad = grads_kept[n]
+            if bad or not abs(loss_graph - loss_eager) <= 1e-3 * abs(loss_eager) + 1e-7:
+                raise GraphMismatch(f"replay {k}: loss {loss_graph} vs eager {loss_eager}; gradient mismatches "
+                                    f"(name, max err, max |g|): {bad[:6]}")
+        self.net.invalidate_packed()
+
+    def _eager_step(self, zero: bool = True):
+        batch = dict(self.static, camera_tables=self.tables, **self.extra)
+        out = self.net(batch)
+        loss = self.loss_fn(out, batch)
+        if zero:
+            self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.clip is not None:
+            torch.nn.utils.clip_grad_value_(self._params, self.clip)
+        self.opt.step()
+        return loss
+
+    def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        for k, dst in self.static.items():
+            src = batch[k]
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        for k, v in camera_tables(self.net.cfg.cas, self.static).items():
+            self.tables[k].copy_(v)
+        self.graph.replay()
+        self.net.invalidate_packed()                       # the inference weight images are stale after every update
+        return self.loss

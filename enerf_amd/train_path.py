@@ -152,7 +152,7 @@ def depth_values(cas, batch, level, D, depth, std, near_far):
             dv = 1.0 / (1.0 / nn_[:, None] + tt * (1.0 / ff_[:, None] - 1.0 / nn_[:, None]))
         else:
             dv = nn_[:, None] + tt * (ff_[:, None] - nn_[:, None])
-    out_nf = dv[:, [0, -1]].detach()
+    out_nf = torch.stack([dv[:, 0], dv[:, -1]], 1).detach()             # (index lists become host->device copies: not capturable)
     if cas.depth_inv[level]:
         out_nf = 1.0 / torch.clamp_min(out_nf, 1e-6)
     return dv.contiguous(), out_nf
@@ -278,7 +278,21 @@ def raw2outputs(raw, z, white_bkgd=False):
     return {"rgb": rgb, "depth": depth, "weights": w}
 
 
-def render_rays(net, rays, level, batch, im_feat, feat_vol, lib=None):
+def camera_tables(cas, batch) -> Dict[str, torch.Tensor]:
+    """Everything the step derives from the cameras alone (the matrix inverses live here): the warp matrices of each
+    level and the per-view constants of the render-side fetches.  forward_train computes it unless the batch already
+    carries it under "camera_tables" — a captured training step (enerf_amd/train_graph.py) runs it eagerly before each
+    replay, because torch.inverse synchronises and cannot be captured."""
+    from .autograd import gather_cameras
+    t: Dict[str, torch.Tensor] = {}
+    for i in range(cas.num):
+        t[f"proj_{i}"] = proj_mats(batch, cas.im_feat_scale[i], cas.volume_scale[i])
+        if cas.render_if[i]:
+            t[f"cam_{i}"], t["tcen"] = gather_cameras(batch, cas.render_scale[i])
+    return t
+
+
+def render_rays(net, rays, level, batch, im_feat, feat_vol, lib=None, tables=None):
     """Network.render_rays (network.py:24-43), differentiable: rays (B,N,12), im_feat (B,S,C,Hf,Wf), feat_vol (B,8,D,h,w)."""
     cas = net.cfg.cas
     Ns = cas.num_samples[level]
@@ -297,7 +311,7 @@ def render_rays(net, rays, level, batch, im_feat, feat_vol, lib=None):
     tex = torch.cat([im_feat, rgbs], 2)
     if lib is not None and getattr(net, "hip_gather", True):
         from .autograd import GatherFn, gather_cameras
-        cam, tcen = gather_cameras(batch, rs)
+        cam, tcen = (tables[f"cam_{level}"], tables["tcen"]) if tables is not None else gather_cameras(batch, rs)
         x, vox = GatherFn.apply(lib, xyz.reshape(B, N * Ns, 3), uvd[..., 2].reshape(B, N * Ns),
                                 uvd[..., :2].reshape(B, N * Ns, 2), tex, feat_vol, cam, tcen)
     else:
@@ -341,9 +355,10 @@ def forward_train(net, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor
     ret: Dict[str, torch.Tensor] = {}
     depth: Optional[torch.Tensor] = None
     std = near_far = None
+    tables = batch["camera_tables"] if "camera_tables" in batch else camera_tables(cas, batch)
     for i in range(cas.num):
         dv, near_far = depth_values(cas, batch, i, cas.volume_planes[i], depth, std, near_far)
-        P = proj_mats(batch, cas.im_feat_scale[i], cas.volume_scale[i])
+        P = tables[f"proj_{i}"]
         vol = FeatureVolumeFn.apply(lib, feats[f"level_{i}"], P, dv) if lib is not None else feature_volume(feats[f"level_{i}"], P, dv)
         if lib is not None and getattr(net, "hip_cost_reg_train", True):
             from .autograd import cost_reg_train
@@ -356,7 +371,7 @@ def forward_train(net, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor
             continue
         rays = build_rays(cas, depth, std, batch[f"rays_{i}"], near_far, i)
         # network_human.py:90 only compacts rays in eval mode (`not self.training`): training renders every ray
-        out = render_rays(net, rays, i, batch, feats[f"level_{cas.render_im_feat_level[i]}"], feat3d, lib)
+        out = render_rays(net, rays, i, batch, feats[f"level_{cas.render_im_feat_level[i]}"], feat3d, lib, tables)
         out["depth_mvs"] = 1.0 / depth if cas.depth_inv[i] else depth
         out["std"] = std
         ret.update({f"{k}_level{i}": v for k, v in out.items()})

@@ -436,6 +436,51 @@ def test_training_step_on_gpu_matches_reference_gradients():
     assert float((img.cpu() - ref).abs().max()) < 1e-4
 
 
+@pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_graphed_training_step_equals_eager_steps():
+    """enerf_amd/train_graph.py: three optimizer steps as hipGraph replays (a different batch each step) leave the same
+    parameters, BatchNorm statistics and losses as three eager steps (differences: fp32 atomics order only)."""
+    from enerf_amd.train_graph import GraphedTrainStep
+    dev = torch.device("cuda:0")
+    batches = []
+    for seed in (7, 8, 9):
+        cfg, b = _train_batch(seed=seed)
+        batches.append({k: v.to(dev) for k, v in b.items()})
+    nets = [_net(cfg).to(dev) for _ in range(2)]
+    opts = [torch.optim.SGD(n.parameters(), lr=1e-3, momentum=0.9) for n in nets]   # (Adam's sign-like first steps amplify atomics-order noise)
+    from enerf_amd.train_graph import mse_loss
+    tree_loss = lambda out, b: sum(LOSS_W[i] * mse_loss(b[f"rgb_{i}"], out[f"rgb_level{i}"]) for i in range(2))
+    gstep = GraphedTrainStep(nets[0], opts[0], tree_loss, batches[0], clip_value=40.0, warmup=1)   # verify=True: replays vs eager
+    # warm-up and capture ran real steps on batches[0]; restore the start state so both nets take the same three steps
+    ref_state = {k: v.clone() for k, v in nets[1].state_dict().items()}
+    nets[0].load_state_dict(ref_state)
+    for st in opts[0].state.values():
+        for v in st.values():
+            if torch.is_tensor(v):
+                v.zero_()
+    losses = [[], []]
+    for b in batches:
+        losses[0].append(float(gstep(b)))
+        out = nets[1](b)
+        loss = _loss(out, b)
+        opts[1].zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_value_(nets[1].parameters(), 40.0)
+        opts[1].step()
+        losses[1].append(float(loss))
+    assert losses[0] == pytest.approx(losses[1], rel=1e-4), losses
+    assert len(set(round(x, 6) for x in losses[0])) == 3              # three different batches really went through
+    sd0, sd1 = nets[0].state_dict(), nets[1].state_dict()
+    for k in sd1:
+        if sd1[k].dtype.is_floating_point:
+            assert float((sd0[k] - sd1[k]).abs().max()) <= 1e-5 + 1e-4 * float(sd1[k].abs().max()), k
+    nets[0].eval()
+    with torch.no_grad():
+        img = nets[0](batches[0])["rgb_level1"]                         # eval after graphed training: re-packed weights
+    assert torch.isfinite(img).all()
+
+
 def _check_mlp_backward(lib, dev):
     """enerf_nerf_mlp_bwd + enerf_gemm_wgrad (NerfMlpFn) against torch autograd through the module's own layers, for both
     MLP widths (F = 11: level 1, F = 35: level 0) and S = 2, 3, 4 views; ragged point counts."""
