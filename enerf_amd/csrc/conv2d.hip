@@ -87,6 +87,12 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
     constexpr int NT = TH * (TW / 16), CTW = NT / 4;      // column tiles per block / per wave
     constexpr int QV = CB / 4 > 0 ? CB / 4 : 1;
     constexpr int NPX = IH * IW;
+    // Stride-2 layers read every other tile pixel per lane: with the tile stored pixel-major, lane j sits 2 pixels
+    // (64 / 128 B) after lane j-1 and a wave touches half of the LDS banks (PMC: bank-conflict cycles 0.85 of the LDS-active
+    // cycles in conv1.0).  So their rows are stored de-interleaved — even pixels, then odd pixels — and a tap (kw) reads
+    // consecutive slots of one parity.
+    constexpr int IWH = (IW + 1) / 2;
+    auto slot = [](int ly, int lx) { return STR == 2 ? (ly * 2 + (lx & 1)) * IWH + (lx >> 1) : ly * IW + lx; };
     ENERF_DYN_SMEM(float, lds);
 
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
@@ -156,6 +162,7 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
             constexpr int NIT = (NPX * QV + 255) / 256;
             float4 sv[NIT];
             bool sk[NIT];
+            int so[NIT];
             const float* base = in + (long long)n * Hi * Wi * CINP + cb * CB;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -163,6 +170,7 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
                 const int px = ic / QV, q = ic - px * QV;
                 const int ly = px / IW, lx = px - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
                 sk[it] = gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+                so[it] = (slot(ly, lx) * QV + q) * 4;
                 const int off = sk[it] ? gy * Wi + gx : 0;
                 sv[it] = *reinterpret_cast<const float4*>(base + (long long)off * CINP + q * 4);
             }
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
             for (int it = 0; it < NIT; ++it) {
                 const int i = threadIdx.x + it * 256;
                 if (i < NPX * QV)
-                    *reinterpret_cast<float4*>(lds + i * 4) = sk[it] ? sv[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(lds + so[it]) = sk[it] ? sv[it] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         __syncthreads();
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
 #pragma unroll
                 for (int c = 0; c < CTW; ++c) {
                     const int tile = wv * CTW + c, tr = tile / (TW / 16), tc = tile - tr * (TW / 16);
-                    const float* p = lds + ((tr * STR + kh) * IW + (tc * 16 + j) * STR + kw) * CB + g * CPL;
+                    const float* p = lds + slot(tr * STR + kh, (tc * 16 + j) * STR + kw) * CB + g * CPL;
                     if (CPL == 4) {
                         const float4 tq = *reinterpret_cast<const float4*>(p);
                         bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
@@ -307,7 +315,7 @@ static void launch_c2(const Conv2dDesc& L, const float* in, float* out, const fl
     const int Ho = (Hi + 2 * P - K) / STR + 1, Wo = (Wi + 2 * P - K) / STR + 1;
     const int tiles_y = cdiv(Ho, TH), tiles_x = cdiv(Wo, 32);
     constexpr int IH = (TH - 1) * STR + K, IW = 31 * STR + K;
-    const size_t shmem = (size_t)IH * IW * CB * sizeof(float);
+    const size_t shmem = (size_t)IH * (STR == 2 ? 2 * ((IW + 1) / 2) : IW) * CB * sizeof(float);   // stride 2: de-interleaved rows
     const unsigned grid = (unsigned)((long long)N * tiles_y * tiles_x);
     ENERF_LAUNCH((k_conv2d<CINP, RT, K, STR, TH, NCHW3, CHAIN>), grid, 256, shmem, st, L.w, L.scale, L.shift, in, out, up,
                  rgb_src, out_stride, L.cout, L.relu, N, Hi, Wi, Ho, Wo, Hc, Wc, tiles_y, tiles_x, L.chain_w, L.chain_shift);

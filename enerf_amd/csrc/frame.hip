@@ -3,6 +3,9 @@
 // plan (buffer carving) + ~25 kernel enqueues here, in one C call, on one stream, with no host synchronisation.
 #include <string.h>
 
+#include <map>
+#include <mutex>
+
 #include "kernels.h"
 
 using namespace enerf;
@@ -210,6 +213,38 @@ int make_plan(const enerf_frame_args_t* a, FramePlan* P) {
 }  // namespace
 }  // namespace enerf
 
+// =====================================================================================================================
+// Side lane of a frame.  Level 0 (warp + CostRegNet + depth regression) consumes only the FeatureNet's coarsest map, and
+// its deep small layers leave most of the chip idle (mfma busy 0.05-0.13 on 80-640 tiles); the FeatureNet's top-down half
+// — up2+lat1, smooth1 (level 1's source maps) and the fused up2+lat0+smooth0 (the render texels, the second largest
+// kernel of the frame) — is needed later.  So enerf_forward forks that half onto a library-owned stream right after the
+// trunk and joins it with events before its first consumer: the two chains overlap inside ONE frame.
+// One lane (stream + 3 events) per caller stream, created on first use, never destroyed (process lifetime).
+// =====================================================================================================================
+#ifndef ENERF_EMU
+namespace {
+struct SideLane { hipStream_t stream; hipEvent_t trunk, l1, l2; };
+SideLane* side_lane(hipStream_t main) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, SideLane*> lanes;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_pair(dev, main);
+    auto it = lanes.find(key);
+    if (it != lanes.end()) return it->second;
+    SideLane* L = new SideLane();
+    bool ok = hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) == hipSuccess;   // (a lowest-priority lane measured the same latency)
+    ok = ok && hipEventCreateWithFlags(&L->trunk, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&L->l1, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&L->l2, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { delete L; L = nullptr; (void)hipGetLastError(); }
+    lanes[key] = L;                                  // a failed creation is remembered: the frame then runs on one stream
+    return L;
+}
+}  // namespace
+#endif
+
 extern "C" {
 
 size_t enerf_mask_compact_workspace_bytes(long long n) { return mask_compact_workspace_bytes(n); }
@@ -261,10 +296,43 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
     // ---- FeatureNet (feature_net.py:27-36) -> channels-last maps; level_2 straight to render texels when it can ----
     float* f[3] = {ws + P.f[0], ws + P.f[1], ws + P.f[2]};
     const int fh[3] = {a->H / 4, a->H / 2, a->H}, fw[3] = {a->W / 4, a->W / 2, a->W}, fc[3] = {32, 16, 8};
+    bool forked = false;                 // the FeatureNet's top-down half runs on the side lane
+    int joined[3] = {1, 1, 1};           // feature level l is visible to the caller's stream
+#ifndef ENERF_EMU
+    SideLane* lane = nullptr;
+#endif
+    auto need_level = [&](int l) {       // call before the first consumer of f[l] on the caller's stream
+#ifndef ENERF_EMU
+        if (forked && !joined[l]) { hipStreamWaitEvent(st, l == 1 ? lane->l1 : lane->l2, 0); joined[l] = 1; }
+#else
+        (void)l;
+#endif
+    };
     if (P.hip_feats) {
-        rc = enerf_feature_net(a->feature_net_packed, a->src_inps, n_img, a->H, a->W, f[0], f[1], f[2], P.tex2 ? 12 : 8,
-                               ws + P.featnet_ws, P.featnet_ws_bytes, a->options, stream);
-        if (rc != ENERF_OK) return rc;
+        const int l2s = P.tex2 ? 12 : 8;
+        auto fstage = [&](int stage, enerf_stream_t s) {
+            return enerf_feature_net_stage(a->feature_net_packed, a->src_inps, n_img, a->H, a->W, f[0], f[1], f[2], l2s,
+                                           ws + P.featnet_ws, P.featnet_ws_bytes, stage, a->options, s);
+        };
+#ifndef ENERF_EMU
+        if (!(a->options && a->options->single_stream)) lane = side_lane(st);
+        if (lane != nullptr) {
+            rc = fstage(ENERF_FEAT_TRUNK, stream);
+            if (rc != ENERF_OK) return rc;
+            hipEventRecord(lane->trunk, st);
+            hipStreamWaitEvent(lane->stream, lane->trunk, 0);
+            rc = fstage(ENERF_FEAT_LEVEL1, (enerf_stream_t)lane->stream);
+            hipEventRecord(lane->l1, lane->stream);
+            if (rc == ENERF_OK) rc = fstage(ENERF_FEAT_LEVEL2, (enerf_stream_t)lane->stream);
+            hipEventRecord(lane->l2, lane->stream);
+            forked = true; joined[1] = joined[2] = 0;
+            if (rc != ENERF_OK) { need_level(1); need_level(2); return rc; }      // never leave the lane un-joined
+        } else
+#endif
+        {
+            rc = fstage(ENERF_FEAT_ALL, stream);
+            if (rc != ENERF_OK) return rc;
+        }
     } else {
         for (int l = 0; l < c.num; ++l)   // the levels that feed a cost volume (texels are packed from NCHW below)
             launch_channels_last(a->feats_nchw[l], f[l], n_img, fc[l], (long long)fh[l] * fw[l], fc[l], st);
@@ -282,14 +350,15 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
         rc = enerf_level_prep(a->src_ixts, a->src_exts, a->tar_ixt, a->tar_ext, a->B, a->S, (float)c.im_feat_scale[i],
                               (float)c.volume_scale[i], proj, a->near_far, pdepth, pstd, pnf, L.D, L.h, L.w, hp, wp,
                               c.depth_inv[i], dv, nf, stream);
-        if (rc != ENERF_OK) return rc;
+        if (rc != ENERF_OK) { need_level(1); need_level(2); return rc; }
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_PREP));
+        need_level(i);                                                 // level i's source maps (side lane for i >= 1)
         rc = enerf_build_feature_volume(f[i], proj, dv, a->B, a->S, L.C, L.Hs, L.Ws, L.D, L.h, L.w, vol, stream);
-        if (rc != ENERF_OK) return rc;
+        if (rc != ENERF_OK) { need_level(1); need_level(2); return rc; }
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_VOLUME));
         rc = enerf_cost_reg(a->cost_reg_packed[i], L.C, i != 0, vol, a->B, L.D, L.h, L.w, feat3d, prob, ws + P.costreg_ws,
                             P.costreg_ws_bytes, a->options, stream);
-        if (rc != ENERF_OK) return rc;
+        if (rc != ENERF_OK) { need_level(1); need_level(2); return rc; }
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_COST_REG));
         launch_depth_regression(prob, dv, a->B, L.D, L.h, L.w, c.depth_inv[i], depth, std, dmvs, st);
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_DEPTH_REG));
@@ -300,6 +369,7 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
         const int fl = c.render_im_feat_level[i];
         const int TEX = 4 * ((L.F + 3) / 4);
         const float* tex;
+        need_level(fl);                                                // the texel source (joined here, inside the texel stage)
         if (fl == 2 && P.tex2) tex = f[2];
         else {
             float* t = ws + L.tex;
@@ -308,7 +378,7 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
             else
                 rc = enerf_pack_img_feat_rgb(a->feats_nchw[fl], fc[fl], fh[fl], fw[fl], a->src_inps, a->H, a->W, L.Hr, L.Wr,
                                              TEX, n_img, t, stream);
-            if (rc != ENERF_OK) return rc;
+            if (rc != ENERF_OK) { need_level(1); need_level(2); return rc; }
             tex = t;
         }
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_TEXELS));
@@ -318,7 +388,7 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
         if (rays8 == nullptr) {
             float* r = ws + L.rays;
             rc = enerf_gen_rays(a->tar_ext, a->tar_ixt, a->B, L.Hr, L.Wr, (float)c.render_scale[i], r, stream);
-            if (rc != ENERF_OK) return rc;
+            if (rc != ENERF_OK) { need_level(1); need_level(2); return rc; }
             rays8 = r;
         }
         // ---- build_rays + render_rays (utils.py:390-420, network.py:24-43), one launch ----
@@ -337,9 +407,10 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
             zero_async(a->rgb[i], (size_t)L.n_rays * 3 * sizeof(float), st);      // torch.zeros_like(...), network_human.py:103
         }
         rc = enerf_render_rays(&ra, stream);
-        if (rc != ENERF_OK) return rc;
+        if (rc != ENERF_OK) { need_level(1); need_level(2); return rc; }
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_RENDER));
     }
+    need_level(1); need_level(2);        // the caller's stream never returns ahead of the side lane
     return check_launch("forward");
 }
 

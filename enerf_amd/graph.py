@@ -30,7 +30,9 @@ class GraphedFrame:
                     net(self.static_in)
             torch.cuda.current_stream().wait_stream(s)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # capture on the warm-up stream: the library's per-stream side lane (frame.hip) then exists before the capture
+            # starts, and the lane's fork/join (event waits) is captured as a two-branch graph
+            with torch.cuda.graph(self.graph, stream=s):
                 self.static_out = net(self.static_in)
         # the graph holds raw addresses of the packed weight images and the FeatureNet scratch, which live OUTSIDE the
         # graph's private pool: keep them alive here and refuse to replay once the network has replaced them

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ENERF_ABI_VERSION 3
+#define ENERF_ABI_VERSION 4
 #define ENERF_OK 0
 #define ENERF_EINVAL (-1)   /* bad argument / unsupported shape */
 #define ENERF_ELAUNCH (-2)  /* HIP launch error */
@@ -44,6 +44,11 @@ typedef struct {
                                         1 = never, 2 = every Cout=8(+1) layer (fewest MFMAs: throughput mode) */
     int featnet_unfused;             /* 1: one launch per FeatureNet layer (no conv0/toplayer/lat0 fusions) */
     int featnet_smooth0_plain;       /* 1: plain 8x32 tiling in the fused smooth0 kernel instead of tap packing */
+    int single_stream;               /* enerf_forward: 1 = every kernel of the frame on the caller's stream, in order.
+                                        0 (default) = the FeatureNet's top-down half (lat1/smooth1, lat0/smooth0), which only
+                                        level 1 and the final render consume, is forked onto a library-owned side stream and
+                                        overlaps level 0's warp + cost regularisation; joined with events before its first
+                                        consumer — still ONE frame, no frames in flight (ABI >= 4) */
 } enerf_options_t;
 
 /* ---- layout adapters at the PyTorch boundary (FeatureNet output is NCHW, network.py:58-67) ---- */

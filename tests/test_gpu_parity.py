@@ -149,6 +149,16 @@ def test_full_size_dtu_eval_vs_oracle_and_properties():
     # north_star tolerance: PSNR against a common pseudo ground truth moves by < 1e-3 dB
     gt = torch.clamp(ref["rgb_level1"] + 0.05 * torch.randn_like(ref["rgb_level1"]), 0, 1)
     assert abs(O.psnr(rgb, gt) - O.psnr(ref["rgb_level1"], gt)) < 1e-3
+    # every optional kernel choice (enerf_options_t) at the full size too: the throughput set the frame pipeline uses, and
+    # the plain fallbacks — same oracle, same tolerance
+    from enerf_amd.lib import Options, throughput_options
+    variants = {"throughput": throughput_options(), "global_only": Options(conv3d_global_only=1),
+                "pk8_off": Options(conv3d_pk8=1), "unfused_fpn": Options(featnet_unfused=1),
+                "plain_smooth0": Options(featnet_smooth0_plain=1)}
+    for name, opt in variants.items():
+        o = net._forward(_to(batch), opt)
+        for k in ref:
+            assert _rel(o[k].cpu(), ref[k]) < REL_TOL, (name, k, _rel(o[k].cpu(), ref[k]))
 
 
 def test_whole_frame_hip_graph_replay_matches_eager():
