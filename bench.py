@@ -191,6 +191,8 @@ def main():
     ap.add_argument("--in-flight", type=int, default=6, help="frames in flight for the pipelined_fps extra")
     ap.add_argument("--sustained-frames", type=int, default=2000)
     ap.add_argument("--graph", action="store_true", help="time whole-frame HIP graph replays (enerf_amd/graph.py)")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="enerf_options_t.single_stream=1: no side lane inside the frame (per-kernel PMC passes want kernels alone)")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 5 instead of rendering: one step = forward + MSE loss + backward + Adam step of "
                          "dtu_pretrain (512x640, 3 views, full-image rays at both levels, bs 1 per GPU), DDP over RCCL for N > 1")
@@ -223,6 +225,9 @@ def main():
     _, S, _, H, W = batch_np["src_inps"].shape
     batch = {k: torch.from_numpy(v).to(dev) for k, v in batch_np.items()}
     last = cas.num - 1
+    if args.single_stream:
+        from enerf_amd.lib import Options
+        net.options = Options(single_stream=1)
 
     if args.graph:
         from enerf_amd.graph import GraphedFrame
@@ -260,6 +265,7 @@ def main():
             "vs_baseline": (fps / BASELINE_FPS_RTX3090) if args.workload == "dtu" else None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "feature_net": args.feature_backend, "hip_graph": bool(args.graph),
+                       "single_stream": bool(args.single_stream),
                        "protocol": "per-frame synchronize (run.py:62-76), one frame at a time, default kernel options "
                                    "(inside the frame the FeatureNet's top-down half runs on the library's side stream)"
                                    if not args.no_sync_per_frame else "frames enqueued back to back on one stream",

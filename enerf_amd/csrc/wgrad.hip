@@ -137,6 +137,101 @@ bool launch_conv_wgrad(const float* A, const float* Bt, int n, int Da, int Ha, i
     return false;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Linear-layer weight gradients: grad_w[a][b] = sum_p A[p][a] * B[p][b] with P up to ~2M rows and 1..89 columns per side.
+// k_conv_wgrad<1,1,1> gives every (16x16) tile pair its own blocks, so the rows of A are re-read tiles_b times and those
+// of B tiles_a times (3 KB per row for the 64 x 88 layer).  Here one wave keeps ALL TA x TB tile accumulators and walks its
+// share of the rows once: TA + TB loads and TA*TB MFMAs per 4 rows, every row read exactly once (612 B for 64 x 89).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void k_gemm_wgrad(const float* __restrict__ A, const float* __restrict__ Bt, int lda, int ldb,
+                                                    int Ca, int Cb, int bias, long long P, float* __restrict__ dW,
+                                                    float* __restrict__ dbias) {
+    constexpr int NT = TA * TB;
+    __shared__ float red[NT][256];
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long long ngroups = cdivl(P, 4);
+    for (long long grp = (long long)blockIdx.x * 4 + wave; grp < ngroups; grp += (long long)gridDim.x * 4) {
+        const long long p = grp * 4 + g;
+        const bool pv = p < P;
+        const long long pc = pv ? p : P - 1;
+        float av[TA], bv[TB];
+#pragma unroll
+        for (int ta = 0; ta < TA; ++ta) {
+            const int ca = ta * 16 + j;
+            av[ta] = (pv && ca < Ca) ? A[pc * lda + ca] : 0.f;
+        }
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) {
+            const int cb = tb * 16 + j;
+            bv[tb] = (pv && cb < Cb) ? Bt[pc * ldb + cb] : 0.f;
+            if (bias && cb == Cb) bv[tb] = pv ? 1.f : 0.f;           // virtual all-ones column -> bias gradient
+        }
+#pragma unroll
+        for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) acc[ta * TB + tb] = ENERF_MFMA_W(av[ta], bv[tb], acc[ta * TB + tb]);
+    }
+    for (int src = 1; src < 4; ++src) {                               // waves 1..3 hand their tiles to wave 0
+        if (wave == src) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[t][r * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][r] += red[t][r * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
+#pragma unroll
+    for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[ta * TB + tb][r];
+                const int a_ch = ta * 16 + 4 * g + r, b_ch = tb * 16 + j;
+                if (a_ch >= Ca || v == 0.f) continue;
+                if (b_ch < Cb) atomic_add_f32(dW + (long long)a_ch * Cb + b_ch, v);
+                else if (bias && b_ch == Cb) atomic_add_f32(dbias + a_ch, v);
+            }
+}
+
+template <int TA>
+static bool launch_gemm_wgrad_ta(int tb, unsigned grid, hipStream_t st, const float* A, const float* Bt, int lda, int ldb, int Ca,
+                                 int Cb, int bias, long long P, float* dW, float* dbias) {
+#define ENERF_GW(TBV) case TBV: ENERF_LAUNCH((k_gemm_wgrad<TA, TBV>), grid, 256, 0, st, A, Bt, lda, ldb, Ca, Cb, bias, P, dW, dbias); return true;
+    switch (tb) { ENERF_GW(1) ENERF_GW(2) ENERF_GW(3) ENERF_GW(4) ENERF_GW(5) ENERF_GW(6) default: return false; }
+#undef ENERF_GW
+}
+// all tile pairs in one wave when they fit (<= 4 x 6 tiles); false -> the caller falls back to k_conv_wgrad<1,1,1>
+bool launch_gemm_wgrad(const float* A, int lda, int Ca, const float* Bt, int ldb, int Cb, long long P, float* dW, float* dbias,
+                       hipStream_t st) {
+    const int ta = cdiv(Ca, 16), tb = cdiv(Cb + (dbias != nullptr), 16);
+    if (ta > 4 || tb > 6) return false;
+    const long long groups = cdivl(P, 4);
+    long long blocks = cdivl(groups, 4 * 16);                         // >= 16 row groups per wave
+    const long long cap = (long long)device_cu_count() * 2;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    const int bias = dbias != nullptr;
+    switch (ta) {
+        case 1: return launch_gemm_wgrad_ta<1>(tb, (unsigned)blocks, st, A, Bt, lda, ldb, Ca, Cb, bias, P, dW, dbias);
+        case 2: return launch_gemm_wgrad_ta<2>(tb, (unsigned)blocks, st, A, Bt, lda, ldb, Ca, Cb, bias, P, dW, dbias);
+        case 3: return launch_gemm_wgrad_ta<3>(tb, (unsigned)blocks, st, A, Bt, lda, ldb, Ca, Cb, bias, P, dW, dbias);
+        default: return launch_gemm_wgrad_ta<4>(tb, (unsigned)blocks, st, A, Bt, lda, ldb, Ca, Cb, bias, P, dW, dbias);
+    }
+}
+
 }  // namespace enerf
 
 using namespace enerf;
@@ -163,6 +258,7 @@ extern "C" int enerf_gemm_wgrad(const float* a, int lda, int Ca, const float* b,
     REQUIRE(P > 0 && P < (1LL << 31), "gemm_wgrad: P out of range");
     zero_async(grad_w, (size_t)Ca * Cb * sizeof(float), (hipStream_t)stream);
     if (grad_bias) zero_async(grad_bias, (size_t)Ca * sizeof(float), (hipStream_t)stream);
-    launch_conv_wgrad(a, b, 1, 1, 1, (int)P, Ca, 1, 1, (int)P, Cb, 1, 1, 1, 1, 0, 0, 0, grad_w, (hipStream_t)stream, lda, ldb, grad_bias);
+    if (!launch_gemm_wgrad(a, lda, Ca, b, ldb, Cb, P, grad_w, grad_bias, (hipStream_t)stream))
+        launch_conv_wgrad(a, b, 1, 1, 1, (int)P, Ca, 1, 1, (int)P, Cb, 1, 1, 1, 1, 0, 0, 0, grad_w, (hipStream_t)stream, lda, ldb, grad_bias);
     return check_launch("gemm_wgrad");
 }

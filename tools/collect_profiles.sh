@@ -13,7 +13,7 @@ BENCH="python $R/bench.py --workload $WL --steps 20 --warmup 5 --no-cpu-baseline
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats_$TAG -o p -- $BENCH > $O/stats.log 2>&1
 cp $(find /tmp/p_stats_$TAG -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats.csv
 [ "$PMC" = "1" ] || exit 0
-PB="python $R/bench.py --workload $WL --steps 3 --warmup 2 --no-cpu-baseline --no-stages --no-sync-per-frame"
+PB="python $R/bench.py --workload $WL --steps 3 --warmup 2 --no-cpu-baseline --no-stages --no-sync-per-frame --single-stream"   # kernels alone: no side lane
 i=0
 for ctr in "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
