@@ -159,6 +159,11 @@ def test_full_size_dtu_eval_vs_oracle_and_properties():
         o = net._forward(_to(batch), opt)
         for k in ref:
             assert _rel(o[k].cpu(), ref[k]) < REL_TOL, (name, k, _rel(o[k].cpu(), ref[k]))
+    # the side lane only changes WHEN the FeatureNet's top-down half runs, not what is computed: bit-identical frames
+    o = net._forward(_to(batch), Options(single_stream=1))
+    torch.cuda.synchronize()
+    for k in out:
+        assert torch.equal(o[k], out[k]), k
 
 
 def test_whole_frame_hip_graph_replay_matches_eager():
