@@ -75,7 +75,8 @@ int costreg_layers(int cin0, int full, LayerSpec* L) {
 }
 bool layer_pk8(const LayerSpec& s) { return s.kind == kConvS1 && (s.cout == 8 || s.idx < 0); }   // conv0, fused heads
 long long layer_floats(const LayerSpec& s) {
-    return conv3d_packed_floats(s.cin, s.cout, s.kind) + 2 * cdiv(s.cout, 16) * 16 + (layer_pk8(s) ? conv3d_pk8_packed_floats(s.cin) : 0);
+    return conv3d_packed_floats(s.cin, s.cout, s.kind) + 2 * cdiv(s.cout, 16) * 16 +
+           (layer_pk8(s) ? conv3d_pk8_packed_floats(s.cin) + conv3d_b4_packed_floats(s.cin) : 0);
 }
 }  // namespace
 
@@ -164,12 +165,17 @@ int enerf_cost_reg_pack(const enerf_costreg_raw_t* raw, float* packed, enerf_str
             REQUIRE(c.w && c.bn_weight && c.bn_bias && c.bn_mean && c.bn_var, "cost_reg_pack: conv%d missing", s.idx);
             launch_conv3d_pack(c.w, nullptr, s.cout, c.bn_weight, c.bn_bias, c.bn_mean, c.bn_var, 1e-5f, s.cin, s.cout,
                                s.kind, p, p + wf, p + wf + cp, (hipStream_t)stream);
-            if (layer_pk8(s)) launch_conv3d_pk8_pack(c.w, nullptr, s.cin, p + wf + 2 * cp, (hipStream_t)stream);
+            if (layer_pk8(s)) {
+                launch_conv3d_pk8_pack(c.w, nullptr, s.cin, p + wf + 2 * cp, (hipStream_t)stream);
+                launch_conv3d_b4_pack(c.w, nullptr, s.cin, p + wf + 2 * cp + conv3d_pk8_packed_floats(s.cin), (hipStream_t)stream);
+            }
         } else {
             REQUIRE(raw->feat_conv_w && raw->depth_conv_w, "cost_reg_pack: heads missing");
             launch_conv3d_pack(raw->feat_conv_w, raw->depth_conv_w, 8, nullptr, nullptr, nullptr, nullptr, 1e-5f, s.cin,
                                s.cout, s.kind, p, p + wf, p + wf + cp, (hipStream_t)stream);
             launch_conv3d_pk8_pack(raw->feat_conv_w, raw->depth_conv_w, s.cin, p + wf + 2 * cp, (hipStream_t)stream);
+            launch_conv3d_b4_pack(raw->feat_conv_w, raw->depth_conv_w, s.cin, p + wf + 2 * cp + conv3d_pk8_packed_floats(s.cin),
+                                  (hipStream_t)stream);
         }
         p += layer_floats(s);
     }
@@ -202,7 +208,8 @@ int enerf_cost_reg(const float* packed, int in_channels, int full, const float* 
         long long wf = conv3d_packed_floats(L[i].cin, L[i].cout, L[i].kind);
         int cp = cdiv(L[i].cout, 16) * 16;
         desc[i] = {p, p + wf, p + wf + cp, L[i].cin, L[i].cout, L[i].kind, L[i].relu,
-                   layer_pk8(L[i]) ? p + wf + 2 * cp : nullptr};                          // scale/shift = 1/0 without BN
+                   layer_pk8(L[i]) ? p + wf + 2 * cp : nullptr,                           // scale/shift = 1/0 without BN
+                   layer_pk8(L[i]) ? p + wf + 2 * cp + conv3d_pk8_packed_floats(L[i].cin) : nullptr};
         p += layer_floats(L[i]);
     }
     long long n0 = (long long)B * D * h * w, n1 = n0 / 8, n2 = n1 / 8, n3 = n2 / 8;

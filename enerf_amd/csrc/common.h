@@ -58,6 +58,13 @@ __device__ __forceinline__ float relu1(float x) {
 
 constexpr int kWave = 64;
 
+// Pin a value in a VGPR at this program point: LLVM's Sink pass otherwise moves a pure arithmetic chain that is only consumed
+// under a late condition (an epilogue store) down into that branch, keeping every operand of the chain alive until then.
+#ifdef ENERF_EMU
+#define ENERF_PIN_VGPR(x) ((void)0)
+#else
+#define ENERF_PIN_VGPR(x) asm volatile("" : "+v"(x))
+#endif
 __host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // v + (v of the lane 16 away) + (32 away) + (48 away): the sum / max over the four lane groups (lanes j, j+16, j+32, j+48)

@@ -631,6 +631,9 @@ bool launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, 
     if (L.kind == kConvS2 && residual == nullptr && out2 == nullptr && lds_ok && vox_in >= 32 * min_vox &&
         launch_conv3d_s2_lds(L, in, out, B, Di, Hi, Wi, st))
         return true;
+    // batched-4x4 path for the Cout=8(+1) stride-1 layers (conv0 of both levels, fused heads): no wasted MFMA rows
+    if (o.conv3d_b4 != 1 && residual == nullptr && lds_ok && vox_in >= min_vox && launch_conv3d_b4(L, in, out, out2, B, Di, Hi, Wi, st))
+        return true;
     // tap-packed path for the Cout=8 stride-1 layers (conv0 of both levels, fused heads): 2/3 of the MFMAs
     if (o.conv3d_pk8 != 1 && residual == nullptr && lds_ok && vox_in >= min_vox &&
         launch_conv3d_pk8(L, in, out, out2, B, Di, Hi, Wi, o.conv3d_pk8 == 2, st))

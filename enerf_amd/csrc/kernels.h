@@ -52,7 +52,12 @@ struct Conv3dDesc {
     const float* shift;     // per-cout epilogue shift (0 without BN)
     int cin, cout, kind, relu;
     const float* w_pk8;     // tap-packed image for stride-1 cout=8(+1) layers (conv3d_pk8.hip) or nullptr
+    const float* w_b4;      // batched-4x4 image for the same layers (conv3d_b4.hip) or nullptr
 };
+// batched 4x4x1 variant for cout = 8 (+ optional depth row on the VALU): see conv3d_b4.hip
+long long conv3d_b4_packed_floats(int cin);
+void launch_conv3d_b4_pack(const float* w, const float* wd, int cin, float* packed, hipStream_t st);
+bool launch_conv3d_b4(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W, hipStream_t st);
 // tap-packed variant for cout = 8 (+ optional depth row): see conv3d_pk8.hip
 long long conv3d_pk8_packed_floats(int cin);
 void launch_conv3d_pk8_pack(const float* w, const float* wd, int cin, float* packed, hipStream_t st);

@@ -44,6 +44,8 @@ typedef struct {
                                         1 = never, 2 = every Cout=8(+1) layer (fewest MFMAs: throughput mode) */
     int featnet_unfused;             /* 1: one launch per FeatureNet layer (no conv0/toplayer/lat0 fusions) */
     int featnet_smooth0_plain;       /* 1: plain 8x32 tiling in the fused smooth0 kernel instead of tap packing */
+    int conv3d_b4;                   /* batched 4x4x1-MFMA kernel for the Cout=8(+1) stride-1 3-D layers (conv0, fused heads):
+                                        0 = on (default), 1 = never (falls back to the tap-packed / plain kernels) */
     int single_stream;               /* enerf_forward: 1 = every kernel of the frame on the caller's stream, in order.
                                         0 (default) = the FeatureNet's top-down half (lat1/smooth1, lat0/smooth0), which only
                                         level 1 and the final render consume, is forked onto a library-owned side stream and

@@ -263,6 +263,17 @@ inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x
     return d;
 }
 
+// v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 blocks, k = 1.  Lane l = 4b + i supplies A_b[i] and B_b[i]; lane 4b + j
+// receives D_b[0..3][j] in its four accumulator registers.
+inline emu_f32x4 __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, emu_f32x4 c, int, int, int) {
+    unsigned lane = emu::ctx()->cur->tid % emu::kWave;
+    auto buf = emu::wave_exchange(a, b);
+    unsigned blk = lane & ~3u;
+    emu_f32x4 d = c;
+    for (int i = 0; i < 4; ++i) d[i] = fmaf(buf[0][blk + i], b, c[i]);
+    return d;
+}
+
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only ever applied to wave-uniform values
 inline void __builtin_amdgcn_s_sleep(int) {}

@@ -138,16 +138,18 @@ def test_empty_ray_list():
     assert out["rgb"].shape == (1, 0, 3) and out["weights"].shape == (1, 0, 2)
 
 
-@pytest.mark.parametrize("force", ["v1", "v2", "pk8"])
+@pytest.mark.parametrize("force", ["v1", "v2", "pk8", "b4"])
 def test_conv3d_variants_agree_with_reference(force):
-    """Both conv3d code paths (global-load V1 incl. the row-split small-layer form, LDS-staged V2, tap-packed) on a
-    case whose volumes are not multiples of the 8x16 LDS box (h,w = 16,24 / 8,12 / 4,6); variants are chosen through
-    the explicit enerf_options_t, not the environment."""
+    """Every conv3d code path (global-load V1 incl. the row-split small-layer form, LDS-staged V2, tap-packed, batched
+    4x4x1 MFMA) on a case whose volumes are not multiples of the 8x16 LDS box (h,w = 16,24 / 8,12 / 4,6); variants are
+    chosen through the explicit enerf_options_t, not the environment."""
     from enerf_amd.lib import Options
     if force == "v1":
         opt = Options(conv3d_global_only=1)
-    else:
-        opt = Options(conv3d_lds_min_voxels=1, conv3d_pk8=2 if force == "pk8" else 1)   # tap-packed kernel: all layers / off
+    elif force == "b4":
+        opt = Options(conv3d_lds_min_voxels=1)                                          # batched-4x4 kernel on conv0 + heads
+    else:                                                                               # tap-packed kernel: all layers / off
+        opt = Options(conv3d_lds_min_voxels=1, conv3d_b4=1, conv3d_pk8=2 if force == "pk8" else 1)
     name = "small_s3_eval"
     cfg, batch, gold = case_config(name), case_batch(name), load_golden(name)
     net = _net(cfg)
