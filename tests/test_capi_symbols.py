@@ -34,7 +34,7 @@ def test_hip_library_builds_and_exports_all_symbols():
 
 def test_gfx950_code_object_contains_mfma(tmp_path):
     """The product kernels really are CDNA4 matrix-core code (not a generic fallback): unbundle the gfx950 code
-    objects into a temp dir, disassemble, and count the fp32 MFMA instruction the kernels are written around."""
+    objects into a temp dir, disassemble, and count the two fp32 MFMA instructions the kernels are written around."""
     import shutil
     from enerf_amd.lib import LIB_PATH
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
@@ -45,15 +45,18 @@ def test_gfx950_code_object_contains_mfma(tmp_path):
     assert "gfx950" in out
     cos = sorted(p for p in os.listdir(tmp_path) if "gfx950" in p)
     assert cos, "no gfx950 code object in the library"
-    n_mfma, other = 0, set()
+    n_mfma, n_b4, other = 0, 0, set()
     for co in cos:
         dis = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(tmp_path / co)], capture_output=True, text=True).stdout
         for m in re.findall(r"\bv_mfma_[a-z0-9_]+", dis):
             if m == "v_mfma_f32_16x16x4_f32":
                 n_mfma += 1
+            elif m == "v_mfma_f32_4x4x1_16b_f32":            # batched 4x4 fp32 shape of conv3d_b4.hip (Cout = 8 layers)
+                n_b4 += 1
             else:
                 other.add(m)
     assert n_mfma > 5000, n_mfma                             # render + conv2d + conv3d kernels (17 k in round 1)
+    assert n_b4 > 5000, n_b4                                 # 27 taps x Cin x 2 halves x voxels-per-lane per b4 kernel
     assert not other, other                                  # exact-fp32 path: no reduced-precision MFMA shapes
     assert not [p for p in os.listdir(os.path.dirname(LIB_PATH)) if "hipv4" in p], "code objects leaked into the package"
 
