@@ -219,11 +219,14 @@ int make_plan(const enerf_frame_args_t* a, FramePlan* P) {
 // — up2+lat1, smooth1 (level 1's source maps) and the fused up2+lat0+smooth0 (the render texels, the second largest
 // kernel of the frame) — is needed later.  So enerf_forward forks that half onto a library-owned stream right after the
 // trunk and joins it with events before its first consumer: the two chains overlap inside ONE frame.
-// One lane (stream + 3 events) per caller stream, created on first use, never destroyed (process lifetime).
+// The render of a non-final cascade level (render_if True,True: lego, training-style eval) is a leaf as well — nothing in the
+// next level reads its rgb/depth/weights — so it is forked onto the lane's second stream after the level's depth regression
+// and joined at the end of the frame.
+// One lane (two streams + events) per caller stream, created on first use, never destroyed (process lifetime).
 // =====================================================================================================================
 #ifndef ENERF_EMU
 namespace {
-struct SideLane { hipStream_t stream; hipEvent_t trunk, l1, l2; };
+struct SideLane { hipStream_t stream, rstream; hipEvent_t trunk, l1, l2, fork, done; };
 SideLane* side_lane(hipStream_t main) {
     static std::mutex mu;
     static std::map<std::pair<int, hipStream_t>, SideLane*> lanes;
@@ -238,6 +241,9 @@ SideLane* side_lane(hipStream_t main) {
     ok = ok && hipEventCreateWithFlags(&L->trunk, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&L->l1, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&L->l2, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&L->rstream, hipStreamNonBlocking) == hipSuccess;       // renders of non-final levels
+    ok = ok && hipEventCreateWithFlags(&L->fork, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&L->done, hipEventDisableTiming) == hipSuccess;
     if (!ok) { delete L; L = nullptr; (void)hipGetLastError(); }
     lanes[key] = L;                                  // a failed creation is remembered: the frame then runs on one stream
     return L;
@@ -276,9 +282,10 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
     float* ws = (float*)a->workspace;
     const enerf_cascade_t& c = a->cas;
     const int n_img = a->B * a->S;
+    hipStream_t cur = st;                // the stream the current stage is enqueued on (the lane's for a forked render)
     auto mark = [&](int slot) {
 #ifndef ENERF_EMU
-        if (a->stage_events != nullptr && a->stage_events[slot] != nullptr) hipEventRecord((hipEvent_t)a->stage_events[slot], st);
+        if (a->stage_events != nullptr && a->stage_events[slot] != nullptr) hipEventRecord((hipEvent_t)a->stage_events[slot], cur);
 #else
         (void)slot;
 #endif
@@ -297,6 +304,7 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
     float* f[3] = {ws + P.f[0], ws + P.f[1], ws + P.f[2]};
     const int fh[3] = {a->H / 4, a->H / 2, a->H}, fw[3] = {a->W / 4, a->W / 2, a->W}, fc[3] = {32, 16, 8};
     bool forked = false;                 // the FeatureNet's top-down half runs on the side lane
+    int render_forks = 0;                // renders of non-final levels enqueued on the lane's second stream
     int joined[3] = {1, 1, 1};           // feature level l is visible to the caller's stream
 #ifndef ENERF_EMU
     SideLane* lane = nullptr;
@@ -307,6 +315,13 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
 #else
         (void)l;
 #endif
+    };
+    auto bail = [&](int code) {          // error exit after a fork: never leave a lane stream un-joined
+#ifndef ENERF_EMU
+        if (render_forks > 0) { hipEventRecord(lane->done, lane->rstream); hipStreamWaitEvent(st, lane->done, 0); }
+#endif
+        need_level(1); need_level(2);
+        return code;
     };
     if (P.hip_feats) {
         const int l2s = P.tex2 ? 12 : 8;
@@ -326,7 +341,7 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
             if (rc == ENERF_OK) rc = fstage(ENERF_FEAT_LEVEL2, (enerf_stream_t)lane->stream);
             hipEventRecord(lane->l2, lane->stream);
             forked = true; joined[1] = joined[2] = 0;
-            if (rc != ENERF_OK) { need_level(1); need_level(2); return rc; }      // never leave the lane un-joined
+            if (rc != ENERF_OK) return bail(rc);      // never leave the lane un-joined
         } else
 #endif
         {
@@ -350,15 +365,15 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
         rc = enerf_level_prep(a->src_ixts, a->src_exts, a->tar_ixt, a->tar_ext, a->B, a->S, (float)c.im_feat_scale[i],
                               (float)c.volume_scale[i], proj, a->near_far, pdepth, pstd, pnf, L.D, L.h, L.w, hp, wp,
                               c.depth_inv[i], dv, nf, stream);
-        if (rc != ENERF_OK) { need_level(1); need_level(2); return rc; }
+        if (rc != ENERF_OK) return bail(rc);
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_PREP));
         need_level(i);                                                 // level i's source maps (side lane for i >= 1)
         rc = enerf_build_feature_volume(f[i], proj, dv, a->B, a->S, L.C, L.Hs, L.Ws, L.D, L.h, L.w, vol, stream);
-        if (rc != ENERF_OK) { need_level(1); need_level(2); return rc; }
+        if (rc != ENERF_OK) return bail(rc);
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_VOLUME));
         rc = enerf_cost_reg(a->cost_reg_packed[i], L.C, i != 0, vol, a->B, L.D, L.h, L.w, feat3d, prob, ws + P.costreg_ws,
                             P.costreg_ws_bytes, a->options, stream);
-        if (rc != ENERF_OK) { need_level(1); need_level(2); return rc; }
+        if (rc != ENERF_OK) return bail(rc);
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_COST_REG));
         launch_depth_regression(prob, dv, a->B, L.D, L.h, L.w, c.depth_inv[i], depth, std, dmvs, st);
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_DEPTH_REG));
@@ -370,15 +385,26 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
         const int TEX = 4 * ((L.F + 3) / 4);
         const float* tex;
         need_level(fl);                                                // the texel source (joined here, inside the texel stage)
+        // a non-final level's render is a leaf of the frame: fork it (its inputs are complete on the caller's stream here)
+        bool render_forked = false;
+        enerf_stream_t rs = stream;
+#ifndef ENERF_EMU
+        if (forked && i + 1 < c.num && !L.masked) {
+            if (render_forks > 0) hipStreamWaitEvent(lane->rstream, lane->done, 0);   // (ordering only: same stream anyway)
+            hipEventRecord(lane->fork, st);
+            hipStreamWaitEvent(lane->rstream, lane->fork, 0);
+            rs = (enerf_stream_t)lane->rstream; cur = lane->rstream; render_forked = true; ++render_forks;
+        }
+#endif
         if (fl == 2 && P.tex2) tex = f[2];
         else {
             float* t = ws + L.tex;
             if (P.hip_feats)
-                rc = enerf_pack_texels_cl(f[fl], fc[fl], a->src_inps, a->H, a->W, L.Hr, L.Wr, TEX, n_img, t, stream);
+                rc = enerf_pack_texels_cl(f[fl], fc[fl], a->src_inps, a->H, a->W, L.Hr, L.Wr, TEX, n_img, t, rs);
             else
                 rc = enerf_pack_img_feat_rgb(a->feats_nchw[fl], fc[fl], fh[fl], fw[fl], a->src_inps, a->H, a->W, L.Hr, L.Wr,
-                                             TEX, n_img, t, stream);
-            if (rc != ENERF_OK) { need_level(1); need_level(2); return rc; }
+                                             TEX, n_img, t, rs);
+            if (rc != ENERF_OK) return bail(rc);
             tex = t;
         }
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_TEXELS));
@@ -387,8 +413,8 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
         const float* rays8 = a->rays[i];
         if (rays8 == nullptr) {
             float* r = ws + L.rays;
-            rc = enerf_gen_rays(a->tar_ext, a->tar_ixt, a->B, L.Hr, L.Wr, (float)c.render_scale[i], r, stream);
-            if (rc != ENERF_OK) { need_level(1); need_level(2); return rc; }
+            rc = enerf_gen_rays(a->tar_ext, a->tar_ixt, a->B, L.Hr, L.Wr, (float)c.render_scale[i], r, rs);
+            if (rc != ENERF_OK) return bail(rc);
             rays8 = r;
         }
         // ---- build_rays + render_rays (utils.py:390-420, network.py:24-43), one launch ----
@@ -404,12 +430,19 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
         ra.options = a->options;
         if (L.masked) {
             ra.ray_index = ray_index; ra.ray_count = ray_count; ra.scatter_rgb = 1;
-            zero_async(a->rgb[i], (size_t)L.n_rays * 3 * sizeof(float), st);      // torch.zeros_like(...), network_human.py:103
+            zero_async(a->rgb[i], (size_t)L.n_rays * 3 * sizeof(float), (hipStream_t)rs);      // torch.zeros_like(...), network_human.py:103
         }
-        rc = enerf_render_rays(&ra, stream);
-        if (rc != ENERF_OK) { need_level(1); need_level(2); return rc; }
+        rc = enerf_render_rays(&ra, rs);
+        if (rc != ENERF_OK) return bail(rc);
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_RENDER));
+#ifndef ENERF_EMU
+        if (render_forked) { hipEventRecord(lane->done, lane->rstream); cur = st; }
+#endif
+        (void)render_forked;
     }
+#ifndef ENERF_EMU
+    if (render_forks > 0) hipStreamWaitEvent(st, lane->done, 0);       // join the forked renders
+#endif
     need_level(1); need_level(2);        // the caller's stream never returns ahead of the side lane
     return check_launch("forward");
 }
