@@ -354,7 +354,7 @@ def main():
             net.static_shapes = False
             result["sustained"] = sus
             result["pipelined_fps"] = {"value": sus["pipelined_fps"], "frames_in_flight": max(1, args.in_flight),
-                                       "options": "enerf_options_t{conv3d_pk8=2}",
+                                       "options": "enerf_options_t{single_stream=1}",
                                        "note": "throughput of frames in flight on separate HIP streams; NOT the reference's "
                                                "protocol, never `value`"}
             if args.workload == "dtu":

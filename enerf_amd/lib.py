@@ -51,7 +51,9 @@ class Options(C.Structure):
 
 # what "most frames per second" prefers over "one frame as fast as possible" (enerf_amd/pipeline.py)
 def throughput_options() -> "Options":
-    return Options(conv3d_pk8=2)
+    # frames in flight already fill the chip: the in-frame side lanes add nothing there (measured equal) and triple the
+    # number of streams the runtime has to map onto its few hardware queues
+    return Options(single_stream=1)
 
 
 def _opt(o):

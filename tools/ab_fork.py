@@ -31,7 +31,7 @@ for name, opt in (("fork", None), ("single", Options(single_stream=1)), ("fork",
     m, p50, seq = lat(opt)
     print(f"{wl} {name:7s} latency mean {m:.4f} ms p50 {p50:.4f} -> {1e3/m:.1f} FPS ; back-to-back {seq:.1f} FPS", flush=True)
 if not human:
-    for name, o in (("fork+pk8", throughput_options()), ("single+pk8", Options(conv3d_pk8=2, single_stream=1))):
+    for name, o in (("lanes", Options()), ("single_stream", throughput_options()), ("lanes", Options()), ("single_stream", throughput_options())):
         net.options = None
         pipe = FramePipeline(net, depth=6, options=o)
         with torch.no_grad():
