@@ -304,7 +304,7 @@ def main():
         # the library's side lane (enerf_options_t.single_stream = 0), so stage intervals on the caller's stream overlap it:
         # `stages_ms` is the attribution pass with single_stream = 1 (every kernel in order on one stream), and
         # `stages_ms_default` the intervals of the frame `value` is timed on (the render interval starts after the join,
-        # so it is the render kernel alone either way — the roofline below uses the default-mode figure).
+        # so the FINAL render is the kernel alone either way — the roofline below uses its default-mode figure).
         from enerf_amd.lib import Options
 
         def stage_pass(opt):
@@ -323,9 +323,9 @@ def main():
         result["stages_ms_default"] = {k: round(v, 4) for k, v in stages_default.items()}
         result["stages_note"] = ("stages_ms: enerf_options_t.single_stream=1 (sequential attribution); stages_ms_default: the "
                                  "default frame, FeatureNet top-down half overlapped with level 0 on the side lane")
-        for k in stages:                                # the render launches are measured in the mode `value` runs in
-            if k.startswith("render_"):
-                stages[k] = stages_default[k]
+        # the final render launch is measured in the mode `value` runs in (it starts after every join: the kernel alone);
+        # a non-final level's render overlaps the next level in that mode, so its single-stream figure is the kernel's own
+        stages[f"render_{last}"] = stages_default[f"render_{last}"]
 
         # sustained legs (>= 2000 frames: long enough for utilisation sampling) and the pipelined throughput
         n_sus = max(0, args.sustained_frames)
