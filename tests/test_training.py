@@ -134,28 +134,33 @@ def _check_hip_backward_stages(lib, dev):
         assert float((raw.grad - gr_ref).abs().max()) <= 1e-4 * float(gr_ref.abs().max()), Ns
         assert float((z.grad - gz_ref).abs().max()) <= 1e-4 * float(gz_ref.abs().max()), Ns
 
-    # --- render-side fetches: get_img_feat + get_vox_feat (points in front of the cameras, some outside the images) ---
+    # --- render-side fetches: get_img_feat + get_vox_feat (points in front of the cameras, some outside the images);
+    #     two batch elements with different camera rigs ---
     from enerf_amd.autograd import GatherFn, gather_cameras
+    _, batch_b = _train_batch(seed=11)
+    batch1 = batch
+    batch = {k: torch.cat([v, batch_b[k].to(dev)], 0) for k, v in batch1.items()}
+    Bg = 2
     for level, (Fc, Ns) in enumerate(((35, 4), (11, 2))):
         rs = cas.render_scale[level]
         Hr, Wr = int(32 * rs), int(64 * rs)
         rays = batch[f"rays_{level}"][:, :200]
         N = rays.shape[1]
         o, d = rays[..., :3], rays[..., 3:6]
-        t = (batch["near_far"].min() + (batch["near_far"].max() - batch["near_far"].min()) * torch.rand(1, N, Ns, generator=g).to(dev))
-        side = (0.0 + 120.0 * torch.randn(1, N, Ns, 3, generator=g)).to(dev) * (torch.rand(1, N, Ns, 1, generator=g).to(dev) < 0.3)
-        xyz = (o[:, :, None] + d[:, :, None] * t[..., None] + side).reshape(1, N * Ns, 3).requires_grad_(True)
-        dn = (torch.rand(1, N * Ns, generator=g) * 1.3 - 0.15).to(dev).requires_grad_(True)
-        uv = (torch.rand(1, N * Ns, 2, generator=g) * torch.tensor([Wr - 1.0, Hr - 1.0])).to(dev)
-        tex = rnd(1, 3, Fc, Hr, Wr).requires_grad_(True)
-        vol = rnd(1, 8, 8, int(32 * cas.volume_scale[level]), int(64 * cas.volume_scale[level])).requires_grad_(True)
-        gx, gv = rnd(1, N * Ns, 3, Fc + 4), rnd(1, N * Ns, 8)
+        t = (batch["near_far"].min() + (batch["near_far"].max() - batch["near_far"].min()) * torch.rand(Bg, N, Ns, generator=g).to(dev))
+        side = (0.0 + 120.0 * torch.randn(Bg, N, Ns, 3, generator=g)).to(dev) * (torch.rand(Bg, N, Ns, 1, generator=g).to(dev) < 0.3)
+        xyz = (o[:, :, None] + d[:, :, None] * t[..., None] + side).reshape(Bg, N * Ns, 3).requires_grad_(True)
+        dn = (torch.rand(Bg, N * Ns, generator=g) * 1.3 - 0.15).to(dev).requires_grad_(True)
+        uv = (torch.rand(Bg, N * Ns, 2, generator=g) * torch.tensor([Wr - 1.0, Hr - 1.0])).to(dev)
+        tex = rnd(Bg, 3, Fc, Hr, Wr).requires_grad_(True)
+        vol = rnd(Bg, 8, 8, int(32 * cas.volume_scale[level]), int(64 * cas.volume_scale[level])).requires_grad_(True)
+        gx, gv = rnd(Bg, N * Ns, 3, Fc + 4), rnd(Bg, N * Ns, 8)
 
         def torch_twin():
             nd = torch.stack([uv[..., 0] / (Wr - 1), uv[..., 1] / (Hr - 1), dn], -1)
-            gg = nd.reshape(1, 1, 1, N * Ns, 3) * 2.0 - 1.0
+            gg = nd.reshape(Bg, 1, 1, N * Ns, 3) * 2.0 - 1.0
             vox = F.grid_sample(vol, gg, align_corners=True)[:, :, 0, 0].permute(0, 2, 1)
-            return T.img_feat(cas, xyz.reshape(1, N, Ns, 3), tex, batch, level), vox
+            return T.img_feat(cas, xyz.reshape(Bg, N, Ns, 3), tex, batch, level), vox
         x_ref, v_ref = torch_twin()
         ((x_ref * gx).sum() + (v_ref * gv).sum()).backward()
         ref = [t_.grad.clone() for t_ in (xyz, dn, tex, vol)]
@@ -519,3 +524,22 @@ def _check_mlp_backward(lib, dev):
 def test_mlp_backward_emulated():
     from emu_lib import emu_lib
     _check_mlp_backward(emu_lib(), torch.device("cpu"))
+
+
+def test_tree_reductions_match_torch():
+    """train_graph.tree_sum / mse_loss (the single-block reductions a captured training step uses) equal torch's, values and
+    gradients, for sizes that are not multiples of 256."""
+    from enerf_amd.train_graph import mse_loss, tree_sum
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 255, 256, 257, 70001):
+        x = torch.randn(n, generator=g, dtype=torch.float64).requires_grad_(True)
+        s = tree_sum(x)
+        assert float(s) == pytest.approx(float(x.sum()), rel=1e-12, abs=1e-12)
+        (gx,) = torch.autograd.grad(s, x)
+        assert torch.equal(gx, torch.ones_like(x))
+    a = torch.randn(1000, 77, generator=g, requires_grad=True)
+    b = torch.randn(1000, 77, generator=g)
+    l1, l2 = mse_loss(a, b), F.mse_loss(a, b)
+    assert float(l1) == pytest.approx(float(l2), rel=1e-6)
+    (g1,), (g2,) = torch.autograd.grad(l1, a), torch.autograd.grad(l2, a)
+    assert float((g1 - g2).abs().max()) < 1e-9
