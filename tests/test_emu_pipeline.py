@@ -60,6 +60,14 @@ def test_batch2_ragged_rays_and_white_bkgd():
         ref = O.forward(cfg, load_weights(), batch)
     for k in ref:
         _close(out[k].numpy(), ref[k].numpy(), 5e-5, k)
+    # the same two-element batch through the LDS-staged / batched-4x4 convolution kernels (the default routes volumes this
+    # small to the global-load kernels): box decomposition with B = 2
+    from enerf_amd.lib import Options
+    net = _net(cfg)
+    net.options = Options(conv3d_lds_min_voxels=1)
+    out = net(batch)
+    for k in ref:
+        _close(out[k].numpy(), ref[k].numpy(), 5e-5, k)
 
 
 def test_render_rays_surface_accepts_reference_volume_layout():
