@@ -507,7 +507,6 @@ __global__ __launch_bounds__(256, 3) void k_smooth0_fused(   // 47 KB LDS -> 3 b
 #pragma unroll
     for (int c = 0; c < (PK ? CTW : 1); ++c) accP[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* wl = wpk + lane;            // PK: the P/Q image [((kh*8 + ks)*2 + pq)*64 + lane]
-    const int q4 = threadIdx.x & 3;          // this thread's channel quad inside a 16-channel pass (items stride 256)
 
 #pragma unroll 1
     for (int cb = 0; cb < 2; ++cb) {
@@ -537,36 +536,40 @@ __global__ __launch_bounds__(256, 3) void k_smooth0_fused(   // 47 KB LDS -> 3 b
                 *reinterpret_cast<const float4*>(f1pre + (((long long)n * H1 + gy) * W1 + gx) * 32 + cb * 16 + q * 4);
         }
         __syncthreads();
-        // ---- build the FPN-sum tile: item = (pixel, channel quad) ----
+        // ---- build the FPN-sum tile: item = 16 pixels x the pass's 16 channels, one per wave at a time ----
+        // lat0 (nn.Conv2d(8,32,1)) runs on the matrix cores: rows = the pass's 16 output channels, k = the 8 conv0 channels
+        // (two k-steps), columns = 16 tile pixels; lane (g, j) then holds channels 4g..4g+3 of pixel j — exactly the float4 it
+        // stores — and adds its own four bilinear blends.  (As 32 lane-local FMAs per (pixel, quad) item this was more
+        // than half of the build phase's VALU work, and the VALU does not overlap the MFMAs of the other waves.)
+        {
+            const float2 a_lat = *reinterpret_cast<const float2*>(lwt + (cb * 16 + j) * 8 + 2 * g);   // A: row j, k = channel 2g + r
+            const float4 bias4 = *reinterpret_cast<const float4*>(lwt + 256 + cb * 16 + 4 * g);
+            constexpr int NT16 = (NPX + 15) / 16;
 #pragma unroll 1
-        for (int i = threadIdx.x; i < NPX * 4; i += 256) {
-            const int px = i >> 2, ly = px / IW, lx = px - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const Lerp1 vy = ac_lerp(gy, sy, H1), vx = ac_lerp(gx, sx, W1);
-                const float* p00 = pat + ((vy.i0 - py0) * PW + (vx.i0 - px0)) * 16 + q4 * 4;
-                const float* p01 = pat + ((vy.i0 - py0) * PW + (vx.i1 - px0)) * 16 + q4 * 4;
-                const float* p10 = pat + ((vy.i1 - py0) * PW + (vx.i0 - px0)) * 16 + q4 * 4;
-                const float* p11 = pat + ((vy.i1 - py0) * PW + (vx.i1 - px0)) * 16 + q4 * 4;
-                const float4 u00 = *reinterpret_cast<const float4*>(p00), u01 = *reinterpret_cast<const float4*>(p01);
-                const float4 u10 = *reinterpret_cast<const float4*>(p10), u11 = *reinterpret_cast<const float4*>(p11);
-                const float4 ca = *reinterpret_cast<const float4*>(c0t + px * 8), cbv = *reinterpret_cast<const float4*>(c0t + px * 8 + 4);
-                float lat[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {    // nn.Conv2d(8,32,1): dot + bias; weights from LDS (4 distinct rows per wave: broadcast reads)
-                    const int m = cb * 16 + q4 * 4 + r;
-                    const float4 w0 = *reinterpret_cast<const float4*>(lwt + m * 8), w1 = *reinterpret_cast<const float4*>(lwt + m * 8 + 4);
-                    float a = w0.x * ca.x;
-                    a += w0.y * ca.y; a += w0.z * ca.z; a += w0.w * ca.w;
-                    a += w1.x * cbv.x; a += w1.y * cbv.y; a += w1.z * cbv.z; a += w1.w * cbv.w;
-                    lat[r] = a + lwt[256 + m];
+            for (int t = wv; t < NT16; t += 4) {
+                const int px = t * 16 + j, pxc = px < NPX ? px : NPX - 1;
+                const int ly = pxc / IW, lx = pxc - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
+                const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const float2 cv = *reinterpret_cast<const float2*>(c0t + pxc * 8 + 2 * g);           // B: k = channel 2g + r of pixel j
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat.x, cv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat.y, cv.y, acc, 0, 0, 0);
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (inside) {
+                    const Lerp1 vy = ac_lerp(gy, sy, H1), vx = ac_lerp(gx, sx, W1);
+                    const float* p00 = pat + ((vy.i0 - py0) * PW + (vx.i0 - px0)) * 16 + g * 4;
+                    const float* p01 = pat + ((vy.i0 - py0) * PW + (vx.i1 - px0)) * 16 + g * 4;
+                    const float* p10 = pat + ((vy.i1 - py0) * PW + (vx.i0 - px0)) * 16 + g * 4;
+                    const float* p11 = pat + ((vy.i1 - py0) * PW + (vx.i1 - px0)) * 16 + g * 4;
+                    const float4 u00 = *reinterpret_cast<const float4*>(p00), u01 = *reinterpret_cast<const float4*>(p01);
+                    const float4 u10 = *reinterpret_cast<const float4*>(p10), u11 = *reinterpret_cast<const float4*>(p11);
+                    o.x = ac_blend(vy, vx, u00.x, u01.x, u10.x, u11.x) + (acc[0] + bias4.x);
+                    o.y = ac_blend(vy, vx, u00.y, u01.y, u10.y, u11.y) + (acc[1] + bias4.y);
+                    o.z = ac_blend(vy, vx, u00.z, u01.z, u10.z, u11.z) + (acc[2] + bias4.z);
+                    o.w = ac_blend(vy, vx, u00.w, u01.w, u10.w, u11.w) + (acc[3] + bias4.w);
                 }
-                o.x = ac_blend(vy, vx, u00.x, u01.x, u10.x, u11.x) + lat[0];
-                o.y = ac_blend(vy, vx, u00.y, u01.y, u10.y, u11.y) + lat[1];
-                o.z = ac_blend(vy, vx, u00.z, u01.z, u10.z, u11.z) + lat[2];
-                o.w = ac_blend(vy, vx, u00.w, u01.w, u10.w, u11.w) + lat[3];
+                if (px < NPX) *reinterpret_cast<float4*>(til + px * TS + g * 4) = o;
             }
-            *reinterpret_cast<float4*>(til + px * TS + q4 * 4) = o;
         }
         __syncthreads();
         // ---- 3x3 conv, 16 input channels of this pass, on the matrix cores ----
