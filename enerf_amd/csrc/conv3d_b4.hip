@@ -63,7 +63,6 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_s1_b4(const float* __restrict
     constexpr int NS = HEADS ? 3 : 2;                              // weight slots per (tap, quad): rows 0-3, rows 4-7(, depth)
     constexpr int HX = BW + 2, HY = BH + 2, HZ = BD + 2, NVOX = HZ * HY * HX;
     constexpr int PLANE = b4_plane_voxels(NVOX) * 4;               // floats per channel-quad plane
-    constexpr int NIT = (NVOX * QV + 255) / 256;
     constexpr int NWF4 = 27 * QV * 12;                             // float4s of one pass's weights (48 floats per (tap, quad))
     constexpr int NWIT = (NWF4 + 255) / 256;
     ENERF_DYN_SMEM(float, lds);
@@ -97,33 +96,37 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_s1_b4(const float* __restrict
         if (cb > 0) __syncthreads();
         {   // stage the haloed box as channel-quad planes (unconditional clamped loads, zero-select afterwards) and this
             // pass's weights: from LDS an A operand costs a broadcast ds_read_b128; from global it was 16 texture-unit
-            // cycles per load for 64 unique bytes — 85 % of the address pipe at two blocks per CU
-            float4 sv[NIT], wq[NWIT];
-            bool sk[NIT];
-            int so[NIT];
+            // cycles per load for 64 unique bytes — 85 % of the address pipe at two blocks per CU.
+            // Row-based mapping: a thread keeps its (column, quad) of a box row and walks rows slot, slot+7, ... — the only
+            // index arithmetic per load is one division of the row number (the flat index -> (dx,dy,dz,q) form cost ~45 VALU
+            // instructions per load, ~15 % of the kernel's issue slots: the kernel is issue bound at three blocks per CU).
+            constexpr int RW = HX * QV, SLOTS = 256 / RW, NR = HZ * HY, NITR = (NR + SLOTS - 1) / SLOTS;
+            const int sub = tid % RW, slot = tid / RW, sdx = sub / QV, sq = sub - sdx * QV;
+            const int gx = x0 + sdx - 1;
+            const bool colok = slot < SLOTS && gx >= 0 && gx < W;
+            float4 sv[NITR], wq[NWIT];
+            bool sk[NITR];
+            const float* src = inb + cb * CB + sq * 4;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int i = tid + it * 256;
-                const int ic = i < NVOX * QV ? i : NVOX * QV - 1;
-                const int vx = ic / QV, q = ic - vx * QV;
-                const int dx = vx % HX, dy = (vx / HX) % HY, dz = vx / (HX * HY);
-                const int gx = x0 + dx - 1, gy = y0 + dy - 1, gz = z0 + dz - 1;
-                sk[it] = gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
-                so[it] = q * PLANE + vx * 4;
+            for (int it = 0; it < NITR; ++it) {
+                const int r = slot + it * SLOTS, dz = r / HY, dy = r - dz * HY;
+                const int gy = y0 + dy - 1, gz = z0 + dz - 1;
+                sk[it] = colok && r < NR && gy >= 0 && gy < H && gz >= 0 && gz < D;
                 const long long off = sk[it] ? (((long long)gz * H + gy) * W + gx) : 0;
-                sv[it] = *reinterpret_cast<const float4*>(inb + off * CIN + cb * CB + q * 4);
+                sv[it] = *reinterpret_cast<const float4*>(src + off * CIN);
             }
 #pragma unroll
-            for (int it = 0; it < NWIT; ++it) {
+            for (int it = 0; it < NWIT; ++it) {                    // the pass's two quads of a tap are 96 contiguous floats
                 const int i = tid + it * 256, ic = i < NWF4 ? i : NWF4 - 1;
-                const int tq = ic / 12, e = ic - tq * 12, tap = tq / QV, q = tq - tap * QV;
-                wq[it] = *reinterpret_cast<const float4*>(wb4 + ((long long)tap * NQ + cb * QV + q) * 48 + e * 4);
+                const int tap = ic / 24, e = ic - tap * 24;
+                wq[it] = *reinterpret_cast<const float4*>(wb4 + ((long long)tap * NQ + cb * QV) * 48 + e * 4);
             }
+            float* dst = lds + sq * PLANE + (slot * HX + sdx) * 4;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int i = tid + it * 256;
-                if (i < NVOX * QV)
-                    *reinterpret_cast<float4*>(lds + so[it]) = sk[it] ? sv[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int it = 0; it < NITR; ++it) {
+                const int r = slot + it * SLOTS;
+                if (slot < SLOTS && r < NR)
+                    *reinterpret_cast<float4*>(dst + it * SLOTS * HX * 4) = sk[it] ? sv[it] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int it = 0; it < NWIT; ++it) {
