@@ -442,9 +442,150 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const float* __restrict__ w
     }
 }
 
+// The same two layers on the batched 4x4x1 matrix instruction (see conv3d_b4.hip): both have Cout = 8, i.e. half of every
+// 16x16x4 tile multiplied zeros (and conv0.0's 3 input channels were padded to a 4-wide k-step).  LANE = PIXEL: a lane
+// feeds its own pixel's input value and receives its own pixel's four output channels; two instructions per input channel
+// cover the 8 outputs.  Stage 1 walks the 340 haloed pixels in flat order (its texel reads and its two plane stores are
+// conflict free that way), stage 2 gives each ds_read_b128 service group 16 consecutive pixels of a row.  The weights are
+// re-laid-out from the 16x16x4 operand images the library already packs (no new pack kernel): per (tap, quad, half) one
+// broadcast float4 per lane (row i = lane & 3).  198 + 288 16x16x4 MFMAs (15.5 k matrix cycles per block) become
+// 324 + 576 4x4x1 MFMAs (8.5 k).
+__global__ __launch_bounds__(256) void k_conv0_fused_b4(const float* __restrict__ w0, const float* __restrict__ scale0,
+                                                        const float* __restrict__ shift0, const float* __restrict__ w1,
+                                                        const float* __restrict__ scale1, const float* __restrict__ shift1,
+                                                        const float* __restrict__ img, float* __restrict__ out, int N, int H,
+                                                        int W, int tiles_y, int tiles_x) {
+    constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, NPX = IH * IW;      // conv0.1 input tile (10 x 34)
+    constexpr int PH = IH + 2, PW = IW + 2, NPP = PH * PW;                        // image patch (12 x 36)
+    ENERF_DYN_SMEM(float, lds);
+    float* pat = lds;                   // [NPP] float4 image texels (4th channel 0)
+    float* til = pat + NPP * 4;         // [2 quads][NPX] float4: conv0.0 output planes
+    float* wl0 = til + 2 * NPX * 4;     // [9 taps][2 halves][4 rows][4: c0 c1 c2 0]
+    float* wl1 = wl0 + 9 * 32;          // [9 taps][2 quads][2 halves][4 rows][4 channels of the quad]
+
+    const int tid = threadIdx.x, lane = tid & 63, li = tid & 3, wv = tid >> 6;
+    const int bid = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+    const int oy0 = ty * TH, ox0 = tx * TW;
+
+    // ---- weights: 16x16x4 operand images -> [row i][k] float4s (W0[o][c][t] = w0[t*64 + c*16 + o]; W1[o][2g+r][t] =
+    //      w1[(2t + r)*64 + g*16 + o], conv2d.hip k_conv2d_pack) ----
+    for (int i = tid; i < 9 * 32 + 9 * 64; i += 256) {
+        if (i < 9 * 32) {
+            const int r = i & 3, row = (i >> 2) & 3, half = (i >> 4) & 1, t = i >> 5;
+            wl0[i] = r < 3 ? w0[t * 64 + r * 16 + 4 * half + row] : 0.f;
+        } else {
+            const int k = i - 9 * 32, r = k & 3, row = (k >> 2) & 3, half = (k >> 4) & 1, q = (k >> 5) & 1, t = k >> 6;
+            const int ch = 4 * q + r;
+            wl1[k] = w1[(t * 2 + (ch & 1)) * 64 + (ch >> 1) * 16 + 4 * half + row];
+        }
+    }
+    {   // ---- image patch -> LDS: one thread per patch pixel, three coalesced plane reads, zero outside ----
+        constexpr int NIT = (NPP + 255) / 256;
+        float v0[NIT], v1[NIT], v2[NIT];
+        bool sk[NIT];
+        const float* base = img + (long long)n * 3 * H * W;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256, ic = i < NPP ? i : NPP - 1;
+            const int ly = ic / PW, lx = ic - ly * PW, gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
+            sk[it] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int off = sk[it] ? gy * W + gx : 0;
+            v0[it] = base[off]; v1[it] = base[H * W + off]; v2[it] = base[2 * H * W + off];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            if (i < NPP)
+                *reinterpret_cast<float4*>(pat + i * 4) =
+                    sk[it] ? make_float4(v0[it], v1[it], v2[it], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 1: conv0.0 + BN + ReLU for the haloed tile, lane = haloed pixel (flat order) -> LDS planes ----
+#pragma unroll 1
+    for (int base = wv * 64; base < NPX; base += 256) {                    // wave-uniform
+        const int p = base + lane, pc = p < NPX ? p : NPX - 1;
+        const int ly = pc / IW, lx = pc - ly * IW;
+        const float* pb = pat + (ly * PW + lx) * 4;
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4 tex = *reinterpret_cast<const float4*>(pb + ((t / 3) * PW + (t % 3)) * 4);
+            const float4 A0 = *reinterpret_cast<const float4*>(wl0 + (t * 2 + 0) * 16 + li * 4);
+            const float4 A1 = *reinterpret_cast<const float4*>(wl0 + (t * 2 + 1) * 16 + li * 4);
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.x, tex.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.x, tex.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.y, tex.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.y, tex.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.z, tex.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.z, tex.z, acc1, 0, 0, 0);
+        }
+        const int gy = oy0 - 1 + ly, gx = ox0 - 1 + lx;
+        const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        if (p < NPX) {
+            float4 o0, o1;
+            o0.x = inside ? relu1(acc0[0] * scale0[0] + shift0[0]) : 0.f; o0.y = inside ? relu1(acc0[1] * scale0[1] + shift0[1]) : 0.f;
+            o0.z = inside ? relu1(acc0[2] * scale0[2] + shift0[2]) : 0.f; o0.w = inside ? relu1(acc0[3] * scale0[3] + shift0[3]) : 0.f;
+            o1.x = inside ? relu1(acc1[0] * scale0[4] + shift0[4]) : 0.f; o1.y = inside ? relu1(acc1[1] * scale0[5] + shift0[5]) : 0.f;
+            o1.z = inside ? relu1(acc1[2] * scale0[6] + shift0[6]) : 0.f; o1.w = inside ? relu1(acc1[3] * scale0[7] + shift0[7]) : 0.f;
+            *reinterpret_cast<float4*>(til + p * 4) = o0;
+            *reinterpret_cast<float4*>(til + (NPX + p) * 4) = o1;
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 2: conv0.1 (8 -> 8), lane = output pixel; service group k of a wave = 16 consecutive pixels of one row ----
+    const int m = lane & 31;
+    const bool g1 = (m >= 4 && m < 12) || (m >= 16 && m < 20) || m >= 28;
+    const int pos = g1 ? (m < 12 ? m - 4 : m < 20 ? m - 8 : m - 16) : (m < 4 ? m : m < 16 ? m - 8 : m - 12);
+    const int kgrp = 2 * (lane >> 5) + (g1 ? 1 : 0);
+    const int row = 2 * wv + (kgrp >> 1), col = (kgrp & 1) * 16 + pos;
+    const float* tb = til + (row * IW + col) * 4;
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int off = ((t / 3) * IW + (t % 3)) * 4;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 bb = *reinterpret_cast<const float4*>(tb + q * NPX * 4 + off);
+            const float4 A0 = *reinterpret_cast<const float4*>(wl1 + ((t * 2 + q) * 2 + 0) * 16 + li * 4);
+            const float4 A1 = *reinterpret_cast<const float4*>(wl1 + ((t * 2 + q) * 2 + 1) * 16 + li * 4);
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.x, bb.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.x, bb.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.y, bb.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.y, bb.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.z, bb.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.z, bb.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.w, bb.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.w, bb.w, acc1, 0, 0, 0);
+        }
+    }
+    // ---- epilogue: BN + ReLU, channels-last store (cout = 8: 32 contiguous bytes per pixel) ----
+    const int oy = oy0 + row, ox = ox0 + col;
+    if (oy >= H || ox >= W) return;
+    const long long o = ((long long)n * H + oy) * W + ox;
+    *reinterpret_cast<float4*>(out + o * 8) =
+        make_float4(relu1(acc0[0] * scale1[0] + shift1[0]), relu1(acc0[1] * scale1[1] + shift1[1]),
+                    relu1(acc0[2] * scale1[2] + shift1[2]), relu1(acc0[3] * scale1[3] + shift1[3]));
+    *reinterpret_cast<float4*>(out + o * 8 + 4) =
+        make_float4(relu1(acc1[0] * scale1[4] + shift1[4]), relu1(acc1[1] * scale1[5] + shift1[5]),
+                    relu1(acc1[2] * scale1[6] + shift1[6]), relu1(acc1[3] * scale1[7] + shift1[7]));
+}
+
+#ifndef ENERF_CONV0_B4
+#define ENERF_CONV0_B4 1
+#endif
 void launch_conv0_fused(const Conv2dDesc& L0, const Conv2dDesc& L1, const float* img, float* out, int N, int H, int W,
                         hipStream_t st) {
     const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
+    if (ENERF_CONV0_B4) {
+        const size_t shmem = (size_t)(12 * 36 * 4 + 2 * 10 * 34 * 4 + 9 * 32 + 9 * 64) * sizeof(float);
+        ENERF_LAUNCH(k_conv0_fused_b4, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, L0.w, L0.scale, L0.shift, L1.w,
+                     L1.scale, L1.shift, img, out, N, H, W, tiles_y, tiles_x);
+        return;
+    }
     const size_t shmem = (size_t)(12 * 36 * 4 + 10 * 34 * 8) * sizeof(float);
     ENERF_LAUNCH(k_conv0_fused, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, L0.w, L0.scale, L0.shift, L1.w, L1.scale,
                  L1.shift, img, out, N, H, W, tiles_y, tiles_x);
