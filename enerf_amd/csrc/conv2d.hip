@@ -799,9 +799,148 @@ void launch_conv2d_pq_pack(const float* w, int cin, float* packed, hipStream_t s
     ENERF_LAUNCH_SIMPLE(k_conv2d_pq_pack, (unsigned)cdiv(total, 256), 256, 0, st, w, cin, packed);
 }
 
+// The same fusion with the 3x3 32 -> 8 convolution on the batched 4x4x1 matrix instruction (conv3d_b4.hip's idea): lane =
+// output pixel, two instructions per input channel cover the 8 outputs, so nothing of the 16x16x4 tile's 16 rows is wasted
+// (the tap-packed variant above still wastes a third) and the tile is a full 8 x 32.  The FPN-sum tile lives in LDS as
+// [channel quad][pixel] float4 planes (the build phase's D layout stores straight into them), every ds_read_b128 service
+// group reads 16 consecutive pixels of a row, and the pass's weights are re-laid-out in LDS from the plain 16x16x4 operand
+// image (W[o][16cb + 4q + r][t] = w[((8t + 4cb + r)*64 + 16q + o], k_conv2d_pack) as broadcast float4s.
+__global__ __launch_bounds__(256, 3) void k_smooth0_b4(const float* __restrict__ w, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ c0,
+                                                       const float* __restrict__ f1pre, const float* __restrict__ lat_w,
+                                                       const float* __restrict__ lat_b, float* __restrict__ out,
+                                                       const float* __restrict__ rgb_src, int out_stride, int N, int H,
+                                                       int W, int tiles_y, int tiles_x) {
+    constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, NPX = IH * IW;             // 10 x 34 halo tile
+    constexpr int PH = 7, PW = 20, NPP = PH * PW;                                       // f1pre patch (half res)
+    ENERF_DYN_SMEM(float, lds);
+    float* c0t = lds;                       // [NPX][8]
+    float* pat = c0t + NPX * 8;             // [NPP][16]   (channels of the current pass)
+    float* til = pat + NPP * 16;            // [4 quads][NPX] float4 planes (16 channels of the current pass)
+    float* lwt = til + 4 * NPX * 4;         // lat0 weight (32x8) + bias (32), staged once
+    float* wl = lwt + 288;                  // [9 taps][4 quads][2 halves][4 rows][4]: the pass's smooth0 weights
+
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, j = lane & 15, wv = tid >> 6, li = tid & 3;
+    const int bid = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+    const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int H1 = H / 2, W1 = W / 2;
+    const float sy = ac_scale(H1, H), sx = ac_scale(W1, W);
+    const int py0 = (int)(sy * (float)max(iy0, 0)), px0 = (int)(sx * (float)max(ix0, 0));   // patch origin (= lerp i0 of the first row/col)
+
+    for (int i = tid; i < 288; i += 256) lwt[i] = i < 256 ? lat_w[i] : lat_b[i - 256];
+    // ---- c0 tile -> LDS (zero outside the image) ----
+    for (int i = tid; i < NPX * 2; i += 256) {
+        const int px = i >> 1, q = i & 1, ly = px / IW, lx = px - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
+        const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const long long off = ok ? ((long long)n * H + gy) * W + gx : 0;
+        const float4 v = *reinterpret_cast<const float4*>(c0 + off * 8 + q * 4);
+        *reinterpret_cast<float4*>(c0t + i * 4) = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // stage-2 lane -> pixel map: service group k of a wave = 16 consecutive pixels of one tile row
+    const int m = lane & 31;
+    const bool g1 = (m >= 4 && m < 12) || (m >= 16 && m < 20) || m >= 28;
+    const int pos = g1 ? (m < 12 ? m - 4 : m < 20 ? m - 8 : m - 16) : (m < 4 ? m : m < 16 ? m - 8 : m - 12);
+    const int kgrp = 2 * (lane >> 5) + (g1 ? 1 : 0);
+    const int row = 2 * wv + (kgrp >> 1), col = (kgrp & 1) * 16 + pos;
+    const float* tb = til + (row * IW + col) * 4;
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int cb = 0; cb < 2; ++cb) {
+        if (cb > 0) __syncthreads();          // previous pass done with pat / til / wl
+        // ---- f1pre patch (16 channels of this pass) and the pass's conv weights -> LDS ----
+        for (int i = tid; i < NPP * 4; i += 256) {
+            const int pp = i >> 2, q = i & 3, pr = pp / PW, pc = pp - pr * PW;
+            const int gy = min(py0 + pr, H1 - 1), gx = min(px0 + pc, W1 - 1);
+            *reinterpret_cast<float4*>(pat + i * 4) =
+                *reinterpret_cast<const float4*>(f1pre + (((long long)n * H1 + gy) * W1 + gx) * 32 + cb * 16 + q * 4);
+        }
+        for (int i = tid; i < 9 * 4 * 32; i += 256) {
+            const int r = i & 3, rw = (i >> 2) & 3, half = (i >> 4) & 1, q = (i >> 5) & 3, t = i >> 7;
+            wl[i] = w[((t * 8 + cb * 4 + r) * 64) + q * 16 + 4 * half + rw];
+        }
+        __syncthreads();
+        // ---- build the FPN-sum tile (lat0 on the matrix cores, see k_smooth0_fused) into the quad planes ----
+        {
+            const float2 a_lat = *reinterpret_cast<const float2*>(lwt + (cb * 16 + j) * 8 + 2 * g);
+            const float4 bias4 = *reinterpret_cast<const float4*>(lwt + 256 + cb * 16 + 4 * g);
+            constexpr int NT16 = (NPX + 15) / 16;
+#pragma unroll 1
+            for (int t = wv; t < NT16; t += 4) {
+                const int px = t * 16 + j, pxc = px < NPX ? px : NPX - 1;
+                const int ly = pxc / IW, lx = pxc - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
+                const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const float2 cv = *reinterpret_cast<const float2*>(c0t + pxc * 8 + 2 * g);
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat.x, cv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat.y, cv.y, acc, 0, 0, 0);
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (inside) {
+                    const Lerp1 vy = ac_lerp(gy, sy, H1), vx = ac_lerp(gx, sx, W1);
+                    const float* p00 = pat + ((vy.i0 - py0) * PW + (vx.i0 - px0)) * 16 + g * 4;
+                    const float* p01 = pat + ((vy.i0 - py0) * PW + (vx.i1 - px0)) * 16 + g * 4;
+                    const float* p10 = pat + ((vy.i1 - py0) * PW + (vx.i0 - px0)) * 16 + g * 4;
+                    const float* p11 = pat + ((vy.i1 - py0) * PW + (vx.i1 - px0)) * 16 + g * 4;
+                    const float4 u00 = *reinterpret_cast<const float4*>(p00), u01 = *reinterpret_cast<const float4*>(p01);
+                    const float4 u10 = *reinterpret_cast<const float4*>(p10), u11 = *reinterpret_cast<const float4*>(p11);
+                    o.x = ac_blend(vy, vx, u00.x, u01.x, u10.x, u11.x) + (acc[0] + bias4.x);
+                    o.y = ac_blend(vy, vx, u00.y, u01.y, u10.y, u11.y) + (acc[1] + bias4.y);
+                    o.z = ac_blend(vy, vx, u00.z, u01.z, u10.z, u11.z) + (acc[2] + bias4.z);
+                    o.w = ac_blend(vy, vx, u00.w, u01.w, u10.w, u11.w) + (acc[3] + bias4.w);
+                }
+                if (px < NPX) *reinterpret_cast<float4*>(til + (g * NPX + px) * 4) = o;
+            }
+        }
+        __syncthreads();
+        // ---- 3x3 conv over the pass's 16 channels: 9 taps x 4 quads x 4 channels x 2 halves of 4x4x1 MFMAs ----
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int off = ((t / 3) * IW + (t % 3)) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4*>(tb + q * NPX * 4 + off);
+                const float4 A0 = *reinterpret_cast<const float4*>(wl + ((t * 4 + q) * 2 + 0) * 16 + li * 4);
+                const float4 A1 = *reinterpret_cast<const float4*>(wl + ((t * 4 + q) * 2 + 1) * 16 + li * 4);
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.x, bb.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.x, bb.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.y, bb.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.y, bb.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.z, bb.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.z, bb.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.w, bb.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.w, bb.w, acc1, 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: bias, channels-last / texel store (cout = 8): a pixel's 8 features (+ rgb texel) from its own lane ----
+    const int oy = oy0 + row, ox = ox0 + col;
+    if (oy >= H || ox >= W) return;
+    const long long o = ((long long)n * H + oy) * W + ox;
+    *reinterpret_cast<float4*>(out + o * out_stride) =
+        make_float4(acc0[0] * scale[0] + shift[0], acc0[1] * scale[1] + shift[1], acc0[2] * scale[2] + shift[2], acc0[3] * scale[3] + shift[3]);
+    *reinterpret_cast<float4*>(out + o * out_stride + 4) =
+        make_float4(acc1[0] * scale[4] + shift[4], acc1[1] * scale[5] + shift[5], acc1[2] * scale[6] + shift[6], acc1[3] * scale[7] + shift[7]);
+    if (rgb_src != nullptr) {
+        const float* sp = rgb_src + (long long)n * 3 * H * W + (long long)oy * W + ox;
+        *reinterpret_cast<float4*>(out + o * out_stride + 8) =
+            make_float4(sp[0] * 0.5f + 0.5f, sp[(long long)H * W] * 0.5f + 0.5f, sp[2LL * H * W] * 0.5f + 0.5f, 0.f);
+    }
+}
+
+#ifndef ENERF_SMOOTH0_B4
+#define ENERF_SMOOTH0_B4 1
+#endif
 void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1pre, const float* lat_w, const float* lat_b,
                           const float* w_pq, float* out, int N, int H, int W, hipStream_t st) {
     const int out_stride = L.out_stride > 0 ? L.out_stride : 8;
+    if (ENERF_SMOOTH0_B4 && w_pq != nullptr) {                         // default: batched-4x4 convolution, 8x32 tiles
+        const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
+        const size_t shmem = (size_t)(340 * 8 + 140 * 16 + 4 * 340 * 4 + 288 + 9 * 4 * 32) * sizeof(float);
+        ENERF_LAUNCH(k_smooth0_b4, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, L.w, L.scale, L.shift, c0, f1pre, lat_w,
+                     lat_b, out, L.rgb_src, out_stride, N, H, W, tiles_y, tiles_x);
+        return;
+    }
     if (w_pq != nullptr) {                                             // tap-packed 8x28 tiles (nullptr: plain 8x32)
         const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 28);
         const size_t shmem = (size_t)(300 * 8 + 140 * 16 + 300 * 20 + 288) * sizeof(float);
