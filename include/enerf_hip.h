@@ -43,7 +43,7 @@ typedef struct {
     int conv3d_pk8;                  /* tap-packed Cout=8 kernel: 0 = where it is faster alone (Cin=16, big heads),
                                         1 = never, 2 = every Cout=8(+1) layer (fewest MFMAs: throughput mode) */
     int featnet_unfused;             /* 1: one launch per FeatureNet layer (no conv0/toplayer/lat0 fusions) */
-    int featnet_smooth0_plain;       /* 1: plain 8x32 tiling in the fused smooth0 kernel instead of tap packing */
+    int featnet_smooth0_plain;       /* 1: the 16x16x4-MFMA form of the fused smooth0 kernel instead of the batched-4x4 one */
     int conv3d_b4;                   /* batched 4x4x1-MFMA kernel for the Cout=8(+1) stride-1 3-D layers (conv0, fused heads):
                                         0 = on (default), 1 = never (falls back to the tap-packed / plain kernels) */
     int single_stream;               /* enerf_forward: 1 = every kernel of the frame on the caller's stream, in order.
