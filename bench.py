@@ -16,6 +16,10 @@ Protocol of ``value`` (SURVEY.md §8d = the reference's run.py:62-76): for each 
 (frame f -> rank f mod G, no data-path collective: scaling = weak; enerf_amd/frame_parallel.py).  Extra keys, never
 ``value``: ``sequential_fps`` (same frames without the per-frame sync), ``pipelined_fps`` (frames in flight on several
 HIP streams with the throughput kernel options), ``sustained`` (>= 2000 frames).  Rank 0 prints ONE JSON line.
+
+``--gpus N`` with N > 1 and no ``WORLD_SIZE`` in the environment (a plain ``python bench.py --gpus 8``) re-executes itself
+under ``torch.distributed.run`` with N ranks on 127.0.0.1; a line whose ``n_gpus`` differs from ``--gpus`` is never printed.
+The timed frames rotate over ``--batches`` (default 4) distinct seeded batches, all resident in HBM before the timed region.
 """
 from __future__ import annotations
 
@@ -81,9 +85,13 @@ def cost_reg_gflop(C, full, D, h, w):
     return f / 1e9
 
 
-def make_workload(name, rank):
+def make_workload(name, seed):
     from enerf_amd.config import EnerfConfig
     from enerf_amd.synth import make_batch, make_lego_batch, make_zju_batch
+    rank = seed
+    if name == "tiny":                                 # launcher tests on the CPU lane emulator only (--emu)
+        cfg = EnerfConfig().with_cas(volume_planes=(8, 8), render_if=(False, True))
+        return cfg, make_batch(32, 64, 3, cfg, seed=rank, textured=True), False, "32x64 launcher-test frame (CPU lane emulator)"
     if name == "dtu":
         cfg = EnerfConfig.dtu_eval()
         return cfg, make_batch(512, 640, 3, cfg, seed=rank, textured=True), False, \
@@ -199,46 +207,90 @@ def main():
     ap.add_argument("--train-eager", action="store_true", help="--train: enqueue every step eagerly instead of one graph replay")
     ap.add_argument("--feature-backend", choices=["hip", "torch"], default="hip",
                     help="FeatureNet on the HIP matrix-core path (default) or in PyTorch-ROCm/MIOpen (north_star's split)")
+    ap.add_argument("--batches", type=int, default=4,
+                    help="distinct seeded input batches the timed frames rotate over (all uploaded before the timed region)")
+    ap.add_argument("--emu", action="store_true",
+                    help="launcher/CI check WITHOUT a GPU: run the same bench flow on the CPU lane emulator of the kernel "
+                         "sources (tests/emu) over gloo with a 32x64 frame; the numbers mean nothing")
     args = ap.parse_args()
+
+    # ---- N > 1 without a launcher: become one.  `python bench.py --gpus 8` must not silently measure one GPU. ----
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        if not args.emu and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible: refusing to "
+                             f"report an n_gpus={args.gpus} line")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}: refusing to print a line whose n_gpus is not --gpus")
+    emu_lib = None
+    if args.emu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from emu_lib import emu_lib as _emu
+        emu_lib = _emu()
+        args.workload, args.no_stages, args.no_cpu_baseline = "tiny", True, True
+        os.environ.setdefault("ENERF_EMU_THREADS", "2")
+        torch.set_num_threads(1)
+        dev = torch.device("cpu")
+        device_sync = lambda: None
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        device_sync = torch.cuda.synchronize
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL
+        if args.emu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL
 
     from __graft_entry__ import _seeded_network
     from enerf_amd.frame_parallel import render_sharded
 
     if args.train:
+        if args.emu:
+            raise SystemExit("--train has no --emu mode (tests/test_training.py covers the 2-rank gloo DDP step)")
         return train_bench(args, rank, world, dev, dist)
+    nb = max(1, args.batches)
     cfg, batch_np, human, workload = make_workload(args.workload, rank)
     cas = cfg.cas
-    net = _seeded_network(cfg, dev, human=human, feature_backend=args.feature_backend)
+    net = _seeded_network(cfg, dev, human=human, feature_backend=args.feature_backend, lib=emu_lib)
     _, S, _, H, W = batch_np["src_inps"].shape
     batch = {k: torch.from_numpy(v).to(dev) for k, v in batch_np.items()}
+    # the timed frames rotate over nb distinct batches (seed = rank + 1000*j), all resident before the timed region: a frame
+    # never finds its own inputs / rays of the previous frame in MALL or L2
+    batches = [batch] + [{k: torch.from_numpy(v).to(dev) for k, v in make_workload(args.workload, rank + 1000 * j)[1].items()}
+                         for j in range(1, nb)]
     last = cas.num - 1
     if args.single_stream:
         from enerf_amd.lib import Options
         net.options = Options(single_stream=1)
 
+    frame_no = [0]
     if args.graph:
         from enerf_amd.graph import GraphedFrame
         net.static_shapes = True
         frame = GraphedFrame(net, batch)
 
         def step():
-            return frame(batch)
+            frame_no[0] += 1
+            return frame(batches[frame_no[0] % nb])
     else:
         def step():
-            return net(batch)
+            frame_no[0] += 1
+            return net(batches[frame_no[0] % nb])
 
     out = None
 
@@ -246,15 +298,22 @@ def main():
         nonlocal out
         out = step()
         if not args.no_sync_per_frame:
-            torch.cuda.synchronize()
+            device_sync()
         return None
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    device_sync()
     # frame f -> rank f mod world: every rank renders `steps` frames; barrier + sync both sides, MAX over ranks
-    _, fps, elapsed = render_sharded(timed_frame, args.steps * world, rank, world, sync=torch.cuda.synchronize)
+    t_rank = time.perf_counter()
+    _, fps, elapsed = render_sharded(timed_frame, args.steps * world, rank, world, sync=device_sync)
+    t_rank = time.perf_counter() - t_rank
     assert bool(torch.isfinite(out[f"rgb_level{last}"]).all()), "non-finite render"
+    per_rank = [args.steps / t_rank]
+    if dist is not None:                                # every rank's own rate next to the aggregate (reporting only)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
 
     result = None
     if rank == 0:
@@ -263,8 +322,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": (fps / BASELINE_FPS_RTX3090) if args.workload == "dtu" else None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "feature_net": args.feature_backend, "hip_graph": bool(args.graph),
+            "dtype": "f32", "data": "synthetic" if not args.emu else "synthetic (CPU lane emulator: launcher check, not a measurement)",
+            "per_rank_fps": [round(v, 2) for v in per_rank],
+            "config": {"workload": workload, "distinct_batches": nb, "feature_net": args.feature_backend, "hip_graph": bool(args.graph),
                        "single_stream": bool(args.single_stream),
                        "protocol": "per-frame synchronize (run.py:62-76), one frame at a time, default kernel options "
                                    "(inside the frame the FeatureNet's top-down half runs on the library's side stream)"
@@ -402,11 +462,18 @@ def main():
         dom = max((k for k in sr if k.startswith("render_")), key=lambda k: stages[k], default=None)
         if dom is not None:
             d = sr[dom]
-            traffic, pmc_note, busy = None, None, None
-            pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_render_{args.workload}.json")   # separate rocprofv3 --pmc passes
-            if os.path.exists(pmc_path):
-                pmc = json.load(open(pmc_path))
-                traffic, pmc_note, busy = pmc.get("hbm_bytes_per_launch"), pmc.get("source"), pmc.get("mfma_busy_frac")
+            # PMC evidence (separate rocprofv3 --pmc passes, tools/collect_profiles.sh) is replayed from profiles/ and tied to
+            # the kernel sources it was collected on: a kernel edit without a PMC refresh shows up as pmc_stale = true
+            from enerf_amd.build import source_digest
+            traffic, pmc_note, busy, pmc_digest = None, None, None, None
+            lib_digest = source_digest()
+            for cand in (f"pmc_render_{args.workload}.json", f"r02_pmc_render_{args.workload}.json"):
+                pmc_path = os.path.join(ROOT, "profiles", cand)
+                if os.path.exists(pmc_path):
+                    pmc = json.load(open(pmc_path))
+                    traffic, pmc_note, busy = pmc.get("hbm_bytes_per_launch"), pmc.get("source"), pmc.get("mfma_busy_frac")
+                    pmc_digest = pmc.get("source_digest")
+                    break
             result["roofline"] = {
                 "kernel": d["kernel"] + f" (level-{dom[-1]} fused render: sample placement + gathers + Agg/NeRF MLP + compositing)",
                 "bound": "mfma", "achieved": d["achieved"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -418,7 +485,8 @@ def main():
                 "note": f"achieved = {d['mfma_tiles_per_16_samples']} fp32 16x16x4 MFMA tiles per 16 samples (the MLP with the "
                         "view-independent halves of global_fc/color.0 evaluated once per point) x samples / launch time",
                 "traffic_measured_live": False, "mfma_pipe_busy_frac_pmc": busy, "pmc_measured_live": False,
-                "traffic_source": pmc_note}
+                "traffic_source": pmc_note, "library_source_digest": lib_digest, "pmc_source_digest": pmc_digest,
+                "pmc_stale": pmc_digest != lib_digest}
 
     # ---- CPU baseline: the oracle (torch CPU restatement of the reference) on this box's host cores + parity ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -442,6 +510,16 @@ def main():
                                   "sample": f"{n_frames} full {H}x{W} {S}-view frame(s) of this workload through "
                                             f"oracle/enerf_oracle.py (torch CPU, {ncores} of {os.cpu_count()} host threads), "
                                             "first small frame untimed"}
+        if args.workload == "dtu":
+            # BASELINE config 1 (configs[0]: the reference's own CPU-runnable case, render_if True,True, planes 48,8 — the
+            # configuration BASELINE.md's 0.122 FPS / 8 cores is quoted on): one frame of the same port, same threads
+            cfg1 = cfg.with_cas(render_if=(True, True))
+            with torch.no_grad():
+                t0 = time.perf_counter()
+                O.forward(cfg1, sd, cb)
+                c1 = time.perf_counter() - t0
+            result["cpu_baseline_config1"] = {"value": 1.0 / c1, "unit": "frames/s", "cores": ncores, "kind": "port",
+                                              "sample": "1 frame, render_if True,True, volume_planes 48,8 (BASELINE configs[0])"}
         net.static_shapes = False
         o = net(batch)
         key = f"rgb_level{last}"

@@ -162,6 +162,98 @@ def run_case(name: str) -> None:
           f"max {rgb.max():.4f}; keys {sorted(out)}")
 
 
+# BASELINE configs 2, 3, 4 at their REAL shapes (the frames tests/test_gpu_parity.py::test_full_size_* and bench.py render).
+# The outputs are too large to commit whole, so each tensor is stored as: every STRIDE-th row (ray / pixel), its float64
+# L2 norm, sum and max|.|, and a 64-bit checksum of the reference's raw bytes (regeneration check).  < 1 MB per case.
+FULL_STRIDE = 97
+FULL_CASES = {
+    "dtu_full": dict(H=512, W=640, S=3, planes=(48, 8), render_if=(False, True), seed=0, textured=True, human=False),
+    "lego_full": dict(H=800, W=800, S=4, planes=(64, 8), render_if=(True, True), seed=5, human=False, rig="lego",
+                      cfg_file="configs/enerf/nerf/lego.yaml"),
+    "zju_full": dict(H=1024, W=1024, S=4, planes=(32, 8), render_if=(False, True), seed=6, human=True, rig="zju",
+                     cfg_file="configs/enerf/zjumocap_eval.yaml"),
+}
+
+
+def sparse_digest(prefix: str, t, save: dict) -> None:
+    """rows[::FULL_STRIDE] of the tensor viewed as (rows, last_dim) + whole-tensor statistics."""
+    import zlib
+    a = np.ascontiguousarray(t.detach().numpy() if hasattr(t, "detach") else t)
+    rows = a.reshape(-1, a.shape[-1]) if a.ndim >= 2 and a.shape[-1] <= 16 else a.reshape(-1, 1)
+    save[f"{prefix}/rows"] = rows[::FULL_STRIDE].copy()
+    save[f"{prefix}/shape"] = np.array(a.shape, np.int64)
+    f = a.astype(np.float64).reshape(-1)
+    save[f"{prefix}/norm"] = np.array(np.sqrt((f * f).sum()))
+    save[f"{prefix}/sum"] = np.array(f.sum())
+    save[f"{prefix}/absmax"] = np.array(np.abs(f).max() if f.size else 0.0)
+    raw = a.tobytes()
+    save[f"{prefix}/crc64"] = np.array([zlib.crc32(raw), zlib.adler32(raw)], np.uint32)   # two 32-bit halves
+
+
+def run_full_case(name: str) -> None:
+    """One full-size frame through the UNMODIFIED reference (network.py:76-113 / network_human.py:69-119) on CPU."""
+    import time
+    from oracle.ref_loader import load_reference
+    from enerf_amd.config import EnerfConfig
+    from enerf_amd.synth import make_batch, make_lego_batch, make_zju_batch
+
+    c = FULL_CASES[name]
+    if "cfg_file" in c:
+        cfg, ref_network = load_reference(c["cfg_file"], [])
+        assert tuple(cfg.enerf.cas_config.volume_planes) == c["planes"]
+        assert tuple(cfg.enerf.cas_config.render_if) == c["render_if"]
+    else:
+        opts = ["enerf.cas_config.volume_planes", ",".join(map(str, c["planes"])),
+                "enerf.cas_config.render_if", ",".join(map(str, c["render_if"]))]
+        cfg, ref_network = load_reference("configs/enerf/dtu_pretrain.yaml", opts)
+    if c["human"]:
+        from lib.networks.enerf import network_human as ref_network  # noqa: F811
+    from lib.networks.enerf import utils as ref_utils
+    torch.manual_seed(0)
+    torch.set_num_threads(1)                       # fixed summation order (SURVEY.md §8c)
+    net = ref_network.Network().eval()
+    sd = seeded_state_dict(net)
+    net.load_state_dict(sd)
+    wnp = np.load(os.path.join(GOLDEN, "weights_seed0.npz"))
+    assert all(np.array_equal(wnp[k], v.numpy()) for k, v in sd.items() if k in wnp.files), "weights differ from weights_seed0"
+    ecfg = EnerfConfig.from_yacs(cfg)
+    if c.get("rig") == "lego":
+        batch_np = make_lego_batch(c["H"], c["W"], c["S"], ecfg, seed=c["seed"])
+    elif c.get("rig") == "zju":
+        batch_np = make_zju_batch(c["H"], c["W"], c["S"], ecfg, seed=c["seed"])
+    else:
+        batch_np = make_batch(c["H"], c["W"], c["S"], ecfg, seed=c["seed"], textured=c["textured"])
+    batch = {k: torch.from_numpy(v) for k, v in batch_np.items()}
+    rec, level = {}, {"i": -1}
+    orig_vol, orig_reg = ref_utils.build_feature_volume, ref_utils.depth_regression
+
+    def vol(*a, **k):
+        level["i"] = k["level"]
+        out = orig_vol(*a, **k)
+        rec[f"nf_{level['i']}"] = out[2]
+        return out
+
+    def reg(*a, **k):
+        out = orig_reg(*a, **k)
+        rec[f"depth_{level['i']}"], rec[f"std_{level['i']}"] = out
+        return out
+    ref_utils.build_feature_volume, ref_utils.depth_regression = vol, reg
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = net(batch)
+    dt = time.perf_counter() - t0
+    save = {}
+    for k, v in out.items():
+        sparse_digest(f"out/{k}", v, save)
+    for k, v in rec.items():
+        sparse_digest(f"mid/{k}", v.reshape(-1, 1), save)
+    save["meta/torch_version"] = np.array(torch.__version__)
+    save["meta/stride"] = np.array(FULL_STRIDE)
+    save["meta/reference_cpu_seconds_1thread"] = np.array(dt)
+    np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **save)
+    print(f"[golden] {name}: {len(save)} arrays, reference forward {dt:.1f} s on 1 thread; keys {sorted(out)}")
+
+
 TRAIN_CASE = dict(H=32, W=64, S=3, planes=(8, 8), render_if=(True, True), seed=7, loss_weight=(0.1, 1.0))
 
 
@@ -232,13 +324,16 @@ def main() -> None:
     if a.case == "train_tiny":
         run_train_case()
         return
+    if a.case in FULL_CASES:
+        run_full_case(a.case)
+        return
     if a.case:
         run_case(a.case)
         return
     wpath = os.path.join(GOLDEN, "weights_seed0.npz")
     if os.path.exists(wpath):
         os.remove(wpath)
-    for name in list(CASES) + ["train_tiny"]:
+    for name in list(CASES) + ["train_tiny"] + list(FULL_CASES):
         subprocess.run([sys.executable, os.path.abspath(__file__), "--case", name], check=True, cwd=ROOT)
 
 

@@ -11,7 +11,7 @@ import torch
 from enerf_amd.config import EnerfConfig
 from enerf_amd.synth import make_batch
 from oracle import enerf_oracle as O
-from golden_cases import CASES, case_batch, case_config, load_golden, load_weights
+from golden_cases import CASES, case_batch, case_config, check_sparse_golden, load_golden, load_weights
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU (run with -m gpu on the MI355X box)")]
@@ -140,6 +140,8 @@ def test_full_size_dtu_eval_vs_oracle_and_properties():
     src = torch.from_numpy(b["src_inps"]) * 0.5 + 0.5                                # rgb is a convex blend x alpha
     assert rgb.min() >= -1e-5 and rgb.max() <= float(src.max()) + 1e-5
     assert d.min() >= 425.0 - 1e-2 and d.max() <= 905.0 + 1e-2                       # inside [near, far]
+    # pinned to the REFERENCE itself at this size: sparse digest of the unmodified reference's outputs (every 97th ray + norms)
+    check_sparse_golden("dtu_full", out, REL_TOL)
     with torch.no_grad():
         ref = O.forward(cfg, load_weights(), batch)
     for k in ref:
@@ -211,9 +213,11 @@ def test_frame_pipeline_two_streams_matches_sequential():
     assert net.options is None                       # the pipeline's choices never leak into the network
 
 
-def _full_size_check(cfg, b, human, keys_psnr):
-    """HIP path vs the oracle on one full-size frame: every output within REL_TOL, PSNR(ours, oracle) > 70 dB, and the
-    north_star bound (PSNR against a common pseudo ground truth moves by < 1e-3 dB)."""
+def _full_size_check(cfg, b, human, keys_psnr, golden):
+    """HIP path on one full-size frame vs (i) the sparse digest of the unmodified REFERENCE's outputs at this size
+    (tests/golden/<golden>.npz, oracle/make_golden.py::FULL_CASES) and (ii) the oracle on every element: every output within
+    REL_TOL, PSNR(ours, oracle) > 70 dB, and the north_star bound (PSNR against a common pseudo ground truth moves by
+    < 1e-3 dB)."""
     batch = {k: torch.from_numpy(v) for k, v in b.items()}
     net = _net(cfg, human)
     out = net(_to(batch))
@@ -221,6 +225,7 @@ def _full_size_check(cfg, b, human, keys_psnr):
     torch.cuda.synchronize()
     for k in out:                                      # run-to-run determinism
         assert torch.equal(out[k], out2[k]), k
+    check_sparse_golden(golden, out, REL_TOL)
     with torch.no_grad():
         ref = O.forward(cfg, load_weights(), batch)
     assert sorted(out) == sorted(ref)
@@ -242,7 +247,7 @@ def test_full_size_lego_800x800_4views_both_levels_vs_oracle():
     k_render_rays<9,4,2> (level 0: C=32, 8 samples) and <3,4,*> (level 1) on 40,000 + 640,000 rays."""
     from enerf_amd.synth import make_lego_batch
     cfg = EnerfConfig()
-    out, ref = _full_size_check(cfg, make_lego_batch(800, 800, 4, cfg, seed=5), False, ("rgb_level0", "rgb_level1"))
+    out, ref = _full_size_check(cfg, make_lego_batch(800, 800, 4, cfg, seed=5), False, ("rgb_level0", "rgb_level1"), "lego_full")
     assert out["rgb_level1"].shape == (1, 640000, 3) and out["rgb_level0"].shape == (1, 40000, 3)
     d = out["depth_level1"].cpu()
     assert d.min() >= 2.5 - 1e-4 and d.max() <= 5.5 + 1e-4
@@ -255,7 +260,7 @@ def test_full_size_zju_1024_4views_masked_vs_oracle():
     from enerf_amd.synth import make_zju_batch
     cfg = EnerfConfig().with_cas(volume_planes=(32, 8), render_if=(False, True))
     b = make_zju_batch(1024, 1024, 4, cfg, seed=6)
-    out, ref = _full_size_check(cfg, b, True, ("rgb_level1",))
+    out, ref = _full_size_check(cfg, b, True, ("rgb_level1",), "zju_full")
     m = torch.from_numpy(b["mask_at_box"]).bool().reshape(-1)
     assert out["rgb_level1"].shape == (1, 1024 * 1024, 3)
     assert float(out["rgb_level1"][0].cpu()[~m].abs().max()) == 0.0              # outside the box: exact zeros

@@ -3,6 +3,8 @@
 reports as roofline.traffic).  HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes): the gfx950 FETCH_SIZE
 correction of MI355X_MICROARCH.md "HBM"; WRITE_SIZE taken as reported."""
 import collections, csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from enerf_amd.build import source_digest      # the digest of the kernel sources these counters were collected on
 
 d, tag = sys.argv[1], sys.argv[2]
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -38,7 +40,8 @@ for r in renders[:1]:
               "fetch_size_kb": r.get("FETCH_SIZE"), "write_size_kb": r.get("WRITE_SIZE"),
               "hbm_bytes_per_launch": r["hbm_bytes_corrected"],
               "correction": "gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md HBM section), WRITE_SIZE as reported",
-              "mfma_busy_frac": r["mfma_busy_frac"]}
+              "mfma_busy_frac": r["mfma_busy_frac"], "wait_inst_any_frac": r.get("SQ_WAIT_INST_ANY_frac"),
+              "source_digest": source_digest()}
         json.dump(js, open(os.path.join(d, f"{tag}_pmc_render.json"), "w"), indent=1)
         print(js)
 print("wrote", out)
