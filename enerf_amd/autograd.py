@@ -76,7 +76,9 @@ class CompositeFn(torch.autograd.Function):
         B, N, Ns = ctx.shape
         g_raw, g_z = ctx.lib.composite_bwd(raw2, z2, _c(g_rgb).reshape(B * N, 3), _c(g_depth).reshape(B * N),
                                            _c(g_weights).reshape(B * N, Ns))
-        return None, g_raw.view(B, N, Ns, 4), g_z.view(B, N, Ns), None
+        # utils.py:595: depth_map = sum(weights * z_vals.detach()) — the sample depths never receive a gradient from the
+        # composited depth (k_composite_bwd's g_z is the un-detached derivative: dropped here)
+        return None, g_raw.view(B, N, Ns, 4), None, None
 
 
 def gather_cameras(batch, render_scale: float):
@@ -210,11 +212,13 @@ class _Block:
         invstd = torch.rsqrt(var + bn.eps)
         scale = (bn.weight.detach().double() * invstd).float()
         shift = (bn.bias.detach().double() - mean * bn.weight.detach().double() * invstd).float()
-        with torch.no_grad():                                                        # running statistics, like nn.BatchNorm3d
-            mom = bn.momentum if bn.momentum is not None else 0.1
-            bn.running_mean.mul_(1 - mom).add_(mean.float(), alpha=mom)
-            bn.running_var.mul_(1 - mom).add_((var * (n / max(n - 1.0, 1.0))).float(), alpha=mom)
-            bn.num_batches_tracked.add_(1)
+        if bn.track_running_stats and bn.running_mean is not None:
+            with torch.no_grad():                                                    # running statistics, like nn.BatchNorm3d
+                bn.num_batches_tracked.add_(1)
+                # momentum=None: cumulative moving average, factor 1/num_batches_tracked (torch.nn.modules.batchnorm)
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1 - mom).add_(mean.float(), alpha=mom)
+                bn.running_var.mul_(1 - mom).add_((var * (n / max(n - 1.0, 1.0))).float(), alpha=mom)
         self.z, self.n, self.mean, self.invstd, self.scale, self.shift = z, n, mean, invstd, scale, shift
         return lib.channel_affine(z, scale, shift, residual=residual, relu=self.relu)
 

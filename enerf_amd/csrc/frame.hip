@@ -226,7 +226,7 @@ int make_plan(const enerf_frame_args_t* a, FramePlan* P) {
 // =====================================================================================================================
 #ifndef ENERF_EMU
 namespace {
-struct SideLane { hipStream_t stream, rstream; hipEvent_t trunk, l1, l2, fork, done; };
+struct SideLane { hipStream_t stream, rstream; hipEvent_t trunk, l1, l2, fork, done; std::mutex busy; };
 SideLane* side_lane(hipStream_t main) {
     static std::mutex mu;
     static std::map<std::pair<int, hipStream_t>, SideLane*> lanes;
@@ -313,6 +313,10 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
     int joined[3] = {1, 1, 1};           // feature level l is visible to the caller's stream
 #ifndef ENERF_EMU
     SideLane* lane = nullptr;
+    // the lane's events are shared by every frame enqueued on this caller stream: two host threads calling enerf_forward on
+    // the SAME stream would interleave hipEventRecord / hipStreamWaitEvent pairs (a wait could bind to the other call's
+    // record).  The enqueue is serialised per lane; the lock is held until this call has enqueued its last join.
+    std::unique_lock<std::mutex> lane_busy;
 #endif
     auto need_level = [&](int l) {       // call before the first consumer of f[l] on the caller's stream
 #ifndef ENERF_EMU
@@ -337,6 +341,7 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
 #ifndef ENERF_EMU
         if (!(a->options && a->options->single_stream)) lane = side_lane(st);
         if (lane != nullptr) {
+            lane_busy = std::unique_lock<std::mutex>(lane->busy);
             rc = fstage(ENERF_FEAT_TRUNK, stream);
             if (rc != ENERF_OK) return rc;
             hipEventRecord(lane->trunk, st);

@@ -15,6 +15,14 @@ from .config import EnerfConfig
 from .lib import EnerfLib, get_lib, stats_from_acc
 
 
+def nearest_resize_index(src: int, dst: int, device) -> torch.Tensor:
+    """Source index of every destination pixel along one axis under cv2.resize(..., interpolation=cv2.INTER_NEAREST):
+    ``min(floor(d * (1 / (dst / src))), src - 1)`` in double precision (OpenCV resizeNN)."""
+    inv = 1.0 / (float(dst) / float(src))
+    idx = torch.floor(torch.arange(dst, dtype=torch.float64) * inv).to(torch.int64).clamp_(max=src - 1)
+    return idx.to(device)
+
+
 class DeviceEvaluator:
     def __init__(self, cfg: EnerfConfig, eval_center: bool = False, eval_depth: bool = False,
                  lib: Optional[EnerfLib] = None):
@@ -58,6 +66,18 @@ class DeviceEvaluator:
                     self.psnrs.append(st["psnr"])
                     if "abs" in st:
                         self.abs.append(st["abs"]); self.acc_2.append(st["acc_2"]); self.acc_10.append(st["acc_10"])
+                    mvs_key = f"depth_mvs_level{i}"
+                    if depth_args and mvs_key in output:
+                        # :91-103 — the cost-volume depth map against the ground truth resized to ITS resolution with
+                        # cv2.INTER_NEAREST (src index = min(floor(dst * src/dst), src-1)), gathered on the device
+                        mvs = output[mvs_key][b]
+                        gt_map = batch["tar_dpt"][b].reshape(h, w)
+                        ys = nearest_resize_index(h, mvs.shape[0], mvs.device)
+                        xs = nearest_resize_index(w, mvs.shape[1], mvs.device)
+                        mvs_gt = gt_map.index_select(0, ys).index_select(1, xs).contiguous()
+                        ms = self.lib.depth_stats(mvs.contiguous(), mvs_gt)
+                        if ms:
+                            self.mvs_abs.append(ms["abs"]); self.mvs_acc_2.append(ms["acc_2"]); self.mvs_acc_10.append(ms["acc_10"])
 
     def summarize(self) -> dict:
         mean = lambda v: sum(v) / len(v) if v else float("nan")
@@ -65,5 +85,7 @@ class DeviceEvaluator:
         ret.update({f"psnr_level{i}": mean(v) for i, v in self.level_psnrs.items()})
         if self.abs:
             ret.update(abs=mean(self.abs), acc_2=mean(self.acc_2), acc_10=mean(self.acc_10))
+        if self.mvs_abs:                 # the reference accumulates these (:101-103) but never prints them; reported here
+            ret.update(mvs_abs=mean(self.mvs_abs), mvs_acc_2=mean(self.mvs_acc_2), mvs_acc_10=mean(self.mvs_acc_10))
         self.reset()
         return ret

@@ -561,7 +561,9 @@ class EnerfLib:
         if not bias:
             return gw
         # the layer's bias gradient = per-channel sums of ``a`` (= d y), from the channels-last copy made above
-        gb = self.channel_sums(a_cl, a_cl)[0].float() if Ca % 4 == 0 else a.sum(dim=[0] + list(range(2, a.dim())))
+        # enerf_channel_sums handles C <= 64 with C/4 dividing 256 (capi.hip); any other width takes the torch reduction
+        fits = Ca % 4 == 0 and Ca <= 64 and 256 % (Ca // 4) == 0
+        gb = self.channel_sums(a_cl, a_cl)[0].float() if fits else a.sum(dim=[0] + list(range(2, a.dim())))
         return gw, gb
 
     def composite(self, raw, z, white_bkgd=False):
@@ -677,6 +679,18 @@ class EnerfLib:
         if not sync:
             return acc
         return stats_from_acc(acc.cpu().tolist())
+
+
+    def depth_stats(self, pred_depth, gt_depth, sync=True):
+        """The depth statistics alone (evaluators/enerf.py:96-103: abs / acc_2 / acc_10 over gt != 0): enerf_eval_stats with
+        no rgb.  Returns dict(abs, acc_2, acc_10) — empty when no pixel has ground truth."""
+        acc = torch.empty((6,), dtype=torch.float64, device=pred_depth.device)
+        self._check(self.dll.enerf_eval_stats(None, None, None, 0, 0, 0, 0, 0, 0, _ptr(pred_depth), _ptr(gt_depth),
+                                              pred_depth.numel(), acc.data_ptr(), self.stream_of(pred_depth)), "eval_stats")
+        if not sync:
+            return acc
+        a = acc.cpu().tolist()
+        return dict(abs=a[2] / a[3], acc_2=a[4] / a[3], acc_10=a[5] / a[3]) if a[3] > 0 else {}
 
 
 def stats_from_acc(a) -> dict:

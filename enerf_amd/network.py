@@ -6,7 +6,9 @@ Same constructor role, same ``forward(batch) -> dict`` / ``render_rays(rays, **k
 unchanged (INTEGRATION.md shows the 6-line module a maintainer drops into ``lib/networks/``).
 
 What runs where:
-  * ``feature_net`` (2-D FPN, feature_net.py:4-36)  — PyTorch-ROCm, as BASELINE.json's north_star asks;
+  * ``feature_net`` (2-D FPN, feature_net.py:4-36)  — ``feature_backend="hip"`` (default): the library's MFMA convolution
+    kernels (csrc/conv2d.hip) inside the same ``enerf_forward`` call; ``feature_backend="torch"``: PyTorch-ROCm/MIOpen,
+    the split BASELINE.json's north_star describes, NCHW maps handed over through the C ABI (kept for A/B);
   * everything else (network.py:80-112)            — hand-written HIP kernels through the C ABI
     (``enerf_amd/lib.py`` -> ``libenerf_hip.so``).  The ``cost_reg_*`` / ``nerf_*`` sub-modules here only
     OWN the parameters (so checkpoints, ``.cuda()``, ``SyncBatchNorm.convert_sync_batchnorm`` keep

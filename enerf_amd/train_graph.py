@@ -55,7 +55,13 @@ class GraphedTrainStep:
 
     ``loss_fn(outputs, batch) -> scalar``.  ``optimizer`` must be capture-safe (``torch.optim.Adam(..., capturable=True)``).
     Every batch passed later must have the tensors (keys, shapes, dtypes) of ``example_batch``.  The returned loss tensor is
-    the graph's own output buffer: read it (``.item()``) before the next call."""
+    the graph's own output buffer: read it (``.item()``) before the next call.
+
+    Construction is side-effect free on the model: the warm-up, the capture and the verification steps DO run optimizer
+    steps on ``example_batch`` (optimizer state must exist before the capture), but parameters, buffers (BatchNorm running
+    statistics, ``num_batches_tracked``) are snapshotted first and restored in place afterwards, and the optimizer's state
+    tensors are zeroed in place (step 0, zero moments: exactly a fresh Adam/AdamW; the graph keeps their addresses).  An
+    optimizer that already carried state before construction gets that state back instead."""
 
     def __init__(self, net, optimizer, loss_fn: Callable, example_batch: Dict[str, torch.Tensor], clip_value: float = 40.0,
                  warmup: int = 3, verify: bool = True, verify_steps: int = 4):
@@ -68,6 +74,8 @@ class GraphedTrainStep:
         self.extra = {k: v for k, v in example_batch.items() if not torch.is_tensor(v)}
         self.tables = {k: v.clone() for k, v in camera_tables(net.cfg.cas, self.static).items()}
         self._params = [p for p in net.parameters() if p.requires_grad]
+        pristine_net = [(t, t.clone()) for t in net.state_dict().values()]
+        pristine_opt = {id(t): t.clone() for st in optimizer.state.values() for t in st.values() if torch.is_tensor(t)}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up on a side stream: lazy initialisation, caches, allocator
@@ -82,6 +90,14 @@ class GraphedTrainStep:
         net.invalidate_packed()
         if verify:
             self._verify(verify_steps)
+        # undo the training the construction did (warm-up + capture + verification steps on example_batch)
+        with torch.no_grad():
+            self._restore(pristine_net)
+            for st in optimizer.state.values():
+                for t in st.values():
+                    if torch.is_tensor(t):
+                        t.copy_(pristine_opt[id(t)]) if id(t) in pristine_opt else t.zero_()
+        net.invalidate_packed()
 
     # ---- replay-vs-eager check (see MEMSET NODES above) ----
     def _snapshot(self):

@@ -272,7 +272,7 @@ def raw2outputs(raw, z, white_bkgd=False):
     w = alpha * T
     rgb = torch.sum(w[..., None] * raw[..., :3], -2)
     w = F.softmax(w, -1)
-    depth = torch.sum(w * z, -1)
+    depth = torch.sum(w * z.detach(), -1)             # utils.py:595: z_vals.detach()
     if white_bkgd:
         rgb = rgb + (1.0 - torch.sum(w, -1)[..., None])
     return {"rgb": rgb, "depth": depth, "weights": w}
@@ -360,7 +360,11 @@ def forward_train(net, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor
         dv, near_far = depth_values(cas, batch, i, cas.volume_planes[i], depth, std, near_far)
         P = tables[f"proj_{i}"]
         vol = FeatureVolumeFn.apply(lib, feats[f"level_{i}"], P, dv) if lib is not None else feature_volume(feats[f"level_{i}"], P, dv)
-        if lib is not None and getattr(net, "hip_cost_reg_train", True):
+        reg = getattr(net, f"cost_reg_{i}")
+        # the HIP training blocks normalise with BATCH statistics: only when every BatchNorm of the net is in training mode;
+        # frozen-BN fine-tuning (bn.eval()) goes through the modules, which honour running statistics
+        bn_batch = all(m.training for m in reg.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm))
+        if lib is not None and getattr(net, "hip_cost_reg_train", True) and bn_batch:
             from .autograd import cost_reg_train
             feat3d, prob = cost_reg_train(lib, getattr(net, f"cost_reg_{i}"), vol)     # conv/BN forward + backward on HIP kernels
         else:

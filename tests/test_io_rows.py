@@ -132,6 +132,25 @@ def test_device_evaluator_emulated():
     mse = np.mean((out["rgb_level1"][0].numpy()[m].astype(np.float64) - batch["rgb_1"][0].numpy()[m]) ** 2)
     assert s["psnr"] == pytest.approx(10 * np.log10(1 / mse), rel=1e-9)
     assert s["abs"] == pytest.approx(1.5, rel=1e-5) and s["acc_2"] == 1.0 and "psnr_level0" in s
+    # MVS-depth statistics (evaluators/enerf.py:91-103): depth_mvs_level1 (16x32) against tar_dpt resized to its resolution with
+    # cv2.INTER_NEAREST = rows/cols min(floor(d * src/dst), src-1) -> here every second row / column; some pixels without gt
+    gt = batch["tar_dpt"][0].clone()
+    gt[::4, ::2] = 0.0                                                 # gt == 0: excluded (:94-95)
+    batch["tar_dpt"] = gt[None]
+    ev.evaluate(out, batch)
+    s = ev.summarize()
+    mvs = out["depth_mvs_level1"][0].numpy()
+    assert mvs.shape == (16, 32)
+    g = gt.numpy()[(np.floor(np.arange(16) * (1.0 / (16 / 32)))).astype(int)][:, (np.floor(np.arange(32) * (1.0 / (32 / 64)))).astype(int)]
+    mk = g != 0.0
+    e = np.abs(mvs[mk] - g[mk])
+    assert mk.sum() == 16 * 32 // 2 + 0 or mk.sum() > 0
+    assert s["mvs_abs"] == pytest.approx(float(e.mean()), rel=1e-6)
+    assert s["mvs_acc_2"] == pytest.approx(float((e < 2).mean()), rel=1e-9)
+    assert s["mvs_acc_10"] == pytest.approx(float((e < 10).mean()), rel=1e-9)
+    from enerf_amd.evaluator import nearest_resize_index
+    assert nearest_resize_index(7, 3, "cpu").tolist() == [0, 2, 4] and nearest_resize_index(5, 5, "cpu").tolist() == [0, 1, 2, 3, 4]
+    assert nearest_resize_index(3, 7, "cpu").tolist() == [0, 0, 0, 1, 1, 2, 2]
 
 
 _needs_gpu = pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
