@@ -207,6 +207,9 @@ def main():
     ap.add_argument("--train-eager", action="store_true", help="--train: enqueue every step eagerly instead of one graph replay")
     ap.add_argument("--feature-backend", choices=["hip", "torch"], default="hip",
                     help="FeatureNet on the HIP matrix-core path (default) or in PyTorch-ROCm/MIOpen (north_star's split)")
+    ap.add_argument("--options", default="",
+                    help="A/B and profiling runs: enerf_options_t fields as 'field:value,field:value' (recorded in config.options); "
+                         "the default line is measured with all-zero options")
     ap.add_argument("--batches", type=int, default=4,
                     help="distinct seeded input batches the timed frames rotate over (all uploaded before the timed region)")
     ap.add_argument("--emu", action="store_true",
@@ -274,9 +277,12 @@ def main():
     batches = [batch] + [{k: torch.from_numpy(v).to(dev) for k, v in make_workload(args.workload, rank + 1000 * j)[1].items()}
                          for j in range(1, nb)]
     last = cas.num - 1
+    opt_fields = {k: int(v) for k, v in (f.split(":") for f in args.options.split(",") if f)}
     if args.single_stream:
+        opt_fields["single_stream"] = 1
+    if opt_fields:
         from enerf_amd.lib import Options
-        net.options = Options(single_stream=1)
+        net.options = Options(**opt_fields)
 
     frame_no = [0]
     if args.graph:
@@ -325,7 +331,7 @@ def main():
             "dtype": "f32", "data": "synthetic" if not args.emu else "synthetic (CPU lane emulator: launcher check, not a measurement)",
             "per_rank_fps": [round(v, 2) for v in per_rank],
             "config": {"workload": workload, "distinct_batches": nb, "feature_net": args.feature_backend, "hip_graph": bool(args.graph),
-                       "single_stream": bool(args.single_stream),
+                       "single_stream": bool(args.single_stream), "options": opt_fields,
                        "protocol": "per-frame synchronize (run.py:62-76), one frame at a time, default kernel options "
                                    "(inside the frame the FeatureNet's top-down half runs on the library's side stream)"
                                    if not args.no_sync_per_frame else "frames enqueued back to back on one stream",

@@ -74,9 +74,11 @@ int costreg_layers(int cin0, int full, LayerSpec* L) {
     return n;
 }
 bool layer_pk8(const LayerSpec& s) { return s.kind == kConvS1 && (s.cout == 8 || s.idx < 0); }   // conv0, fused heads
+bool layer_t2pair(const LayerSpec& s) { return s.kind == kConvT2 && s.cin == 16 && s.cout == 8; }   // conv11
 long long layer_floats(const LayerSpec& s) {
     return conv3d_packed_floats(s.cin, s.cout, s.kind) + 2 * cdiv(s.cout, 16) * 16 +
-           (layer_pk8(s) ? conv3d_pk8_packed_floats(s.cin) + conv3d_b4_packed_floats(s.cin) : 0);
+           (layer_pk8(s) ? conv3d_pk8_packed_floats(s.cin) + conv3d_b4_packed_floats(s.cin) : 0) +
+           (layer_t2pair(s) ? conv3d_t2_pair_floats() : 0);
 }
 }  // namespace
 
@@ -165,6 +167,7 @@ int enerf_cost_reg_pack(const enerf_costreg_raw_t* raw, float* packed, enerf_str
             REQUIRE(c.w && c.bn_weight && c.bn_bias && c.bn_mean && c.bn_var, "cost_reg_pack: conv%d missing", s.idx);
             launch_conv3d_pack(c.w, nullptr, s.cout, c.bn_weight, c.bn_bias, c.bn_mean, c.bn_var, 1e-5f, s.cin, s.cout,
                                s.kind, p, p + wf, p + wf + cp, (hipStream_t)stream);
+            if (layer_t2pair(s)) launch_conv3d_t2_pair_pack(p, p + wf + 2 * cp, (hipStream_t)stream);   // from the image just packed
             if (layer_pk8(s)) {
                 launch_conv3d_pk8_pack(c.w, nullptr, s.cin, p + wf + 2 * cp, (hipStream_t)stream);
                 launch_conv3d_b4_pack(c.w, nullptr, s.cin, p + wf + 2 * cp + conv3d_pk8_packed_floats(s.cin), (hipStream_t)stream);
@@ -190,6 +193,14 @@ size_t enerf_cost_reg_workspace_bytes(int full, int B, int D, int h, int w) {
 int enerf_cost_reg(const float* packed, int in_channels, int full, const float* vol, int B, int D, int h, int w,
                    float* feat, float* prob, void* workspace, size_t workspace_bytes, const enerf_options_t* options,
                    enerf_stream_t stream) {
+    return cost_reg_run(packed, in_channels, full, vol, 0, B, D, h, w, feat, prob, workspace, workspace_bytes, options,
+                        (hipStream_t)stream);
+}
+}  // extern "C"
+namespace enerf {
+int cost_reg_run(const float* packed, int in_channels, int full, const float* vol, int vol_planar, int B, int D, int h, int w,
+                 float* feat, float* prob, void* workspace, size_t workspace_bytes, const enerf_options_t* options,
+                 hipStream_t stream) {
     REQUIRE(packed && vol && feat && prob && workspace, "cost_reg: null pointer");
     REQUIRE(in_channels == 8 || in_channels == 16 || in_channels == 32, "cost_reg: in_channels=%d unsupported (8/16/32)",
             in_channels);
@@ -209,7 +220,8 @@ int enerf_cost_reg(const float* packed, int in_channels, int full, const float* 
         int cp = cdiv(L[i].cout, 16) * 16;
         desc[i] = {p, p + wf, p + wf + cp, L[i].cin, L[i].cout, L[i].kind, L[i].relu,
                    layer_pk8(L[i]) ? p + wf + 2 * cp : nullptr,                           // scale/shift = 1/0 without BN
-                   layer_pk8(L[i]) ? p + wf + 2 * cp + conv3d_pk8_packed_floats(L[i].cin) : nullptr};
+                   layer_pk8(L[i]) ? p + wf + 2 * cp + conv3d_pk8_packed_floats(L[i].cin) : nullptr,
+                   layer_t2pair(L[i]) ? p + wf + 2 * cp : nullptr, 0, 0};
         p += layer_floats(L[i]);
     }
     long long n0 = (long long)B * D * h * w, n1 = n0 / 8, n2 = n1 / 8, n3 = n2 / 8;
@@ -217,6 +229,12 @@ int enerf_cost_reg(const float* packed, int in_channels, int full, const float* 
     auto take = [&](long long nf) { float* r = ws; ws += nf; return r; };
     float *c0 = take(n0 * 8), *c1 = take(n1 * 16), *c2 = take(n1 * 16), *c3 = take(n2 * 32), *c4 = take(n2 * 32);
     float *y9 = take(n1 * 16), *y11 = take(n0 * 8);
+    // layouts between producer/consumer pairs that are BOTH on the asynchronous kernels: the cost volume (warp -> conv0) and
+    // conv11's output (-> fused heads) travel as channel-quad planes (conv3d_b4.hip k_conv3d_s1_b4g)
+    if (vol_planar && !conv3d_routes_b4_glds(opt, n0, D))
+        return fail(ENERF_EINVAL, "cost_reg: a quad-planar volume needs the asynchronously staged conv0 kernel (conv3d_b4 0/2, D % 4 == 0, >= conv3d_lds_min_voxels)");
+    desc[0].in_planar = vol_planar;
+    if (conv3d_routes_b4_glds(opt, n0, D) && conv3d_routes_t2_pair(opt, n1)) desc[n - 2].out_planar = desc[n - 1].in_planar = 1;
     int i = 0;
     bool ok = true;
     ok &= launch_conv3d(desc[i++], vol, nullptr, c0, nullptr, B, D, h, w, opt, st);                    // conv0
@@ -238,6 +256,8 @@ int enerf_cost_reg(const float* packed, int in_channels, int full, const float* 
     if (!ok) return fail(ENERF_EINVAL, "cost_reg: a layer shape has no kernel (in_channels=%d full=%d)", in_channels, full);
     return check_launch("cost_reg");
 }
+}  // namespace enerf
+extern "C" {
 
 int enerf_depth_regression(const float* prob, const float* depth_values, int B, int D, int h, int w, int depth_inv,
                            float* depth, float* std, enerf_stream_t stream) {

@@ -56,6 +56,33 @@ __device__ __forceinline__ float relu1(float x) {
 #endif
 }
 
+// ---- asynchronous global -> LDS copies (global_load_lds_dwordx4: the LDS-DMA path of gfx950) -------------------------------
+// glds16(src, dst_wave_base, lane): every lane supplies ITS OWN 16-byte global source; the destination is the wave-uniform
+// LDS base + lane * 16 (the hardware's rule, not a choice).  No VGPR holds the data, so a block can have the next pass's tile in
+// flight during this pass's MFMAs without the register cost of a staged prefetch.  Completion is tracked by vmcnt:
+// glds_wait_all() = s_waitcnt vmcnt(0) as inline asm (hipcc's own __syncthreads would drain it too, but also fences), and
+// block_barrier_raw() is the bare s_barrier that lets a copy issued BEFORE it stay in flight ACROSS it
+// (cdna_hip_programming.md "Pipelining across barriers").  The CPU lane emulator copies immediately.
+#ifdef ENERF_EMU
+__device__ __forceinline__ void glds16(const float* src, float* dst_wave_base, int lane) {
+    for (int k = 0; k < 4; ++k) dst_wave_base[lane * 4 + k] = src[k];
+}
+__device__ __forceinline__ void glds_wait_all() {}
+__device__ __forceinline__ void block_barrier_raw() { __syncthreads(); }
+#else
+__device__ __forceinline__ void glds16(const float* src, float* dst_wave_base, int lane) {
+    (void)lane;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void block_barrier_raw() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+#endif
+
 constexpr int kWave = 64;
 
 // Pin a value in a VGPR at this program point: LLVM's Sink pass otherwise moves a pure arithmetic chain that is only consumed

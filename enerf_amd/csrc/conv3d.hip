@@ -389,7 +389,7 @@ static void launch_one(const Conv3dDesc& L, const float* in, const float* residu
 // voxel tiles, favour wave count when it does not (the deep levels have 80..2000 tiles for 1024 SIMDs).
 template <int CIN, int KIND>
 static bool dispatch_rt(const Conv3dDesc& L, const float* in, const float* residual, float* out, float* out2, int B,
-                        int Di, int Hi, int Wi, hipStream_t st) {
+                        int Di, int Hi, int Wi, int small_variant, hipStream_t st) {
     const int rt_total = cdiv(L.cout, 16);
     long long n = (KIND == kConvS1) ? (long long)B * Di * Hi * Wi
                   : (KIND == kConvS2) ? (long long)B * ((Di - 1) / 2 + 1) * ((Hi - 1) / 2 + 1) * ((Wi - 1) / 2 + 1)
@@ -397,6 +397,12 @@ static bool dispatch_rt(const Conv3dDesc& L, const float* in, const float* resid
     const long long tiles = cdivl(n, 16);
     const int ct_default = rt_total == 1 ? 4 : (rt_total == 2 ? 2 : 1);
     const bool small = cdivl(tiles, ct_default) < 1024;      // fewer waves than SIMDs: split finer
+    if (small && KIND != kConvT2 && CIN >= 16 && small_variant >= 2) {
+        // A/B (enerf_options_t.conv3d_small_variant): operand reuse instead of wave count for the deep layers
+        if (small_variant == 2 && rt_total >= 2) { launch_one<CIN, 2, KIND, 2>(L, in, residual, out, out2, B, Di, Hi, Wi, st); return true; }
+        launch_one<CIN, 1, KIND, 4>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
+        return true;
+    }
     if (small) {
         // taps split by kd over three waves + LDS reduction (a 9-way split and no split both measured slower)
         if (KIND != kConvT2 && CIN >= 16) launch_one<CIN, 1, KIND, 1, (KIND != kConvT2 && CIN >= 16 ? 3 : 1)>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
@@ -412,12 +418,12 @@ static bool dispatch_rt(const Conv3dDesc& L, const float* in, const float* resid
 }
 template <int KIND>
 static bool dispatch_cin(const Conv3dDesc& L, const float* in, const float* residual, float* out, float* out2, int B,
-                         int Di, int Hi, int Wi, hipStream_t st) {
+                         int Di, int Hi, int Wi, int sv, hipStream_t st) {
     switch (L.cin) {
-        case 8: return dispatch_rt<8, KIND>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
-        case 16: return dispatch_rt<16, KIND>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
-        case 32: return dispatch_rt<32, KIND>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
-        case 64: return dispatch_rt<64, KIND>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
+        case 8: return dispatch_rt<8, KIND>(L, in, residual, out, out2, B, Di, Hi, Wi, sv, st);
+        case 16: return dispatch_rt<16, KIND>(L, in, residual, out, out2, B, Di, Hi, Wi, sv, st);
+        case 32: return dispatch_rt<32, KIND>(L, in, residual, out, out2, B, Di, Hi, Wi, sv, st);
+        case 64: return dispatch_rt<64, KIND>(L, in, residual, out, out2, B, Di, Hi, Wi, sv, st);
         default: return false;
     }
 }
@@ -623,7 +629,15 @@ bool launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, 
     const bool lds_ok = !o.conv3d_global_only;
     const long long min_vox = o.conv3d_lds_min_voxels > 0 ? o.conv3d_lds_min_voxels : 16384;
     const long long vox_in = (long long)B * Di * Hi * Wi;
-    // LDS-staged transposed path (conv11 of both nets, 16 -> 8).  Level-1 conv11: 30.8 -> 25.3 us; level 0 is slower (19 vs 15)
+    // every-class transposed kernels (conv3d_t2.hip): conv11 (16 -> 8, x-parity-paired MFMA rows) and conv9 (32 -> 16)
+    if (L.kind == kConvT2 && out2 == nullptr && lds_ok && o.conv3d_t2_variant != 1) {
+        // measured (profiles/r03_conv3d_layers.txt): conv11 16.3 vs 24.0 us (level 1), 10.3 vs 15.2 (level 0); conv9 10.7 vs
+        // 17.2 (level 1) but 10.1 vs 9.1 at level 0's 3840 positions (240 q-tiles: too few blocks)
+        const bool big = L.cout == 8 ? vox_in >= min_vox : vox_in >= min_vox / 2;
+        if ((big || o.conv3d_t2_variant == 2) && launch_conv3d_t2_all(L, in, residual, out, B, Di, Hi, Wi, st)) return true;
+    }
+    if (L.out_planar) return false;                    // only the kernel above writes channel-quad planes
+    // round-2 LDS-staged transposed path (conv11, 16 -> 8, one class per MFMA): kept for A/B (conv3d_t2_variant = 1)
     if (L.kind == kConvT2 && out2 == nullptr && lds_ok && 8 * vox_in >= 32 * min_vox &&
         launch_conv3d_t2_lds(L, in, residual, out, B, Di, Hi, Wi, st))
         return true;
@@ -632,8 +646,9 @@ bool launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, 
         launch_conv3d_s2_lds(L, in, out, B, Di, Hi, Wi, st))
         return true;
     // batched-4x4 path for the Cout=8(+1) stride-1 layers (conv0 of both levels, fused heads): no wasted MFMA rows
-    if (o.conv3d_b4 != 1 && residual == nullptr && lds_ok && vox_in >= min_vox && launch_conv3d_b4(L, in, out, out2, B, Di, Hi, Wi, st))
+    if (o.conv3d_b4 != 1 && residual == nullptr && lds_ok && vox_in >= min_vox && launch_conv3d_b4(L, in, out, out2, B, Di, Hi, Wi, o.conv3d_b4 != 3, st))
         return true;
+    if (L.in_planar) return false;                     // only the asynchronously staged b4 kernel reads channel-quad planes
     // tap-packed path for the Cout=8 stride-1 layers (conv0 of both levels, fused heads): 2/3 of the MFMAs
     if (o.conv3d_pk8 != 1 && residual == nullptr && lds_ok && vox_in >= min_vox &&
         launch_conv3d_pk8(L, in, out, out2, B, Di, Hi, Wi, o.conv3d_pk8 == 2, st))
@@ -650,11 +665,25 @@ bool launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, 
         if (ok) return true;
     }
     switch (L.kind) {
-        case kConvS1: return dispatch_cin<kConvS1>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
-        case kConvS2: return dispatch_cin<kConvS2>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
-        case kConvT2: return dispatch_cin<kConvT2>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
+        case kConvS1: return dispatch_cin<kConvS1>(L, in, residual, out, out2, B, Di, Hi, Wi, o.conv3d_small_variant, st);
+        case kConvS2: return dispatch_cin<kConvS2>(L, in, residual, out, out2, B, Di, Hi, Wi, o.conv3d_small_variant, st);
+        case kConvT2: return dispatch_cin<kConvT2>(L, in, residual, out, out2, B, Di, Hi, Wi, o.conv3d_small_variant, st);
         default: return false;
     }
+}
+
+// The layout decisions enerf_cost_reg / enerf_forward make BEFORE the launches must mirror the routing above.
+bool conv3d_routes_b4_glds(const Options& o, long long vox, int D) {
+    const long long min_vox = o.conv3d_lds_min_voxels > 0 ? o.conv3d_lds_min_voxels : 16384;
+    return o.conv3d_b4 != 1 && o.conv3d_b4 != 3 && !o.conv3d_global_only && vox >= min_vox && D % 4 == 0;
+}
+bool conv3d_routes_t2_pair(const Options& o, long long vox_in) {
+    const long long min_vox = o.conv3d_lds_min_voxels > 0 ? o.conv3d_lds_min_voxels : 16384;
+    return !o.conv3d_global_only && o.conv3d_t2_variant != 1 && (vox_in >= min_vox || o.conv3d_t2_variant == 2);
+}
+bool cost_reg_wants_planar_volume(const enerf_options_t& o, int in_channels, int B, int D, int h, int w) {
+    (void)in_channels;
+    return conv3d_routes_b4_glds(o, (long long)B * D * h * w, D);
 }
 
 }  // namespace enerf

@@ -211,6 +211,164 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_s1_b4(const float* __restrict
     }
 }
 
+// =====================================================================================================================
+// k_conv3d_s1_b4g — the same convolution with ASYNCHRONOUS staging (global_load_lds) and two LDS buffers.
+// Why: the kernel above is a strict stage -> barrier -> 27 taps -> barrier chain per 8-channel pass; the co-resident blocks of
+// a CU run in lockstep, so nothing covers the staging.  Measured (r03): level-1 conv0 53.6 us against 33.8 us of batched-4x4
+// issue time; level-0 conv0 (480 blocks for 256 CUs: <= 2 waves per SIMD) 47.1 us against 25.4.  Here a pass is ONE channel
+// quad (4 input channels): its haloed box is a single [voxel] float4 plane (17 KB) + 3.4-5 KB of weights, which every wave
+// requests with <= 7 global_load_lds instructions and no VGPRs; the copy of pass q+1 is issued right after the barrier that
+// opens pass q and lands during pass q's 27 x 16 MFMAs.  One bare s_barrier per pass (the copy stays in flight across it),
+// two 21.5-23.5 KB buffers: three blocks per CU as before.  Per-lane source offsets (the halo geometry) are computed once.
+// =====================================================================================================================
+__device__ float g_b4_zeros[64];                                  // source of the zero padding (a lane's 16 bytes)
+
+template <int CIN, int BD, bool HEADS>
+__global__ __launch_bounds__(256, 3) void k_conv3d_s1_b4g(const float* __restrict__ wb4, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ in,
+                                                          float* __restrict__ out, float* __restrict__ out2, int relu, int B,
+                                                          int D, int H, int W, int nbd, int nbh, int nbw, int in_planar) {
+    constexpr int BH = 8, BW = 16, V = BD / 2;
+    constexpr int NQ = CIN / 4, NS = HEADS ? 3 : 2;
+    constexpr int HX = BW + 2, HY = BH + 2, HZ = BD + 2, NVOX = HZ * HY * HX;
+    constexpr int NCH = (NVOX + 63) / 64, PLANE = NCH * 64 * 4;   // plane chunks of 64 voxels (one glds instruction each)
+    constexpr int NW4 = 27 * NS * 4, NWCH = (NW4 + 63) / 64;      // float4s / chunks of one pass's weights
+    constexpr int BUF = PLANE + NWCH * 64 * 4;                    // floats per buffer
+    constexpr int MYCH = (NCH + 3) / 4, MYW = (NWCH + 3) / 4;     // chunks per wave
+    ENERF_DYN_SMEM(float, lds);
+
+    const int tid = threadIdx.x, li = tid & 3, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31;
+    const bool g1 = (m >= 4 && m < 12) || (m >= 16 && m < 20) || m >= 28;
+    const int xl = g1 ? (m < 12 ? m - 4 : m < 20 ? m - 8 : m - 16) : (m < 4 ? m : m < 16 ? m - 8 : m - 12);
+    const int yl = 4 * (wv & 1) + 2 * (lane >> 5) + (g1 ? 1 : 0), zl = wv >> 1;
+    int t = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+    const int bw = t % nbw; t /= nbw;
+    const int bh = t % nbh; t /= nbh;
+    const int bd = t % nbd;
+    const int b = t / nbd;
+    const int x0 = bw * BW, y0 = bh * BH, z0 = bd * BD;
+    const float* inb = in + (long long)b * D * H * W * CIN;
+    // input addressing: channels-last (voxel stride CIN, quad stride 4) or channel-quad planes (voxel stride 4, quad stride
+    // D*H*W*4): with planes a pass reads 16 CONSECUTIVE bytes per voxel and whole cache lines per box row
+    const long long vstride = in_planar ? 4 : CIN, qstride = in_planar ? (long long)D * H * W * 4 : 4;
+
+    // ---- per-lane sources, computed once: chunk c = wv + 4k of the plane holds voxels 64c .. 64c+63 of the haloed box ----
+    long long src_off[MYCH];                                       // element offset of the voxel (channel 0), or -1: zeros
+#pragma unroll
+    for (int k = 0; k < MYCH; ++k) {
+        const int v = (wv + 4 * k) * 64 + lane;
+        const int dz = v / (HY * HX), r2 = v - dz * (HY * HX), dy = r2 / HX, dx = r2 - dy * HX;
+        const int gx = x0 + dx - 1, gy = y0 + dy - 1, gz = z0 + dz - 1;
+        const bool ok = v < NVOX && gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
+        src_off[k] = ok ? (((long long)gz * H + gy) * W + gx) * vstride : -1;
+    }
+    int w_off[MYW];                                                // float offset inside (tap, quad)'s 48 floats + tap stride
+#pragma unroll
+    for (int k = 0; k < MYW; ++k) {
+        const int i = (wv + 4 * k) * 64 + lane, ic = i < NW4 ? i : NW4 - 1;
+        const int tap = ic / (NS * 4), e = ic - tap * (NS * 4);
+        w_off[k] = tap * NQ * 48 + e * 4;
+    }
+    auto issue = [&](int cq, float* buf) {
+#pragma unroll
+        for (int k = 0; k < MYCH; ++k)
+            if (wv + 4 * k < NCH)                                  // wave-uniform
+                glds16(src_off[k] >= 0 ? inb + src_off[k] + cq * qstride : g_b4_zeros, buf + (wv + 4 * k) * 256, lane);
+#pragma unroll
+        for (int k = 0; k < MYW; ++k)
+            if (wv + 4 * k < NWCH)
+                glds16(wb4 + w_off[k] + cq * 48, buf + PLANE + (wv + 4 * k) * 256, lane);
+    };
+
+    f32x4 acc[V][2];
+    float dacc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { acc[v][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[v][1] = f32x4{0.f, 0.f, 0.f, 0.f}; dacc[v] = 0.f; }
+
+    issue(0, lds);
+#pragma unroll 1
+    for (int cq = 0; cq < NQ; ++cq) {
+        float* buf = lds + (cq & 1) * BUF;
+        glds_wait_all();                                           // this wave's copies of pass cq have landed
+        block_barrier_raw();                                       // everyone's have; everyone is done reading the other buffer
+        if (cq + 1 < NQ) issue(cq + 1, lds + ((cq + 1) & 1) * BUF);
+        const float* lbase = buf + ((zl * HY + yl) * HX + xl) * 4;
+        const float* wbase = buf + PLANE + li * 4;
+        auto read_a = [&](int tap, float4 (&aq)[NS]) {
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) aq[sl] = *reinterpret_cast<const float4*>(wbase + tap * (NS * 16) + sl * 16);
+        };
+        auto read_b = [&](int tap, float4 (&bv)[V]) {
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+#pragma unroll
+            for (int v = 0; v < V; ++v) bv[v] = *reinterpret_cast<const float4*>(lbase + (((2 * v + kd) * HY + kh) * HX + kw) * 4);
+        };
+        float4 aq[2][NS], bq[2][V];
+        read_a(0, aq[0]);
+        read_b(0, bq[0]);
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            if (tap + 1 < 27) { read_a(tap + 1, aq[(tap + 1) & 1]); read_b(tap + 1, bq[(tap + 1) & 1]); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (HEADS) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float4 bb = bq[tap & 1][v], wd = aq[tap & 1][NS - 1];
+                    dacc[v] = __builtin_fmaf(wd.x, bb.x, dacc[v]);
+                    dacc[v] = __builtin_fmaf(wd.y, bb.y, dacc[v]);
+                    dacc[v] = __builtin_fmaf(wd.z, bb.z, dacc[v]);
+                    dacc[v] = __builtin_fmaf(wd.w, bb.w, dacc[v]);
+                    ENERF_PIN_VGPR(dacc[v]);
+                }
+            }
+            const float4 A0 = aq[tap & 1][0], A1 = aq[tap & 1][1];
+            const float a0[4] = {A0.x, A0.y, A0.z, A0.w}, a1[4] = {A1.x, A1.y, A1.z, A1.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float4 bb = bq[tap & 1][v];
+                    const float bx = r == 0 ? bb.x : r == 1 ? bb.y : r == 2 ? bb.z : bb.w;
+                    acc[v][0] = ENERF_MFMA4(a0[r], bx, acc[v][0]);
+                    acc[v][1] = ENERF_MFMA4(a1[r], bx, acc[v][1]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    const int x = x0 + xl, y = y0 + yl;
+    if (x >= W || y >= H) return;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int z = z0 + zl + 2 * v;
+        if (z >= D) continue;
+        const long long o = (((long long)b * D + z) * H + y) * W + x;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float yv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                yv[r] = acc[v][half][r] * scale[4 * half + r] + shift[4 * half + r];
+                if (relu) yv[r] = fmaxf(yv[r], 0.f);
+            }
+            *reinterpret_cast<float4*>(out + o * 8 + 4 * half) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+        }
+        if (HEADS && out2 != nullptr) out2[o] = dacc[v] * scale[8] + shift[8];
+    }
+}
+
+template <int CIN, int BD, bool HEADS>
+static void launch_b4g(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W, hipStream_t st) {
+    constexpr int NVOX = (BD + 2) * 10 * 18, NCH = (NVOX + 63) / 64, NS = HEADS ? 3 : 2, NWCH = (27 * NS * 4 + 63) / 64;
+    const int nbd = cdiv(D, BD), nbh = cdiv(H, 8), nbw = cdiv(W, 16);
+    const size_t shmem = (size_t)2 * (NCH + NWCH) * 64 * 4 * sizeof(float);
+    const unsigned grid = (unsigned)((long long)B * nbd * nbh * nbw);
+    ENERF_LAUNCH((k_conv3d_s1_b4g<CIN, BD, HEADS>), grid, 256, shmem, st, L.w_b4, L.scale, L.shift, in, out, out2, L.relu, B, D,
+                 H, W, nbd, nbh, nbw, L.in_planar);
+}
+
 template <int CIN, int BD, bool HEADS>
 static void launch_b4(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W, hipStream_t st) {
     constexpr int QV = 2, NVOX = (BD + 2) * 10 * 18;
@@ -220,18 +378,24 @@ static void launch_b4(const Conv3dDesc& L, const float* in, float* out, float* o
     ENERF_LAUNCH((k_conv3d_s1_b4<CIN, BD, HEADS>), grid, 256, shmem, st, L.w_b4, L.scale, L.shift, in, out, out2, L.relu, B, D,
                  H, W, nbd, nbh, nbw);
 }
-bool launch_conv3d_b4(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W, hipStream_t st) {
+bool launch_conv3d_b4(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W, bool glds,
+                      hipStream_t st) {
     if (L.w_b4 == nullptr || L.kind != kConvS1) return false;
+    if (L.in_planar && !(glds && D % 4 == 0)) return false;       // only the glds kernel reads quad planes
     const bool heads = L.cout == 9 && out2 != nullptr;
     if (!(L.cout == 8 && out2 == nullptr) && !heads) return false;
     const bool bd4 = D % 4 == 0;
     if (heads) {                                                   // the fused heads of both nets have Cin = 8
         if (L.cin != 8) return false;
-        if (bd4) launch_b4<8, 4, true>(L, in, out, out2, B, D, H, W, st); else launch_b4<8, 2, true>(L, in, out, out2, B, D, H, W, st);
+        if (glds && bd4) launch_b4g<8, 4, true>(L, in, out, out2, B, D, H, W, st);
+        else if (bd4) launch_b4<8, 4, true>(L, in, out, out2, B, D, H, W, st);
+        else launch_b4<8, 2, true>(L, in, out, out2, B, D, H, W, st);
         return true;
     }
 #define ENERF_B4(CINV) \
-    if (bd4) launch_b4<CINV, 4, false>(L, in, out, out2, B, D, H, W, st); else launch_b4<CINV, 2, false>(L, in, out, out2, B, D, H, W, st); \
+    if (glds && bd4) launch_b4g<CINV, 4, false>(L, in, out, out2, B, D, H, W, st); \
+    else if (bd4) launch_b4<CINV, 4, false>(L, in, out, out2, B, D, H, W, st); \
+    else launch_b4<CINV, 2, false>(L, in, out, out2, B, D, H, W, st); \
     return true;
     switch (L.cin) {
         case 8: ENERF_B4(8)

@@ -378,11 +378,21 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
         if (rc != ENERF_OK) return bail(rc);
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_PREP));
         need_level(i);                                                 // level i's source maps (side lane for i >= 1)
-        rc = enerf_build_feature_volume(f[i], proj, dv, a->B, a->S, L.C, L.Hs, L.Ws, L.D, L.h, L.w, vol, stream);
+        // the volume goes to conv0 as channel-quad planes when conv0 runs on the asynchronously staged kernel (one quad per pass)
+        const int vol_planar = cost_reg_wants_planar_volume(resolve_options(a->options), L.C, a->B, L.D, L.h, L.w) ? 1 : 0;
+        if (!vol_planar)
+            rc = enerf_build_feature_volume(f[i], proj, dv, a->B, a->S, L.C, L.Hs, L.Ws, L.D, L.h, L.w, vol, stream);
+        else {      // same argument checks as the C entry (shapes come from the validated plan; the 32-bit limits are re-checked)
+            REQUIRE((long long)a->B * a->S * L.Hs * L.Ws * L.C < (1LL << 32) && (long long)L.Hs * L.Ws < (1LL << 23) &&
+                    (long long)a->B * L.D * L.h * L.w * (L.C / 4) < (1LL << 31) && (long long)L.h * L.w < (1LL << 23),
+                    "forward: level %d volume too large for 32-bit indices", i);
+            launch_feature_volume(f[i], proj, dv, a->B, a->S, L.C, L.Hs, L.Ws, L.D, L.h, L.w, vol, st, 1);
+            rc = check_launch("build_feature_volume");
+        }
         if (rc != ENERF_OK) return bail(rc);
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_VOLUME));
-        rc = enerf_cost_reg(a->cost_reg_packed[i], L.C, i != 0, vol, a->B, L.D, L.h, L.w, feat3d, prob, ws + P.costreg_ws,
-                            P.costreg_ws_bytes, a->options, stream);
+        rc = cost_reg_run(a->cost_reg_packed[i], L.C, i != 0, vol, vol_planar, a->B, L.D, L.h, L.w, feat3d, prob, ws + P.costreg_ws,
+                          P.costreg_ws_bytes, a->options, st);
         if (rc != ENERF_OK) return bail(rc);
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_COST_REG));
         launch_depth_regression(prob, dv, a->B, L.D, L.h, L.w, c.depth_inv[i], depth, std, dmvs, st);

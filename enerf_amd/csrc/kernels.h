@@ -41,8 +41,16 @@ void launch_build_rays(const float* rays8, const float* depth, const float* std,
                        int w, int Hr, int Wr, int depth_inv, float* rays12, hipStream_t st);
 
 // ---- volume.hip ---------------------------------------------------------------------------------
+// planar = 1: vol as channel-quad planes (B, C/4, D, h, w, 4) instead of channels-last (B, D, h, w, C)
 void launch_feature_volume(const float* feat_nhwc, const float* proj, const float* dv, int B, int S, int C, int Hs,
-                           int Ws, int D, int h, int w, float* vol, hipStream_t st);
+                           int Ws, int D, int h, int w, float* vol, hipStream_t st, int planar = 0);
+// does enerf_cost_reg read a quad-planar volume for this shape under these options? (enerf_forward asks before the warp)
+bool cost_reg_wants_planar_volume(const enerf_options_t& o, int in_channels, int B, int D, int h, int w);
+bool conv3d_routes_b4_glds(const enerf_options_t& o, long long vox, int D);     // mirrors launch_conv3d's routing
+bool conv3d_routes_t2_pair(const enerf_options_t& o, long long vox_in);
+// enerf_cost_reg with the volume layout made explicit (vol_planar = 1: channel-quad planes, see launch_feature_volume)
+int cost_reg_run(const float* packed, int in_channels, int full, const float* vol, int vol_planar, int B, int D, int h, int w,
+                 float* feat, float* prob, void* workspace, size_t workspace_bytes, const enerf_options_t* options, hipStream_t st);
 
 // ---- conv3d.hip ---------------------------------------------------------------------------------
 enum ConvKind { kConvS1 = 0, kConvS2 = 1, kConvT2 = 2 };
@@ -53,11 +61,17 @@ struct Conv3dDesc {
     int cin, cout, kind, relu;
     const float* w_pk8;     // tap-packed image for stride-1 cout=8(+1) layers (conv3d_pk8.hip) or nullptr
     const float* w_b4;      // batched-4x4 image for the same layers (conv3d_b4.hip) or nullptr
+    const float* w_t2pair;  // x-parity-paired image of a transposed 16 -> 8 layer (conv3d_t2.hip) or nullptr
+    int in_planar;          // input is channel-quad planes (B, cin/4, D, H, W, 4): only the glds b4 kernel reads that
+    int out_planar;         // output as channel-quad planes: only the class-paired transposed kernel writes that
 };
+long long conv3d_t2_pair_floats();
+void launch_conv3d_t2_pair_pack(const float* packed, float* paired, hipStream_t st);   // from the class-major packed image
 // batched 4x4x1 variant for cout = 8 (+ optional depth row on the VALU): see conv3d_b4.hip
 long long conv3d_b4_packed_floats(int cin);
 void launch_conv3d_b4_pack(const float* w, const float* wd, int cin, float* packed, hipStream_t st);
-bool launch_conv3d_b4(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W, hipStream_t st);
+bool launch_conv3d_b4(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W, bool glds,
+                      hipStream_t st);   // glds: the asynchronously staged variant (global_load_lds, two LDS buffers)
 // tap-packed variant for cout = 8 (+ optional depth row): see conv3d_pk8.hip
 long long conv3d_pk8_packed_floats(int cin);
 void launch_conv3d_pk8_pack(const float* w, const float* wd, int cin, float* packed, hipStream_t st);
@@ -65,6 +79,8 @@ bool launch_conv3d_s2_lds(const Conv3dDesc& L, const float* in, float* out, int 
                           hipStream_t st);   // LDS-staged stride-2 variant, Cin = 8, Cout <= 16 (conv3d_s2.hip)
 bool launch_conv3d_t2_lds(const Conv3dDesc& L, const float* in, const float* residual, float* out, int B, int Di, int Hi,
                           int Wi, hipStream_t st);   // LDS-staged transposed variant, 16 -> 8 (conv3d_t2.hip)
+bool launch_conv3d_t2_all(const Conv3dDesc& L, const float* in, const float* residual, float* out, int B, int Di, int Hi,
+                          int Wi, hipStream_t st);   // every-class transposed kernel: 16 -> 8 (class-paired), 32 -> 16 (conv3d_t2.hip)
 bool launch_conv3d_pk8(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,
                        bool all_layers, hipStream_t st);
 // number of floats of the packed weight image for a layer

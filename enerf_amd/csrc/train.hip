@@ -84,8 +84,9 @@ __global__ __launch_bounds__(256) void k_channel_affine(const float* __restrict_
 using namespace enerf;
 extern "C" {
 
+static bool layer_has_t2pair(int cin, int cout, int kind) { return kind == kConvT2 && cin == 16 && cout == 8; }
 long long enerf_conv3d_layer_packed_floats(int cin, int cout, int kind) {
-    return conv3d_packed_floats(cin, cout, kind) + 2 * cdiv(cout, 16) * 16;
+    return conv3d_packed_floats(cin, cout, kind) + 2 * cdiv(cout, 16) * 16 + (layer_has_t2pair(cin, cout, kind) ? conv3d_t2_pair_floats() : 0);
 }
 int enerf_conv3d_layer_pack(const float* w, int cin, int cout, int kind, float* packed, enerf_stream_t stream) {
     REQUIRE(w && packed, "conv3d_layer_pack: null pointer");
@@ -95,6 +96,7 @@ int enerf_conv3d_layer_pack(const float* w, int cin, int cout, int kind, float* 
     const int cp = cdiv(cout, 16) * 16;
     launch_conv3d_pack(w, nullptr, cout, nullptr, nullptr, nullptr, nullptr, 1e-5f, cin, cout, kind, packed, packed + wf,
                        packed + wf + cp, (hipStream_t)stream);
+    if (layer_has_t2pair(cin, cout, kind)) launch_conv3d_t2_pair_pack(packed, packed + wf + 2 * cp, (hipStream_t)stream);
     return check_launch("conv3d_layer_pack");
 }
 int enerf_conv3d_layer(const float* packed, int cin, int cout, int kind, const float* in, const float* residual, float* out, int B,
@@ -102,7 +104,8 @@ int enerf_conv3d_layer(const float* packed, int cin, int cout, int kind, const f
     REQUIRE(packed && in && out && B > 0 && Di > 0 && Hi > 0 && Wi > 0, "conv3d_layer: bad arguments");
     const long long wf = conv3d_packed_floats(cin, cout, kind);
     const int cp = cdiv(cout, 16) * 16;
-    Conv3dDesc d = {packed, packed + wf, packed + wf + cp, cin, cout, kind, 0, nullptr};
+    Conv3dDesc d = {packed, packed + wf, packed + wf + cp, cin, cout, kind, 0, nullptr, nullptr,
+                    layer_has_t2pair(cin, cout, kind) ? packed + wf + 2 * cp : nullptr};
     if (!launch_conv3d(d, in, residual, out, nullptr, B, Di, Hi, Wi, resolve_options(options), (hipStream_t)stream))
         return fail(ENERF_EINVAL, "conv3d_layer: no kernel for %d -> %d kind %d", cin, cout, kind);
     return check_launch("conv3d_layer");

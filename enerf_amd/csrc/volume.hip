@@ -21,7 +21,7 @@ namespace enerf {
 template <int CQ>  // CQ = C/4 lanes per voxel
 __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict__ feat, const float* __restrict__ proj,
                                                         const float* __restrict__ dv, int B, int S, int Hs, int Ws,
-                                                        int D, int h, int w, float inv_w, float* __restrict__ vol) {
+                                                        int D, int h, int w, float inv_w, int planar, float* __restrict__ vol) {
     constexpr int C = CQ * 4;
     // Block -> voxels, XCD-aware: the dispatcher puts block i on XCD i % 8 and every XCD has a private 4 MiB L2, so
     // with the raster order every XCD gathers from the whole of every source image (PMC: 245 MB of fabric reads
@@ -65,6 +65,9 @@ __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict_
         // ---- this lane's view ----
         const int sv = min(s0 + cq, S - 1);
         const float* P = proj + (b * S + sv) * 12;
+        // IEEE divisions, as the reference (utils.py:72,80-83).  Measured in round 3: two refined reciprocals instead (<= 1.5 ulp
+        // off) save 0.7 us per launch but move the ill-conditioned BatchNorm-weight gradients of conv0 by 6e-3 relative in
+        // the training path, which shares this arithmetic — not worth it.
         const float px = P[0] * fx + P[1] * fy + P[2] + P[3] / depth;       // utils.py:72
         const float py = P[4] * fx + P[5] * fy + P[6] + P[7] / depth;
         const float pz = P[8] * fx + P[9] * fy + P[10] + P[11] / depth;
@@ -103,19 +106,23 @@ __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict_
     m = s1.y * inv_s; o.y = s2.y * inv_s - m * m;
     m = s1.z * inv_s; o.z = s2.z * inv_s - m * m;
     m = s1.w * inv_s; o.w = s2.w * inv_s - m * m;
-    if (live) *reinterpret_cast<float4*>(vol + (long long)vox * C + cq * 4) = o;
+    // planar: channel-quad planes (B, C/4, D, h, w, 4) — what the asynchronously staged conv0 reads (one quad per pass: a
+    // channels-last voxel would give it 16 useful bytes of every 64-128-byte line, re-fetched once per pass)
+    const unsigned nvp = (unsigned)(D * h * w);
+    const long long oidx = planar ? ((long long)((unsigned)b * CQ + cq) * nvp + (vox - (unsigned)b * nvp)) * 4 : (long long)vox * C + cq * 4;
+    if (live) *reinterpret_cast<float4*>(vol + oidx) = o;
 }
 
 void launch_feature_volume(const float* feat_nhwc, const float* proj, const float* dv, int B, int S, int C, int Hs,
-                           int Ws, int D, int h, int w, float* vol, hipStream_t st) {
+                           int Ws, int D, int h, int w, float* vol, hipStream_t st, int planar) {
     // 8 row bands (one per XCD), each padded to a whole number of blocks: grid = 8 x blocks-per-band
     const int rb = (h + 7) / 8;
     const long long band_threads = (long long)B * D * rb * w * (C / 4);
     unsigned grid = 8u * (unsigned)cdivl(band_threads, 256);
     switch (C) {
-        case 32: ENERF_LAUNCH(k_feature_volume<8>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, 1.f / (float)w, vol); break;
-        case 16: ENERF_LAUNCH(k_feature_volume<4>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, 1.f / (float)w, vol); break;
-        case 8: ENERF_LAUNCH(k_feature_volume<2>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, 1.f / (float)w, vol); break;
+        case 32: ENERF_LAUNCH(k_feature_volume<8>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, 1.f / (float)w, planar, vol); break;
+        case 16: ENERF_LAUNCH(k_feature_volume<4>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, 1.f / (float)w, planar, vol); break;
+        case 8: ENERF_LAUNCH(k_feature_volume<2>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, 1.f / (float)w, planar, vol); break;
         default: break;   // validated by the C-ABI layer
     }
 }

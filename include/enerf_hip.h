@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ENERF_ABI_VERSION 4
+#define ENERF_ABI_VERSION 5
 #define ENERF_OK 0
 #define ENERF_EINVAL (-1)   /* bad argument / unsupported shape */
 #define ENERF_ELAUNCH (-2)  /* HIP launch error */
@@ -45,12 +45,22 @@ typedef struct {
     int featnet_unfused;             /* 1: one launch per FeatureNet layer (no conv0/toplayer/lat0 fusions) */
     int featnet_smooth0_plain;       /* 1: the 16x16x4-MFMA form of the fused smooth0 kernel instead of the batched-4x4 one */
     int conv3d_b4;                   /* batched 4x4x1-MFMA kernel for the Cout=8(+1) stride-1 3-D layers (conv0, fused heads):
-                                        0 = on (default), 1 = never (falls back to the tap-packed / plain kernels) */
+                                        0 = on (default; since ABI 5 the asynchronously staged kernel: global_load_lds, two LDS
+                                        buffers, one channel quad per pass, cost volume / conv11 output handed over as
+                                        channel-quad planes), 1 = never (falls back to the tap-packed / plain kernels),
+                                        2 = same as 0, 3 = on, the round-2 register-staged kernel (A/B) */
     int single_stream;               /* enerf_forward: 1 = every kernel of the frame on the caller's stream, in order.
                                         0 (default) = the FeatureNet's top-down half (lat1/smooth1, lat0/smooth0), which only
                                         level 1 and the final render consume, is forked onto a library-owned side stream and
                                         overlaps level 0's warp + cost regularisation; joined with events before its first
                                         consumer — still ONE frame, no frames in flight (ABI >= 4) */
+    int conv3d_t2_variant;           /* transposed 3-D layers (conv9 32->16, conv11 16->8), ABI >= 5: 0 = the every-class LDS kernel
+                                        with x-parity-paired MFMA rows where it measured faster (default); 1 = the round-2
+                                        kernels only (A/B); 2 = the every-class kernel for every layer it handles */
+    int conv3d_small_variant;        /* deep (< 1024 wave-tile) stride-1/2 layers, ABI >= 5: 0 = default choice per layer;
+                                        1 = taps split over 3 waves + LDS reduce, one tile per wave (the round-2 default);
+                                        2 = no tap split, 2 row tiles x 2 column tiles per wave (operand reuse over wave count);
+                                        3 = no tap split, 1 row tile x 4 column tiles */
 } enerf_options_t;
 
 /* ---- layout adapters at the PyTorch boundary (FeatureNet output is NCHW, network.py:58-67) ---- */

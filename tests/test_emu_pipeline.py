@@ -68,6 +68,12 @@ def test_batch2_ragged_rays_and_white_bkgd():
     out = net(batch)
     for k in ref:
         _close(out[k].numpy(), ref[k].numpy(), 5e-5, k)
+    # (that default routes conv0 / the heads through the asynchronously staged kernels — global_load_lds, channel-quad-planar
+    # cost volume and conv11 output — and the transposed layers through the every-class kernels); the round-2 kernels, B = 2
+    net.options = Options(conv3d_lds_min_voxels=1, conv3d_b4=3, conv3d_t2_variant=1)
+    out = net(batch)
+    for k in ref:
+        _close(out[k].numpy(), ref[k].numpy(), 5e-5, k)
 
 
 def test_render_rays_surface_accepts_reference_volume_layout():

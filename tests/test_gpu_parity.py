@@ -156,7 +156,10 @@ def test_full_size_dtu_eval_vs_oracle_and_properties():
     from enerf_amd.lib import Options, throughput_options
     variants = {"throughput": throughput_options(), "global_only": Options(conv3d_global_only=1),
                 "pk8_off": Options(conv3d_pk8=1), "unfused_fpn": Options(featnet_unfused=1),
-                "plain_smooth0": Options(featnet_smooth0_plain=1)}
+                "plain_smooth0": Options(featnet_smooth0_plain=1),
+                "t2_round2": Options(conv3d_t2_variant=1), "t2_all": Options(conv3d_t2_variant=2),
+                "small_rt2ct2": Options(conv3d_small_variant=2), "small_ct4": Options(conv3d_small_variant=3),
+                "small_split3": Options(conv3d_small_variant=1), "b4_round2": Options(conv3d_b4=3)}
     for name, opt in variants.items():
         o = net._forward(_to(batch), opt)
         for k in ref:
