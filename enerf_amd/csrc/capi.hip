@@ -200,7 +200,7 @@ int enerf_cost_reg(const float* packed, int in_channels, int full, const float* 
 namespace enerf {
 int cost_reg_run(const float* packed, int in_channels, int full, const float* vol, int vol_planar, int B, int D, int h, int w,
                  float* feat, float* prob, void* workspace, size_t workspace_bytes, const enerf_options_t* options,
-                 hipStream_t stream) {
+                 hipStream_t stream, const CostRegHook* hook) {
     REQUIRE(packed && vol && feat && prob && workspace, "cost_reg: null pointer");
     REQUIRE(in_channels == 8 || in_channels == 16 || in_channels == 32, "cost_reg: in_channels=%d unsupported (8/16/32)",
             in_channels);
@@ -237,9 +237,13 @@ int cost_reg_run(const float* packed, int in_channels, int full, const float* vo
     if (conv3d_routes_b4_glds(opt, n0, D) && conv3d_routes_t2_pair(opt, n1)) desc[n - 2].out_planar = desc[n - 1].in_planar = 1;
     int i = 0;
     bool ok = true;
+    auto hooked = [&](int layer) { if (hook != nullptr && hook->after_layer == layer) hook->fn(hook->ctx); };
     ok &= launch_conv3d(desc[i++], vol, nullptr, c0, nullptr, B, D, h, w, opt, st);                    // conv0
+    hooked(0);
     ok &= launch_conv3d(desc[i++], c0, nullptr, c1, nullptr, B, D, h, w, opt, st);                     // conv1 (s2)
+    hooked(1);
     ok &= launch_conv3d(desc[i++], c1, nullptr, c2, nullptr, B, D / 2, h / 2, w / 2, opt, st);         // conv2
+    hooked(2);
     ok &= launch_conv3d(desc[i++], c2, nullptr, c3, nullptr, B, D / 2, h / 2, w / 2, opt, st);         // conv3 (s2)
     ok &= launch_conv3d(desc[i++], c3, nullptr, c4, nullptr, B, D / 4, h / 4, w / 4, opt, st);         // conv4
     const float* x = c4;

@@ -470,14 +470,30 @@ __global__ __launch_bounds__(256) void k_conv0_fused_b4(const float* __restrict_
 
     // ---- weights: 16x16x4 operand images -> [row i][k] float4s (W0[o][c][t] = w0[t*64 + c*16 + o]; W1[o][2g+r][t] =
     //      w1[(2t + r)*64 + g*16 + o], conv2d.hip k_conv2d_pack) ----
-    for (int i = tid; i < 9 * 32 + 9 * 64; i += 256) {
-        if (i < 9 * 32) {
-            const int r = i & 3, row = (i >> 2) & 3, half = (i >> 4) & 1, t = i >> 5;
-            wl0[i] = r < 3 ? w0[t * 64 + r * 16 + 4 * half + row] : 0.f;
-        } else {
-            const int k = i - 9 * 32, r = k & 3, row = (k >> 2) & 3, half = (k >> 4) & 1, q = (k >> 5) & 1, t = k >> 6;
-            const int ch = 4 * q + r;
-            wl1[k] = w1[(t * 2 + (ch & 1)) * 64 + (ch >> 1) * 16 + 4 * half + row];
+    {   // (all loads first, then the LDS stores: as a plain loop this was load -> vmcnt(0) -> store, four serial L2 round trips)
+        constexpr int NWI = (9 * 32 + 9 * 64 + 255) / 256;
+        float wv[NWI];
+#pragma unroll
+        for (int it = 0; it < NWI; ++it) {
+            const int i = tid + it * 256, ic = i < 9 * 32 + 9 * 64 ? i : 9 * 32 + 9 * 64 - 1;
+            const float* src;
+            bool zero = false;
+            if (ic < 9 * 32) {
+                const int r = ic & 3, row = (ic >> 2) & 3, half = (ic >> 4) & 1, t = ic >> 5;
+                zero = r >= 3;
+                src = w0 + t * 64 + (r < 3 ? r : 0) * 16 + 4 * half + row;
+            } else {
+                const int k = ic - 9 * 32, r = k & 3, row = (k >> 2) & 3, half = (k >> 4) & 1, q = (k >> 5) & 1, t = k >> 6;
+                const int ch = 4 * q + r;
+                src = w1 + (t * 2 + (ch & 1)) * 64 + (ch >> 1) * 16 + 4 * half + row;
+            }
+            const float v = *src;
+            wv[it] = zero ? 0.f : v;
+        }
+#pragma unroll
+        for (int it = 0; it < NWI; ++it) {
+            const int i = tid + it * 256;
+            if (i < 9 * 32 + 9 * 64) wl0[i] = wv[it];              // wl1 follows wl0 contiguously
         }
     }
     {   // ---- image patch -> LDS: one thread per patch pixel, three coalesced plane reads, zero outside ----
@@ -819,6 +835,8 @@ __global__ __launch_bounds__(256, 3) void k_smooth0_b4(const float* __restrict__
     float* til = pat + NPP * 16;            // [4 quads][NPX] float4 planes (16 channels of the current pass)
     float* lwt = til + 4 * NPX * 4;         // lat0 weight (32x8) + bias (32), staged once
     float* wl = lwt + 288;                  // [9 taps][4 quads][2 halves][4 rows][4]: the pass's smooth0 weights
+    float* tabs = wl + 9 * 4 * 32;          // bilinear tables of the x2 align-corners upsample: 10 tile rows + 34 tile columns,
+                                            // {patch offset of i0, of i1 (floats; < 0: outside the image), l0, l1} each
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, j = lane & 15, wv = tid >> 6, li = tid & 3;
     const int bid = (int)xcd_contiguous(blockIdx.x, gridDim.x);
@@ -828,14 +846,44 @@ __global__ __launch_bounds__(256, 3) void k_smooth0_b4(const float* __restrict__
     const float sy = ac_scale(H1, H), sx = ac_scale(W1, W);
     const int py0 = (int)(sy * (float)max(iy0, 0)), px0 = (int)(sx * (float)max(ix0, 0));   // patch origin (= lerp i0 of the first row/col)
 
-    for (int i = tid; i < 288; i += 256) lwt[i] = i < 256 ? lat_w[i] : lat_b[i - 256];
-    // ---- c0 tile -> LDS (zero outside the image) ----
-    for (int i = tid; i < NPX * 2; i += 256) {
-        const int px = i >> 1, q = i & 1, ly = px / IW, lx = px - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
-        const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const long long off = ok ? ((long long)n * H + gy) * W + gx : 0;
-        const float4 v = *reinterpret_cast<const float4*>(c0 + off * 8 + q * 4);
-        *reinterpret_cast<float4*>(c0t + i * 4) = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    {   // ---- lat0 weights + the c0 tile -> LDS (zero outside the image).  ALL loads are issued before the first LDS store:
+        // written as `for (i = tid; ...) lds[i] = global[...]` hipcc emits load -> s_waitcnt vmcnt(0) -> store per iteration,
+        // i.e. one exposed L2/HBM round trip per iteration and thread (the staging loops of this kernel were ~12 us of
+        // serial latency per block) ----
+        constexpr int NC0 = (NPX * 2 + 255) / 256;
+        float4 cv[NC0];
+        bool ck[NC0];
+        const float lw0 = lat_w[tid], lw1 = tid < 32 ? lat_b[tid] : 0.f;
+#pragma unroll
+        for (int it = 0; it < NC0; ++it) {
+            const int i = tid + it * 256, ic = i < NPX * 2 ? i : NPX * 2 - 1;
+            const int px = ic >> 1, q = ic & 1, ly = px / IW, lx = px - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
+            ck[it] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const long long off = ck[it] ? ((long long)n * H + gy) * W + gx : 0;
+            cv[it] = *reinterpret_cast<const float4*>(c0 + off * 8 + q * 4);
+        }
+        lwt[tid] = lw0;
+        if (tid < 32) lwt[256 + tid] = lw1;
+#pragma unroll
+        for (int it = 0; it < NC0; ++it) {
+            const int i = tid + it * 256;
+            if (i < NPX * 2) *reinterpret_cast<float4*>(c0t + i * 4) = ck[it] ? cv[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (tid < IH + IW) {
+        // The upsample's source rows / columns and weights depend on the tile row / column only: computed ONCE per block here
+        // (each build-loop iteration of each pass redid both ac_lerp's, the divisions and four pointer computations per lane —
+        // the build phase's VALU work equalled the convolution's matrix time, and the two do not overlap on a SIMD).
+        const bool isrow = tid < IH;
+        const int k = isrow ? tid : tid - IH, gq = (isrow ? iy0 : ix0) + k, lim = isrow ? H : W;
+        const Lerp1 v = ac_lerp(min(max(gq, 0), lim - 1), isrow ? sy : sx, isrow ? H1 : W1);
+        const int unit = isrow ? PW * 16 : 16, org = isrow ? py0 : px0;
+        const bool ok = gq >= 0 && gq < lim;
+        float4 e;
+        e.x = __int_as_float(ok ? (v.i0 - org) * unit : -1);
+        e.y = __int_as_float(ok ? (v.i1 - org) * unit : -1);
+        e.z = v.l0; e.w = v.l1;
+        *reinterpret_cast<float4*>(tabs + tid * 4) = e;
     }
     // stage-2 lane -> pixel map: service group k of a wave = 16 consecutive pixels of one tile row
     const int m = lane & 31;
@@ -848,17 +896,39 @@ __global__ __launch_bounds__(256, 3) void k_smooth0_b4(const float* __restrict__
 
 #pragma unroll 1
     for (int cb = 0; cb < 2; ++cb) {
-        if (cb > 0) __syncthreads();          // previous pass done with pat / til / wl
-        // ---- f1pre patch (16 channels of this pass) and the pass's conv weights -> LDS ----
-        for (int i = tid; i < NPP * 4; i += 256) {
-            const int pp = i >> 2, q = i & 3, pr = pp / PW, pc = pp - pr * PW;
+        // ---- f1pre patch (16 channels of this pass) and the pass's conv weights -> LDS; loads first (before the barrier that
+        // ends the previous pass: their latency overlaps the other waves' last taps), stores after ----
+        constexpr int NPF = (NPP * 4 + 255) / 256, NWF = (9 * 4 * 2 * 4 + 255) / 256;
+        float4 pv[NPF], wv4[NWF];
+#pragma unroll
+        for (int it = 0; it < NPF; ++it) {
+            const int i = tid + it * 256, ic = i < NPP * 4 ? i : NPP * 4 - 1;
+            const int pp = ic >> 2, q = ic & 3, pr = pp / PW, pc = pp - pr * PW;
             const int gy = min(py0 + pr, H1 - 1), gx = min(px0 + pc, W1 - 1);
-            *reinterpret_cast<float4*>(pat + i * 4) =
-                *reinterpret_cast<const float4*>(f1pre + (((long long)n * H1 + gy) * W1 + gx) * 32 + cb * 16 + q * 4);
+            pv[it] = *reinterpret_cast<const float4*>(f1pre + (((long long)n * H1 + gy) * W1 + gx) * 32 + cb * 16 + q * 4);
         }
-        for (int i = tid; i < 9 * 4 * 32; i += 256) {
-            const int r = i & 3, rw = (i >> 2) & 3, half = (i >> 4) & 1, q = (i >> 5) & 3, t = i >> 7;
-            wl[i] = w[((t * 8 + cb * 4 + r) * 64) + q * 16 + 4 * half + rw];
+        // weights: wl[((t*4 + q)*2 + half)*16 + rw*4 + r] = w[(t*8 + cb*4 + r)*64 + q*16 + 4*half + rw]: the source is contiguous
+        // in rw, so one float4 load per (t, q, half, r) and four scalar LDS stores
+#pragma unroll
+        for (int it = 0; it < NWF; ++it) {
+            const int i = tid + it * 256, ic = i < 288 ? i : 287;
+            const int r = ic & 3, half = (ic >> 2) & 1, q = (ic >> 3) & 3, t = ic >> 5;
+            wv4[it] = *reinterpret_cast<const float4*>(w + ((t * 8 + cb * 4 + r) * 64) + q * 16 + 4 * half);
+        }
+        if (cb > 0) __syncthreads();          // previous pass done with pat / til / wl
+#pragma unroll
+        for (int it = 0; it < NPF; ++it) {
+            const int i = tid + it * 256;
+            if (i < NPP * 4) *reinterpret_cast<float4*>(pat + i * 4) = pv[it];
+        }
+#pragma unroll
+        for (int it = 0; it < NWF; ++it) {
+            const int i = tid + it * 256;
+            if (i < 288) {
+                const int r = i & 3, half = (i >> 2) & 1, q = (i >> 3) & 3, t = i >> 5;
+                float* d = wl + ((t * 4 + q) * 2 + half) * 16 + r;
+                d[0] = wv4[it].x; d[4] = wv4[it].y; d[8] = wv4[it].z; d[12] = wv4[it].w;
+            }
         }
         __syncthreads();
         // ---- build the FPN-sum tile (lat0 on the matrix cores, see k_smooth0_fused) into the quad planes ----
@@ -869,21 +939,22 @@ __global__ __launch_bounds__(256, 3) void k_smooth0_b4(const float* __restrict__
 #pragma unroll 1
             for (int t = wv; t < NT16; t += 4) {
                 const int px = t * 16 + j, pxc = px < NPX ? px : NPX - 1;
-                const int ly = pxc / IW, lx = pxc - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
-                const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const int ly = (pxc * 241) >> 13, lx = pxc - ly * IW;                    // pxc / 34 for pxc < 340
+                const float4 rt = *reinterpret_cast<const float4*>(tabs + ly * 4);
+                const float4 ct = *reinterpret_cast<const float4*>(tabs + (IH + lx) * 4);
+                const int ro0 = __float_as_int(rt.x), ro1 = __float_as_int(rt.y), co0 = __float_as_int(ct.x), co1 = __float_as_int(ct.y);
+                const bool inside = (ro0 | co0) >= 0;
                 const float2 cv = *reinterpret_cast<const float2*>(c0t + pxc * 8 + 2 * g);
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat.x, cv.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat.y, cv.y, acc, 0, 0, 0);
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (inside) {
-                    const Lerp1 vy = ac_lerp(gy, sy, H1), vx = ac_lerp(gx, sx, W1);
-                    const float* p00 = pat + ((vy.i0 - py0) * PW + (vx.i0 - px0)) * 16 + g * 4;
-                    const float* p01 = pat + ((vy.i0 - py0) * PW + (vx.i1 - px0)) * 16 + g * 4;
-                    const float* p10 = pat + ((vy.i1 - py0) * PW + (vx.i0 - px0)) * 16 + g * 4;
-                    const float* p11 = pat + ((vy.i1 - py0) * PW + (vx.i1 - px0)) * 16 + g * 4;
-                    const float4 u00 = *reinterpret_cast<const float4*>(p00), u01 = *reinterpret_cast<const float4*>(p01);
-                    const float4 u10 = *reinterpret_cast<const float4*>(p10), u11 = *reinterpret_cast<const float4*>(p11);
+                    Lerp1 vy, vx;
+                    vy.l0 = rt.z; vy.l1 = rt.w; vx.l0 = ct.z; vx.l1 = ct.w; vy.i0 = vy.i1 = vx.i0 = vx.i1 = 0;
+                    const float* pb = pat + g * 4;
+                    const float4 u00 = *reinterpret_cast<const float4*>(pb + ro0 + co0), u01 = *reinterpret_cast<const float4*>(pb + ro0 + co1);
+                    const float4 u10 = *reinterpret_cast<const float4*>(pb + ro1 + co0), u11 = *reinterpret_cast<const float4*>(pb + ro1 + co1);
                     o.x = ac_blend(vy, vx, u00.x, u01.x, u10.x, u11.x) + (acc[0] + bias4.x);
                     o.y = ac_blend(vy, vx, u00.y, u01.y, u10.y, u11.y) + (acc[1] + bias4.y);
                     o.z = ac_blend(vy, vx, u00.z, u01.z, u10.z, u11.z) + (acc[2] + bias4.z);
@@ -936,7 +1007,7 @@ void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1p
     const int out_stride = L.out_stride > 0 ? L.out_stride : 8;
     if (ENERF_SMOOTH0_B4 && w_pq != nullptr) {                         // default: batched-4x4 convolution, 8x32 tiles
         const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
-        const size_t shmem = (size_t)(340 * 8 + 140 * 16 + 4 * 340 * 4 + 288 + 9 * 4 * 32) * sizeof(float);
+        const size_t shmem = (size_t)(340 * 8 + 140 * 16 + 4 * 340 * 4 + 288 + 9 * 4 * 32 + 44 * 4) * sizeof(float);
         ENERF_LAUNCH(k_smooth0_b4, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, L.w, L.scale, L.shift, c0, f1pre, lat_w,
                      lat_b, out, L.rgb_src, out_stride, N, H, W, tiles_y, tiles_x);
         return;

@@ -309,6 +309,9 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
     float* f[3] = {ws + P.f[0], ws + P.f[1], ws + P.f[2]};
     const int fh[3] = {a->H / 4, a->H / 2, a->H}, fw[3] = {a->W / 4, a->W / 2, a->W}, fc[3] = {32, 16, 8};
     bool forked = false;                 // the FeatureNet's top-down half runs on the side lane
+    int gate_mode = 1;                   // see enerf_options_t.side_gate (resolved below)
+    bool stage2_enqueued = true;         // the FeatureNet's last stage (smooth0) has been enqueued (false while gated)
+    int stage2_rc = ENERF_OK;
     int render_forks = 0;                // renders of non-final levels enqueued on the lane's second stream
     int joined[3] = {1, 1, 1};           // feature level l is visible to the caller's stream
 #ifndef ENERF_EMU
@@ -348,8 +351,22 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
             hipStreamWaitEvent(lane->stream, lane->trunk, 0);
             rc = fstage(ENERF_FEAT_LEVEL1, (enerf_stream_t)lane->stream);
             hipEventRecord(lane->l1, lane->stream);
-            if (rc == ENERF_OK) rc = fstage(ENERF_FEAT_LEVEL2, (enerf_stream_t)lane->stream);
-            hipEventRecord(lane->l2, lane->stream);
+            // The last stage (lat0 + smooth0 -> render texels) is needed only by the final render.  Enqueued here (default) it
+            // shares the chip with level 0; GATED (enerf_options_t.side_gate >= 2) it is enqueued later, from inside the last
+            // level's cost regularisation, behind an event, to run beside that level's small deep layers instead.  Measured in
+            // round 3 (profiles/r03_ab_side_gate.txt): gating LOSES 1-2 % on all three workloads — the early start wins.
+            gate_mode = a->options ? a->options->side_gate : 0;
+            if (gate_mode == 0) gate_mode = 1;
+            const int lastl = c.num - 1;
+            const bool gateable = c.num >= 2 && P.tex2 && c.render_if[lastl] && c.render_im_feat_level[lastl] == 2;
+            for (int l = 0; l < lastl && gateable; ++l)                       // nobody before the last level may need level_2
+                if (c.render_if[l] && c.render_im_feat_level[l] == 2) gate_mode = 1;
+            if (!gateable) gate_mode = 1;
+            if (gate_mode == 1) {
+                if (rc == ENERF_OK) rc = fstage(ENERF_FEAT_LEVEL2, (enerf_stream_t)lane->stream);
+                hipEventRecord(lane->l2, lane->stream);
+                stage2_enqueued = true;
+            }
             forked = true; joined[1] = joined[2] = 0;
             if (rc != ENERF_OK) return bail(rc);      // never leave the lane un-joined
         } else
@@ -364,6 +381,24 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
     }
     mark(ENERF_STAGE_FEATURE_NET);
 
+#ifndef ENERF_EMU
+    // deferred enqueue of the FeatureNet's last stage on the side lane, behind an event recorded on the caller's stream NOW
+    struct GateCtx { void* self; };
+    auto enqueue_stage2 = [&]() {
+        if (stage2_enqueued || lane == nullptr) return;
+        hipEventRecord(lane->fork, st);                               // "the chain has reached this point"
+        hipStreamWaitEvent(lane->stream, lane->fork, 0);
+        const int l2s = P.tex2 ? 12 : 8;
+        stage2_rc = enerf_feature_net_stage(a->feature_net_packed, a->src_inps, n_img, a->H, a->W, f[0], f[1], f[2], l2s,
+                                            ws + P.featnet_ws, P.featnet_ws_bytes, ENERF_FEAT_LEVEL2, a->options,
+                                            (enerf_stream_t)lane->stream);
+        hipEventRecord(lane->l2, lane->stream);
+        stage2_enqueued = true;
+    };
+    auto* enq_ptr = &enqueue_stage2;
+    CostRegHook hook = {[](void* ctx) { (*static_cast<decltype(enq_ptr)>(ctx))(); }, enq_ptr, gate_mode == 4 ? 2 : 0};
+    if (forked && gate_mode != 1) stage2_enqueued = false;
+#endif
     const float *pdepth = nullptr, *pstd = nullptr, *pnf = nullptr;
     int hp = 0, wp = 0;
     for (int i = 0; i < c.num; ++i) {
@@ -391,8 +426,18 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
         }
         if (rc != ENERF_OK) return bail(rc);
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_VOLUME));
+        const CostRegHook* hk = nullptr;
+#ifndef ENERF_EMU
+        if (!stage2_enqueued && i == c.num - 1) {
+            if (gate_mode == 3) enqueue_stage2(); else hk = &hook;
+        }
+#endif
         rc = cost_reg_run(a->cost_reg_packed[i], L.C, i != 0, vol, vol_planar, a->B, L.D, L.h, L.w, feat3d, prob, ws + P.costreg_ws,
-                          P.costreg_ws_bytes, a->options, st);
+                          P.costreg_ws_bytes, a->options, st, hk);
+#ifndef ENERF_EMU
+        if (!stage2_enqueued && i == c.num - 1) enqueue_stage2();     // (an error path inside cost_reg skipped the hook)
+        if (rc == ENERF_OK && stage2_rc != ENERF_OK) rc = stage2_rc;
+#endif
         if (rc != ENERF_OK) return bail(rc);
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_COST_REG));
         launch_depth_regression(prob, dv, a->B, L.D, L.h, L.w, c.depth_inv[i], depth, std, dmvs, st);

@@ -49,8 +49,12 @@ bool cost_reg_wants_planar_volume(const enerf_options_t& o, int in_channels, int
 bool conv3d_routes_b4_glds(const enerf_options_t& o, long long vox, int D);     // mirrors launch_conv3d's routing
 bool conv3d_routes_t2_pair(const enerf_options_t& o, long long vox_in);
 // enerf_cost_reg with the volume layout made explicit (vol_planar = 1: channel-quad planes, see launch_feature_volume)
+// hook: called on the host right after layer `after_layer` (0 = conv0) has been enqueued (enerf_forward uses it to start a
+// side-lane stage at that point of the chain); nullptr = none
+struct CostRegHook { void (*fn)(void* ctx); void* ctx; int after_layer; };
 int cost_reg_run(const float* packed, int in_channels, int full, const float* vol, int vol_planar, int B, int D, int h, int w,
-                 float* feat, float* prob, void* workspace, size_t workspace_bytes, const enerf_options_t* options, hipStream_t st);
+                 float* feat, float* prob, void* workspace, size_t workspace_bytes, const enerf_options_t* options, hipStream_t st,
+                 const CostRegHook* hook = nullptr);
 
 // ---- conv3d.hip ---------------------------------------------------------------------------------
 enum ConvKind { kConvS1 = 0, kConvS2 = 1, kConvT2 = 2 };

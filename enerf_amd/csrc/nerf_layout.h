@@ -51,21 +51,27 @@ __device__ __forceinline__ float dot4(f32x4 a, f32x4 b, float acc) {
 // k-step ks+1 are read while the MFMAs of k-step ks run (a two-deep register ring), pinned with sched_barrier — left
 // alone, hipcc emits `ds_read; s_waitcnt lgkmcnt(0); mfma; mfma` and exposes one LDS latency per MFMA pair.
 // A(e) = this lane's element of tile e = ks*NV + v; B(ks) = the k-step's B operand.
+#ifndef ENERF_CHAIN_DEPTH
+#define ENERF_CHAIN_DEPTH 2          // register ring depth: A operands are read DEPTH-1 k-steps ahead of their MFMAs
+#endif
 template <int NK, int NV, class AF, class BF>
 __device__ __forceinline__ void mfma_chain(f32x4 (&acc)[NV], AF A, BF B) {
-    float ring[2][NV];
+    constexpr int DP = ENERF_CHAIN_DEPTH;
+    float ring[DP][NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) ring[0][v] = A(v);
+    for (int k = 0; k < DP - 1 && k < NK; ++k)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) ring[k][v] = A(k * NV + v);
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
-        if (ks + 1 < NK) {
+        if (ks + DP - 1 < NK) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) ring[(ks + 1) & 1][v] = A((ks + 1) * NV + v);
+            for (int v = 0; v < NV; ++v) ring[(ks + DP - 1) % DP][v] = A((ks + DP - 1) * NV + v);
         }
         __builtin_amdgcn_sched_barrier(0);
         const float b = B(ks);
 #pragma unroll
-        for (int v = 0; v < NV; ++v) acc[v] = ENERF_MFMA(ring[ks & 1][v], b, acc[v]);
+        for (int v = 0; v < NV; ++v) acc[v] = ENERF_MFMA(ring[ks % DP][v], b, acc[v]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }

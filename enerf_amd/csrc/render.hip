@@ -30,6 +30,10 @@
 // two waves per SIMD fail to hide.  Algorithmic FLOPs/point: SURVEY.md §8a (50,952 at level 1).
 #include "nerf_layout.h"
 
+#ifndef ENERF_RENDER_PREFETCH
+#define ENERF_RENDER_PREFETCH 0      // 1: the level-1 kernel gathers sample k+1 during sample k's Agg phase (see PF below)
+#endif
+
 namespace enerf {
 
 long long nerf_packed_floats(int F) { return nerf_layout(F).total; }
@@ -123,7 +127,7 @@ template <int R> struct Stage { static constexpr int kTex = 4 * R, kStride = 4 *
 //   MLP phase, lane (g, j): channels [gR, gR+R) of every view come back from the LDS records as MFMA B operands; the
 //     rest is the k-ordered MFMA chain described at the top of this file.
 // WPE = waves per SIMD the register budget is sized for (512 / WPE VGPRs): blocks per CU x WAVES / 4
-template <int R, int S, int WAVES, int WPE>
+template <int R, int S, int WAVES, int WPE, bool PFK = false>
 __global__ __launch_bounds__(64 * WAVES)
 #ifndef ENERF_EMU
 __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
@@ -139,8 +143,23 @@ void k_render_rays(RenderArgs a) {
     float* stage_all = tcen + ((a.B * 4 + 15) & ~15);    // WAVES * S * 16 * SST
 
     // ---- prologue: stage weights + camera table ----
-    for (int i = threadIdx.x * 4; i < L.total; i += blockDim.x * 4)
-        *reinterpret_cast<float4*>(wl + i) = *reinterpret_cast<const float4*>(a.packed + i);
+    {   // weight image (42-56 KB) -> LDS with every load in flight before the first store: the plain copy loop compiles to
+        // load -> s_waitcnt vmcnt(0) -> ds_write per iteration (11-14 serial L2 round trips at the head of every block)
+        constexpr int MAXW4 = (R == 3 ? 10560 : 14528) / 4;                 // nerf_layout(11 | 35).total / 4 (the launcher checks)
+        constexpr int NWI = (MAXW4 + 64 * WAVES - 1) / (64 * WAVES);
+        float4 wq[NWI];
+        const int n4 = L.total / 4;
+#pragma unroll
+        for (int it = 0; it < NWI; ++it) {
+            const int i = (int)threadIdx.x + it * 64 * WAVES;
+            wq[it] = *reinterpret_cast<const float4*>(a.packed + (i < n4 ? i : n4 - 1) * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < NWI; ++it) {
+            const int i = (int)threadIdx.x + it * 64 * WAVES;
+            if (i < n4) *reinterpret_cast<float4*>(wl + i * 4) = wq[it];
+        }
+    }
     for (int i = threadIdx.x; i < a.B * (S + 1); i += blockDim.x) {
         int b = i / (S + 1), s = i - b * (S + 1);
         const float* E = (s < S) ? a.src_exts + ((long long)b * S + s) * 16 : a.tar_ext + (long long)b * 16;
@@ -181,7 +200,7 @@ void k_render_rays(RenderArgs a) {
 #define A_LR0(e) wlane[L.lr0 + (e) * 64]
 #define A_C0P(e) wlane[L.c0p + (e) * 64]
 #define A_C0V(e) wlane[L.c0v + (e) * 64]
-    float* stage = stage_all + wave_in_block * (S * 16 * SST);
+    float* stage = stage_all + wave_in_block * ((PFK ? 2 : 1) * S * 16 * SST);
     const int sv = g < S ? g : S - 1;                    // the source view this lane's geometry works on
     float* my_rec = stage + (sv * 16 + j) * SST;         // record this lane writes (lane groups >= S write nothing)
     const float* rd_rec = stage + j * SST + g * R;       // + s*16*SST: channels [gR, gR+R) of view s, point j
@@ -250,11 +269,19 @@ void k_render_rays(RenderArgs a) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) wk[k] = 0.f;
 
-#pragma unroll 1
-        for (int k = 0; k < Ns; ++k) {
-            // Keep the MFMA A operands (weights) in LDS (measured: holding all 155 tiles in registers at one wave per SIMD,
-            // 512-entry budget, is 40 % slower — hipcc parks them in AGPRs and copies each back with v_accvgpr_read).
-            asm volatile("" ::: "memory");
+        // ---------- the gather of one sample, in two halves so that a sample's loads can be in flight during the PREVIOUS
+        // sample's Agg MFMAs (PF, below): issue = placement, projection, taps, ALL loads, direction code;
+        // finish = trilinear weights, blends, the (view, point) record into LDS, the voxel feature pair ----------
+        struct GatherRegs {
+            float2 vt[8];
+            f32x4 tq[(R <= 3 ? 1 : 2)][4][(R <= 3 ? R : 3)];
+            const float* tp[4];
+            float tw[4], wz[2];
+            f32x4 dirc;
+        };
+        constexpr int QB = R <= 3 ? R : 3, NRND = R / QB, NBUF = NRND > 1 ? 2 : 1;
+        static_assert(R % QB == 0, "texel chunk rounds");
+        auto gather_issue = [&](int k, GatherRegs& G) {
             // ---------- sample placement (utils.py:425-436) ----------
             float tk = (Ns == 1) ? 0.5f : linspace01(k, Ns);
             float z = rn + (rf - rn) * tk;
@@ -262,7 +289,6 @@ void k_render_rays(RenderArgs a) {
             float X = ox + dx * zz, Y = oy + dy * zz, Z = oz + dz * zz;
             float dn = a.depth_inv ? (vn - z) * fast_rcp(clamp_min(vn - vf, 1e-6f))
                                    : (z - vn) * fast_rcp(clamp_min(vf - vn, 1e-6f));
-
             // ---------- addresses first, then ALL gathers of the sample in flight together, then the arithmetic that does
             // not need them, then the blends.  The sched_barriers pin that order: left alone, hipcc sinks every load to
             // its first use under register pressure — eight voxel taps became eight serial memory round trips.
@@ -274,38 +300,33 @@ void k_render_rays(RenderArgs a) {
             const float gx = ((px * rz) * rcpW) * 2.f - 1.f, gy = ((py * rz) * rcpH) * 2.f - 1.f;
             const Taps2 t = gs_taps2<true>(gs_unnorm(gx, a.Wr), gs_unnorm(gy, a.Hr), a.Wr, a.Hr);
             const int r0 = mul24(t.y0, a.Wr), r1 = mul24(t.y1, a.Wr);
-            const float* tp[4] = {a.tex + (toff + (unsigned)mul24(r0 + t.x0, TEX)), a.tex + (toff + (unsigned)mul24(r0 + t.x1, TEX)),
-                                  a.tex + (toff + (unsigned)mul24(r1 + t.x0, TEX)), a.tex + (toff + (unsigned)mul24(r1 + t.x1, TEX))};
-            const float tw[4] = {t.w00, t.w01, t.w10, t.w11};
+            G.tp[0] = a.tex + (toff + (unsigned)mul24(r0 + t.x0, TEX)); G.tp[1] = a.tex + (toff + (unsigned)mul24(r0 + t.x1, TEX));
+            G.tp[2] = a.tex + (toff + (unsigned)mul24(r1 + t.x0, TEX)); G.tp[3] = a.tex + (toff + (unsigned)mul24(r1 + t.x1, TEX));
+            G.tw[0] = t.w00; G.tw[1] = t.w01; G.tw[2] = t.w10; G.tw[3] = t.w11;
             // voxel feature: trilinear, zeros padding (utils.py:457); lane group g fetches channels 2g, 2g+1
             float iz = gs_unnorm(dn * 2.f - 1.f, a.D);
             iz = fabsf(iz) < 1e8f ? iz : -10.f;
             const float fz = floorf(iz);
             const int z0 = (int)fz;
-            float wz[2] = {(fz + 1.f) - iz, iz - fz};
+            G.wz[0] = (fz + 1.f) - iz; G.wz[1] = iz - fz;
             int zo[2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int zc = z0 + c;
-                wz[c] = (unsigned)zc < (unsigned)a.D ? wz[c] : 0.f;
+                G.wz[c] = (unsigned)zc < (unsigned)a.D ? G.wz[c] : 0.f;
                 zo[c] = mul24(min(max(zc, 0), a.D - 1), a.h * a.w);
             }
             __builtin_amdgcn_sched_barrier(0);
-            float2 vt[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c)                 // order tnw,tne,tsw,tse,bnw,bne,bsw,bse
-                vt[c] = *reinterpret_cast<const float2*>(a.vol + ((unsigned)(zo[c >> 2] + oxy[c & 3]) * 8u + voff));
+                G.vt[c] = *reinterpret_cast<const float2*>(a.vol + ((unsigned)(zo[c >> 2] + oxy[c & 3]) * 8u + voff));
             // texel channels are gathered QB float4 chunks per tap at a time; R = 9 takes three rounds, two of them in flight
-            constexpr int QB = R <= 3 ? R : 3, NRND = R / QB, NBUF = NRND > 1 ? 2 : 1;
-            static_assert(R % QB == 0, "texel chunk rounds");
-            f32x4 blend[R];
-            f32x4 tq[NBUF][4][QB];
 #pragma unroll
             for (int rd = 0; rd < NBUF; ++rd)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int q = 0; q < QB; ++q) tq[rd][c][q] = lds4(tp[c] + 4 * (rd * QB + q));
+                    for (int q = 0; q < QB; ++q) G.tq[rd][c][q] = lds4(G.tp[c] + 4 * (rd * QB + q));
             __builtin_amdgcn_sched_barrier(0);
             // direction code (utils.py:707-720) while the gathers are in flight
             float tx = X - tc4[0], ty = Y - tc4[1], tz = Z - tc4[2];
@@ -316,19 +337,22 @@ void k_render_rays(RenderArgs a) {
             sx *= sir; sy *= sir; sz *= sir;
             const float ex = tx - sx, ey = ty - sy, ez = tz - sz;
             const float eir = fast_rcp(fmaxf(fast_sqrt(ex * ex + ey * ey + ez * ez), 1e-6f));
-            const f32x4 dirc = f32x4{ex * eir, ey * eir, ez * eir, tx * sx + ty * sy + tz * sz};
+            G.dirc = f32x4{ex * eir, ey * eir, ez * eir, tx * sx + ty * sy + tz * sz};
+        };
+        auto gather_finish = [&](GatherRegs& G, float* rec, float (&vox)[2]) {
             float vw[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) vw[c] = wxy[c & 3] * wz[c >> 2];
+            for (int c = 0; c < 8; ++c) vw[c] = wxy[c & 3] * G.wz[c >> 2];
             __builtin_amdgcn_sched_barrier(0);
+            f32x4 blend[R];
 #pragma unroll
             for (int rd = 0; rd < NRND; ++rd) {
 #pragma unroll
                 for (int q = 0; q < QB; ++q) {
-                    f32x4 acc = tq[rd % NBUF][0][q] * tw[0];
-                    acc += tq[rd % NBUF][1][q] * tw[1];
-                    acc += tq[rd % NBUF][2][q] * tw[2];
-                    acc += tq[rd % NBUF][3][q] * tw[3];
+                    f32x4 acc = G.tq[rd % NBUF][0][q] * G.tw[0];
+                    acc += G.tq[rd % NBUF][1][q] * G.tw[1];
+                    acc += G.tq[rd % NBUF][2][q] * G.tw[2];
+                    acc += G.tq[rd % NBUF][3][q] * G.tw[3];
                     blend[rd * QB + q] = acc;
                 }
                 if (rd + NBUF < NRND) {                 // refill the buffer just consumed (R = 9 only)
@@ -336,30 +360,56 @@ void k_render_rays(RenderArgs a) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
 #pragma unroll
-                        for (int q = 0; q < QB; ++q) tq[rd % NBUF][c][q] = lds4(tp[c] + 4 * ((rd + NBUF) * QB + q));
+                        for (int q = 0; q < QB; ++q) G.tq[rd % NBUF][c][q] = lds4(G.tp[c] + 4 * ((rd + NBUF) * QB + q));
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (g < S) {
 #pragma unroll
-                for (int q = 0; q < R; ++q) *reinterpret_cast<f32x4*>(my_rec + 4 * q) = blend[q];
-                *reinterpret_cast<f32x4*>(my_rec + TEX) = dirc;
+                for (int q = 0; q < R; ++q) *reinterpret_cast<f32x4*>(rec + 4 * q) = blend[q];
+                *reinterpret_cast<f32x4*>(rec + TEX) = G.dirc;
             }
-            float vox[2] = {0.f, 0.f};
+            vox[0] = 0.f; vox[1] = 0.f;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                vox[0] += vt[c].x * vw[c];
-                vox[1] += vt[c].y * vw[c];
+                vox[0] += G.vt[c].x * vw[c];
+                vox[1] += G.vt[c].y * vw[c];
+            }
+        };
+        // PF: software pipelining across the samples of a ray tile (R = 3 only: the 74 registers of a sample in flight fit
+        // beside the Agg phase, not beside the wider level-0 MLP).  Records are double-buffered in LDS.
+        constexpr bool PF = PFK;
+        constexpr int RECBUF = S * 16 * SST;              // floats of one record buffer of a wave
+        GatherRegs GR;
+        float vox_next[2] = {0.f, 0.f};
+        if (PF) {
+            gather_issue(0, GR);
+            gather_finish(GR, my_rec, vox_next);
+        }
+#pragma unroll 1
+        for (int k = 0; k < Ns; ++k) {
+            // Keep the MFMA A operands (weights) in LDS (measured: holding all 155 tiles in registers at one wave per SIMD,
+            // 512-entry budget, is 40 % slower — hipcc parks them in AGPRs and copies each back with v_accvgpr_read).
+            asm volatile("" ::: "memory");
+            float vox[2];
+            const int rb = PF ? (k & 1) * RECBUF : 0;     // this sample's record buffer
+            if (!PF) {
+                gather_issue(k, GR);
+                gather_finish(GR, my_rec, vox);
+            } else {
+                vox[0] = vox_next[0]; vox[1] = vox_next[1];
             }
             wave_sync();                              // the records of this tile are written: read them back as B operands
             float x[S][R], dsel[S];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) x[s][r] = rd_rec[s * 16 * SST + r];
-                dsel[s] = rd_dir[s * 16 * SST];
+                for (int r = 0; r < R; ++r) x[s][r] = rd_rec[rb + s * 16 * SST + r];
+                dsel[s] = rd_dir[rb + s * 16 * SST];
             }
             wave_sync();                              // ... before the next sample overwrites them
+            const bool more = PF && k + 1 < Ns;           // uniform
+            if (more) gather_issue(k + 1, GR);            // the next sample's loads fly during this sample's Agg phase
 
             // ---------- Agg (nerf.py:74-89) ----------
             float av[S][R];
@@ -450,6 +500,8 @@ void k_render_rays(RenderArgs a) {
                 for (int e = 0; e < 8; ++e) aggv[0] = ENERF_MFMA(afc[e], G[e >> 2][e & 3], aggv[0]);
             }
             const f32x4 agg = relu4(aggv[0]);
+
+            if (more) gather_finish(GR, my_rec + ((k + 1) & 1) * RECBUF, vox_next);   // blends + record of sample k+1 (other buffer)
 
             // ---------- NeRF trunk (nerf.py:33-37) ----------
             f32x4 hid[4];
@@ -564,20 +616,20 @@ void k_render_rays(RenderArgs a) {
     }
 }
 
-template <int R, int WAVES, int OCC>
+template <int R, int WAVES, int OCC, bool PFK = false>
 static int dispatch_s(const RenderArgs& a, unsigned grid, size_t shmem, hipStream_t st) {
     constexpr int WPE = (WAVES * OCC + 3) / 4;
     switch (a.S) {
-        case 2: ENERF_LAUNCH((k_render_rays<R, 2, WAVES, WPE>), grid, 64 * WAVES, shmem, st, a); return 0;
-        case 3: ENERF_LAUNCH((k_render_rays<R, 3, WAVES, WPE>), grid, 64 * WAVES, shmem, st, a); return 0;
-        case 4: ENERF_LAUNCH((k_render_rays<R, 4, WAVES, WPE>), grid, 64 * WAVES, shmem, st, a); return 0;
+        case 2: ENERF_LAUNCH((k_render_rays<R, 2, WAVES, WPE, PFK>), grid, 64 * WAVES, shmem, st, a); return 0;
+        case 3: ENERF_LAUNCH((k_render_rays<R, 3, WAVES, WPE, PFK>), grid, 64 * WAVES, shmem, st, a); return 0;
+        case 4: ENERF_LAUNCH((k_render_rays<R, 4, WAVES, WPE, PFK>), grid, 64 * WAVES, shmem, st, a); return 0;
         default: return -3;
     }
 }
 template <int R, int WAVES>
-static size_t render_shmem(const RenderArgs& a) {
+static size_t render_shmem(const RenderArgs& a, int record_buffers = 1) {
     return ((size_t)nerf_layout(a.F).total + (size_t)a.B * a.S * kCamStride + (size_t)((a.B * 4 + 15) & ~15) +
-            (size_t)WAVES * a.S * 16 * Stage<R>::kStride) * sizeof(float);
+            (size_t)WAVES * record_buffers * a.S * 16 * Stage<R>::kStride) * sizeof(float);
 }
 int launch_render_rays(const RenderArgs& a, hipStream_t st) {
     if (a.n_samples < 1 || a.n_samples > 8) return -1;
@@ -602,11 +654,16 @@ int launch_render_rays(const RenderArgs& a, hipStream_t st) {
 #ifndef ENERF_RENDER_OCC
 #define ENERF_RENDER_OCC 2
 #endif
+    if (nerf_layout(a.F).total > (R == 3 ? 10560 : 14528)) return -6;      // the kernel's weight-staging bound (F = 11 / 35)
     if (R == 3) {                                                                                              // C = 8
         const size_t shmem = render_shmem<3, ENERF_RENDER_WAVES>(a);
         if (shmem > 160 * 1024 / ENERF_RENDER_OCC) return -2;
         const unsigned grid = grid_for(ENERF_RENDER_WAVES, ENERF_RENDER_OCC);
         if (grid == 0) return 0;
+        // sample-pipelined variant (two record buffers per wave) when it still fits two blocks per CU and there is a next sample
+        const size_t shmem_pf = render_shmem<3, ENERF_RENDER_WAVES>(a, 2);
+        if (ENERF_RENDER_PREFETCH != 0 && a.n_samples > 1 && shmem_pf <= 160 * 1024 / ENERF_RENDER_OCC)
+            return dispatch_s<3, ENERF_RENDER_WAVES, ENERF_RENDER_OCC, true>(a, grid, shmem_pf, st);
         return dispatch_s<3, ENERF_RENDER_WAVES, ENERF_RENDER_OCC>(a, grid, shmem, st);
     }
     if (R == 9) {                                                                   // C = 32: one 8-wave block per CU

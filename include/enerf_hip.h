@@ -54,6 +54,13 @@ typedef struct {
                                         level 1 and the final render consume, is forked onto a library-owned side stream and
                                         overlaps level 0's warp + cost regularisation; joined with events before its first
                                         consumer — still ONE frame, no frames in flight (ABI >= 4) */
+    int side_gate;                   /* enerf_forward, ABI >= 5: WHEN the side lane starts the FeatureNet's last stage (lat0 + smooth0,
+                                        the render texels: needed only at the end of the frame, and the largest side kernel).
+                                        0 / 1 = ungated (default: right behind lat1/smooth1, overlapping level 0);
+                                        2 = gated behind the LAST cascade level's conv0 (beside that level's small deep layers;
+                                        measured 1-2 % slower on dtu / lego / zju: profiles/r03_ab_side_gate.txt);
+                                        3 = at the start of the last level (after the previous depth regression);
+                                        4 = behind the last level's conv2 */
     int conv3d_t2_variant;           /* transposed 3-D layers (conv9 32->16, conv11 16->8), ABI >= 5: 0 = the every-class LDS kernel
                                         with x-parity-paired MFMA rows where it measured faster (default); 1 = the round-2
                                         kernels only (A/B); 2 = the every-class kernel for every layer it handles */

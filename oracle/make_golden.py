@@ -255,18 +255,18 @@ def run_full_case(name: str) -> None:
 
 
 TRAIN_CASE = dict(H=32, W=64, S=3, planes=(8, 8), render_if=(True, True), seed=7, loss_weight=(0.1, 1.0))
+TRAIN_CASES = {"train_tiny": TRAIN_CASE,
+               # a mid-size step: 128x160, 16 + 8 planes, 20,480 + 1,280 rays
+               "train_small": dict(H=128, W=160, S=3, planes=(16, 8), render_if=(True, True), seed=8, loss_weight=(0.1, 1.0))}
 
 
 def grad_digest(g: torch.Tensor) -> dict:
-    """Full gradient for small parameters; head + tail + norm + sum for the big ones (keeps the fixture small)."""
+    """The FULL gradient of every parameter (436,012 floats per case) + its float64 norm."""
     f = g.detach().reshape(-1)
-    if f.numel() <= 4096:
-        return {"full": f.numpy()}
-    return {"head": f[:2048].numpy(), "tail": f[-2048:].numpy(), "norm": np.array(float(f.double().norm())),
-            "sum": np.array(float(f.double().sum()))}
+    return {"full": f.numpy(), "norm": np.array(float(f.double().norm()))}
 
 
-def run_train_case() -> None:
+def run_train_case(case: str = "train_tiny") -> None:
     """One training step of the UNMODIFIED reference network (``.train()``: BN batch statistics, autograd) under the MSE
     part of lib/train/losses/enerf.py:21-24 (loss_weight from dtu_pretrain.yaml:43; the VGG perceptual term needs
     downloaded torchvision weights and is left out).  Writes tests/golden/train_tiny.npz: loss, outputs, parameter
@@ -275,7 +275,7 @@ def run_train_case() -> None:
     from enerf_amd.config import EnerfConfig
     from enerf_amd.synth import make_batch
 
-    c = TRAIN_CASE
+    c = TRAIN_CASES[case]
     opts = ["enerf.cas_config.volume_planes", ",".join(map(str, c["planes"])),
             "enerf.cas_config.render_if", ",".join(map(str, c["render_if"]))]
     cfg, ref_network = load_reference("configs/enerf/dtu_pretrain.yaml", opts)
@@ -312,8 +312,8 @@ def run_train_case() -> None:
         if name.endswith("running_mean") or name.endswith("running_var"):
             save[f"buf/{name}"] = buf.numpy()
     save["meta/torch_version"] = np.array(torch.__version__)
-    np.savez_compressed(os.path.join(GOLDEN, "train_tiny.npz"), **save)
-    print(f"[golden] train_tiny: loss {float(loss):.6f}; {n_grad} parameter gradients; {len(save)} arrays")
+    np.savez_compressed(os.path.join(GOLDEN, f"{case}.npz"), **save)
+    print(f"[golden] {case}: loss {float(loss):.6f}; {n_grad} parameter gradients; {len(save)} arrays")
 
 
 def main() -> None:
@@ -321,8 +321,8 @@ def main() -> None:
     ap.add_argument("--case", default=None)
     a = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
-    if a.case == "train_tiny":
-        run_train_case()
+    if a.case in TRAIN_CASES:
+        run_train_case(a.case)
         return
     if a.case in FULL_CASES:
         run_full_case(a.case)
@@ -333,7 +333,7 @@ def main() -> None:
     wpath = os.path.join(GOLDEN, "weights_seed0.npz")
     if os.path.exists(wpath):
         os.remove(wpath)
-    for name in list(CASES) + ["train_tiny"] + list(FULL_CASES):
+    for name in list(CASES) + list(TRAIN_CASES) + list(FULL_CASES):
         subprocess.run([sys.executable, os.path.abspath(__file__), "--case", name], check=True, cwd=ROOT)
 
 
