@@ -183,32 +183,41 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
         }
         __syncthreads();
 
+        // B operands (tile pixels from LDS) of tap (kh, kw) for this wave's column tiles
+        auto read_b = [&](int kh, int kw, float (&bv)[CTW][4]) {
+#pragma unroll
+            for (int c = 0; c < CTW; ++c) {
+                const int tile = wv * CTW + c, tr = tile / (TW / 16), tc = tile - tr * (TW / 16);
+                const float* p = lds + slot(tr * STR + kh, (tc * 16 + j) * STR + kw) * CB + g * CPL;
+                if (CPL == 4) {
+                    const float4 tq = *reinterpret_cast<const float4*>(p);
+                    bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
+                } else if (CPL == 2) {
+                    const float2 tq = *reinterpret_cast<const float2*>(p);
+                    bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = 0.f; bv[c][3] = 0.f;
+                } else {
+                    bv[c][0] = p[0]; bv[c][1] = 0.f; bv[c][2] = 0.f; bv[c][3] = 0.f;
+                }
+            }
+        };
+        // One tap row; the B operands of tap kw+1 are read while the MFMAs of tap kw run (two-deep register ring pinned with
+        // sched_barrier).  Measured (profiles/r03_conv2d_ablation.txt, r03_kv3): conv1.0 28.0 -> 25.9 us, the others unchanged.
         auto compute = [&](int kh, const float (&aq)[NAQ]) {
+            float bq[2][CTW][4];
+            read_b(kh, 0, bq[0]);
 #pragma unroll
             for (int kw = 0; kw < K; ++kw) {
-                float bv[CTW][4];
-#pragma unroll
-                for (int c = 0; c < CTW; ++c) {
-                    const int tile = wv * CTW + c, tr = tile / (TW / 16), tc = tile - tr * (TW / 16);
-                    const float* p = lds + slot(tr * STR + kh, (tc * 16 + j) * STR + kw) * CB + g * CPL;
-                    if (CPL == 4) {
-                        const float4 tq = *reinterpret_cast<const float4*>(p);
-                        bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
-                    } else if (CPL == 2) {
-                        const float2 tq = *reinterpret_cast<const float2*>(p);
-                        bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = 0.f; bv[c][3] = 0.f;
-                    } else {
-                        bv[c][0] = p[0]; bv[c][1] = 0.f; bv[c][2] = 0.f; bv[c][3] = 0.f;
-                    }
-                }
+                if (kw + 1 < K) read_b(kh, kw + 1, bq[(kw + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < CPL; ++r)
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                         for (int c = 0; c < CTW; ++c)
-                            acc[c][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[(kw * CPL + r) * RT + rt], bv[c][r],
+                            acc[c][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[(kw * CPL + r) * RT + rt], bq[kw & 1][c][r],
                                                                               acc[c][rt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
         if (K <= 3) {
