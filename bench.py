@@ -426,6 +426,27 @@ def main():
             if args.workload == "dtu":
                 result["vs_baseline_pipelined"] = round(sus["pipelined_fps"] / BASELINE_FPS_RTX3090, 2)
 
+        # ---- north_star's split kept visible: the same frames with the FeatureNet in PyTorch-ROCm (MIOpen), NCHW maps handed
+        #      through the C ABI (feature_backend="torch"); an extra key, never `value` ----
+        if args.feature_backend == "hip" and not human:
+            try:
+                net_t = _seeded_network(cfg, dev, human=human, feature_backend="torch")
+                for _ in range(10):
+                    net_t(batches[0])
+                torch.cuda.synchronize()
+                lt = []
+                for f in range(60):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    net_t(batches[f % nb])
+                    torch.cuda.synchronize()
+                    lt.append(time.perf_counter() - t1)
+                result["feature_backend_torch"] = {"value": round(len(lt) / sum(lt), 1), "unit": "frames/s",
+                                                   "note": "same protocol, FeatureNet in PyTorch-ROCm/MIOpen (north_star's split); 60 frames"}
+                del net_t
+            except Exception as e:                      # an extra: never let it take the line down
+                result["feature_backend_torch"] = {"error": str(e)[:200]}
+
         # ---- rooflines: per stage, and the dominant kernel as the contract's `roofline` object ----
         sr = {}
         for i in range(cas.num):

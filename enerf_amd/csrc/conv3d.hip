@@ -634,7 +634,7 @@ bool launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, 
         // measured (profiles/r03_conv3d_layers.txt): conv11 16.3 vs 24.0 us (level 1), 10.3 vs 15.2 (level 0); conv9 10.7 vs
         // 17.2 (level 1) but 10.1 vs 9.1 at level 0's 3840 positions (240 q-tiles: too few blocks)
         const bool big = L.cout == 8 ? vox_in >= min_vox : vox_in >= min_vox / 2;
-        if ((big || o.conv3d_t2_variant == 2) && launch_conv3d_t2_all(L, in, residual, out, B, Di, Hi, Wi, st)) return true;
+        if ((big || o.conv3d_t2_variant >= 2) && launch_conv3d_t2_all(L, in, residual, out, B, Di, Hi, Wi, st)) return true;
     }
     if (L.out_planar) return false;                    // only the kernel above writes channel-quad planes
     // round-2 LDS-staged transposed path (conv11, 16 -> 8, one class per MFMA): kept for A/B (conv3d_t2_variant = 1)
@@ -679,7 +679,7 @@ bool conv3d_routes_b4_glds(const Options& o, long long vox, int D) {
 }
 bool conv3d_routes_t2_pair(const Options& o, long long vox_in) {
     const long long min_vox = o.conv3d_lds_min_voxels > 0 ? o.conv3d_lds_min_voxels : 16384;
-    return !o.conv3d_global_only && o.conv3d_t2_variant != 1 && (vox_in >= min_vox || o.conv3d_t2_variant == 2);
+    return !o.conv3d_global_only && o.conv3d_t2_variant != 1 && (vox_in >= min_vox || o.conv3d_t2_variant >= 2);
 }
 bool cost_reg_wants_planar_volume(const enerf_options_t& o, int in_channels, int B, int D, int h, int w) {
     (void)in_channels;

@@ -272,10 +272,12 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_s1_b4g(const float* __restric
         w_off[k] = tap * NQ * 48 + e * 4;
     }
     auto issue = [&](int cq, float* buf) {
+#if !(defined(ENERF_ABL_B4G) && (ENERF_ABL_B4G & 2))            // ablation: no input staging (weights only)
 #pragma unroll
         for (int k = 0; k < MYCH; ++k)
             if (wv + 4 * k < NCH)                                  // wave-uniform
                 glds16(src_off[k] >= 0 ? inb + src_off[k] + cq * qstride : g_b4_zeros, buf + (wv + 4 * k) * 256, lane);
+#endif
 #pragma unroll
         for (int k = 0; k < MYW; ++k)
             if (wv + 4 * k < NWCH)
@@ -308,9 +310,14 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_s1_b4g(const float* __restric
         float4 aq[2][NS], bq[2][V];
         read_a(0, aq[0]);
         read_b(0, bq[0]);
+#if defined(ENERF_ABL_B4G) && (ENERF_ABL_B4G & 1)               // ablation (tools/build_variant.py): 9 of the 27 taps
+        constexpr int NTAP = 9;
+#else
+        constexpr int NTAP = 27;
+#endif
 #pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
-            if (tap + 1 < 27) { read_a(tap + 1, aq[(tap + 1) & 1]); read_b(tap + 1, bq[(tap + 1) & 1]); }
+        for (int tap = 0; tap < NTAP; ++tap) {
+            if (tap + 1 < NTAP) { read_a(tap + 1, aq[(tap + 1) & 1]); read_b(tap + 1, bq[(tap + 1) & 1]); }
             __builtin_amdgcn_sched_barrier(0);
             if (HEADS) {
 #pragma unroll

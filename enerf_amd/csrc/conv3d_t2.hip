@@ -365,7 +365,9 @@ bool launch_conv3d_t2_all(const Conv3dDesc& L, const float* in, const float* res
     if (L.kind != kConvT2) return false;
     if (L.out_planar && !(L.cin == 16 && L.cout == 8 && L.w_t2pair != nullptr)) return false;
     if ((long long)B * 8 * Di * Hi * Wi * L.cout >= (1LL << 32)) return false;                        // 32-bit output offsets
-    if (L.cin == 16 && L.cout == 8 && L.w_t2pair != nullptr) { launch_t2_all<16, 8, 2, 4>(L, in, residual, out, B, Di, Hi, Wi, st); return true; }
+    // q-boxes (measured, tools/bench_conv3d_layers.py): conv11 1 x 4 x 16 (15.8 / 9.7 us at level 1 / 0; 2 x 4 x 16: 16.5 / 10.5;
+    // 2 x 8 x 16: 21.0 / 12.5), conv9 1 x 4 x 16 (10.9 us; 1 x 8 x 16: 15.9)
+    if (L.cin == 16 && L.cout == 8 && L.w_t2pair != nullptr) { launch_t2_all<16, 8, 1, 4>(L, in, residual, out, B, Di, Hi, Wi, st); return true; }
     if (L.cin == 32 && L.cout == 16) { launch_t2_all<32, 16, 1, 4>(L, in, residual, out, B, Di, Hi, Wi, st); return true; }
     return false;
 }
