@@ -903,18 +903,17 @@ __global__ __launch_bounds__(256, 3) void k_smooth0_b4(const float* __restrict__
     const float* tb = til + (row * IW + col) * 4;
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 1
-    for (int cb = 0; cb < 2; ++cb) {
-        // ---- f1pre patch (16 channels of this pass) and the pass's conv weights -> LDS; loads first (before the barrier that
-        // ends the previous pass: their latency overlaps the other waves' last taps), stores after ----
-        constexpr int NPF = (NPP * 4 + 255) / 256, NWF = (9 * 4 * 2 * 4 + 255) / 256;
-        float4 pv[NPF], wv4[NWF];
+    // The passes' f1pre patches (16 channels each) and conv weights: loads first, LDS stores after the barrier that ends the
+    // previous pass.  (ext-vector registers: as float4 arrays hipcc kept the staged values in SCRATCH — 64 B per lane, 188 MB of
+    // scratch traffic per launch, found through WRITE_SIZE in the PMC pass.)
+    constexpr int NPF = (NPP * 4 + 255) / 256, NWF = (9 * 4 * 2 * 4 + 255) / 256;
+    auto load_pass = [&](int cb, f32x4 (&pv)[NPF], f32x4 (&wv4)[NWF]) {
 #pragma unroll
         for (int it = 0; it < NPF; ++it) {
             const int i = tid + it * 256, ic = i < NPP * 4 ? i : NPP * 4 - 1;
             const int pp = ic >> 2, q = ic & 3, pr = pp / PW, pc = pp - pr * PW;
             const int gy = min(py0 + pr, H1 - 1), gx = min(px0 + pc, W1 - 1);
-            pv[it] = *reinterpret_cast<const float4*>(f1pre + (((long long)n * H1 + gy) * W1 + gx) * 32 + cb * 16 + q * 4);
+            pv[it] = *reinterpret_cast<const f32x4*>(f1pre + (((long long)n * H1 + gy) * W1 + gx) * 32 + cb * 16 + q * 4);
         }
         // weights: wl[((t*4 + q)*2 + half)*16 + rw*4 + r] = w[(t*8 + cb*4 + r)*64 + q*16 + 4*half + rw]: the source is contiguous
         // in rw, so one float4 load per (t, q, half, r) and four scalar LDS stores
@@ -922,13 +921,24 @@ __global__ __launch_bounds__(256, 3) void k_smooth0_b4(const float* __restrict__
         for (int it = 0; it < NWF; ++it) {
             const int i = tid + it * 256, ic = i < 288 ? i : 287;
             const int r = ic & 3, half = (ic >> 2) & 1, q = (ic >> 3) & 3, t = ic >> 5;
-            wv4[it] = *reinterpret_cast<const float4*>(w + ((t * 8 + cb * 4 + r) * 64) + q * 16 + 4 * half);
+            wv4[it] = *reinterpret_cast<const f32x4*>(w + ((t * 8 + cb * 4 + r) * 64) + q * 16 + 4 * half);
         }
+    };
+#ifndef ENERF_S0_HOIST
+#define ENERF_S0_HOIST 0             // 1: both passes' loads issued before the first pass (20 more live registers)
+#endif
+    f32x4 pvs[2][NPF], wvs[2][NWF];
+    if (ENERF_S0_HOIST) { load_pass(0, pvs[0], wvs[0]); load_pass(1, pvs[1], wvs[1]); }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        if (!ENERF_S0_HOIST) load_pass(cb, pvs[cb], wvs[cb]);
+        f32x4 (&pv)[NPF] = pvs[cb];
+        f32x4 (&wv4)[NWF] = wvs[cb];
         if (cb > 0) __syncthreads();          // previous pass done with pat / til / wl
 #pragma unroll
         for (int it = 0; it < NPF; ++it) {
             const int i = tid + it * 256;
-            if (i < NPP * 4) *reinterpret_cast<float4*>(pat + i * 4) = pv[it];
+            if (i < NPP * 4) *reinterpret_cast<f32x4*>(pat + i * 4) = pv[it];
         }
 #pragma unroll
         for (int it = 0; it < NWF; ++it) {
@@ -936,7 +946,7 @@ __global__ __launch_bounds__(256, 3) void k_smooth0_b4(const float* __restrict__
             if (i < 288) {
                 const int r = i & 3, half = (i >> 2) & 1, q = (i >> 3) & 3, t = i >> 5;
                 float* d = wl + ((t * 4 + q) * 2 + half) * 16 + r;
-                d[0] = wv4[it].x; d[4] = wv4[it].y; d[8] = wv4[it].z; d[12] = wv4[it].w;
+                d[0] = wv4[it][0]; d[4] = wv4[it][1]; d[8] = wv4[it][2]; d[12] = wv4[it][3];
             }
         }
         __syncthreads();

@@ -90,6 +90,27 @@ def test_training_step_matches_reference_gradients(case):
             np.testing.assert_allclose(buf.numpy(), g[f"buf/{name}"], rtol=1e-4, atol=1e-6, err_msg=name)
 
 
+def test_mid_size_step_is_ill_conditioned_in_the_reference():
+    """Why the 128x160 fixture cannot carry the 5e-4 bound of the 32x64 one: the reference's OWN gradients (torch-op path = the
+    reference's ops; bit-identical forward) are not reproducible beyond ~1e-3 at this size.  A 1e-6 relative perturbation of the
+    cost volume — smaller than the difference between two fp32 summation orders of the warp — moves some parameter gradients
+    by more than 1e-3 of their largest element."""
+    from enerf_amd import train_path as T
+    g = np.load(os.path.join(GOLDEN, "train_small.npz"))
+    cfg, batch = _train_batch(**TRAIN_CASES["train_small"])
+    gen = torch.Generator().manual_seed(0)
+    orig = T.feature_volume
+    T.feature_volume = lambda f, P, dv: (lambda v: v * (1 + 1e-6 * (torch.rand(v.shape, generator=gen) * 2 - 1)))(orig(f, P, dv))
+    try:
+        net = _net(cfg)
+        _loss(net(batch), batch).backward()
+    finally:
+        T.feature_volume = orig
+    errs = _grad_errors([(n, p.grad) for n, p in net.named_parameters() if p.grad is not None], g)
+    assert max(errs.values()) > 1e-3, max(errs.values())          # (measured 7e-3; with 1 vs 8 CPU threads alone: 1.8e-3)
+    assert max(errs.values()) < GPU_GRAD_TOL_MID                   # ... and the bound used on the GPU has head-room over it
+
+
 def _check_hip_backward_stages(lib, dev):
     """Every autograd.Function of enerf_amd/autograd.py (HIP forward + HIP backward through the C ABI) against the same
     stage in torch ops (enerf_amd/train_path.py), values and gradients."""
@@ -425,6 +446,13 @@ def test_two_rank_ddp_gradients_equal_mean_of_single_process_gradients():
 
 
 GPU_GRAD_TOL = 5e-4            # max|grad - reference| / max|reference| per parameter, every element (fp32 atomics reorder sums)
+# The 128x160 step is ILL-CONDITIONED IN THE REFERENCE ITSELF: its own parameter gradients move by ~2e-3 between 1 and 8 CPU
+# threads and by ~7e-3 when the cost volume is perturbed by 1e-6 relative (test_mid_size_step_is_ill_conditioned_in_the_reference
+# below: BatchNorm batch statistics + the floor() of every bilinear sample position).  A different summation order anywhere
+# upstream (here: the HIP warp's 1e-6-level differences, MIOpen, atomics) is such a perturbation, so the end-to-end bound at this
+# size is 1.5e-2; the 5e-4 bound holds at 32x64, and every HIP backward stage is pinned to its torch twin separately
+# (_check_hip_backward_stages: with the reference's forward values the HIP warp backward reproduces the gradients to 4e-5).
+GPU_GRAD_TOL_MID = 1.5e-2
 
 
 @pytest.mark.gpu
@@ -459,8 +487,9 @@ def test_training_step_on_gpu_matches_reference_gradients():
     assert float(loss2) == pytest.approx(float(g2["loss"]), rel=1e-4)
     loss2.backward()
     errs2 = _grad_errors([(n, p.grad) for n, p in net2.named_parameters() if p.grad is not None], g2)
-    bad2 = {n: e for n, e in errs2.items() if e > GPU_GRAD_TOL}
+    bad2 = {n: e for n, e in errs2.items() if e > GPU_GRAD_TOL_MID}
     assert len(errs2) >= 110 and not bad2, bad2
+    assert float(np.median(list(errs2.values()))) < 2e-3
     opt = torch.optim.Adam(net.parameters(), lr=5e-4)
     opt.step()
     net.eval()
