@@ -483,7 +483,8 @@ def main():
                 tiles = render_mfma_tiles_per_16(S, R)
                 fl = tiles * 2 * 16 * 16 * 4 / 16.0 * n_samples
                 ach = fl / (t * 1e-3) / 1e12
-                sr[f"render_{i}"] = {"kernel": f"k_render_rays<{R},{S},{'4,2' if R == 3 else '8,2'}>", "bound": "mfma",
+                shape = ("12,3 (lean: 3 waves/SIMD)" if cas.num_samples[i] <= 2 else "4,2") if R == 3 else "8,2"
+                sr[f"render_{i}"] = {"kernel": f"k_render_rays<{R},{S},{shape}>", "bound": "mfma",
                                      "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                      "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "avg_launch_ms": round(t, 4),
                                      "mfma_tiles_per_16_samples": tiles, "samples": n_samples,

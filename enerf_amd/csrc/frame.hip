@@ -400,6 +400,8 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
     if (forked && gate_mode != 1) stage2_enqueued = false;
 #endif
     const float *pdepth = nullptr, *pstd = nullptr, *pnf = nullptr;
+    const float *pending_prob = nullptr, *pending_dv = nullptr;       // a depth regression deferred into the next level's prep
+    int pending_D = 0, pending_inv = 0;
     int hp = 0, wp = 0;
     for (int i = 0; i < c.num; ++i) {
         const LevelPlan& L = P.L[i];
@@ -407,9 +409,25 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
         float *prob = ws + L.prob, *depth = ws + L.depth;
         float* std = L.render ? a->std[i] : ws + L.std;
         float* dmvs = L.render ? a->depth_mvs[i] : nullptr;
-        rc = enerf_level_prep(a->src_ixts, a->src_exts, a->tar_ixt, a->tar_ext, a->B, a->S, (float)c.im_feat_scale[i],
-                              (float)c.volume_scale[i], proj, a->near_far, pdepth, pstd, pnf, L.D, L.h, L.w, hp, wp,
-                              c.depth_inv[i], dv, nf, stream);
+        // the previous level's depth regression rides in this level's prep launch when that level is not rendered (its depth /
+        // std are then only this level's inputs): one launch instead of two on the critical chain between the levels
+        bool prep_done = false;
+        if (pending_prob != nullptr) {
+            prep_done = launch_regress_and_values(a->src_ixts, a->src_exts, a->tar_ixt, a->tar_ext, a->S, (float)c.im_feat_scale[i],
+                                                  (float)c.volume_scale[i], proj, pending_prob, pending_dv, pnf, pending_D, hp, wp,
+                                                  pending_inv, const_cast<float*>(pdepth), const_cast<float*>(pstd), a->B, L.D,
+                                                  L.h, L.w, c.depth_inv[i], dv, nf, st);
+            if (!prep_done)         // shape outside the fused kernel's limits: the two separate launches
+                launch_depth_regression(pending_prob, pending_dv, a->B, pending_D, hp, wp, pending_inv,
+                                        const_cast<float*>(pdepth), const_cast<float*>(pstd), nullptr, st);
+            pending_prob = nullptr;
+        }
+        if (!prep_done)
+            rc = enerf_level_prep(a->src_ixts, a->src_exts, a->tar_ixt, a->tar_ext, a->B, a->S, (float)c.im_feat_scale[i],
+                                  (float)c.volume_scale[i], proj, a->near_far, pdepth, pstd, pnf, L.D, L.h, L.w, hp, wp,
+                                  c.depth_inv[i], dv, nf, stream);
+        else
+            rc = check_launch("level_prep");
         if (rc != ENERF_OK) return bail(rc);
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_PREP));
         need_level(i);                                                 // level i's source maps (side lane for i >= 1)
@@ -440,7 +458,9 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
 #endif
         if (rc != ENERF_OK) return bail(rc);
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_COST_REG));
-        launch_depth_regression(prob, dv, a->B, L.D, L.h, L.w, c.depth_inv[i], depth, std, dmvs, st);
+        const bool defer_regression = !L.render && i + 1 < c.num && !(a->options && a->options->fuse_depth_prep == 1);
+        if (defer_regression) { pending_prob = prob; pending_dv = dv; pending_D = L.D; pending_inv = c.depth_inv[i]; }
+        else launch_depth_regression(prob, dv, a->B, L.D, L.h, L.w, c.depth_inv[i], depth, std, dmvs, st);
         mark(ENERF_STAGE_LEVEL(i, ENERF_STAGE_DEPTH_REG));
         pdepth = depth; pstd = std; pnf = nf; hp = L.h; wp = L.w;
         if (!L.render) continue;

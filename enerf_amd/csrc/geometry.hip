@@ -374,6 +374,104 @@ void launch_depth_regression(const float* prob, const float* dv, int B, int D, i
 }
 
 // -------------------------------------------------------------------------------------------------
+// depth_regression of level i-1 + get_depth_values (+ get_proj_mats) of level i in ONE launch (round 3).  Between two cascade
+// levels the chain was cost_reg -> k_depth_regression (6.7 us) -> k_depth_values (6.4 us) -> warp: two tiny dependent launches
+// on the frame's critical path.  Here a block owns a 16 x 16 tile of level-i pixels: it first computes the softmax moments of
+// the <= 12 x 12 coarse pixels its align-corners upsample taps touch (same lane mapping and arithmetic as
+// k_depth_regression: bit-identical values; neighbouring blocks recompute shared coarse pixels and write identical bits),
+// keeps them in LDS, and then runs k_depth_values' per-pixel arithmetic for its tile.  Used when level i-1 is not rendered.
+// -------------------------------------------------------------------------------------------------
+constexpr int kRvTile = 16, kRvPatch = 12;
+__global__ __launch_bounds__(256) void k_regress_and_values(const float* __restrict__ prob_p, const float* __restrict__ dv_p,
+                                                            const float* __restrict__ nf_p, int Dp, int hp, int wp,
+                                                            int depth_inv_p, float* __restrict__ depth_p,
+                                                            float* __restrict__ std_p, int B, int D, int h, int w,
+                                                            int depth_inv, float* __restrict__ dv, float* __restrict__ nf_out,
+                                                            int tiles_y, int tiles_x, ProjJob pj) {
+    __shared__ float cd[kRvPatch * kRvPatch], cs[kRvPatch * kRvPatch];
+    if (pj.proj != nullptr && blockIdx.x == gridDim.x - 1)
+        for (int q = threadIdx.x; q < B * pj.S; q += blockDim.x)
+            proj_one(q, pj.src_ixts, pj.src_exts, pj.tar_ixt, pj.tar_ext, pj.S, pj.src_scale, pj.tar_scale, pj.proj);
+    int t = blockIdx.x;
+    const int txi = t % tiles_x; t /= tiles_x;
+    const int tyi = t % tiles_y;
+    const int b = t / tiles_y;
+    const int y0 = tyi * kRvTile, x0 = txi * kRvTile;
+    const int y1 = min(y0 + kRvTile, h) - 1, x1 = min(x0 + kRvTile, w) - 1;
+    const float sy = ac_scale(hp, h), sx = ac_scale(wp, w);
+    const int cy0 = ac_lerp(y0, sy, hp).i0, cy1 = ac_lerp(y1, sy, hp).i1;
+    const int cx0 = ac_lerp(x0, sx, wp).i0, cx1 = ac_lerp(x1, sx, wp).i1;
+    const int prows = cy1 - cy0 + 1, pcols = cx1 - cx0 + 1, npatch = prows * pcols;      // <= kRvPatch^2 (launcher checks the scale)
+    const int hwp = hp * wp;
+    // ---- phase 1: softmax moments of the patch (k_depth_regression's mapping: 16 pixels x 4 depth slices per wave) ----
+    const int lane = threadIdx.x & 63, sl = lane >> 4, wv = threadIdx.x >> 6;
+    for (int base = 0; base < npatch; base += 64) {
+        const int c = base + wv * 16 + (lane & 15);
+        const bool okc = c < npatch;
+        const int cc = okc ? c : npatch - 1;
+        const int pr_ = cc / pcols, pc_ = cc - pr_ * pcols;
+        const int pcoarse = (cy0 + pr_) * wp + (cx0 + pc_);
+        const float* pr = prob_p + (long long)b * Dp * hwp + pcoarse;
+        const float* dp = dv_p + (long long)b * Dp * hwp + pcoarse;
+        float mu, var;
+        if (Dp <= 16) depth_moments_regs<4>(pr, dp, Dp, hwp, sl, depth_inv_p, mu, var);
+        else depth_moments_regs<16>(pr, dp, Dp, hwp, sl, depth_inv_p, mu, var);          // Dp <= 64 (launcher)
+        if (okc && sl == 0) {
+            const float sd = sqrtf(clamp_min(var, 1e-10f));
+            cd[cc] = mu; cs[cc] = sd;
+            depth_p[(long long)b * hwp + pcoarse] = mu;                                  // (identical bits from every block that
+            std_p[(long long)b * hwp + pcoarse] = sd;                                    //  shares this coarse pixel)
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: k_depth_values' arithmetic for this tile's pixels, all D planes per thread ----
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int y = y0 + ty, x = x0 + tx;
+    if (y >= h || x >= w) return;
+    const Lerp1 ly = ac_lerp(y, sy, hp), lx = ac_lerp(x, sx, wp);
+    const int q00 = (ly.i0 - cy0) * pcols + (lx.i0 - cx0), q01 = (ly.i0 - cy0) * pcols + (lx.i1 - cx0);
+    const int q10 = (ly.i1 - cy0) * pcols + (lx.i0 - cx0), q11 = (ly.i1 - cy0) * pcols + (lx.i1 - cx0);
+    const int o00 = ly.i0 * wp + lx.i0, o01 = ly.i0 * wp + lx.i1, o10 = ly.i1 * wp + lx.i0, o11 = ly.i1 * wp + lx.i1;
+    const float* n0 = nf_p + (long long)b * 2 * hwp;
+    const float* n1 = n0 + hwp;
+    const float d = ac_blend(ly, lx, cd[q00], cd[q01], cd[q10], cd[q11]);
+    const float s = ac_blend(ly, lx, cs[q00], cs[q01], cs[q10], cs[q11]);
+    const float a0 = ac_blend(ly, lx, n0[o00], n0[o01], n0[o10], n0[o11]);
+    const float a1 = ac_blend(ly, lx, n1[o00], n1[o01], n1[o10], n1[o11]);
+    float lo = d + s, hi = d - s;
+    if (lo > a0) lo = a0;         // utils.py:123-125
+    if (hi < a1) hi = a1;         // utils.py:126-127
+    const float nn = 1.f / lo, ff = 1.f / hi;                                            // utils.py:128
+    const float inn = 1.f / nn, iff = 1.f / ff;
+    const int hw = h * w, p = y * w + x;
+    for (int k = 0; k < D; ++k) {
+        const float tk = linspace01(k, D);
+        const float v = depth_inv ? 1.f / (inn + tk * (iff - inn)) : nn + tk * (ff - nn);
+        dv[((long long)b * D + k) * hw + p] = v;
+        if (k == 0 || k == D - 1) {               // utils.py:149-150 (k == 0 == D-1 writes both)
+            const float e = depth_inv ? 1.f / clamp_min(v, 1e-6f) : v;
+            if (k == 0) nf_out[((long long)b * 2 + 0) * hw + p] = e;
+            if (k == D - 1) nf_out[((long long)b * 2 + 1) * hw + p] = e;
+        }
+    }
+}
+// false: shape not handled (nothing launched) — the caller then uses k_depth_regression + k_depth_values
+bool launch_regress_and_values(const float* src_ixts, const float* src_exts, const float* tar_ixt, const float* tar_ext, int S,
+                               float src_scale, float tar_scale, float* proj, const float* prob_p, const float* dv_p,
+                               const float* nf_p, int Dp, int hp, int wp, int depth_inv_p, float* depth_p, float* std_p, int B,
+                               int D, int h, int w, int depth_inv, float* dv, float* nf_out, hipStream_t st) {
+    if (Dp > 64 || h < hp || w < wp) return false;
+    // the coarse patch of a 16-pixel tile side: (16 - 1) * scale + 2 taps (+1 for rounding) must fit kRvPatch
+    const float sy = ac_scale(hp, h), sx = ac_scale(wp, w);
+    if ((int)(15.f * sy) + 3 > kRvPatch || (int)(15.f * sx) + 3 > kRvPatch) return false;
+    const int tiles_y = cdiv(h, kRvTile), tiles_x = cdiv(w, kRvTile);
+    ProjJob pj = {src_ixts, src_exts, tar_ixt, tar_ext, proj, S, src_scale, tar_scale};
+    ENERF_LAUNCH(k_regress_and_values, (unsigned)(B * tiles_y * tiles_x), 256, 0, st, prob_p, dv_p, nf_p, Dp, hp, wp, depth_inv_p,
+                 depth_p, std_p, B, D, h, w, depth_inv, dv, nf_out, tiles_y, tiles_x, pj);
+    return true;
+}
+
+// -------------------------------------------------------------------------------------------------
 // build_rays (utils.py:390-420): x(Hr/h) align-corners upsample of {depth, std, near_far}, per-ray
 // [near, far] clamped into the volume bounds, gathered at the ray's integer (u, v); appended to the
 // 8-float ray -> 12 floats [o(3), d(3), u, v, ray_near, ray_far, vol_near, vol_far].

@@ -37,6 +37,12 @@ void launch_level_prep(const float* src_ixts, const float* src_exts, const float
 // depth_mvs (optional): 1/depth for disparity-space levels, depth otherwise (network.py:105-108)
 void launch_depth_regression(const float* prob, const float* dv, int B, int D, int h, int w, int depth_inv,
                              float* depth, float* std, float* depth_mvs, hipStream_t st);
+// depth_regression of the previous (not rendered) level + proj_mats + depth_values of this level in one launch; false = shape
+// not handled, nothing launched
+bool launch_regress_and_values(const float* src_ixts, const float* src_exts, const float* tar_ixt, const float* tar_ext, int S,
+                               float src_scale, float tar_scale, float* proj, const float* prob_p, const float* dv_p,
+                               const float* nf_p, int Dp, int hp, int wp, int depth_inv_p, float* depth_p, float* std_p, int B,
+                               int D, int h, int w, int depth_inv, float* dv, float* nf_out, hipStream_t st);
 void launch_build_rays(const float* rays8, const float* depth, const float* std, const float* nf, int B, int N, int h,
                        int w, int Hr, int Wr, int depth_inv, float* rays12, hipStream_t st);
 

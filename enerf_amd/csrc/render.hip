@@ -127,7 +127,7 @@ template <int R> struct Stage { static constexpr int kTex = 4 * R, kStride = 4 *
 //   MLP phase, lane (g, j): channels [gR, gR+R) of every view come back from the LDS records as MFMA B operands; the
 //     rest is the k-ordered MFMA chain described at the top of this file.
 // WPE = waves per SIMD the register budget is sized for (512 / WPE VGPRs): blocks per CU x WAVES / 4
-template <int R, int S, int WAVES, int WPE, bool PFK = false>
+template <int R, int S, int WAVES, int WPE, bool PFK = false, bool LEANK = false>
 __global__ __launch_bounds__(64 * WAVES)
 #ifndef ENERF_EMU
 __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
@@ -256,18 +256,21 @@ void k_render_rays(RenderArgs a) {
         }
         // ---- this lane's view: camera constants of (b, sv) ----
         const float* cb = cam + ((long long)b * S + sv) * kCamStride;
-        const f32x4 cm0 = lds4(cb), cm1 = lds4(cb + 4), cm2 = lds4(cb + 8), cm3 = lds4(cb + 12);
-        const f32x4 tc4 = lds4(tcen + b * 4);
+        // LEANK (the level-1 build: 157 instead of 184 VGPRs -> three waves per SIMD): the 20 camera constants are re-read from
+        // LDS per sample instead of living in registers, and two per-sample weights are kept instead of eight
+        f32x4 cm0, cm1, cm2, cm3, tc4;
+        if (!LEANK) { cm0 = lds4(cb); cm1 = lds4(cb + 4); cm2 = lds4(cb + 8); cm3 = lds4(cb + 12); tc4 = lds4(tcen + b * 4); }
         const unsigned toff = (unsigned)b * (unsigned)(S * a.Hr * a.Wr * TEX) + (unsigned)sv * (unsigned)(a.Hr * a.Wr * TEX);
         const float rcpW = fast_rcp((float)(a.Wr - 1)), rcpH = fast_rcp((float)(a.Hr - 1));
 
         float Tacc = 1.f;                 // transmittance, raw2outputs utils.py:588-589
-        float wk[8];                      // per-sample weights (Ns <= 8)
+        constexpr int NSM = (LEANK && R == 3) ? 2 : 8;      // samples kept per ray (lean level-1 build: Ns <= 2, the launcher checks)
+        float wk[NSM];                    // per-sample weights
         float rgbacc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) rgbacc[r] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) wk[k] = 0.f;
+        for (int k = 0; k < NSM; ++k) wk[k] = 0.f;
 
         // ---------- the gather of one sample, in two halves so that a sample's loads can be in flight during the PREVIOUS
         // sample's Agg MFMAs (PF, below): issue = placement, projection, taps, ALL loads, direction code;
@@ -282,6 +285,7 @@ void k_render_rays(RenderArgs a) {
         constexpr int QB = R <= 3 ? R : 3, NRND = R / QB, NBUF = NRND > 1 ? 2 : 1;
         static_assert(R % QB == 0, "texel chunk rounds");
         auto gather_issue = [&](int k, GatherRegs& G) {
+            if (LEANK) { cm0 = lds4(cb); cm1 = lds4(cb + 4); cm2 = lds4(cb + 8); cm3 = lds4(cb + 12); tc4 = lds4(tcen + b * 4); }
             // ---------- sample placement (utils.py:425-436) ----------
             float tk = (Ns == 1) ? 0.5f : linspace01(k, Ns);
             float z = rn + (rf - rn) * tk;
@@ -575,21 +579,21 @@ void k_render_rays(RenderArgs a) {
                 rgbacc[r] += wgt * col;
             }
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
+            for (int kk = 0; kk < NSM; ++kk)
                 if (kk == k) wk[kk] = wgt;
         }
 
         // ---------- depth from softmaxed weights (utils.py:593-595) + stores ----------
         float m = wk[0];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) if (k < Ns) m = fmaxf(m, wk[k]);
+        for (int k = 1; k < NSM; ++k) if (k < Ns) m = fmaxf(m, wk[k]);
         float se = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) if (k < Ns) { wk[k] = fast_exp(wk[k] - m); se += wk[k]; }
+        for (int k = 0; k < NSM; ++k) if (k < Ns) { wk[k] = fast_exp(wk[k] - m); se += wk[k]; }
         se = fast_rcp(se);
         float depth = 0.f, accw = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < NSM; ++k)
             if (k < Ns) {
                 wk[k] *= se;
                 float tk = (Ns == 1) ? 0.5f : linspace01(k, Ns);
@@ -610,19 +614,19 @@ void k_render_rays(RenderArgs a) {
             if (g == 0) {
                 a.depth[ray] = depth;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) if (k < Ns) a.weights[ray * Ns + k] = wk[k];
+                for (int k = 0; k < NSM; ++k) if (k < Ns) a.weights[ray * Ns + k] = wk[k];
             }
         }
     }
 }
 
-template <int R, int WAVES, int OCC, bool PFK = false>
+template <int R, int WAVES, int OCC, bool PFK = false, bool LEANK = false>
 static int dispatch_s(const RenderArgs& a, unsigned grid, size_t shmem, hipStream_t st) {
     constexpr int WPE = (WAVES * OCC + 3) / 4;
     switch (a.S) {
-        case 2: ENERF_LAUNCH((k_render_rays<R, 2, WAVES, WPE, PFK>), grid, 64 * WAVES, shmem, st, a); return 0;
-        case 3: ENERF_LAUNCH((k_render_rays<R, 3, WAVES, WPE, PFK>), grid, 64 * WAVES, shmem, st, a); return 0;
-        case 4: ENERF_LAUNCH((k_render_rays<R, 4, WAVES, WPE, PFK>), grid, 64 * WAVES, shmem, st, a); return 0;
+        case 2: ENERF_LAUNCH((k_render_rays<R, 2, WAVES, WPE, PFK, LEANK>), grid, 64 * WAVES, shmem, st, a); return 0;
+        case 3: ENERF_LAUNCH((k_render_rays<R, 3, WAVES, WPE, PFK, LEANK>), grid, 64 * WAVES, shmem, st, a); return 0;
+        case 4: ENERF_LAUNCH((k_render_rays<R, 4, WAVES, WPE, PFK, LEANK>), grid, 64 * WAVES, shmem, st, a); return 0;
         default: return -3;
     }
 }
@@ -648,6 +652,12 @@ int launch_render_rays(const RenderArgs& a, hipStream_t st) {
         const long long blocks = cdivl(ntiles, waves), resident = (long long)cus * occ;
         return (unsigned)(blocks < resident ? blocks : resident);
     };
+#ifndef ENERF_R9_LEAN
+#define ENERF_R9_LEAN 1              // level-0 kernel (C = 32): camera constants re-read from LDS per sample (fewer spills)
+#endif
+#ifndef ENERF_RENDER_LEAN12
+#define ENERF_RENDER_LEAN12 1        // 0: the round-2 launch shape for every level-1 render (A/B)
+#endif
 #ifndef ENERF_RENDER_WAVES
 #define ENERF_RENDER_WAVES 4
 #endif
@@ -655,6 +665,17 @@ int launch_render_rays(const RenderArgs& a, hipStream_t st) {
 #define ENERF_RENDER_OCC 2
 #endif
     if (nerf_layout(a.F).total > (R == 3 ? 10560 : 14528)) return -6;      // the kernel's weight-staging bound (F = 11 / 35)
+    if (R == 3 && a.n_samples <= 2 && ENERF_RENDER_LEAN12) {        // C = 8, the cascade's last level: 12-wave blocks, one per CU
+        // Measured (profiles/r03_render_waves.txt, S = 3): 4-wave blocks x 2 per CU at 184 VGPRs 199.5 us; the same with the lean
+        // register set (157) 196.5; 12-wave blocks x 1 (THREE waves per SIMD, 159 VGPRs, no spills) 190.7; 6-wave blocks x 2 254.8
+        // (uneven over the SIMDs).  Round 2's 12-wave attempt spilled at 168 VGPRs (215 us).
+        const size_t shmem = render_shmem<3, 12>(a);
+        if (shmem <= 160 * 1024) {
+            const unsigned grid = grid_for(12, 1);
+            if (grid == 0) return 0;
+            return dispatch_s<3, 12, 1, false, true>(a, grid, shmem, st);
+        }
+    }
     if (R == 3) {                                                                                              // C = 8
         const size_t shmem = render_shmem<3, ENERF_RENDER_WAVES>(a);
         if (shmem > 160 * 1024 / ENERF_RENDER_OCC) return -2;
@@ -671,7 +692,7 @@ int launch_render_rays(const RenderArgs& a, hipStream_t st) {
         if (shmem > 160 * 1024) return -2;
         const unsigned grid = grid_for(8, 1);
         if (grid == 0) return 0;
-        return dispatch_s<9, 8, 1>(a, grid, shmem, st);
+        return dispatch_s<9, 8, 1, false, ENERF_R9_LEAN != 0>(a, grid, shmem, st);
     }
     return -4;
 }

@@ -61,6 +61,9 @@ typedef struct {
                                         measured 1-2 % slower on dtu / lego / zju: profiles/r03_ab_side_gate.txt);
                                         3 = at the start of the last level (after the previous depth regression);
                                         4 = behind the last level's conv2 */
+    int fuse_depth_prep;             /* enerf_forward, ABI >= 5: 0 = the depth regression of a NOT rendered level runs inside the
+                                        next level's prep launch (k_regress_and_values: one launch instead of two between
+                                        cascade levels); 1 = separate launches (round 2) */
     int conv3d_t2_variant;           /* transposed 3-D layers (conv9 32->16, conv11 16->8), ABI >= 5: 0 = the every-class LDS kernel
                                         with x-parity-paired MFMA rows where it measured faster (default); 1 = the round-2
                                         kernels only (A/B); 2 = the every-class kernel for every layer it handles */
