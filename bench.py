@@ -107,7 +107,19 @@ def make_workload(name, seed):
     raise SystemExit(f"unknown workload {name}")
 
 
-def train_bench(args, rank, world, dev, dist):
+def emit_line(result):
+    """Rank 0's ONE JSON line, as the LAST line of stdout: RCCL prints a version banner through C stdio (block-buffered on a
+    pipe, so it would surface at process exit, after Python's line) — flush C stdio first, then print."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(json.dumps(result), flush=True)
+
+
+def train_bench(args, rank, world, dev, dist, emu_lib=None):
     """Config 5: trainer.py:56-63 on the drop-in network — forward (train mode, BN batch statistics),
     the MSE part of losses/enerf.py:21-24, backward (DDP gradient all-reduce over RCCL when world > 1),
     clip_grad_value_(40), Adam step.  Data-parallel: one sample per GPU per step (dtu_pretrain.yaml:60), weak scaling."""
@@ -117,15 +129,30 @@ def train_bench(args, rank, world, dev, dist):
     from enerf_amd.config import EnerfConfig
     from enerf_amd.synth import make_batch
     cfg = EnerfConfig()                                                  # dtu_pretrain.yaml: planes 64,8, render_if True,True
-    net = _seeded_network(cfg, dev).train()
+    emu = emu_lib is not None
+    H, W = (32, 64) if emu else (512, 640)
+    if emu:     # launcher / step-structure dry run on the CPU lane emulator over gloo: the step the graph would capture, run eagerly
+        cfg = cfg.with_cas(volume_planes=(8, 8))
+    net = _seeded_network(cfg, dev, lib=emu_lib).train()
     model = net
-    if world > 1:
-        from torch.nn.parallel import DistributedDataParallel as DDP
-        model = DDP(torch.nn.SyncBatchNorm.convert_sync_batchnorm(net), device_ids=[dev.index], output_device=dev.index,
-                    find_unused_parameters=True)                         # trainer.py:15-22
-    graphed = world == 1 and not args.train_eager                        # one hipGraph replay per step (train_graph.py)
+    graphed = not args.train_eager and not emu                           # one hipGraph replay per step (train_graph.py)
+    device_sync = (lambda: None) if emu else torch.cuda.synchronize
+    dp = world > 1 or dist is not None                                   # --train-dp1: the data-parallel step on a 1-rank group
+    if dp and world == 1:
+        from enerf_amd import autograd as _A
+        _A.SYNC_SINGLE_RANK = True
+    if world > 1 and emu:
+        net.feature_net.eval()                # torch's SyncBatchNorm refuses CPU tensors: the 2-D FPN's BatchNorm stays out of
+        for i in range(2):                    # the dry run; the cost-volume networks' statistics exchange (autograd._sync_sums) is in
+            setattr(net, f"cost_reg_{i}", torch.nn.SyncBatchNorm.convert_sync_batchnorm(getattr(net, f"cost_reg_{i}")))
+    elif dp:
+        net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)         # trainer.py:16
+        model = net
+        if not graphed:                                                  # trainer.py:17-22 as written: the eager DDP step
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            model = DDP(net, device_ids=[dev.index], output_device=dev.index, find_unused_parameters=True)
     opt = torch.optim.Adam(net.parameters(), lr=5e-4, capturable=graphed)
-    b = make_batch(512, 640, 3, cfg, seed=rank, textured=True)
+    b = make_batch(H, W, 3, cfg, seed=rank, textured=True)
     rng = np.random.default_rng(rank)
     for i in range(2):
         b[f"rgb_{i}"] = rng.uniform(0, 1, size=(1, b[f"rays_{i}"].shape[1], 3)).astype(np.float32)
@@ -146,44 +173,56 @@ def train_bench(args, rank, world, dev, dist):
         opt.step()
         return loss
     launch_note = "eager"
+    if emu:         # the step the graph captures (train_graph.train_step + FlatGradSync), enqueued eagerly on the emulator
+        from enerf_amd.train_graph import FlatGradSync, train_step
+        sync = FlatGradSync(net) if world > 1 else None
+        if sync is not None:
+            sync.broadcast()
+        step = lambda: train_step(net, opt, loss_fn, batch, 40.0, sync)
+        launch_note = "DRY RUN on the CPU lane emulator over gloo: train_graph.train_step with the flat gradient all-reduce, not captured"
     if graphed:
         try:
-            gstep = GraphedTrainStep(net, opt, loss_fn, batch, clip_value=40.0)   # verifies replays against eager steps
+            gstep = GraphedTrainStep(net, opt, loss_fn, batch, clip_value=40.0, distributed=dp)   # verifies replays against eager steps
             step = lambda: gstep(batch)                                  # copies the batch in, camera tables, one replay
-            launch_note = "one hipGraph replay per step (enerf_amd/train_graph.py; replays verified against eager steps)"
-        except GraphMismatch as e:
+            launch_note = "one hipGraph replay per step (enerf_amd/train_graph.py; replays verified against eager steps)" + \
+                (": the flat gradient all-reduce and the SyncBatchNorm statistics exchanges are graph nodes" if dp else "")
+        except GraphMismatch as e:                                       # the verdict is collective: every rank lands here together
             launch_note = f"eager (graph replay failed verification: {str(e)[:200]})"
+            if dp:
+                from enerf_amd.train_graph import FlatGradSync, train_step
+                sync = FlatGradSync(net)
+                step = lambda: train_step(net, opt, loss_fn, batch, 40.0, sync)
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    device_sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    device_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
-    torch.cuda.synchronize()
+    device_sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    device_sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if dist is not None:
+        dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({
+        emit_line(({
             "metric": "training samples/sec (dtu_pretrain, 512x640, 3 src views, full-image rays at both levels)",
             "value": world * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "final_loss": float(loss),
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not emu else "synthetic (CPU lane emulator, 32x64: launcher check, not a measurement)", "final_loss": float(loss.detach()),
             "config": {"workload": "BASELINE config 5: DTU dtu_pretrain training, one sample per GPU per step, MSE loss "
                                    "(losses/enerf.py:21-24; the VGG perceptual term needs downloaded weights), Adam, "
-                                   "clip_grad_value_ 40", "parallelism": f"DDP x{world} + SyncBatchNorm over RCCL" if world > 1 else "single GPU",
+                                   "clip_grad_value_ 40", "parallelism": (f"data-parallel x{world} + SyncBatchNorm over {'gloo' if emu else 'RCCL'} (" + ("DistributedDataParallel" if model is not net else "one flat gradient all-reduce per step") + ")") if dp else "single GPU",
                        "step_launch": launch_note,
                        "backward": "HIP forward+backward: cost-reg nets (MFMA conv/dgrad/wgrad, BN-train), Agg+NeRF MLP (fused), warp+variance, depth regression, compositing, render-side fetches (bilinear texel + trilinear volume gathers, direction code), FeatureNet conv wgrad; PyTorch-ROCm autograd: FeatureNet conv forward/dgrad + BN2d, geometry glue"}}))
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 def main():
@@ -205,6 +244,9 @@ def main():
                     help="BASELINE config 5 instead of rendering: one step = forward + MSE loss + backward + Adam step of "
                          "dtu_pretrain (512x640, 3 views, full-image rays at both levels, bs 1 per GPU), DDP over RCCL for N > 1")
     ap.add_argument("--train-eager", action="store_true", help="--train: enqueue every step eagerly instead of one graph replay")
+    ap.add_argument("--train-dp1", action="store_true",
+                    help="--train --gpus 1: take the DATA-PARALLEL step on a 1-rank RCCL group (SyncBatchNorm conversion, statistics "
+                         "exchanges and the flat gradient all-reduce captured as graph nodes) — what a 1-GPU box can measure of the N > 1 step")
     ap.add_argument("--feature-backend", choices=["hip", "torch"], default="hip",
                     help="FeatureNet on the HIP matrix-core path (default) or in PyTorch-ROCm/MIOpen (north_star's split)")
     ap.add_argument("--options", default="",
@@ -251,9 +293,10 @@ def main():
         dev = torch.device("cuda", local)
         device_sync = torch.cuda.synchronize
     dist = None
-    if world > 1:
+    if world > 1 or (args.train and args.train_dp1):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))   # (set by the launcher for N > 1)
         if args.emu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -263,9 +306,7 @@ def main():
     from enerf_amd.frame_parallel import render_sharded
 
     if args.train:
-        if args.emu:
-            raise SystemExit("--train has no --emu mode (tests/test_training.py covers the 2-rank gloo DDP step)")
-        return train_bench(args, rank, world, dev, dist)
+        return train_bench(args, rank, world, dev, dist, emu_lib)
     nb = max(1, args.batches)
     cfg, batch_np, human, workload = make_workload(args.workload, rank)
     cas = cfg.cas
@@ -564,10 +605,10 @@ def main():
         err = float((o[key].cpu() - ref[key]).abs().max())
         result["parity_vs_oracle"] = {f"{key}_max_abs": err, "psnr_db": O.psnr(o[key].cpu(), ref[key])}
 
-    if rank == 0:
-        print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        emit_line(result)
 
 
 if __name__ == "__main__":

@@ -178,16 +178,32 @@ def conv_module(lib, m, x):
 _S1, _S2, _T2 = 0, 1, 2
 
 
+SYNC_SINGLE_RANK = False     # tests: run the statistics exchange on a 1-rank group too (captures RCCL nodes on a 1-GPU box)
+
+
 def _sync_sums(bn, s1, s2, n, count_is_global=False):
     """SyncBatchNorm (trainer.py:16): batch statistics over all ranks — one small all-reduce per layer and direction.
-    ``n`` is this rank's position count (summed over ranks here) unless ``count_is_global``."""
+    ``n`` is this rank's position count (summed over ranks here) unless ``count_is_global``.  The global count stays ON THE
+    DEVICE (a 0-d float64 tensor riding in the same buffer as the sums): no host read, so the step can be enqueued without
+    a synchronisation per layer and captured into a hipGraph with the collectives inside (train_graph.py)."""
     import torch.distributed as dist
-    if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        buf = torch.cat([s1, s2, torch.tensor([0.0 if count_is_global else float(n)], dtype=torch.float64, device=s1.device)])
+    if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and \
+            (dist.get_world_size() > 1 or SYNC_SINGLE_RANK):
+        if count_is_global:
+            buf = torch.cat([s1, s2])
+            dist.all_reduce(buf)
+            c = s1.numel()
+            return buf[:c], buf[c:], n
+        buf = torch.cat([s1, s2, s1.new_full((1,), float(n))])               # fill kernel, not a host copy: capture-safe
         dist.all_reduce(buf)
         c = s1.numel()
-        return buf[:c], buf[c:2 * c], (float(n) if count_is_global else float(buf[-1]))   # host-side count for the divisions
+        return buf[:c], buf[c:2 * c], buf[2 * c]
     return s1, s2, float(n)
+
+
+def _bessel(n):
+    """n / max(n - 1, 1) for a host or device count."""
+    return n / torch.clamp(n - 1.0, min=1.0) if torch.is_tensor(n) else n / max(n - 1.0, 1.0)
 
 
 class _Block:
@@ -218,7 +234,7 @@ class _Block:
                 # momentum=None: cumulative moving average, factor 1/num_batches_tracked (torch.nn.modules.batchnorm)
                 mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
                 bn.running_mean.mul_(1 - mom).add_(mean.float(), alpha=mom)
-                bn.running_var.mul_(1 - mom).add_((var * (n / max(n - 1.0, 1.0))).float(), alpha=mom)
+                bn.running_var.mul_(1 - mom).add_((var * _bessel(n)).float(), alpha=mom)
         self.z, self.n, self.mean, self.invstd, self.scale, self.shift = z, n, mean, invstd, scale, shift
         return lib.channel_affine(z, scale, shift, residual=residual, relu=self.relu)
 

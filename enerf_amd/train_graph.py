@@ -9,7 +9,16 @@ into the captured input buffers.
 What stays outside the graph: the camera-only tables (train_path.camera_tables: 4x4 inverses — torch.inverse synchronises,
 which a capture does not allow); they are recomputed eagerly before every replay into the buffers the graph reads.
 
-Single-process only: under DDP the bucketed all-reduce hooks belong to the eager step (bench.py keeps it for N > 1).
+DATA-PARALLEL (trainer.py:15-22; ``distributed=True``): the same ONE graph per rank, with the collectives inside it.
+DistributedDataParallel's reducer (autograd hooks, bucket views, a host-side bookkeeping pass per step) is an eager-step
+device; what it computes is the mean over ranks of 436,012 floats.  ``FlatGradSync`` does exactly that as ONE all-reduce of
+ONE flat 1.7 MB buffer enqueued after the backward pass — RCCL's kernel is a graph node like any other — and the
+SyncBatchNorm statistics exchanges (torch's SyncBatchNorm in the FeatureNet, autograd._sync_sums in the cost-volume
+networks: one C-sized all-reduce per layer and direction, the global count kept on the device) are captured the same way.
+(BatchNorm layer k+1 normalises what layer k produced from the GLOBAL statistics of layer k, so those ~46 exchanges are a
+dependency chain: they cannot be merged into one buffer without changing SyncBatchNorm's arithmetic; captured, each costs
+its ~10 us of xGMI latency and no host time.)  Every rank must construct the step at the same point (the constructor runs
+collectives and agrees on the verification verdict collectively).
 
 MEMSET NODES.  On this stack (ROCm 7.2 / PyTorch 2.10, MI355X) a hipMemsetAsync captured into a large graph does not replay
 reliably: tools/micro/graph_reduce_check.py captures nothing but torch reductions (whose multi-block kernels reset their
@@ -21,7 +30,7 @@ semaphores with a memset) and gets wrong sums in about half of the replays.  Con
   * ``GraphedTrainStep(verify=True)`` (the default) replays a few steps against eager steps from the same state and
     compares every gradient before the graph is trusted; a mismatch raises ``GraphMismatch`` (bench.py then runs eager).
 """
-from typing import Callable, Dict
+from typing import Callable, Dict, Iterable, Optional
 
 import torch
 
@@ -50,6 +59,52 @@ def mse_loss(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return tree_sum(d * d) / d.numel()
 
 
+class FlatGradSync:
+    """DistributedDataParallel's gradient averaging (trainer.py:17-22) as ONE collective: the gradients of all parameters
+    that have one are packed into one flat buffer, all-reduced once, scaled by 1/world and unpacked in place.  Parameters
+    whose gradient is None (not on the loss's path — what ``find_unused_parameters=True`` tolerates) are skipped; with a
+    static configuration that set is the same on every rank.  Works eagerly on any backend (gloo in the CPU tests) and
+    inside a hipGraph capture on RCCL.  ``broadcast()`` is DDP's construction-time parameter/buffer broadcast from rank 0."""
+
+    def __init__(self, module: torch.nn.Module, group=None):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("FlatGradSync needs an initialised torch.distributed process group")
+        self.dist, self.group, self.module = dist, group, module
+        self.world = dist.get_world_size(group)
+        self.params = [p for p in module.parameters() if p.requires_grad]
+
+    def broadcast(self):
+        with torch.no_grad():
+            for t in list(self.module.parameters()) + list(self.module.buffers()):
+                self.dist.broadcast(t, 0, group=self.group)
+
+    def __call__(self):
+        grads = [p.grad for p in self.params if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        self.dist.all_reduce(flat, group=self.group)
+        flat.mul_(1.0 / self.world)
+        torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+
+
+def train_step(net, optimizer, loss_fn, batch, clip_value: Optional[float] = 40.0, grad_sync: Optional[Callable] = None,
+               zero: bool = True, params: Optional[Iterable] = None):
+    """trainer.py:56-63: forward, loss, backward, (gradient averaging over ranks,) clip_grad_value_, optimizer step."""
+    out = net(batch)
+    loss = loss_fn(out, batch)
+    if zero:
+        optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync()
+    if clip_value is not None:
+        torch.nn.utils.clip_grad_value_(list(params) if params is not None else [p for p in net.parameters() if p.requires_grad], clip_value)
+    optimizer.step()
+    return loss
+
+
 class GraphedTrainStep:
     """``step = GraphedTrainStep(net, optimizer, loss_fn, example_batch); loss = step(batch)``.
 
@@ -64,12 +119,17 @@ class GraphedTrainStep:
     optimizer that already carried state before construction gets that state back instead."""
 
     def __init__(self, net, optimizer, loss_fn: Callable, example_batch: Dict[str, torch.Tensor], clip_value: float = 40.0,
-                 warmup: int = 3, verify: bool = True, verify_steps: int = 4):
+                 warmup: int = 3, verify: bool = True, verify_steps: int = 4, distributed: bool = False, group=None):
+        """``distributed=True``: data-parallel step (see DATA-PARALLEL above) — ``net`` is the plain network (SyncBatchNorm
+        converted, NOT wrapped in DistributedDataParallel); parameters and buffers are broadcast from rank 0 first."""
         if not net.training:
             raise ValueError("GraphedTrainStep captures a training step: call net.train() first")
         if warmup < 1:
             raise ValueError("at least one eager warm-up step: optimizer state must exist before the capture")
         self.net, self.opt, self.loss_fn, self.clip = net, optimizer, loss_fn, clip_value
+        self.sync = FlatGradSync(net, group) if distributed else None
+        if self.sync is not None:
+            self.sync.broadcast()
         self.static = {k: v.clone() for k, v in example_batch.items() if torch.is_tensor(v)}
         self.extra = {k: v for k, v in example_batch.items() if not torch.is_tensor(v)}
         self.tables = {k: v.clone() for k, v in camera_tables(net.cfg.cas, self.static).items()}
@@ -130,22 +190,19 @@ class GraphedTrainStep:
                     if not (err <= 2e-3 * scale + 1e-9):
                         bad.append((n, err, scale))
                 p.grad = grads_kept[n]
-            if bad or not abs(loss_graph - loss_eager) <= 1e-3 * abs(loss_eager) + 1e-7:
+            failed = bool(bad) or not abs(loss_graph - loss_eager) <= 1e-3 * abs(loss_eager) + 1e-7
+            if self.sync is not None:                       # one verdict for all ranks: nobody leaves the collectives alone
+                flag = torch.tensor([1.0 if failed else 0.0], device=self.loss.device)
+                self.sync.dist.all_reduce(flag, op=self.sync.dist.ReduceOp.MAX, group=self.sync.group)
+                failed = bool(flag.item())
+            if failed:
                 raise GraphMismatch(f"replay {k}: loss {loss_graph} vs eager {loss_eager}; gradient mismatches "
                                     f"(name, max err, max |g|): {bad[:6]}")
         self.net.invalidate_packed()
 
     def _eager_step(self, zero: bool = True):
         batch = dict(self.static, camera_tables=self.tables, **self.extra)
-        out = self.net(batch)
-        loss = self.loss_fn(out, batch)
-        if zero:
-            self.opt.zero_grad(set_to_none=True)
-        loss.backward()
-        if self.clip is not None:
-            torch.nn.utils.clip_grad_value_(self._params, self.clip)
-        self.opt.step()
-        return loss
+        return train_step(self.net, self.opt, self.loss_fn, batch, self.clip, self.sync, zero, self._params)
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         for k, dst in self.static.items():

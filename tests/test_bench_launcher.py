@@ -47,3 +47,20 @@ def test_single_rank_emu_line_and_refusal_of_mismatched_world():
     p = _run(["--gpus", "2", "--emu", "--steps", "2"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and not _json_lines(p.stdout)
     assert "refusing" in p.stderr
+
+
+def test_train_gpus2_dry_run_takes_the_flat_data_parallel_step():
+    """``bench.py --train --gpus 2``: two self-spawned ranks run the step the hipGraph captures on a
+    GPU — train_graph.train_step with ONE flat gradient all-reduce and the cost-volume networks' SyncBatchNorm exchange —
+    eagerly on the emulator over gloo.  Both ranks must finish and agree on one line with n_gpus 2."""
+    from emu_lib import emu_lib
+    emu_lib()
+    p = _run(["--train", "--gpus", "2", "--emu", "--steps", "1", "--warmup", "0"], timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["unit"] == "samples/s"
+    assert "one flat gradient all-reduce per step" in d["config"]["parallelism"]
+    assert "DRY RUN" in d["config"]["step_launch"]
+    assert d["final_loss"] == d["final_loss"] and 0 < d["final_loss"] < 10

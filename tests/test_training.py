@@ -445,6 +445,61 @@ def test_two_rank_ddp_gradients_equal_mean_of_single_process_gradients():
         assert np.abs(v - mean).max() <= 2e-5 * max(np.abs(mean).max(), 1e-12) + 1e-10, n
 
 
+def _flat_sync_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, HERE)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.set_num_threads(1)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from enerf_amd.train_graph import FlatGradSync, train_step
+        cfg, batch = _train_batch(seed=40 + rank)                          # a different sample per rank
+        nets = [_net(cfg), _net(cfg)]
+        with torch.no_grad():                                              # rank 1 starts from DIFFERENT weights: both schemes
+            if rank == 1:                                                  # must begin by adopting rank 0's
+                for net in nets:
+                    for p in net.parameters():
+                        p.mul_(1.01)
+        opts = [torch.optim.SGD(n.parameters(), lr=1e-2, momentum=0.9) for n in nets]
+        ddp = DDP(nets[0], find_unused_parameters=True)                    # trainer.py:17-22 (broadcasts rank 0's state)
+        sync = FlatGradSync(nets[1])
+        sync.broadcast()
+        for _ in range(2):
+            loss_a = train_step(ddp, opts[0], _loss, batch, 40.0, None, params=list(nets[0].parameters()))
+            loss_b = train_step(nets[1], opts[1], _loss, batch, 40.0, sync)
+        sd = [{k: v.numpy().copy() for k, v in n.state_dict().items()} for n in nets]
+        q.put((rank, float(loss_a.detach()), float(loss_b.detach()), sd[0], sd[1]))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, "ERROR: " + traceback.format_exc(), None, None, None))
+
+
+def test_flat_gradient_sync_step_equals_distributed_data_parallel_step():
+    """train_graph.FlatGradSync (ONE all-reduce of one flat buffer after backward — the data-parallel step the hipGraph
+    captures) leaves exactly the parameters DistributedDataParallel's step leaves: two ranks, two optimizer steps each,
+    different samples per rank, rank 1 starting from different weights."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30100 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_flat_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=900) for _ in procs], key=lambda r: r[0])
+    [p.join(60) for p in procs]
+    for r in res:
+        assert not isinstance(r[1], str), r[1]
+    for rank, loss_a, loss_b, sd_ddp, sd_flat in res:
+        assert loss_a == pytest.approx(loss_b, rel=1e-6)
+        for k, v in sd_ddp.items():
+            # (running statistics: with PLAIN BatchNorm they are per-rank quantities that DDP overwrites with rank 0's before
+            # every forward; under the trainer's SyncBatchNorm they are identical on all ranks by construction)
+            if v.dtype.kind == "f" and "running" not in k:
+                assert np.abs(v - sd_flat[k]).max() <= 1e-6 * max(np.abs(v).max(), 1e-12) + 1e-9, (rank, k)
+    for k, v in res[0][4].items():                                         # and both ranks hold the same model
+        if v.dtype.kind == "f" and "running" not in k:
+            np.testing.assert_allclose(v, res[1][4][k], rtol=1e-6, atol=1e-9, err_msg=k)
+
+
 GPU_GRAD_TOL = 5e-4            # max|grad - reference| / max|reference| per parameter, every element (fp32 atomics reorder sums)
 # The 128x160 step is ILL-CONDITIONED IN THE REFERENCE ITSELF: its own parameter gradients move by ~2e-3 between 1 and 8 CPU
 # threads and by ~7e-3 when the cost volume is perturbed by 1e-6 relative (test_mid_size_step_is_ill_conditioned_in_the_reference
@@ -547,6 +602,62 @@ def test_graphed_training_step_equals_eager_steps():
     with torch.no_grad():
         img = nets[0](batches[0])["rgb_level1"]                         # eval after graphed training: re-packed weights
     assert torch.isfinite(img).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_graphed_data_parallel_step_captures_its_collectives():
+    """train_graph.GraphedTrainStep(distributed=True) on a 1-rank RCCL group (a 1-GPU box cannot hold two ranks): the flat
+    gradient all-reduce and the cost-volume networks' SyncBatchNorm statistics exchanges (forced on for the 1-rank group) are
+    RCCL kernels INSIDE the captured graph; the replays must equal eager steps (the constructor verifies that, and three
+    further steps are compared with an eager twin here)."""
+    import torch.distributed as tdist
+    from enerf_amd import autograd as A
+    from enerf_amd.train_graph import GraphedTrainStep, mse_loss
+    dev = torch.device("cuda:0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(30300 + os.getpid() % 2000))
+    tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    A.SYNC_SINGLE_RANK = True
+    try:
+        batches = []
+        for seed in (7, 8, 9):
+            cfg, b = _train_batch(seed=seed)
+            batches.append({k: v.to(dev) for k, v in b.items()})
+        nets = [torch.nn.SyncBatchNorm.convert_sync_batchnorm(_net(cfg)).to(dev) for _ in range(2)]     # trainer.py:16
+        assert isinstance(nets[0].cost_reg_0.conv0.bn, torch.nn.SyncBatchNorm)
+        opts = [torch.optim.SGD(n.parameters(), lr=1e-3, momentum=0.9) for n in nets]
+        tree_loss = lambda out, b: sum(LOSS_W[i] * mse_loss(b[f"rgb_{i}"], out[f"rgb_level{i}"]) for i in range(2))
+        calls = {"n": 0}
+        real = tdist.all_reduce
+
+        def counting(*a, **k):
+            calls["n"] += 1
+            return real(*a, **k)
+        tdist.all_reduce = counting
+        try:
+            gstep = GraphedTrainStep(nets[0], opts[0], tree_loss, batches[0], clip_value=40.0, warmup=1, distributed=True)
+        finally:
+            tdist.all_reduce = real
+        # per ENQUEUED step (1 warm-up + the capture + 4 eager verification steps; replays issue none from Python): one flat
+        # gradient all-reduce + two exchanges per BatchNorm3d layer of the two cost-volume networks (7 + 10 layers)
+        assert calls["n"] >= 6 * (1 + 2 * 17), calls
+        losses = [[], []]
+        for b in batches:
+            losses[0].append(float(gstep(b)))
+            loss = _loss(nets[1](b), b)
+            opts[1].zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_value_(nets[1].parameters(), 40.0)
+            opts[1].step()
+            losses[1].append(float(loss))
+        assert losses[0] == pytest.approx(losses[1], rel=1e-4), losses
+        sd0, sd1 = nets[0].state_dict(), nets[1].state_dict()
+        for k in sd1:
+            if sd1[k].dtype.is_floating_point:
+                assert float((sd0[k] - sd1[k]).abs().max()) <= 1e-5 + 1e-4 * float(sd1[k].abs().max()), k
+    finally:
+        A.SYNC_SINGLE_RANK = False
+        tdist.destroy_process_group()
 
 
 def _check_mlp_backward(lib, dev):
