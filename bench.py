@@ -119,6 +119,48 @@ def emit_line(result):
     print(json.dumps(result), flush=True)
 
 
+class _PerceptualVGG16(torch.nn.Module):
+    """The trainer's perceptual term (losses/vgg_perceptual_loss.py:4-46 as used by losses/enerf.py:30-38): L1 distances
+    between the VGG16 ``features[:4] / [4:9] / [9:16] / [16:23]`` activations (conv1_2, conv2_2, conv3_3, conv4_3 after
+    ReLU) of the rendered and the target image, both normalised with the ImageNet mean/std.  torchvision and its pretrained
+    weights are not available offline: the architecture is restated here with RANDOM-INIT (seeded, frozen) weights — the
+    cost of the term (forward of both images, backward into the rendering) is config 5's, its value is not.
+    PyTorch-ROCm/MIOpen, like the trainer's; ``reduce`` is the sum used for the L1 means (train_graph.tree_sum under
+    capture)."""
+
+    def __init__(self, reduce):
+        super().__init__()
+        cfgs = [[(3, 64), (64, 64)], [(64, 128), (128, 128)], [(128, 256), (256, 256), (256, 256)],
+                [(256, 512), (512, 512), (512, 512)]]
+        gen = torch.Generator().manual_seed(16)
+        blocks = []
+        for bi, convs in enumerate(cfgs):
+            layers = [torch.nn.MaxPool2d(2, 2)] if bi else []
+            for cin, cout in convs:
+                c = torch.nn.Conv2d(cin, cout, 3, padding=1)
+                with torch.no_grad():
+                    c.weight.copy_(torch.randn(c.weight.shape, generator=gen) * (2.0 / (cin * 9)) ** 0.5)
+                    c.bias.zero_()
+                layers += [c, torch.nn.ReLU(inplace=True)]
+            blocks.append(torch.nn.Sequential(*layers))
+        self.blocks = torch.nn.ModuleList(blocks).eval()
+        for p in self.parameters():
+            p.requires_grad = False
+        self.register_buffer("mean", torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
+        self.register_buffer("std", torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
+        self.reduce = reduce
+
+    def forward(self, inp, tar):
+        x, y = (inp - self.mean) / self.std, (tar - self.mean) / self.std
+        loss = 0.0
+        for blk in self.blocks:
+            x = blk(x)
+            with torch.no_grad():
+                y = blk(y)
+            loss = loss + self.reduce((x - y).abs()) / x.numel()          # F.l1_loss, mean reduction
+        return loss
+
+
 def train_bench(args, rank, world, dev, dist, emu_lib=None):
     """Config 5: trainer.py:56-63 on the drop-in network — forward (train mode, BN batch statistics),
     the MSE part of losses/enerf.py:21-24, backward (DDP gradient all-reduce over RCCL when world > 1),
@@ -161,8 +203,18 @@ def train_bench(args, rank, world, dev, dist, emu_lib=None):
     from enerf_amd.train_graph import GraphedTrainStep, GraphMismatch, mse_loss as tree_mse
     mse = tree_mse if graphed else F.mse_loss          # same value; the tree form keeps memset nodes out of the graph
 
-    def loss_fn(out, bt):
-        return sum(w * mse(bt[f"rgb_{i}"], out[f"rgb_level{i}"]) for i, w in enumerate((0.1, 1.0)))
+    from enerf_amd.train_graph import tree_sum
+    perceptual = None if (args.no_perceptual or emu) else _PerceptualVGG16(tree_sum if graphed else torch.sum).to(dev)
+
+    def loss_fn(out, bt):                                                # losses/enerf.py:16-38 (train_img True,True)
+        loss = 0.0
+        for i, w in enumerate((0.1, 1.0)):
+            loss = loss + w * mse(bt[f"rgb_{i}"], out[f"rgb_level{i}"])
+            if perceptual is not None:
+                hi, wi = int(H * cfg.cas.render_scale[i]), int(W * cfg.cas.render_scale[i])
+                img = lambda t: t.reshape(-1, hi, wi, 3).permute(0, 3, 1, 2)
+                loss = loss + 0.01 * w * perceptual(img(out[f"rgb_level{i}"]), img(bt[f"rgb_{i}"]))
+        return loss
 
     def step():
         out = model(batch)
@@ -219,8 +271,9 @@ def train_bench(args, rank, world, dev, dist, emu_lib=None):
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not emu else "synthetic (CPU lane emulator, 32x64: launcher check, not a measurement)", "final_loss": float(loss.detach()),
             "config": {"workload": "BASELINE config 5: DTU dtu_pretrain training, one sample per GPU per step, MSE loss "
-                                   "(losses/enerf.py:21-24; the VGG perceptual term needs downloaded weights), Adam, "
-                                   "clip_grad_value_ 40", "parallelism": (f"data-parallel x{world} + SyncBatchNorm over {'gloo' if emu else 'RCCL'} (" + ("DistributedDataParallel" if model is not net else "one flat gradient all-reduce per step") + ")") if dp else "single GPU",
+                                   "(losses/enerf.py:21-24)" + (" + 0.01 x VGG16 perceptual L1 at both levels (losses/enerf.py:30-38; the "
+                                   "architecture with seeded random-init weights: no pretrained weights offline)" if perceptual is not None
+                                   else " (the VGG perceptual term switched off)") + ", Adam, clip_grad_value_ 40", "parallelism": (f"data-parallel x{world} + SyncBatchNorm over {'gloo' if emu else 'RCCL'} (" + ("DistributedDataParallel" if model is not net else "one flat gradient all-reduce per step") + ")") if dp else "single GPU",
                        "step_launch": launch_note,
                        "backward": "HIP forward+backward: cost-reg nets (MFMA conv/dgrad/wgrad, BN-train), Agg+NeRF MLP (fused), warp+variance, depth regression, compositing, render-side fetches (bilinear texel + trilinear volume gathers, direction code), FeatureNet conv wgrad; PyTorch-ROCm autograd: FeatureNet conv forward/dgrad + BN2d, geometry glue"}}))
 
@@ -244,6 +297,7 @@ def main():
                     help="BASELINE config 5 instead of rendering: one step = forward + MSE loss + backward + Adam step of "
                          "dtu_pretrain (512x640, 3 views, full-image rays at both levels, bs 1 per GPU), DDP over RCCL for N > 1")
     ap.add_argument("--train-eager", action="store_true", help="--train: enqueue every step eagerly instead of one graph replay")
+    ap.add_argument("--no-perceptual", action="store_true", help="--train: leave the VGG16 perceptual term out of the loss")
     ap.add_argument("--train-dp1", action="store_true",
                     help="--train --gpus 1: take the DATA-PARALLEL step on a 1-rank RCCL group (SyncBatchNorm conversion, statistics "
                          "exchanges and the flat gradient all-reduce captured as graph nodes) — what a 1-GPU box can measure of the N > 1 step")

@@ -176,10 +176,10 @@ class GraphedTrainStep:
             snap = self._snapshot()
             self.graph.replay()
             g_graph = {n: p.grad.clone() for n, p in self.net.named_parameters() if p.grad is not None}
-            loss_graph = float(self.loss)
+            loss_graph = float(self.loss.detach())
             self._restore(snap)
             grads_kept = {n: p.grad for n, p in self.net.named_parameters()}      # the graph's own gradient buffers
-            loss_eager = float(self._eager_step())           # zero_grad(set_to_none) detaches the graph's buffers: put them back
+            loss_eager = float(self._eager_step().detach())           # zero_grad(set_to_none) detaches the graph's buffers: put them back
             bad = []
             for n, p in self.net.named_parameters():
                 ge, gg = p.grad, g_graph.get(n)
