@@ -230,7 +230,7 @@ void k_render_rays(RenderArgs a) {
             rn = q2.x; rf = q2.y; vn = q2.z; vf = q2.w;
         }
         // ---- per-ray part of the voxel fetch (network.py:37 then utils.py:457): the (x, y) taps do not depend on the sample
-        // 32-bit element offsets from the (uniform) tensor bases (the launcher checks both tensors hold < 2^32 floats)
+        // 32-bit element offsets from the (uniform) tensor bases (the launcher checks both tensors hold < 2^30 floats: byte offsets fit 32 bits)
         const unsigned voff = (unsigned)b * (unsigned)(a.D * a.h * a.w * 8) + 2u * g;
         float wxy[4];
         int oxy[4];
@@ -278,12 +278,15 @@ void k_render_rays(RenderArgs a) {
         struct GatherRegs {
             float2 vt[8];
             f32x4 tq[(R <= 3 ? 1 : 2)][4][(R <= 3 ? R : 3)];
-            const float* tp[4];
+            unsigned tp[4];                 // BYTE offsets from a.tex: `uniform base + 32-bit lane offset` is the saddr form of
+                                            // global_load (no 64-bit VALU address per gather)
             float tw[4], wz[2];
             f32x4 dirc;
         };
         constexpr int QB = R <= 3 ? R : 3, NRND = R / QB, NBUF = NRND > 1 ? 2 : 1;
         static_assert(R % QB == 0, "texel chunk rounds");
+        const char* const texb = reinterpret_cast<const char*>(a.tex);
+        const char* const volb = reinterpret_cast<const char*>(a.vol);
         auto gather_issue = [&](int k, GatherRegs& G) {
             if (LEANK) { cm0 = lds4(cb); cm1 = lds4(cb + 4); cm2 = lds4(cb + 8); cm3 = lds4(cb + 12); tc4 = lds4(tcen + b * 4); }
             // ---------- sample placement (utils.py:425-436) ----------
@@ -304,8 +307,8 @@ void k_render_rays(RenderArgs a) {
             const float gx = ((px * rz) * rcpW) * 2.f - 1.f, gy = ((py * rz) * rcpH) * 2.f - 1.f;
             const Taps2 t = gs_taps2<true>(gs_unnorm(gx, a.Wr), gs_unnorm(gy, a.Hr), a.Wr, a.Hr);
             const int r0 = mul24(t.y0, a.Wr), r1 = mul24(t.y1, a.Wr);
-            G.tp[0] = a.tex + (toff + (unsigned)mul24(r0 + t.x0, TEX)); G.tp[1] = a.tex + (toff + (unsigned)mul24(r0 + t.x1, TEX));
-            G.tp[2] = a.tex + (toff + (unsigned)mul24(r1 + t.x0, TEX)); G.tp[3] = a.tex + (toff + (unsigned)mul24(r1 + t.x1, TEX));
+            G.tp[0] = (toff + (unsigned)mul24(r0 + t.x0, TEX)) * 4u; G.tp[1] = (toff + (unsigned)mul24(r0 + t.x1, TEX)) * 4u;
+            G.tp[2] = (toff + (unsigned)mul24(r1 + t.x0, TEX)) * 4u; G.tp[3] = (toff + (unsigned)mul24(r1 + t.x1, TEX)) * 4u;
             G.tw[0] = t.w00; G.tw[1] = t.w01; G.tw[2] = t.w10; G.tw[3] = t.w11;
             // voxel feature: trilinear, zeros padding (utils.py:457); lane group g fetches channels 2g, 2g+1
             float iz = gs_unnorm(dn * 2.f - 1.f, a.D);
@@ -323,14 +326,14 @@ void k_render_rays(RenderArgs a) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < 8; ++c)                 // order tnw,tne,tsw,tse,bnw,bne,bsw,bse
-                G.vt[c] = *reinterpret_cast<const float2*>(a.vol + ((unsigned)(zo[c >> 2] + oxy[c & 3]) * 8u + voff));
+                G.vt[c] = *reinterpret_cast<const float2*>(volb + ((unsigned)(zo[c >> 2] + oxy[c & 3]) * 8u + voff) * 4u);
             // texel channels are gathered QB float4 chunks per tap at a time; R = 9 takes three rounds, two of them in flight
 #pragma unroll
             for (int rd = 0; rd < NBUF; ++rd)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int q = 0; q < QB; ++q) G.tq[rd][c][q] = lds4(G.tp[c] + 4 * (rd * QB + q));
+                    for (int q = 0; q < QB; ++q) G.tq[rd][c][q] = lds4(reinterpret_cast<const float*>(texb + G.tp[c]) + 4 * (rd * QB + q));
             __builtin_amdgcn_sched_barrier(0);
             // direction code (utils.py:707-720) while the gathers are in flight
             float tx = X - tc4[0], ty = Y - tc4[1], tz = Z - tc4[2];
@@ -364,7 +367,7 @@ void k_render_rays(RenderArgs a) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
 #pragma unroll
-                        for (int q = 0; q < QB; ++q) G.tq[rd % NBUF][c][q] = lds4(G.tp[c] + 4 * ((rd + NBUF) * QB + q));
+                        for (int q = 0; q < QB; ++q) G.tq[rd % NBUF][c][q] = lds4(reinterpret_cast<const float*>(texb + G.tp[c]) + 4 * ((rd + NBUF) * QB + q));
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -638,8 +641,8 @@ static size_t render_shmem(const RenderArgs& a, int record_buffers = 1) {
 int launch_render_rays(const RenderArgs& a, hipStream_t st) {
     if (a.n_samples < 1 || a.n_samples > 8) return -1;
     const int R = (a.F + 3) / 4;
-    // 32-bit element offsets and 24-bit index multiplies inside the kernel
-    if ((long long)a.B * a.S * a.Hr * a.Wr * 4 * R >= (1LL << 32) || (long long)a.B * a.D * a.h * a.w * 8 >= (1LL << 32) ||
+    // 32-bit BYTE offsets and 24-bit index multiplies inside the kernel
+    if ((long long)a.B * a.S * a.Hr * a.Wr * 4 * R >= (1LL << 30) || (long long)a.B * a.D * a.h * a.w * 8 >= (1LL << 30) ||
         (long long)a.Hr * a.Wr >= (1LL << 23) || (long long)a.h * a.w >= (1LL << 23) || a.D >= (1 << 23))
         return -5;
     const long long ntiles = cdivl((long long)a.B * a.N, 16);
