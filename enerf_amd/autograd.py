@@ -206,23 +206,19 @@ def _bessel(n):
     return n / torch.clamp(n - 1.0, min=1.0) if torch.is_tensor(n) else n / max(n - 1.0, 1.0)
 
 
-class _Block:
-    """One Conv3d/ConvTranspose3d + BatchNorm3d (+ ReLU) (+ skip add) in training mode."""
+class _BatchNormTrain:
+    """BatchNorm (+ ReLU) (+ skip add) in training mode on a channels-last tensor z (..., C): batch statistics, running
+    statistics update, normalise — and the backward — on the two channel kernels of train.hip.  Shared by the 3-D blocks
+    of the cost-volume networks and the 2-D blocks of the FeatureNet."""
 
-    def __init__(self, lib, w, bn, kind, relu):
-        self.lib, self.w, self.bn, self.kind, self.relu = lib, w, bn, kind, relu
-        if kind == _T2:
-            self.cin, self.cout = w.shape[0], w.shape[1]
-        else:
-            self.cout, self.cin = w.shape[0], w.shape[1]
+    def __init__(self, lib, bn, relu):
+        self.lib, self.bn, self.relu = lib, bn, relu
 
-    def forward(self, x, residual=None):
+    def forward(self, z, residual=None):
         lib, bn = self.lib, self.bn
-        self.x = x
-        packed = lib.conv3d_layer_pack(self.w.detach().contiguous(), self.cin, self.cout, self.kind)
-        z = lib.conv3d_layer(packed, self.cin, self.cout, self.kind, x)
+        C_ = z.shape[-1]
         s1, s2 = lib.channel_sums(z, z)
-        s1, s2, n = _sync_sums(bn, s1, s2, z.numel() // self.cout)
+        s1, s2, n = _sync_sums(bn, s1, s2, z.numel() // C_)
         mean = s1 / n
         var = (s2 / n - mean * mean).clamp_min(0.0)                                  # biased (normalisation)
         invstd = torch.rsqrt(var + bn.eps)
@@ -239,8 +235,7 @@ class _Block:
         return lib.channel_affine(z, scale, shift, residual=residual, relu=self.relu)
 
     def backward(self, g):
-        """g = gradient w.r.t. the block's output (the skip branch's share is the same tensor).  Returns
-        (grad_input, grad_weight, grad_bn_weight, grad_bn_bias)."""
+        """g = gradient w.r.t. the normalised (+ ReLU) output -> (d z, d gamma, d beta)."""
         lib, bn, z = self.lib, self.bn, self.z
         mask = dict(z_mask=z, mask_scale=self.scale, mask_shift=self.shift) if self.relu else {}
         sg, sgz = lib.channel_sums(g, z, **mask)                                     # sum gm, sum gm*z over this rank
@@ -251,6 +246,32 @@ class _Block:
         k2 = -sc * self.invstd * (self.invstd * (sgz - self.mean * sg)) / n
         k3 = -sc * sg / n - k2 * self.mean
         dz = lib.channel_affine(g, self.scale, k3.float(), b=z, q=k2.float(), **mask)
+        return dz, dgamma.float(), dbeta.float()
+
+
+class _Block:
+    """One Conv3d/ConvTranspose3d + BatchNorm3d (+ ReLU) (+ skip add) in training mode."""
+
+    def __init__(self, lib, w, bn, kind, relu):
+        self.lib, self.w, self.kind = lib, w, kind
+        self.norm = _BatchNormTrain(lib, bn, relu)
+        if kind == _T2:
+            self.cin, self.cout = w.shape[0], w.shape[1]
+        else:
+            self.cout, self.cin = w.shape[0], w.shape[1]
+
+    def forward(self, x, residual=None):
+        lib = self.lib
+        self.x = x
+        packed = lib.conv3d_layer_pack(self.w.detach().contiguous(), self.cin, self.cout, self.kind)
+        z = lib.conv3d_layer(packed, self.cin, self.cout, self.kind, x)
+        return self.norm.forward(z, residual)
+
+    def backward(self, g):
+        """g = gradient w.r.t. the block's output (the skip branch's share is the same tensor).  Returns
+        (grad_input, grad_weight, grad_bn_weight, grad_bn_bias)."""
+        lib = self.lib
+        dz, dgamma, dbeta = self.norm.backward(g)
         w = self.w.detach()
         if self.kind == _S1:                                                         # dgrad: flipped, channel-transposed
             wd = w.flip(2, 3, 4).transpose(0, 1).contiguous()
@@ -265,7 +286,7 @@ class _Block:
             pk = lib.conv3d_layer_pack(w.contiguous(), self.cout, self.cin, _S2)
             gx = lib.conv3d_layer(pk, self.cout, self.cin, _S2, dz)
             gw = lib.conv_wgrad_cl(self.x, dz, 2)
-        return gx, gw, dgamma.float(), dbeta.float()
+        return gx, gw, dgamma, dbeta
 
 
 class CostRegTrainFn(torch.autograd.Function):
@@ -365,6 +386,130 @@ def cost_reg_train(lib, m, vol):
             ctx.order = order
             return CostRegTrainFn.forward(ctx, *a)
     return _Fn.apply(lib, m, vol, *params)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# FeatureNet (feature_net.py:4-36) in TRAINING mode, forward and backward on the HIP kernels: every convolution on the
+# inference path's MFMA kernel with an identity epilogue (enerf_conv2d_layer; the top-down `up2 + lateral` adds ride in the
+# lateral convolution's epilogue exactly as in inference), the input gradients of the stride-1 layers on the same kernel
+# (flipped, channel-transposed weights), BatchNorm2d on the channel kernels shared with the cost-volume networks, weight
+# gradients on the matrix cores.  Everything stays channels-last between the image and the three output maps.  Still
+# torch ops: the input gradients of the two stride-2 5x5 layers (a transposed 5x5 convolution: no kernel of ours) and the
+# adjoint of the 2x bilinear upsampling.
+# ---------------------------------------------------------------------------------------------------------------------
+class _Conv2d:
+    """One convolution of the FeatureNet on channels-last tensors (cin = 3: the NCHW image batch)."""
+
+    def __init__(self, lib, conv):
+        self.lib, self.conv = lib, conv
+        self.cout, self.cin, self.k, _ = conv.weight.shape
+        self.stride = int(conv.stride[0])
+
+    def forward(self, x, up=None):
+        lib, w = self.lib, self.conv.weight.detach()
+        self.x = x
+        bias = None if self.conv.bias is None else self.conv.bias.detach()
+        return lib.conv2d_layer(lib.conv2d_layer_pack(w.contiguous(), bias, self.cin, self.cout, self.k), self.cin, self.cout, self.k,
+                                self.stride, x, up)
+
+    def backward(self, dz, need_input=True):
+        """dz = gradient w.r.t. the convolution's output (channels-last) -> (grad_input or None, grad_weight, grad_bias or None)."""
+        lib, w = self.lib, self.conv.weight.detach()
+        x_cl = self.x if self.cin != 3 else self.x.permute(0, 2, 3, 1).contiguous()
+        gw = lib.conv_wgrad_cl2d(dz, x_cl, self.k, self.stride)
+        gb = None if self.conv.bias is None else lib.channel_sums(dz, dz)[0].float()
+        gx = None
+        if need_input and self.stride == 1:                    # the stride-1 kernel on the flipped, channel-transposed weights
+            wd = w.flip(2, 3).transpose(0, 1).contiguous()
+            gx = lib.conv2d_layer(lib.conv2d_layer_pack(wd, None, self.cout, self.cin, self.k), self.cout, self.cin, self.k, 1, dz)
+        elif need_input:                                        # transposed 5x5 stride-2 convolution: the library op
+            N, H, W, _ = self.x.shape
+            gx = torch.nn.grad.conv2d_input((N, self.cin, H, W), w, dz.permute(0, 3, 1, 2), self.stride, (self.k - 1) // 2)
+            gx = gx.permute(0, 2, 3, 1).contiguous()
+        return gx, gw, gb
+
+
+def _up2_adjoint(g_cl):
+    """Adjoint of F.interpolate(scale_factor=2, bilinear, align_corners=True) (feature_net.py:24-25) on a channels-last map."""
+    N, H, W, C_ = g_cl.shape
+    g = torch.ops.aten.upsample_bilinear2d_backward(g_cl.permute(0, 3, 1, 2), [H, W], [N, C_, H // 2, W // 2], True, None, None)
+    return g.permute(0, 2, 3, 1).contiguous()
+
+
+_FEAT_ORDER = ("conv0.0", "conv0.1", "conv1.0", "conv1.1", "conv2.0", "conv2.1", "toplayer", "lat1", "lat0", "smooth1", "smooth0")
+
+
+class FeatureNetTrainFn(torch.autograd.Function):
+    """x (N,3,H,W) -> (f2 (N,32,H/4,W/4), smooth1(f1) (N,16,H/2,W/2), smooth0(f0) (N,8,H,W)) through the ``FeatureNet``
+    parameter module ``m`` in training mode.  The outputs are NCHW VIEWS of channels-last tensors (what the warp and the
+    render-side fetch read)."""
+
+    @staticmethod
+    def forward(ctx, lib: EnerfLib, m, x, *params):
+        conv, norm = {}, {}
+
+        def cbr(name, t):
+            blk = getattr(m, name[:5])[int(name[6])]
+            conv[name] = _Conv2d(lib, blk.conv)
+            norm[name] = _BatchNormTrain(lib, blk.bn, True)
+            return norm[name].forward(conv[name].forward(t))
+
+        def plain(name, t, up=None):
+            conv[name] = _Conv2d(lib, getattr(m, name))
+            return conv[name].forward(t, up)
+        c0 = cbr("conv0.1", cbr("conv0.0", x.contiguous()))
+        c1 = cbr("conv1.1", cbr("conv1.0", c0))
+        c2 = cbr("conv2.1", cbr("conv2.0", c1))
+        f2 = plain("toplayer", c2)
+        f1 = plain("lat1", c1, up=f2)                           # up2(f2) + lat1(c1)
+        f0 = plain("lat0", c0, up=f1)
+        s1 = plain("smooth1", f1)
+        s0 = plain("smooth0", f0)
+        ctx.conv, ctx.norm = conv, norm
+        return f2.permute(0, 3, 1, 2), s1.permute(0, 3, 1, 2), s0.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g_f2, g_s1, g_s0):
+        conv, norm = ctx.conv, ctx.norm
+        grads = {}
+        cl = lambda g: g.permute(0, 2, 3, 1).contiguous()       # (a no-op when the gradient arrives as a channels-last view)
+
+        def plain_back(name, g):
+            gx, gw, gb = conv[name].backward(g)
+            grads[name] = (gw, gb)
+            return gx
+
+        def cbr_back(name, g, need_input=True):
+            dz, dgamma, dbeta = norm[name].backward(g)
+            gx, gw, _ = conv[name].backward(dz, need_input)
+            grads[name] = (gw, dgamma, dbeta)
+            return gx
+        g_f0 = plain_back("smooth0", cl(g_s0))
+        g_c0 = plain_back("lat0", g_f0)
+        g_f1 = _up2_adjoint(g_f0) + plain_back("smooth1", cl(g_s1))
+        g_c1 = plain_back("lat1", g_f1)
+        g_top = _up2_adjoint(g_f1) + cl(g_f2)
+        g_c2 = plain_back("toplayer", g_top)
+        g_c1 = g_c1 + cbr_back("conv2.0", cbr_back("conv2.1", g_c2))
+        g_c0 = g_c0 + cbr_back("conv1.0", cbr_back("conv1.1", g_c1))
+        cbr_back("conv0.0", cbr_back("conv0.1", g_c0), need_input=False)
+        out = []
+        for name in _FEAT_ORDER:
+            out.extend(grads[name])
+        return (None, None, None) + tuple(out)
+
+
+def feature_net_train(lib, m, x):
+    """Apply FeatureNetTrainFn with the module's parameters as differentiable inputs (fixed order)."""
+    params = []
+    for name in _FEAT_ORDER:
+        if name.startswith("conv"):
+            blk = getattr(m, name[:5])[int(name[6])]
+            params += [blk.conv.weight, blk.bn.weight, blk.bn.bias]
+        else:
+            c = getattr(m, name)
+            params += [c.weight, c.bias]
+    return FeatureNetTrainFn.apply(lib, m, x, *params)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -1073,6 +1073,12 @@ int launch_conv2d(const Conv2dDesc& L, const float* in, float* out, const float*
             else launch_c2<32, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             return 0;
         case 32 * 10000 + 8 * 100 + 31: launch_c2<32, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;  // smooth0
+        // input gradients of the training path (enerf_conv2d_layer): dgrad(stride-1 conv cin -> cout) is the stride-1 conv
+        // cout -> cin on the flipped, channel-transposed weights; the shapes above cover conv0.1 / conv1.1 / conv2.1 / toplayer
+        case 16 * 10000 + 32 * 100 + 31: launch_c2<16, 2, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // d smooth1
+        case 8 * 10000 + 32 * 100 + 31: launch_c2<8, 2, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;   // d smooth0
+        case 32 * 10000 + 16 * 100 + 11: launch_c2<32, 1, 1, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // d lat1
+        case 32 * 10000 + 8 * 100 + 11: launch_c2<32, 1, 1, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;  // d lat0
         default: return -1;
     }
 }

@@ -110,6 +110,30 @@ int enerf_conv3d_layer(const float* packed, int cin, int cout, int kind, const f
         return fail(ENERF_EINVAL, "conv3d_layer: no kernel for %d -> %d kind %d", cin, cout, kind);
     return check_launch("conv3d_layer");
 }
+// ---- one FeatureNet convolution (feature_net.py:7-22) with an identity epilogue (+ bias), channels-last in and out ----
+long long enerf_conv2d_layer_packed_floats(int cin, int cout, int k) { return conv2d_packed_floats(cin, cout, k) + 2 * cdiv(cout, 16) * 16; }
+int enerf_conv2d_layer_pack(const float* w, const float* bias, int cin, int cout, int k, float* packed, enerf_stream_t stream) {
+    REQUIRE(w && packed, "conv2d_layer_pack: null pointer");
+    REQUIRE((cin == 3 || cin == 8 || cin == 16 || cin == 32) && (cout == 8 || cout == 16 || cout == 32) && (k == 1 || k == 3 || k == 5),
+            "conv2d_layer_pack: unsupported layer %d -> %d k %d", cin, cout, k);
+    const long long wf = conv2d_packed_floats(cin, cout, k);
+    const int cp = cdiv(cout, 16) * 16;
+    launch_conv2d_pack(w, bias, nullptr, nullptr, nullptr, nullptr, 1e-5f, cin, cout, k, packed, packed + wf, packed + wf + cp,
+                       (hipStream_t)stream);
+    return check_launch("conv2d_layer_pack");
+}
+int enerf_conv2d_layer(const float* packed, int cin, int cout, int k, int stride, const float* in, const float* up, float* out, int N,
+                       int Hi, int Wi, enerf_stream_t stream) {
+    REQUIRE(packed && in && out && N > 0 && Hi > 0 && Wi > 0 && (stride == 1 || stride == 2), "conv2d_layer: bad arguments");
+    const long long wf = conv2d_packed_floats(cin, cout, k);
+    const int cp = cdiv(cout, 16) * 16, P = (k - 1) / 2;
+    const int Ho = (Hi + 2 * P - k) / stride + 1, Wo = (Wi + 2 * P - k) / stride + 1;
+    if (up) REQUIRE(Ho % 2 == 0 && Wo % 2 == 0, "conv2d_layer: the upsampled map needs even output sizes");
+    Conv2dDesc d = {packed, packed + wf, packed + wf + cp, cin, cout, k, stride, 0, 0, nullptr, nullptr, nullptr};
+    if (launch_conv2d(d, in, out, up, N, Hi, Wi, Ho / 2, Wo / 2, (hipStream_t)stream) != 0)
+        return fail(ENERF_EINVAL, "conv2d_layer: no kernel for %d -> %d k %d stride %d", cin, cout, k, stride);
+    return check_launch("conv2d_layer");
+}
 int enerf_channel_sums(const float* a, const float* b, const float* z_mask, const float* mask_scale, const float* mask_shift,
                        long long n, int C, double* sums, enerf_stream_t stream) {
     REQUIRE(a && b && sums && n > 0 && C >= 4 && C <= 64 && C % 4 == 0 && (256 % (C / 4)) == 0, "channel_sums: bad arguments (C in 4..64, power-of-two quads)");

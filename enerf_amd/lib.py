@@ -14,7 +14,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libenerf_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _f = C.c_void_p     # device float*
 _i = C.c_int
@@ -167,6 +167,9 @@ _SIGNATURES = {
     "enerf_conv3d_layer_packed_floats": (_ll, [_i, _i, _i]),
     "enerf_conv3d_layer_pack": (_i, [_f, _i, _i, _i, _f, _f]),
     "enerf_conv3d_layer": (_i, [_f, _i, _i, _i, _f, _f, _f, _i, _i, _i, _i, C.POINTER(Options), _f]),
+    "enerf_conv2d_layer_packed_floats": (_ll, [_i, _i, _i]),
+    "enerf_conv2d_layer_pack": (_i, [_f, _f, _i, _i, _i, _f, _f]),
+    "enerf_conv2d_layer": (_i, [_f, _i, _i, _i, _i, _f, _f, _f, _i, _i, _i, _f]),
     "enerf_channel_sums": (_i, [_f, _f, _f, _f, _f, _ll, _i, C.c_void_p, _f]),
     "enerf_channel_affine": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _ll, _i, _f, _f]),
     "enerf_composite": (_i, [_f, _f, _ll, _i, _i, _f, _f, _f, _f]),
@@ -452,6 +455,26 @@ class EnerfLib:
                                                 _opt(options), self.stream_of(x_cl)), "conv3d_layer")
         return out
 
+    # training-mode FeatureNet convolutions (train.hip: enerf_conv2d_layer): weights (cout,cin,k,k), padding (k-1)/2
+    def conv2d_layer_pack(self, w, bias, cin, cout, k):
+        packed = torch.empty((self.dll.enerf_conv2d_layer_packed_floats(cin, cout, k),), dtype=torch.float32, device=w.device)
+        self._check(self.dll.enerf_conv2d_layer_pack(_ptr(w), _ptr(bias), cin, cout, k, _ptr(packed), self.stream_of(w)), "conv2d_layer_pack")
+        return packed
+
+    def conv2d_layer(self, packed, cin, cout, k, stride, x, up=None):
+        """x channels-last (N,H,W,cin) — for cin = 3 the NCHW image batch (N,3,H,W) — -> channels-last (N,Ho,Wo,cout);
+        ``up`` (N,Ho/2,Wo/2,cout) is upsampled 2x (bilinear, align_corners) and added."""
+        if cin == 3:
+            N, _, H, W = x.shape
+        else:
+            N, H, W, _ = x.shape
+        P = (k - 1) // 2
+        Ho, Wo = (H + 2 * P - k) // stride + 1, (W + 2 * P - k) // stride + 1
+        out = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+        self._check(self.dll.enerf_conv2d_layer(_ptr(packed), cin, cout, k, stride, _ptr(x), _ptr(up), _ptr(out), N, H, W,
+                                                self.stream_of(x)), "conv2d_layer")
+        return out
+
     def channel_sums(self, a, b, z_mask=None, mask_scale=None, mask_shift=None):
         """(sum_p a*m, sum_p a*m*b) per channel in fp64; tensors channels-last (..., C)."""
         Cc = a.shape[-1]
@@ -540,6 +563,16 @@ class EnerfLib:
         gw = torch.empty((Ca, Cb, 3, 3, 3), dtype=torch.float32, device=a_cl.device)
         self._check(self.dll.enerf_conv_wgrad(_ptr(a_cl), _ptr(b_cl), n, Da, Ha, Wa, Ca, Db, Hb, Wb, Cb, 3, 3, 3, int(stride),
                                               1, 1, 1, _ptr(gw), self.stream_of(a_cl)), "conv_wgrad")
+        return gw
+
+    def conv_wgrad_cl2d(self, a_cl, b_cl, k, stride):
+        """k x k weight gradient (padding (k-1)/2) from channels-last 2-D tensors a (n,Ha,Wa,Ca), b (n,Hb,Wb,Cb) -> (Ca,Cb,k,k)."""
+        n, Ha, Wa, Ca = a_cl.shape
+        _, Hb, Wb, Cb = b_cl.shape
+        p = (k - 1) // 2
+        gw = torch.empty((Ca, Cb, k, k), dtype=torch.float32, device=a_cl.device)
+        self._check(self.dll.enerf_conv_wgrad(_ptr(a_cl), _ptr(b_cl), n, 1, Ha, Wa, Ca, 1, Hb, Wb, Cb, 1, k, k, int(stride),
+                                              0, p, p, _ptr(gw), self.stream_of(a_cl)), "conv_wgrad")
         return gw
 
     def conv_wgrad(self, a, b, kernel, stride, padding, bias=False):

@@ -8,15 +8,19 @@ What runs where in training (state of this round, stated plainly):
   * every stage is expressed on the network's OWN parameter modules (``feature_net``, ``cost_reg_i.conv*.{conv,bn}``,
     ``nerf_i.*``), so BatchNorm uses batch statistics (SyncBatchNorm under the reference trainer), the running statistics
     are updated exactly like the reference's, and autograd sees every parameter;
-  * HIP kernels in BOTH directions (``enerf_amd/autograd.py``): the cost-volume warp + variance (feature scatter-add and
-    the depth gradient through the warp grid), both cost-regularisation networks end to end (MFMA convolutions and input
-    gradients, BatchNorm-train kernels, MFMA weight gradients), depth regression, the Agg + NeRF MLP (fused forward, fused
-    recompute-backward, weight gradients as position reductions on the matrix cores), alpha compositing, and the weight
-    gradients of the FeatureNet convolutions;
-  * still PyTorch-ROCm ops under autograd: the FeatureNet's convolution forward / input gradient and BatchNorm2d (the
-    north_star keeps the 2-D FPN in PyTorch), the render-side gathers (grid_sample and its backward) and the per-ray
-    geometry glue.  This is GPU code (no CPU fallback, nothing from ``oracle/``), checked against the reference's own
-    gradients (tests/test_training.py, tests/golden/train_tiny.npz) with the HIP stages switched on and off.
+  * HIP kernels in BOTH directions (``enerf_amd/autograd.py``): the whole FeatureNet (every convolution and the input
+    gradients of its stride-1 layers on the inference path's MFMA kernel, BatchNorm2d-train on the channel kernels, weight
+    gradients on the matrix cores, channels-last from the image to the three output maps: ``FeatureNetTrainFn``), the
+    cost-volume warp + variance (feature scatter-add and the depth gradient through the warp grid), both
+    cost-regularisation networks end to end (MFMA convolutions and input gradients, BatchNorm-train kernels, MFMA weight
+    gradients), depth regression, the render-side fetches (bilinear texel + trilinear volume gathers, direction code), the
+    Agg + NeRF MLP (fused forward, fused recompute-backward, weight gradients as position reductions on the matrix cores)
+    and alpha compositing;
+  * still PyTorch-ROCm ops under autograd: the input gradients of the FeatureNet's two stride-2 5x5 convolutions (a
+    transposed 5x5 convolution), the adjoint of its 2x bilinear upsampling, and the per-ray geometry glue.  With frozen
+    BatchNorm (``bn.eval()`` fine-tuning) the FeatureNet / cost-reg nets run through their modules instead (library
+    convolutions, HIP weight gradients).  This is GPU code (no CPU fallback, nothing from ``oracle/``), checked against the
+    reference's own gradients (tests/test_training.py, tests/golden/train_tiny.npz) with the HIP stages switched on and off.
 The inference path (eval mode) never comes here: it is the single ``enerf_forward`` C call.
 
 Semantics follow the reference line by line where gradients are concerned: the in-place masked clamps of
@@ -49,8 +53,14 @@ def _conv(lib, m, t):
     return conv_module(lib, m, t)
 
 
-def feature_net_forward(m, x, lib=None):
-    """FeatureNet.forward (feature_net.py:27-36) on the ``FeatureNet`` parameter module, convolutions through ``_conv``."""
+def feature_net_forward(m, x, lib=None, hip_train=True):
+    """FeatureNet.forward (feature_net.py:27-36) on the ``FeatureNet`` parameter module.  With the HIP library and every
+    BatchNorm2d in training mode the whole net runs on the HIP kernels in both directions (autograd.FeatureNetTrainFn);
+    otherwise (frozen BatchNorm, ``hip_train=False``, no library) through the modules, convolutions through ``_conv``."""
+    if lib is not None and hip_train and all(b.training for b in m.modules() if isinstance(b, torch.nn.modules.batchnorm._BatchNorm)):
+        from .autograd import feature_net_train
+        return feature_net_train(lib, m, x)
+
     def cbr(blk, t):
         return F.relu(blk.bn(_conv(lib, blk.conv, t)), inplace=True)
     c0 = cbr(m.conv0[1], cbr(m.conv0[0], x))
@@ -349,7 +359,8 @@ def forward_train(net, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor
     lib = _hip_lib(net, batch["src_inps"])
     src = batch["src_inps"]
     B, S, _, H, W = src.shape
-    f2, f1, f0 = feature_net_forward(net.feature_net, src.view(B * S, 3, H, W), lib)          # network.py:58-67
+    f2, f1, f0 = feature_net_forward(net.feature_net, src.view(B * S, 3, H, W), lib,
+                                     getattr(net, "hip_feature_net_train", True))                 # network.py:58-67
     feats = {"level_2": f0.reshape(B, S, f0.shape[1], H, W), "level_1": f1.reshape(B, S, f1.shape[1], H // 2, W // 2),
              "level_0": f2.reshape(B, S, f2.shape[1], H // 4, W // 4)}
     ret: Dict[str, torch.Tensor] = {}

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ENERF_ABI_VERSION 5
+#define ENERF_ABI_VERSION 6
 #define ENERF_OK 0
 #define ENERF_EINVAL (-1)   /* bad argument / unsupported shape */
 #define ENERF_ELAUNCH (-2)  /* HIP launch error */
@@ -325,6 +325,17 @@ int enerf_conv_wgrad(const float* a_cl, const float* b_cl, int n, int Da, int Ha
  *       or 1: BN batch statistics (a = b = z) and the d beta / d gamma reductions of its backward (a = grad, b = z).
  *   enerf_channel_affine  out = f(a*m*p[c] + b*q[c] + r[c]) (+ residual), f = ReLU if relu: BN normalise + ReLU + skip add,
  *       and the input gradient of BN.  All tensors channels-last (n, C). */
+/*   enerf_conv2d_layer[_pack]  (ABI v6) one FeatureNet convolution (feature_net.py:7-22: k 1/3/5, stride 1/2, padding (k-1)/2,
+ *       weights (cout,cin,k,k), optional bias) on the inference path's MFMA kernel with an identity epilogue, for the
+ *       training-mode FeatureNet.  in: channels-last (N,Hi,Wi,cin) — for cin = 3 the NCHW image batch (N,3,Hi,Wi) as the
+ *       batch holds it; out: channels-last (N,Ho,Wo,cout); up (optional): a channels-last (N,Ho/2,Wo/2,cout) map that is
+ *       upsampled 2x (bilinear, align_corners) and added (feature_net.py:24-25).  Supported (cin,cout,k,stride): the eleven
+ *       FeatureNet layers and the input gradients of its stride-1 layers (dgrad = the stride-1 conv cout -> cin on the
+ *       flipped, channel-transposed weights): 16->32 k3, 8->32 k3, 32->16 k1, 32->8 k1. */
+long long enerf_conv2d_layer_packed_floats(int cin, int cout, int k);
+int enerf_conv2d_layer_pack(const float* w, const float* bias, int cin, int cout, int k, float* packed, enerf_stream_t stream);
+int enerf_conv2d_layer(const float* packed, int cin, int cout, int k, int stride, const float* in, const float* up, float* out, int N,
+                       int Hi, int Wi, enerf_stream_t stream);
 long long enerf_conv3d_layer_packed_floats(int cin, int cout, int kind);
 int enerf_conv3d_layer_pack(const float* w, int cin, int cout, int kind, float* packed, enerf_stream_t stream);
 int enerf_conv3d_layer(const float* packed, int cin, int cout, int kind, const float* in, const float* residual, float* out, int B,
