@@ -142,6 +142,24 @@ def test_capi_rejects_bad_arguments():
         lib.depth_regression(torch.zeros(1, 4, 4, 4, dtype=torch.float64), torch.ones(1, 4, 4, 4), True)
 
 
+def test_frame_sizes_the_reference_cannot_run_fail_loudly():
+    """With the reference's cascade (volume_scale 0.125 / 0.5) only image sizes that are multiples of 32 survive its own U-Net
+    skip additions (cost_reg_net.py:41-44, 81-84: a 7-row volume comes back from conv11 with 8 rows): the reference raises
+    a size-mismatch RuntimeError there (restated by the oracle), and the HIP path must raise too — never render garbage.
+    (This is also why every reference-generated golden has a multiple-of-32 size: int(H*scale) never floors for them.)"""
+    from enerf_amd.config import EnerfConfig
+    from enerf_amd.synth import make_batch
+    from oracle import enerf_oracle as O
+    cfg = EnerfConfig().with_cas(volume_planes=(8, 8), render_if=(True, True))
+    for H, W in ((60, 100), (48, 80)):
+        batch = {k: torch.from_numpy(v) for k, v in make_batch(H, W, 3, cfg, seed=1, textured=True).items()}
+        with pytest.raises(RuntimeError, match="must match the size"):
+            O.forward(cfg, load_weights(), batch)
+        with pytest.raises(EnerfError, match="divisible by 4"):
+            with torch.no_grad():
+                _net(cfg)(batch)
+
+
 def test_empty_ray_list():
     name = "tiny_s3"
     cfg, batch, g = case_config(name), case_batch(name), load_golden(name)
