@@ -214,3 +214,32 @@ class GraphedTrainStep:
         self.graph.replay()
         self.net.invalidate_packed()                       # the inference weight images are stale after every update
         return self.loss
+
+
+class GraphedTrainSteps:
+    """One captured step per batch SHAPE.  The reference's DTU training draws the number of source views per sample
+    (``dtu_pretrain.yaml:71-72``: S in {2, 3, 4} with probabilities .1/.8/.1), so a run sees a handful of distinct shape
+    signatures, each static: ``GraphedTrainSteps(net, optimizer, loss_fn, [batch_S2, batch_S3, batch_S4])`` captures one
+    hipGraph for each up front (same parameters, same optimizer state tensors; every graph owns its activation pool and
+    gradient buffers) and ``step(batch)`` replays the one that matches.  Data-parallel: ranks may replay DIFFERENT graphs in
+    the same step — the sequence and sizes of the collectives (C-sized SyncBatchNorm exchanges, the flat gradient buffer) do
+    not depend on S — but every rank must construct the set from example batches in the same order."""
+
+    def __init__(self, net, optimizer, loss_fn: Callable, example_batches, **kwargs):
+        self.steps = {}
+        for b in example_batches:
+            k = self.key(b)
+            if k not in self.steps:
+                self.steps[k] = GraphedTrainStep(net, optimizer, loss_fn, b, **kwargs)
+
+    @staticmethod
+    def key(batch):
+        return tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in batch.items() if torch.is_tensor(v)))
+
+    def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        try:
+            step = self.steps[self.key(batch)]
+        except KeyError:
+            raise KeyError("GraphedTrainSteps: no graph was captured for this batch's shapes "
+                           f"({[(k, s) for k, s, _ in self.key(batch)][:4]} ...); pass an example of it to the constructor") from None
+        return step(batch)

@@ -681,6 +681,44 @@ def test_graphed_training_step_equals_eager_steps():
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_graphed_steps_per_source_view_count_equal_eager_steps():
+    """train_graph.GraphedTrainSteps: the trainer draws S in {2,3,4} per sample (dtu_pretrain.yaml:71-72) — one captured graph
+    per shape, all on the same parameters and optimizer state.  Five steps alternating S = 3, 2, 3, 4, 2 as replays leave the
+    parameters, BatchNorm statistics and losses of five eager steps."""
+    from enerf_amd.train_graph import GraphedTrainSteps, mse_loss
+    dev = torch.device("cuda:0")
+    by_s = {}
+    for S_ in (2, 3, 4):
+        cfg, b = _train_batch(seed=30 + S_, S=S_)
+        by_s[S_] = {k: v.to(dev) for k, v in b.items()}
+    nets = [_net(cfg).to(dev) for _ in range(2)]
+    opts = [torch.optim.SGD(n.parameters(), lr=1e-3, momentum=0.9) for n in nets]
+    tree_loss = lambda out, b: sum(LOSS_W[i] * mse_loss(b[f"rgb_{i}"], out[f"rgb_level{i}"]) for i in range(2))
+    gsteps = GraphedTrainSteps(nets[0], opts[0], tree_loss, [by_s[3], by_s[2], by_s[4]], clip_value=40.0, warmup=1)
+    assert len(gsteps.steps) == 3
+    for k, v in nets[1].state_dict().items():                           # three constructions, no net change
+        assert torch.equal(nets[0].state_dict()[k], v), k
+    losses = [[], []]
+    for S_ in (3, 2, 3, 4, 2):
+        b = by_s[S_]
+        losses[0].append(float(gsteps(b)))
+        loss = _loss(nets[1](b), b)
+        opts[1].zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_value_(nets[1].parameters(), 40.0)
+        opts[1].step()
+        losses[1].append(float(loss))
+    assert losses[0] == pytest.approx(losses[1], rel=1e-4), losses
+    sd0, sd1 = nets[0].state_dict(), nets[1].state_dict()
+    for k in sd1:
+        if sd1[k].dtype.is_floating_point:
+            assert float((sd0[k] - sd1[k]).abs().max()) <= 1e-5 + 1e-4 * float(sd1[k].abs().max()), k
+    with pytest.raises(KeyError, match="no graph was captured"):
+        gsteps({k: (v[:, :1] if k.startswith("rays_") or k.startswith("rgb_") else v) for k, v in by_s[3].items()})
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
 def test_graphed_data_parallel_step_captures_its_collectives():
     """train_graph.GraphedTrainStep(distributed=True) on a 1-rank RCCL group (a 1-GPU box cannot hold two ranks): the flat
     gradient all-reduce and the cost-volume networks' SyncBatchNorm statistics exchanges (forced on for the 1-rank group) are
