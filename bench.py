@@ -183,14 +183,10 @@ def train_bench(args, rank, world, dev, dist, emu_lib=None):
     if dp and world == 1:
         from enerf_amd import autograd as _A
         _A.SYNC_SINGLE_RANK = True
-    if world > 1 and emu:
-        net.feature_net.eval()                # torch's SyncBatchNorm refuses CPU tensors: the 2-D FPN's BatchNorm stays out of
-        for i in range(2):                    # the dry run; the cost-volume networks' statistics exchange (autograd._sync_sums) is in
-            setattr(net, f"cost_reg_{i}", torch.nn.SyncBatchNorm.convert_sync_batchnorm(getattr(net, f"cost_reg_{i}")))
-    elif dp:
+    if dp:   # (every BatchNorm runs inside the HIP training functions, whose statistics exchange works on gloo as well)
         net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)         # trainer.py:16
         model = net
-        if not graphed:                                                  # trainer.py:17-22 as written: the eager DDP step
+        if not graphed and not emu:                                      # trainer.py:17-22 as written: the eager DDP step
             from torch.nn.parallel import DistributedDataParallel as DDP
             model = DDP(net, device_ids=[dev.index], output_device=dev.index, find_unused_parameters=True)
     opt = torch.optim.Adam(net.parameters(), lr=5e-4, capturable=graphed)

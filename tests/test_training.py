@@ -434,9 +434,11 @@ def _syncbn_worker(rank, world, port, q):
         net = Network(cfg, lib=emu_lib())                                  # HIP training stages on (lane emulator)
         net.load_state_dict(load_weights(), strict=False)
         net.train()
-        net.feature_net.eval()            # torch's SyncBatchNorm refuses CPU tensors: keep the 2-D FPN out of the batch coupling
-        for i in range(2):                # trainer.py:16 on the cost-reg nets, whose BatchNorm runs inside CostRegTrainFn
-            setattr(net, f"cost_reg_{i}", torch.nn.SyncBatchNorm.convert_sync_batchnorm(getattr(net, f"cost_reg_{i}")))
+        # trainer.py:16 on the WHOLE network: every BatchNorm (FeatureNet 2-D, cost-reg 3-D) runs inside the HIP training
+        # functions, whose statistics exchange (autograd._sync_sums) works on any backend (torch's own SyncBatchNorm forward,
+        # which refuses CPU tensors, is never called on this path)
+        net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
+        assert isinstance(net.feature_net.conv0[0].bn, torch.nn.SyncBatchNorm)
         loss = _loss(net(parts[rank]), parts[rank])
         loss.backward()
         grads = {}
@@ -444,7 +446,7 @@ def _syncbn_worker(rank, world, port, q):
             if p.grad is not None:
                 dist.all_reduce(p.grad)
                 grads[n] = (p.grad / world).numpy()
-        q.put((rank, grads, {n: b.numpy().copy() for n, b in net.named_buffers() if n.endswith("running_var") and "cost_reg" in n}))
+        q.put((rank, grads, {n: b.numpy().copy() for n, b in net.named_buffers() if n.endswith("running_var")}))
         dist.destroy_process_group()
     except Exception as e:                                                 # never leave the parent waiting
         import traceback
@@ -452,8 +454,9 @@ def _syncbn_worker(rank, world, port, q):
 
 
 def test_two_rank_syncbn_on_hip_training_path_equals_one_process_with_batch_two():
-    """trainer.py:15-22 on the HIP training path: SyncBatchNorm statistics all-reduced inside CostRegTrainFn (one small
-    all-reduce per BN layer and direction) + gradient averaging == one process with both samples in one batch."""
+    """trainer.py:15-22 on the HIP training path: SyncBatchNorm statistics of EVERY BatchNorm of the network (FeatureNet and
+    both cost-volume networks) all-reduced inside the HIP training functions (one small all-reduce per BN layer and
+    direction) + gradient averaging == one process with both samples in one batch."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29900 + (os.getpid() % 2000)
@@ -466,14 +469,14 @@ def test_two_rank_syncbn_on_hip_training_path_equals_one_process_with_batch_two(
     torch.set_num_threads(1)
     cfg, full, _ = _batch2()
     net = _net(cfg)                                                    # torch-op path, plain BatchNorm, B = 2
-    net.feature_net.eval()
     _loss(net(full), full).backward()
     ref = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
     checked = 0
     for n, v in res[0][1].items():
         assert np.allclose(v, res[1][1][n], rtol=1e-5, atol=1e-9), n   # both ranks hold the averaged gradients
         r = ref[n].numpy()
-        assert np.abs(v - r).max() <= 5e-3 * max(np.abs(r).max(), 1e-12) + 1e-9, (n, float(np.abs(v - r).max() / max(np.abs(r).max(), 1e-12)))
+        tol = 1.5e-2      # two different summation orders of the same ill-conditioned step (see GPU_GRAD_TOL_MID's note)
+        assert np.abs(v - r).max() <= tol * max(np.abs(r).max(), 1e-12) + 1e-9, (n, float(np.abs(v - r).max() / max(np.abs(r).max(), 1e-12)))
         checked += 1
     assert checked > 80
     for n, v in res[0][2].items():                                     # running_var from the global statistics
