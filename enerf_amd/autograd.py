@@ -173,7 +173,7 @@ def conv_module(lib, m, x):
 # convolutions and their input gradients on the inference path's MFMA kernels (enerf_conv3d_layer), weight gradients on
 # the matrix cores (enerf_conv_wgrad), BatchNorm batch statistics / normalise+ReLU+skip / backward on the two channel
 # kernels of train.hip.  Everything between the cost volume and (feat, prob) stays channels-last on the device; only
-# C-sized vectors (means, scales, d gamma, d beta) are touched by torch ops.
+# C-sized vectors (means, scales, d gamma, d beta) come from one coefficient kernel per BatchNorm and direction.
 # ---------------------------------------------------------------------------------------------------------------------
 _S1, _S2, _T2 = 0, 1, 2
 
@@ -181,72 +181,48 @@ _S1, _S2, _T2 = 0, 1, 2
 SYNC_SINGLE_RANK = False     # tests: run the statistics exchange on a 1-rank group too (captures RCCL nodes on a 1-GPU box)
 
 
-def _sync_sums(bn, s1, s2, n, count_is_global=False):
-    """SyncBatchNorm (trainer.py:16): batch statistics over all ranks — one small all-reduce per layer and direction.
-    ``n`` is this rank's position count (summed over ranks here) unless ``count_is_global``.  The global count stays ON THE
-    DEVICE (a 0-d float64 tensor riding in the same buffer as the sums): no host read, so the step can be enqueued without
-    a synchronisation per layer and captured into a hipGraph with the collectives inside (train_graph.py)."""
-    import torch.distributed as dist
-    if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and \
-            (dist.get_world_size() > 1 or SYNC_SINGLE_RANK):
-        if count_is_global:
-            buf = torch.cat([s1, s2])
-            dist.all_reduce(buf)
-            c = s1.numel()
-            return buf[:c], buf[c:], n
-        buf = torch.cat([s1, s2, s1.new_full((1,), float(n))])               # fill kernel, not a host copy: capture-safe
-        dist.all_reduce(buf)
-        c = s1.numel()
-        return buf[:c], buf[c:2 * c], buf[2 * c]
-    return s1, s2, float(n)
-
-
-def _bessel(n):
-    """n / max(n - 1, 1) for a host or device count."""
-    return n / torch.clamp(n - 1.0, min=1.0) if torch.is_tensor(n) else n / max(n - 1.0, 1.0)
-
-
 class _BatchNormTrain:
     """BatchNorm (+ ReLU) (+ skip add) in training mode on a channels-last tensor z (..., C): batch statistics, running
-    statistics update, normalise — and the backward — on the two channel kernels of train.hip.  Shared by the 3-D blocks
-    of the cost-volume networks and the 2-D blocks of the FeatureNet."""
+    statistics update, normalise — and the backward — on the channel kernels of train.hip: per direction one statistics
+    launch, one C-sized coefficient launch (enerf_bn_train[_bwd]_coeffs, fp64) and one affine launch; under SyncBatchNorm
+    (trainer.py:16) one small all-reduce of the statistics (+ the position count, which stays on the device) in between.
+    Shared by the 3-D blocks of the cost-volume networks and the 2-D blocks of the FeatureNet."""
 
     def __init__(self, lib, bn, relu):
         self.lib, self.bn, self.relu = lib, bn, relu
 
+    @staticmethod
+    def _synced(bn):
+        import torch.distributed as dist
+        return isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and \
+            (dist.get_world_size() > 1 or SYNC_SINGLE_RANK)
+
     def forward(self, z, residual=None):
         lib, bn = self.lib, self.bn
         C_ = z.shape[-1]
-        s1, s2 = lib.channel_sums(z, z)
-        s1, s2, n = _sync_sums(bn, s1, s2, z.numel() // C_)
-        mean = s1 / n
-        var = (s2 / n - mean * mean).clamp_min(0.0)                                  # biased (normalisation)
-        invstd = torch.rsqrt(var + bn.eps)
-        scale = (bn.weight.detach().double() * invstd).float()
-        shift = (bn.bias.detach().double() - mean * bn.weight.detach().double() * invstd).float()
-        if bn.track_running_stats and bn.running_mean is not None:
-            with torch.no_grad():                                                    # running statistics, like nn.BatchNorm3d
-                bn.num_batches_tracked.add_(1)
-                # momentum=None: cumulative moving average, factor 1/num_batches_tracked (torch.nn.modules.batchnorm)
-                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                bn.running_mean.mul_(1 - mom).add_(mean.float(), alpha=mom)
-                bn.running_var.mul_(1 - mom).add_((var * _bessel(n)).float(), alpha=mom)
-        self.z, self.n, self.mean, self.invstd, self.scale, self.shift = z, n, mean, invstd, scale, shift
-        return lib.channel_affine(z, scale, shift, residual=residual, relu=self.relu)
+        sums, n = lib.channel_sums_raw(z, z), z.numel() // C_
+        if self._synced(bn):
+            import torch.distributed as dist
+            buf = torch.cat([sums.view(-1), sums.new_full((1,), float(n))])          # fill kernel, not a host copy: capture-safe
+            dist.all_reduce(buf)
+            sums, n = buf[:2 * C_].view(2, C_), buf[2 * C_:]                         # the global count stays on the device
+        self.mean_invstd, ss = lib.bn_train_coeffs(sums, n, bn)
+        self.z, self.n, self.scale, self.shift = z, n, ss[0], ss[1]
+        return lib.channel_affine(z, self.scale, self.shift, residual=residual, relu=self.relu)
 
     def backward(self, g):
         """g = gradient w.r.t. the normalised (+ ReLU) output -> (d z, d gamma, d beta)."""
         lib, bn, z = self.lib, self.bn, self.z
         mask = dict(z_mask=z, mask_scale=self.scale, mask_shift=self.shift) if self.relu else {}
-        sg, sgz = lib.channel_sums(g, z, **mask)                                     # sum gm, sum gm*z over this rank
-        dbeta = sg                                                                   # parameter gradients stay LOCAL (DDP
-        dgamma = self.invstd * (sgz - self.mean * sg)                                # averages them), like torch's SyncBatchNorm
-        sg, sgz, n = _sync_sums(bn, sg, sgz, self.n, count_is_global=True)           # the input gradient needs the global sums
-        sc = self.scale.double()
-        k2 = -sc * self.invstd * (self.invstd * (sgz - self.mean * sg)) / n
-        k3 = -sc * sg / n - k2 * self.mean
-        dz = lib.channel_affine(g, self.scale, k3.float(), b=z, q=k2.float(), **mask)
-        return dz, dgamma.float(), dbeta.float()
+        local = lib.channel_sums_raw(g, z, **mask)                                   # sum gm, sum gm*z over this rank
+        glob = local
+        if self._synced(bn):                                                         # the input gradient needs the global sums;
+            import torch.distributed as dist                                         # d gamma / d beta stay LOCAL (DDP averages
+            glob = local.clone()                                                     # them), like torch's SyncBatchNorm
+            dist.all_reduce(glob)
+        dgb, k23 = lib.bn_train_bwd_coeffs(local, glob, self.n, self.mean_invstd, self.scale)
+        dz = lib.channel_affine(g, self.scale, k23[1], b=z, q=k23[0], **mask)
+        return dz, dgb[0], dgb[1]
 
 
 class _Block:

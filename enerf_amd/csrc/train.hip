@@ -79,6 +79,54 @@ __global__ __launch_bounds__(256) void k_channel_affine(const float* __restrict_
     *reinterpret_cast<float4*>(out + i * 4) = make_float4(y[0], y[1], y[2], y[3]);
 }
 
+// ---- BatchNorm-train per-channel coefficients: the C-sized arithmetic between the statistics kernel (and its all-reduce
+// under SyncBatchNorm) and the affine kernel, in ONE launch instead of ~20 C-element torch kernels per layer and direction
+// (40 BatchNorm layers x 2 directions per training step).  fp64 like the torch expressions it replaces. ----
+// forward: sums = [sum z, sum z^2] -> mean, invstd (fp64), scale = gamma*invstd, shift = beta - mean*gamma*invstd (fp32),
+// running statistics updated in place (unbiased variance; momentum < 0: cumulative average 1/num_batches_tracked)
+__global__ void k_bn_train_coeffs(const double* __restrict__ sums, const double* __restrict__ count_dev, double count_host,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta, double eps, double momentum,
+                                  float* __restrict__ running_mean, float* __restrict__ running_var,
+                                  const long long* __restrict__ nbt, int C, double* __restrict__ mean_invstd,
+                                  float* __restrict__ scale_shift) {
+    const int c = threadIdx.x;
+    const double n = count_dev != nullptr ? *count_dev : count_host;
+    const long long tracked = nbt != nullptr ? *nbt : 1;   // already counts this batch (the caller increments it first)
+    if (c >= C) return;
+    const double mean = sums[c] / n;
+    double var = sums[C + c] / n - mean * mean;            // biased (normalisation)
+    var = var > 0.0 ? var : 0.0;
+    const double invstd = 1.0 / sqrt(var + eps);
+    mean_invstd[c] = mean;
+    mean_invstd[C + c] = invstd;
+    const double g = (double)gamma[c];
+    scale_shift[c] = (float)(g * invstd);
+    scale_shift[C + c] = (float)((double)beta[c] - mean * g * invstd);
+    if (running_mean != nullptr) {
+        const float mom = (float)(momentum >= 0.0 ? momentum : 1.0 / (double)tracked);
+        const double nm1 = n - 1.0 > 1.0 ? n - 1.0 : 1.0;
+        running_mean[c] = running_mean[c] * (1.f - mom) + (float)mean * mom;
+        running_var[c] = running_var[c] * (1.f - mom) + (float)(var * (n / nm1)) * mom;
+    }
+}
+// backward: local sums [sum g*m, sum g*m*z] -> d gamma, d beta (parameter gradients stay per-rank, like torch's
+// SyncBatchNorm); global sums -> the input-gradient coefficients d z = g*m*scale + z*k2 + k3
+__global__ void k_bn_train_bwd_coeffs(const double* __restrict__ local, const double* __restrict__ global_,
+                                      const double* __restrict__ count_dev, double count_host,
+                                      const double* __restrict__ mean_invstd, const float* __restrict__ scale, int C,
+                                      float* __restrict__ dgamma_dbeta, float* __restrict__ k2k3) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    const double n = count_dev != nullptr ? *count_dev : count_host;
+    const double mean = mean_invstd[c], invstd = mean_invstd[C + c];
+    dgamma_dbeta[c] = (float)(invstd * (local[C + c] - mean * local[c]));
+    dgamma_dbeta[C + c] = (float)local[c];
+    const double sc = (double)scale[c], sg = global_[c], sgz = global_[C + c];
+    const double k2 = -sc * invstd * (invstd * (sgz - mean * sg)) / n;
+    k2k3[c] = (float)k2;
+    k2k3[C + c] = (float)(-sc * sg / n - k2 * mean);
+}
+
 }  // namespace enerf
 
 using namespace enerf;
@@ -145,6 +193,26 @@ int enerf_channel_sums(const float* a, const float* b, const float* z_mask, cons
     if (blocks < 1) blocks = 1;
     ENERF_LAUNCH(k_channel_sums, (unsigned)blocks, 256, 0, (hipStream_t)stream, a, b, z_mask, mask_scale, mask_shift, n, C, sums);
     return check_launch("channel_sums");
+}
+int enerf_bn_train_coeffs(const double* sums, const double* count_dev, double count_host, const float* gamma, const float* beta,
+                          double eps, double momentum, float* running_mean, float* running_var, const long long* num_batches_tracked,
+                          int C, double* mean_invstd, float* scale_shift, enerf_stream_t stream) {
+    REQUIRE(sums && gamma && beta && mean_invstd && scale_shift && C >= 1 && C <= 256, "bn_train_coeffs: bad arguments (C in 1..256)");
+    REQUIRE(count_dev || count_host > 0.0, "bn_train_coeffs: no position count");
+    REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_coeffs: running_mean and running_var come together");
+    ENERF_LAUNCH_SIMPLE(k_bn_train_coeffs, 1, 256, 0, (hipStream_t)stream, sums, count_dev, count_host, gamma, beta, eps, momentum,
+                        running_mean, running_var, num_batches_tracked, C, mean_invstd, scale_shift);
+    return check_launch("bn_train_coeffs");
+}
+int enerf_bn_train_bwd_coeffs(const double* sums_local, const double* sums_global, const double* count_dev, double count_host,
+                              const double* mean_invstd, const float* scale, int C, float* dgamma_dbeta, float* k2k3,
+                              enerf_stream_t stream) {
+    REQUIRE(sums_local && sums_global && mean_invstd && scale && dgamma_dbeta && k2k3 && C >= 1 && C <= 256,
+            "bn_train_bwd_coeffs: bad arguments (C in 1..256)");
+    REQUIRE(count_dev || count_host > 0.0, "bn_train_bwd_coeffs: no position count");
+    ENERF_LAUNCH_SIMPLE(k_bn_train_bwd_coeffs, 1, 256, 0, (hipStream_t)stream, sums_local, sums_global, count_dev, count_host,
+                        mean_invstd, scale, C, dgamma_dbeta, k2k3);
+    return check_launch("bn_train_bwd_coeffs");
 }
 int enerf_channel_affine(const float* a, const float* b, const float* p, const float* q, const float* r, const float* z_mask,
                          const float* mask_scale, const float* mask_shift, const float* residual, int relu, long long n, int C,

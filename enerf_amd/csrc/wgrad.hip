@@ -35,23 +35,35 @@ struct WgradGeom {
     long long npos;              // n * Da * Ha * Wa
 };
 
-template <int KD, int KH, int KW>
-__global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ A, const float* __restrict__ Bt, WgradGeom q,
-                                                    float* __restrict__ dW, float* __restrict__ dbias) {
-    constexpr int NT = KD * KH * KW;
-    __shared__ float red[NT][256];                      // one wave's partial tiles at a time (27 KB at 27 taps)
+__device__ float g_wgrad_zeros[4];          // the address padding taps and dead lanes load from
+
+// SPLIT: the taps are split (by their leading kernel dimension) over SPLIT waves of a block, PL position-lanes each: a wave keeps
+// NT/SPLIT accumulators (36 instead of 108 registers at 3x3x3) and 1 + NT/SPLIT loads per group in flight, so six to eight
+// waves fit a SIMD instead of two and the loads' latency hides (conv0 / heads, 655k positions: 311-326 -> see DESIGN.md).
+template <int KD, int KH, int KW, int SPLIT, int PL>
+__global__ __launch_bounds__(SPLIT * PL * 64) void k_conv_wgrad(const float* __restrict__ A, const float* __restrict__ Bt, WgradGeom q,
+                                                                float* __restrict__ dW, float* __restrict__ dbias,
+                                                                float* __restrict__ scratch) {
+    constexpr int NT = KD * KH * KW, NTW = NT / SPLIT;
+    static_assert(SPLIT == 1 || (KD > 1 && SPLIT == KD) || (KD == 1 && SPLIT == KH), "the tap split is the leading kernel dimension");
+    __shared__ float red[PL > 1 ? NT : 1][256];         // partial tiles of the position-lanes >= 1, one lane at a time
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
+    const int ts = __builtin_amdgcn_readfirstlane(wave % SPLIT), pl = wave / SPLIT;     // tap subset (scalar), position lane
     const int pair = blockIdx.x / q.chunks, chunk = blockIdx.x - pair * q.chunks;
     const int ta = pair / q.tiles_b, tb = pair - ta * q.tiles_b;
     const int ca = ta * 16 + j, cb = tb * 16 + j;
     const bool ca_ok = ca < q.Ca, cb_ok = cb < q.Cb;
-    // positions of this wave: groups of 4, interleaved over (chunk, wave) so every block sees the whole volume
+    // positions of this wave: groups of 4, interleaved over (chunk, position lane) so every block sees the whole volume
     const long long ngroups = cdivl(q.npos, 4);
-    const long long stride_g = (long long)q.chunks * 4;
-    f32x4 acc[NT];
+    const long long stride_g = (long long)q.chunks * PL;
+    f32x4 acc[NTW];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (long long grp = (long long)chunk * 4 + wave; grp < ngroups; grp += stride_g) {
+    for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // One group = 4 positions x (1 A value + NTW shifted B values per lane) -> NTW MFMAs.  Every load is UNCONDITIONAL: a padding
+    // tap / dead lane reads a zero page instead (`ok ? B[i] : 0` makes hipcc branch around each load and wait vmcnt(0) on it),
+    // and the loads of group i+1 are issued before the MFMAs of group i.
+    const float* const zero = g_wgrad_zeros;
+    auto issue = [&](long long grp, float& av, float (&bv)[NTW]) {
         const long long p = grp * 4 + g;
         const bool pv = p < q.npos;
         const unsigned pc = (unsigned)(pv ? p : q.npos - 1);           // npos < 2^31 (checked by the C entry)
@@ -61,62 +73,149 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ A,
         const unsigned r2 = r1 / (unsigned)q.Ha;
         const int oh = (int)(r1 - r2 * (unsigned)q.Ha);
         const int b = (int)(r2 / (unsigned)q.Da), od = (int)(r2 - (unsigned)b * (unsigned)q.Da);
-        const float av = (pv && ca_ok) ? A[(long long)pc * q.lda + ca] : 0.f;
+        const float* ap = (pv && ca_ok) ? A + ((long long)pc * q.lda + ca) : zero;
+        av = *ap;
         const int id0 = od * q.stride - q.pad_d, ih0 = oh * q.stride - q.pad_h, iw0 = ow * q.stride - q.pad_w;
         const long long bbase = (long long)b * q.Db;
-        float bv[NT];
+        const bool lane_ok = pv && cb_ok;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int kd = t / (KH * KW), kh = (t / KW) % KH, kw = t % KW;
+        for (int k = 0; k < NTW; ++k) {
+            // tap (kd, kh, kw) of this wave's k-th accumulator: the split is by the leading kernel dimension, so only that
+            // coordinate depends on the wave (a scalar) and the others are compile-time constants of k
+            int kd, kh, kw;
+            if (SPLIT == 1) { kd = k / (KH * KW); kh = (k / KW) % KH; kw = k % KW; }
+            else if (KD > 1) { kd = ts; kh = k / KW; kw = k % KW; }          // SPLIT == KD
+            else { kd = 0; kh = ts; kw = k; }                                // SPLIT == KH
             const int id = id0 + kd, ih = ih0 + kh, iw = iw0 + kw;
-            const bool ok = pv && cb_ok && (unsigned)id < (unsigned)q.Db && (unsigned)ih < (unsigned)q.Hb && (unsigned)iw < (unsigned)q.Wb;
-            const long long bi = ((bbase + (ok ? id : 0)) * q.Hb + (ok ? ih : 0)) * q.Wb + (ok ? iw : 0);
-            bv[t] = ok ? Bt[bi * q.ldb + cb] : 0.f;
-            if (NT == 1 && q.bias && cb == q.Cb) bv[t] = pv ? 1.f : 0.f;
+            const bool ok = lane_ok && (unsigned)id < (unsigned)q.Db && (unsigned)ih < (unsigned)q.Hb && (unsigned)iw < (unsigned)q.Wb;
+            const long long bi = ((bbase + id) * q.Hb + ih) * q.Wb + iw;
+            const float* bp = ok ? Bt + (bi * q.ldb + cb) : zero;
+            bv[k] = *bp;
         }
+        if (NT == 1 && q.bias && cb == q.Cb) bv[0] = pv ? 1.f : 0.f;
+    };
+    float av0, av1, bv0[NTW], bv1[NTW];
+    long long grp = (long long)chunk * PL + pl;
+    if (grp < ngroups) issue(grp, av0, bv0);
+    for (; grp < ngroups; grp += 2 * stride_g) {
+        const bool more1 = grp + stride_g < ngroups;                   // uniform
+        if (more1) issue(grp + stride_g, av1, bv1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = ENERF_MFMA_W(av, bv[t], acc[t]);
+        for (int t = 0; t < NTW; ++t) acc[t] = ENERF_MFMA_W(av0, bv0[t], acc[t]);
+        if (!more1) break;
+        if (grp + 2 * stride_g < ngroups) issue(grp + 2 * stride_g, av0, bv0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t] = ENERF_MFMA_W(av1, bv1[t], acc[t]);
     }
-    // block reduction: waves 1..3 hand their tiles to wave 0 through LDS, one wave per round; wave 0 commits
-    for (int src = 1; src < 4; ++src) {
-        if (wave == src) {
+    // block reduction: position lanes 1.. hand their tiles to lane 0 of the same tap subset through LDS, one lane per round
+    for (int src = 1; src < PL; ++src) {
+        if (pl == src) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NTW; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[t][r * 64 + lane] = acc[t][r];
+                for (int r = 0; r < 4; ++r) red[PL > 1 ? ts * NTW + t : 0][r * 64 + lane] = acc[t][r];
         }
         __syncthreads();
-        if (wave == 0) {
+        if (pl == 0) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NTW; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[t][r] += red[t][r * 64 + lane];
+                for (int r = 0; r < 4; ++r) acc[t][r] += red[PL > 1 ? ts * NTW + t : 0][r * 64 + lane];
         }
         __syncthreads();
     }
-    if (wave == 0) {
+    if (pl != 0) return;
+    if (scratch != nullptr) {       // two-stage commit: this block's partial tiles, plain coalesced stores (k_wgrad_reduce sums them)
+        float* sp = scratch + ((long long)blockIdx.x * NT + ts * NTW) * 256 + lane;       // blockIdx.x = pair * chunks + chunk
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+        for (int t = 0; t < NTW; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = acc[t][r];
-                const int a_ch = ta * 16 + 4 * g + r, b_ch = tb * 16 + j;      // D layout: rows 4g+r of column j
-                if (a_ch < q.Ca && b_ch < q.Cb && v != 0.f) atomic_add_f32(dW + ((long long)a_ch * q.Cb + b_ch) * NT + t, v);
-                if (NT == 1 && q.bias && a_ch < q.Ca && b_ch == q.Cb && v != 0.f) atomic_add_f32(dbias + a_ch, v);
-            }
+            for (int r = 0; r < 4; ++r) sp[t * 256 + r * 64] = acc[t][r];
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < NTW; ++k) {
+        const int t = ts * NTW + k;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = acc[k][r];
+            const int a_ch = ta * 16 + 4 * g + r, b_ch = tb * 16 + j;      // D layout: rows 4g+r of column j
+            if (a_ch < q.Ca && b_ch < q.Cb && v != 0.f) atomic_add_f32(dW + ((long long)a_ch * q.Cb + b_ch) * NT + t, v);
+            if (NT == 1 && q.bias && a_ch < q.Ca && b_ch == q.Cb && v != 0.f) atomic_add_f32(dbias + a_ch, v);
         }
     }
 }
 
-template <int KD, int KH, int KW>
-static void launch_wgrad_k(const float* A, const float* Bt, const WgradGeom& q, float* dW, float* dbias, hipStream_t st) {
+// Second stage of the weight-gradient commit.  With fp32 atomics every block adds its NT x 256 partial sums to the SAME few KB
+// of dW: 640-1024 blocks x 6912 atomics onto 6912 addresses run at ~13 G atomics/s — measured 310-580 us per cost-volume layer
+// against 7-58 us of MFMA issue time, 7 ms of a 28 ms training step.  Instead every block stores its partial tile set and this
+// kernel sums them: item I = (pair or 0, tile/tap t), one 1024-thread block per (item, register r): wave w sums the chunks
+// c = w, w+16, ... of its 64 lanes' element, the 16 waves meet in LDS, wave 0 writes dW (and dbias) with plain stores —
+// deterministic, and no pre-zeroing of dW.
+//   conv (gemm == 0): scratch[((pair*chunks + c)*nt + t)*256 + e], pair = (ta, tb), t = tap, dW[(a*Cb + b)*nt + t]
+//   gemm (gemm == 1): scratch[(c*nt + t)*256 + e], t = ta*tiles_b + tb, dW[a*Cb + b]
+__global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__ scratch, int chunks, int nt, int tiles_b, int Ca,
+                                                       int Cb, int bias, int gemm, float* __restrict__ dW,
+                                                       float* __restrict__ dbias) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+    const int r = blockIdx.x & 3, item = blockIdx.x >> 2;
+    const int pair = gemm ? 0 : item / nt, t = gemm ? item : item - pair * nt;
+    const float* sp = scratch + (((long long)pair * chunks) * nt + t) * 256 + r * 64 + lane;
+    const long long cstride = (long long)nt * 256;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = w;
+    for (; c + 48 < chunks; c += 64) {                      // four independent loads in flight per thread
+        s0 += sp[c * cstride]; s1 += sp[(c + 16) * cstride]; s2 += sp[(c + 32) * cstride]; s3 += sp[(c + 48) * cstride];
+    }
+    for (; c < chunks; c += 16) s0 += sp[c * cstride];
+    red[w][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w != 0) return;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[k][lane];
+    const int ta = gemm ? t / tiles_b : pair / tiles_b, tb = gemm ? t - ta * tiles_b : pair - ta * tiles_b;
+    const int a_ch = ta * 16 + 4 * g + r, b_ch = tb * 16 + j;          // D layout: rows 4g+r of column j
+    if (a_ch >= Ca) return;
+    if (b_ch < Cb) dW[gemm ? (long long)a_ch * Cb + b_ch : ((long long)a_ch * Cb + b_ch) * nt + t] = v;
+    else if (bias && b_ch == Cb && (gemm || nt == 1)) dbias[a_ch] = v;
+}
+static void launch_wgrad_reduce(const float* scratch, int pairs, int chunks, int nt, int tiles_b, int Ca, int Cb, int bias, int gemm,
+                                float* dW, float* dbias, hipStream_t st) {
+    ENERF_LAUNCH(k_wgrad_reduce, (unsigned)(pairs * nt * 4), 1024, 0, st, scratch, chunks, nt, tiles_b, Ca, Cb, bias, gemm, dW, dbias);
+}
+
+template <int KD, int KH, int KW, int SPLIT, int PL>
+static void launch_wgrad_k(const float* A, const float* Bt, const WgradGeom& q, float* dW, float* dbias, float* scratch, hipStream_t st) {
     const unsigned grid = (unsigned)(q.tiles_a * q.tiles_b * q.chunks);
-    ENERF_LAUNCH((k_conv_wgrad<KD, KH, KW>), grid, 256, 0, st, A, Bt, q, dW, dbias);
+    ENERF_LAUNCH((k_conv_wgrad<KD, KH, KW, SPLIT, PL>), grid, SPLIT * PL * 64, 0, st, A, Bt, q, dW, dbias, scratch);
+    if (scratch != nullptr)
+        launch_wgrad_reduce(scratch, q.tiles_a * q.tiles_b, q.chunks, KD * KH * KW, q.tiles_b, q.Ca, q.Cb, q.bias, 0, dW, dbias, st);
+}
+// position lanes per block for a kernel shape (the tap split is the leading kernel dimension; 1x1x1: four position lanes)
+// measured (MI355X, config-5 shapes): the tap split wins on the layers with few positions (32 -> 19 us) and loses on the 245k /
+// 655k-position ones (311 -> 358 us: three waves re-read every A value and row), which therefore keep one wave per group
+static bool wgrad_split(int taps, long long npos) { return taps == 25 || ((taps == 27 || taps == 9) && npos < 200000); }
+static int wgrad_pl(int taps, long long npos) { return taps == 25 ? 1 : (wgrad_split(taps, npos) ? 2 : 4); }
+// position chunks (= blocks per channel-tile pair): enough blocks to fill the chip, >= 8 position groups per wave
+static int wgrad_chunks(long long npos, int pairs, int taps, bool two_stage) {
+    const long long groups = cdivl(npos, 4);
+    long long want = (long long)device_cu_count() * (two_stage ? 2 : 4) / pairs;
+    if (want < 1) want = 1;
+    const long long maxc = cdivl(groups, wgrad_pl(taps, npos) * 8);
+    return (int)(want < maxc ? want : (maxc < 1 ? 1 : maxc));
+}
+size_t conv_wgrad_workspace_bytes(long long npos, int Ca, int Cb, int taps, int bias) {
+    const int pairs = cdiv(Ca, 16) * cdiv(Cb + bias, 16);
+    return (size_t)pairs * wgrad_chunks(npos, pairs, taps, true) * taps * 256 * sizeof(float);
 }
 
 bool launch_conv_wgrad(const float* A, const float* Bt, int n, int Da, int Ha, int Wa, int Ca, int Db, int Hb, int Wb, int Cb,
                        int kd, int kh, int kw, int stride, int pad_d, int pad_h, int pad_w, float* dW, hipStream_t st, int lda = 0,
-                       int ldb = 0, float* dbias = nullptr) {
+                       int ldb = 0, float* dbias = nullptr, void* workspace = nullptr, size_t workspace_bytes = 0) {
     WgradGeom q;
     q.bias = dbias != nullptr;
     q.lda = lda > 0 ? lda : Ca; q.ldb = ldb > 0 ? ldb : Cb;
@@ -124,16 +223,22 @@ bool launch_conv_wgrad(const float* A, const float* Bt, int n, int Da, int Ha, i
     q.stride = stride; q.pad_d = pad_d; q.pad_h = pad_h; q.pad_w = pad_w;
     q.tiles_a = cdiv(Ca, 16); q.tiles_b = cdiv(Cb + q.bias, 16);
     q.npos = (long long)n * Da * Ha * Wa;
-    // enough blocks to fill the chip a few times over, few enough that the final atomics stay cheap
-    const long long groups = cdivl(q.npos, 4);
-    long long want = (long long)device_cu_count() * 4 / (q.tiles_a * q.tiles_b);
-    if (want < 1) want = 1;
-    const long long maxc = cdivl(groups, 4 * 8);                     // >= 8 position groups per wave
-    q.chunks = (int)(want < maxc ? want : (maxc < 1 ? 1 : maxc));
-    if (kd == 3 && kh == 3 && kw == 3) { launch_wgrad_k<3, 3, 3>(A, Bt, q, dW, dbias, st); return true; }
-    if (kd == 1 && kh == 3 && kw == 3) { launch_wgrad_k<1, 3, 3>(A, Bt, q, dW, dbias, st); return true; }
-    if (kd == 1 && kh == 5 && kw == 5) { launch_wgrad_k<1, 5, 5>(A, Bt, q, dW, dbias, st); return true; }
-    if (kd == 1 && kh == 1 && kw == 1) { launch_wgrad_k<1, 1, 1>(A, Bt, q, dW, dbias, st); return true; }
+    const int taps = kd * kh * kw, pairs = q.tiles_a * q.tiles_b;
+    float* scratch = (workspace != nullptr && workspace_bytes >= conv_wgrad_workspace_bytes(q.npos, Ca, Cb, taps, q.bias)) ? (float*)workspace : nullptr;
+    q.chunks = wgrad_chunks(q.npos, pairs, taps, scratch != nullptr);
+    const bool split = wgrad_split(taps, q.npos);
+    if (kd == 3 && kh == 3 && kw == 3) {
+        if (split) launch_wgrad_k<3, 3, 3, 3, 2>(A, Bt, q, dW, dbias, scratch, st);       // wave = (kd, position lane)
+        else launch_wgrad_k<3, 3, 3, 1, 4>(A, Bt, q, dW, dbias, scratch, st);
+        return true;
+    }
+    if (kd == 1 && kh == 3 && kw == 3) {
+        if (split) launch_wgrad_k<1, 3, 3, 3, 2>(A, Bt, q, dW, dbias, scratch, st);       // wave = (kh, position lane)
+        else launch_wgrad_k<1, 3, 3, 1, 4>(A, Bt, q, dW, dbias, scratch, st);
+        return true;
+    }
+    if (kd == 1 && kh == 5 && kw == 5) { launch_wgrad_k<1, 5, 5, 5, 1>(A, Bt, q, dW, dbias, scratch, st); return true; }   // wave = kh
+    if (kd == 1 && kh == 1 && kw == 1) { launch_wgrad_k<1, 1, 1, 1, 4>(A, Bt, q, dW, dbias, scratch, st); return true; }
     return false;
 }
 
@@ -146,7 +251,7 @@ bool launch_conv_wgrad(const float* A, const float* Bt, int n, int Da, int Ha, i
 template <int TA, int TB>
 __global__ __launch_bounds__(256) void k_gemm_wgrad(const float* __restrict__ A, const float* __restrict__ Bt, int lda, int ldb,
                                                     int Ca, int Cb, int bias, long long P, float* __restrict__ dW,
-                                                    float* __restrict__ dbias) {
+                                                    float* __restrict__ dbias, float* __restrict__ scratch) {
     constexpr int NT = TA * TB;
     __shared__ float red[NT][256];
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
@@ -192,6 +297,14 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(const float* __restrict__ A,
         __syncthreads();
     }
     if (wave != 0) return;
+    if (scratch != nullptr) {       // two-stage commit (k_wgrad_reduce, gemm mode)
+        float* sp = scratch + ((long long)blockIdx.x * NT) * 256 + lane;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sp[t * 256 + r * 64] = acc[t][r];
+        return;
+    }
 #pragma unroll
     for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
@@ -208,43 +321,65 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(const float* __restrict__ A,
 
 template <int TA>
 static bool launch_gemm_wgrad_ta(int tb, unsigned grid, hipStream_t st, const float* A, const float* Bt, int lda, int ldb, int Ca,
-                                 int Cb, int bias, long long P, float* dW, float* dbias) {
-#define ENERF_GW(TBV) case TBV: ENERF_LAUNCH((k_gemm_wgrad<TA, TBV>), grid, 256, 0, st, A, Bt, lda, ldb, Ca, Cb, bias, P, dW, dbias); return true;
+                                 int Cb, int bias, long long P, float* dW, float* dbias, float* scratch) {
+#define ENERF_GW(TBV) case TBV: ENERF_LAUNCH((k_gemm_wgrad<TA, TBV>), grid, 256, 0, st, A, Bt, lda, ldb, Ca, Cb, bias, P, dW, dbias, scratch); return true;
     switch (tb) { ENERF_GW(1) ENERF_GW(2) ENERF_GW(3) ENERF_GW(4) ENERF_GW(5) ENERF_GW(6) default: return false; }
 #undef ENERF_GW
 }
-// all tile pairs in one wave when they fit (<= 4 x 6 tiles); false -> the caller falls back to k_conv_wgrad<1,1,1>
-bool launch_gemm_wgrad(const float* A, int lda, int Ca, const float* Bt, int ldb, int Cb, long long P, float* dW, float* dbias,
-                       hipStream_t st) {
-    const int ta = cdiv(Ca, 16), tb = cdiv(Cb + (dbias != nullptr), 16);
-    if (ta > 4 || tb > 6) return false;
+static long long gemm_wgrad_blocks(long long P) {
     const long long groups = cdivl(P, 4);
     long long blocks = cdivl(groups, 4 * 16);                         // >= 16 row groups per wave
     const long long cap = (long long)device_cu_count() * 2;
     if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
+    return blocks < 1 ? 1 : blocks;
+}
+size_t gemm_wgrad_workspace_bytes(long long P, int Ca, int Cb, int bias) {
+    const int ta = cdiv(Ca, 16), tb = cdiv(Cb + bias, 16);
+    if (ta > 4 || tb > 6) return conv_wgrad_workspace_bytes(P, Ca, Cb, 1, bias);      // the k_conv_wgrad<1,1,1> fallback
+    return (size_t)gemm_wgrad_blocks(P) * ta * tb * 256 * sizeof(float);
+}
+// all tile pairs in one wave when they fit (<= 4 x 6 tiles); false -> the caller falls back to k_conv_wgrad<1,1,1>
+bool launch_gemm_wgrad(const float* A, int lda, int Ca, const float* Bt, int ldb, int Cb, long long P, float* dW, float* dbias,
+                       hipStream_t st, void* workspace = nullptr, size_t workspace_bytes = 0) {
     const int bias = dbias != nullptr;
+    const int ta = cdiv(Ca, 16), tb = cdiv(Cb + bias, 16);
+    if (ta > 4 || tb > 6) return false;
+    const long long blocks = gemm_wgrad_blocks(P);
+    float* scratch = (workspace != nullptr && workspace_bytes >= gemm_wgrad_workspace_bytes(P, Ca, Cb, bias)) ? (float*)workspace : nullptr;
+    bool ok;
     switch (ta) {
-        case 1: return launch_gemm_wgrad_ta<1>(tb, (unsigned)blocks, st, A, Bt, lda, ldb, Ca, Cb, bias, P, dW, dbias);
-        case 2: return launch_gemm_wgrad_ta<2>(tb, (unsigned)blocks, st, A, Bt, lda, ldb, Ca, Cb, bias, P, dW, dbias);
-        case 3: return launch_gemm_wgrad_ta<3>(tb, (unsigned)blocks, st, A, Bt, lda, ldb, Ca, Cb, bias, P, dW, dbias);
-        default: return launch_gemm_wgrad_ta<4>(tb, (unsigned)blocks, st, A, Bt, lda, ldb, Ca, Cb, bias, P, dW, dbias);
+        case 1: ok = launch_gemm_wgrad_ta<1>(tb, (unsigned)blocks, st, A, Bt, lda, ldb, Ca, Cb, bias, P, dW, dbias, scratch); break;
+        case 2: ok = launch_gemm_wgrad_ta<2>(tb, (unsigned)blocks, st, A, Bt, lda, ldb, Ca, Cb, bias, P, dW, dbias, scratch); break;
+        case 3: ok = launch_gemm_wgrad_ta<3>(tb, (unsigned)blocks, st, A, Bt, lda, ldb, Ca, Cb, bias, P, dW, dbias, scratch); break;
+        default: ok = launch_gemm_wgrad_ta<4>(tb, (unsigned)blocks, st, A, Bt, lda, ldb, Ca, Cb, bias, P, dW, dbias, scratch); break;
     }
+    if (ok && scratch != nullptr) launch_wgrad_reduce(scratch, 1, (int)blocks, ta * tb, tb, Ca, Cb, bias, 1, dW, dbias, st);
+    return ok;
 }
 
 }  // namespace enerf
 
 using namespace enerf;
-extern "C" int enerf_conv_wgrad(const float* a_cl, const float* b_cl, int n, int Da, int Ha, int Wa, int Ca, int Db, int Hb, int Wb,
-                                int Cb, int kd, int kh, int kw, int stride, int pad_d, int pad_h, int pad_w, float* grad_w,
-                                enerf_stream_t stream) {
+extern "C" {
+// scratch for the two-stage (atomic-free, deterministic) commit of the weight gradients; without it the entries fall back to
+// fp32 atomics onto grad_w (correct, several times slower: see k_wgrad_reduce)
+size_t enerf_conv_wgrad_workspace_bytes(long long positions_a, int Ca, int Cb, int kd, int kh, int kw) {
+    return conv_wgrad_workspace_bytes(positions_a, Ca, Cb, kd * kh * kw, 0);
+}
+size_t enerf_gemm_wgrad_workspace_bytes(long long P, int Ca, int Cb, int with_bias) { return gemm_wgrad_workspace_bytes(P, Ca, Cb, with_bias != 0); }
+
+int enerf_conv_wgrad(const float* a_cl, const float* b_cl, int n, int Da, int Ha, int Wa, int Ca, int Db, int Hb, int Wb,
+                     int Cb, int kd, int kh, int kw, int stride, int pad_d, int pad_h, int pad_w, float* grad_w, void* workspace,
+                     size_t workspace_bytes, enerf_stream_t stream) {
     REQUIRE(a_cl && b_cl && grad_w, "conv_wgrad: null pointer");
     REQUIRE(n > 0 && Da > 0 && Ha > 0 && Wa > 0 && Ca > 0 && Db > 0 && Hb > 0 && Wb > 0 && Cb > 0 && stride >= 1,
             "conv_wgrad: bad shape");
     REQUIRE((long long)n * Da * Ha * Wa < (1LL << 31) && (long long)n * Db * Hb * Wb < (1LL << 31), "conv_wgrad: more than 2^31 positions");
-    zero_async(grad_w, (size_t)Ca * Cb * kd * kh * kw * sizeof(float), (hipStream_t)stream);
+    const bool two_stage = workspace != nullptr &&
+                           workspace_bytes >= conv_wgrad_workspace_bytes((long long)n * Da * Ha * Wa, Ca, Cb, kd * kh * kw, 0);
+    if (!two_stage) zero_async(grad_w, (size_t)Ca * Cb * kd * kh * kw * sizeof(float), (hipStream_t)stream);
     if (!launch_conv_wgrad(a_cl, b_cl, n, Da, Ha, Wa, Ca, Db, Hb, Wb, Cb, kd, kh, kw, stride, pad_d, pad_h, pad_w, grad_w,
-                           (hipStream_t)stream))
+                           (hipStream_t)stream, 0, 0, nullptr, workspace, workspace_bytes))
         return fail(ENERF_EINVAL, "conv_wgrad: kernel %dx%dx%d unsupported (3x3x3, 1x3x3, 1x5x5, 1x1x1)", kd, kh, kw);
     return check_launch("conv_wgrad");
 }
@@ -252,13 +387,20 @@ extern "C" int enerf_conv_wgrad(const float* a_cl, const float* b_cl, int n, int
 // Plain position-reduction GEMM: grad_w[a][b] = sum_p A[p][a] * B[p][b] — the weight gradient of a Linear layer from its
 // pre-activation gradient A (P rows, Ca used columns of rows lda floats wide) and its input B (P x Cb, rows ldb wide).
 // grad_bias (nullable): the layer's bias gradient sum_p A[p][a], from the same pass (a virtual all-ones column of B).
-extern "C" int enerf_gemm_wgrad(const float* a, int lda, int Ca, const float* b, int ldb, int Cb, long long P, float* grad_w,
-                                float* grad_bias, enerf_stream_t stream) {
+int enerf_gemm_wgrad(const float* a, int lda, int Ca, const float* b, int ldb, int Cb, long long P, float* grad_w,
+                     float* grad_bias, void* workspace, size_t workspace_bytes, enerf_stream_t stream) {
     REQUIRE(a && b && grad_w && Ca > 0 && Cb > 0 && lda >= Ca && ldb >= Cb, "gemm_wgrad: bad arguments");
     REQUIRE(P > 0 && P < (1LL << 31), "gemm_wgrad: P out of range");
-    zero_async(grad_w, (size_t)Ca * Cb * sizeof(float), (hipStream_t)stream);
-    if (grad_bias) zero_async(grad_bias, (size_t)Ca * sizeof(float), (hipStream_t)stream);
-    if (!launch_gemm_wgrad(a, lda, Ca, b, ldb, Cb, P, grad_w, grad_bias, (hipStream_t)stream))
-        launch_conv_wgrad(a, b, 1, 1, 1, (int)P, Ca, 1, 1, (int)P, Cb, 1, 1, 1, 1, 0, 0, 0, grad_w, (hipStream_t)stream, lda, ldb, grad_bias);
+    const bool two_stage = workspace != nullptr && workspace_bytes >= gemm_wgrad_workspace_bytes(P, Ca, Cb, grad_bias != nullptr);
+    if (!two_stage) {
+        zero_async(grad_w, (size_t)Ca * Cb * sizeof(float), (hipStream_t)stream);
+        if (grad_bias) zero_async(grad_bias, (size_t)Ca * sizeof(float), (hipStream_t)stream);
+        workspace = nullptr;
+    }
+    if (!launch_gemm_wgrad(a, lda, Ca, b, ldb, Cb, P, grad_w, grad_bias, (hipStream_t)stream, workspace, workspace_bytes))
+        launch_conv_wgrad(a, b, 1, 1, 1, (int)P, Ca, 1, 1, (int)P, Cb, 1, 1, 1, 1, 0, 0, 0, grad_w, (hipStream_t)stream, lda, ldb, grad_bias,
+                          workspace, workspace_bytes);
     return check_launch("gemm_wgrad");
 }
+
+}  // extern "C"

@@ -158,9 +158,11 @@ _SIGNATURES = {
     "enerf_forward": (_i, [C.POINTER(FrameArgs), _f]),
     "enerf_build_feature_volume_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f]),
     "enerf_depth_regression_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f, _f]),
-    "enerf_conv_wgrad": (_i, [_f, _f] + [_i] * 16 + [_f, _f]),
+    "enerf_conv_wgrad_workspace_bytes": (C.c_size_t, [_ll, _i, _i, _i, _i, _i]),
+    "enerf_conv_wgrad": (_i, [_f, _f] + [_i] * 16 + [_f, C.c_void_p, C.c_size_t, _f]),
+    "enerf_gemm_wgrad_workspace_bytes": (C.c_size_t, [_ll, _i, _i, _i]),
     "enerf_nerf_mlp_bwd": (_i, [C.POINTER(MlpBwdArgs), _f]),
-    "enerf_gemm_wgrad": (_i, [_f, _i, _i, _f, _i, _i, _ll, _f, _f, _f]),
+    "enerf_gemm_wgrad": (_i, [_f, _i, _i, _f, _i, _i, _ll, _f, _f, C.c_void_p, C.c_size_t, _f]),
     "enerf_nerf_mlp_fwd": (_i, [_f, _f, _f, _ll, _i, _i, _f, _f]),
     "enerf_gather_fwd": (_i, [C.POINTER(GatherArgs), _f]),
     "enerf_gather_bwd": (_i, [C.POINTER(GatherArgs), _f]),
@@ -171,6 +173,9 @@ _SIGNATURES = {
     "enerf_conv2d_layer_pack": (_i, [_f, _f, _i, _i, _i, _f, _f]),
     "enerf_conv2d_layer": (_i, [_f, _i, _i, _i, _i, _f, _f, _f, _i, _i, _i, _f]),
     "enerf_channel_sums": (_i, [_f, _f, _f, _f, _f, _ll, _i, C.c_void_p, _f]),
+    "enerf_bn_train_coeffs": (_i, [C.c_void_p, C.c_void_p, C.c_double, _f, _f, C.c_double, C.c_double, _f, _f, C.c_void_p, _i,
+                                   C.c_void_p, _f, _f]),
+    "enerf_bn_train_bwd_coeffs": (_i, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, _f, _i, _f, _f, _f]),
     "enerf_channel_affine": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _ll, _i, _f, _f]),
     "enerf_composite": (_i, [_f, _f, _ll, _i, _i, _f, _f, _f, _f]),
     "enerf_composite_bwd": (_i, [_f, _f, _f, _f, _f, _ll, _i, _f, _f, _f]),
@@ -218,6 +223,11 @@ class EnerfLib:
     @staticmethod
     def stream_of(t: torch.Tensor):
         return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else None
+
+    @staticmethod
+    def _scratch(nbytes: int, device):
+        """Per-call scratch from torch's caching allocator (stream-ordered, graph-capture safe)."""
+        return torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=device)
 
     def _check(self, rc: int, what: str):
         if rc != 0:
@@ -483,6 +493,41 @@ class EnerfLib:
                                                 a.numel() // Cc, Cc, sums.data_ptr(), self.stream_of(a)), "channel_sums")
         return sums[0], sums[1]
 
+    def channel_sums_raw(self, a, b, z_mask=None, mask_scale=None, mask_shift=None):
+        """channel_sums as ONE (2, C) fp64 tensor [sum a*m ; sum a*m*b] (what the all-reduce and the coefficient kernels take)."""
+        Cc = a.shape[-1]
+        sums = torch.empty((2, Cc), dtype=torch.float64, device=a.device)
+        self._check(self.dll.enerf_channel_sums(_ptr(a), _ptr(b), _ptr(z_mask), _ptr(mask_scale), _ptr(mask_shift),
+                                                a.numel() // Cc, Cc, sums.data_ptr(), self.stream_of(a)), "channel_sums")
+        return sums
+
+    def bn_train_coeffs(self, sums, count, bn):
+        """(2,C) fp64 sums + position count (python number, or a 1-element fp64 device tensor) + the BatchNorm module ->
+        mean_invstd (2,C) fp64, scale_shift (2,C) fp32; updates the module's running statistics in place."""
+        Cc = sums.shape[1]
+        mi = torch.empty((2, Cc), dtype=torch.float64, device=sums.device)
+        ss = torch.empty((2, Cc), dtype=torch.float32, device=sums.device)
+        track = bn.track_running_stats and bn.running_mean is not None
+        if track:
+            with torch.no_grad():
+                bn.num_batches_tracked.add_(1)
+        cd, ch = (count.data_ptr(), 0.0) if torch.is_tensor(count) else (None, float(count))
+        self._check(self.dll.enerf_bn_train_coeffs(sums.data_ptr(), cd, ch, _ptr(bn.weight.detach()), _ptr(bn.bias.detach()), float(bn.eps),
+                                                   -1.0 if bn.momentum is None else float(bn.momentum),
+                                                   _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
+                                                   bn.num_batches_tracked.data_ptr() if track else None, Cc, mi.data_ptr(), _ptr(ss),
+                                                   self.stream_of(sums)), "bn_train_coeffs")
+        return mi, ss
+
+    def bn_train_bwd_coeffs(self, local, glob, count, mean_invstd, scale):
+        Cc = local.shape[1]
+        dgb = torch.empty((2, Cc), dtype=torch.float32, device=local.device)
+        k23 = torch.empty((2, Cc), dtype=torch.float32, device=local.device)
+        cd, ch = (count.data_ptr(), 0.0) if torch.is_tensor(count) else (None, float(count))
+        self._check(self.dll.enerf_bn_train_bwd_coeffs(local.data_ptr(), glob.data_ptr(), cd, ch, mean_invstd.data_ptr(), _ptr(scale), Cc,
+                                                       _ptr(dgb), _ptr(k23), self.stream_of(local)), "bn_train_bwd_coeffs")
+        return dgb, k23
+
     def channel_affine(self, a, p, r, b=None, q=None, z_mask=None, mask_scale=None, mask_shift=None, residual=None, relu=False):
         Cc = a.shape[-1]
         out = torch.empty_like(a)
@@ -501,8 +546,9 @@ class EnerfLib:
             raise EnerfError("gemm_wgrad: rows must be contiguous")
         gw = torch.empty((Ca, Cb), dtype=torch.float32, device=a.device)
         gb = torch.empty((Ca,), dtype=torch.float32, device=a.device) if bias else None
+        ws = self._scratch(self.dll.enerf_gemm_wgrad_workspace_bytes(P, Ca, Cb, int(bias)), a.device)
         self._check(self.dll.enerf_gemm_wgrad(a.data_ptr(), a.stride(0), Ca, b.data_ptr(), b.stride(0), Cb, P, _ptr(gw),
-                                              _ptr(gb), self.stream_of(a)), "gemm_wgrad")
+                                              _ptr(gb), ws.data_ptr(), ws.numel(), self.stream_of(a)), "gemm_wgrad")
         return (gw, gb) if bias else gw
 
     def nerf_mlp_fwd(self, vox, x, packed, S, F):
@@ -561,8 +607,9 @@ class EnerfLib:
         n, Da, Ha, Wa, Ca = a_cl.shape
         _, Db, Hb, Wb, Cb = b_cl.shape
         gw = torch.empty((Ca, Cb, 3, 3, 3), dtype=torch.float32, device=a_cl.device)
+        ws = self._scratch(self.dll.enerf_conv_wgrad_workspace_bytes(n * Da * Ha * Wa, Ca, Cb, 3, 3, 3), a_cl.device)
         self._check(self.dll.enerf_conv_wgrad(_ptr(a_cl), _ptr(b_cl), n, Da, Ha, Wa, Ca, Db, Hb, Wb, Cb, 3, 3, 3, int(stride),
-                                              1, 1, 1, _ptr(gw), self.stream_of(a_cl)), "conv_wgrad")
+                                              1, 1, 1, _ptr(gw), ws.data_ptr(), ws.numel(), self.stream_of(a_cl)), "conv_wgrad")
         return gw
 
     def conv_wgrad_cl2d(self, a_cl, b_cl, k, stride):
@@ -571,8 +618,9 @@ class EnerfLib:
         _, Hb, Wb, Cb = b_cl.shape
         p = (k - 1) // 2
         gw = torch.empty((Ca, Cb, k, k), dtype=torch.float32, device=a_cl.device)
+        ws = self._scratch(self.dll.enerf_conv_wgrad_workspace_bytes(n * Ha * Wa, Ca, Cb, 1, k, k), a_cl.device)
         self._check(self.dll.enerf_conv_wgrad(_ptr(a_cl), _ptr(b_cl), n, 1, Ha, Wa, Ca, 1, Hb, Wb, Cb, 1, k, k, int(stride),
-                                              0, p, p, _ptr(gw), self.stream_of(a_cl)), "conv_wgrad")
+                                              0, p, p, _ptr(gw), ws.data_ptr(), ws.numel(), self.stream_of(a_cl)), "conv_wgrad")
         return gw
 
     def conv_wgrad(self, a, b, kernel, stride, padding, bias=False):
@@ -588,9 +636,10 @@ class EnerfLib:
         a_cl = self.channels_last(a.contiguous().reshape(n, Ca, pa), n, Ca, pa)
         b_cl = self.channels_last(b.contiguous().reshape(n, Cb, pb), n, Cb, pb)
         gw = torch.empty((Ca, Cb) + tuple(kernel), dtype=torch.float32, device=a.device)
+        ws = self._scratch(self.dll.enerf_conv_wgrad_workspace_bytes(n * pa, Ca, Cb, kernel[0], kernel[1], kernel[2]), a.device)
         self._check(self.dll.enerf_conv_wgrad(_ptr(a_cl), _ptr(b_cl), n, ga[0], ga[1], ga[2], Ca, gb[0], gb[1], gb[2], Cb,
                                               kernel[0], kernel[1], kernel[2], int(stride), padding[0], padding[1], padding[2],
-                                              _ptr(gw), self.stream_of(a)), "conv_wgrad")
+                                              _ptr(gw), ws.data_ptr(), ws.numel(), self.stream_of(a)), "conv_wgrad")
         gw = gw if nd == 3 else gw.reshape(Ca, Cb, kernel[1], kernel[2])
         if not bias:
             return gw

@@ -13,8 +13,8 @@ DATA-PARALLEL (trainer.py:15-22; ``distributed=True``): the same ONE graph per r
 DistributedDataParallel's reducer (autograd hooks, bucket views, a host-side bookkeeping pass per step) is an eager-step
 device; what it computes is the mean over ranks of 436,012 floats.  ``FlatGradSync`` does exactly that as ONE all-reduce of
 ONE flat 1.7 MB buffer enqueued after the backward pass — RCCL's kernel is a graph node like any other — and the
-SyncBatchNorm statistics exchanges (torch's SyncBatchNorm in the FeatureNet, autograd._sync_sums in the cost-volume
-networks: one C-sized all-reduce per layer and direction, the global count kept on the device) are captured the same way.
+SyncBatchNorm statistics exchanges (autograd._BatchNormTrain, for the FeatureNet and the cost-volume networks alike: one
+C-sized all-reduce per layer and direction, the global count kept on the device) are captured the same way.
 (BatchNorm layer k+1 normalises what layer k produced from the GLOBAL statistics of layer k, so those ~46 exchanges are a
 dependency chain: they cannot be merged into one buffer without changing SyncBatchNorm's arithmetic; captured, each costs
 its ~10 us of xGMI latency and no host time.)  Every rank must construct the step at the same point (the constructor runs

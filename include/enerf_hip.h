@@ -312,9 +312,15 @@ int enerf_forward(const enerf_frame_args_t* args, enerf_stream_t stream);
  *       grad_w[a][b][kd][kh][kw] = sum over positions o of the A grid of A[a][o] * B[b][o*stride + k - pad]
  *       a_cl (n, Da*Ha*Wa, Ca) and b_cl (n, Db*Hb*Wb, Cb) channels-last.  Conv{2,3}d: A = grad_output, B = input ->
  *       (Cout,Cin,k..); ConvTranspose3d(k3,s2,p1,op1): A = input, B = grad_output -> (Cin,Cout,k..).  2-D layers pass
- *       Da = Db = kd = 1.  Kernels 3x3x3, 1x3x3, 1x5x5, 1x1x1.  grad_w is zeroed here (fp32 atomics accumulate into it). */
+ *       Da = Db = kd = 1.  Kernels 3x3x3, 1x3x3, 1x5x5, 1x1x1.
+ *       workspace (ABI v6): enerf_conv_wgrad_workspace_bytes(positions of the A grid incl. n, Ca, Cb, kd, kh, kw) bytes of
+ *       scratch for the two-stage commit (every block stores its partial tiles, a second kernel sums them: deterministic,
+ *       no atomics).  NULL / too small: grad_w is zeroed and the blocks add into it with fp32 atomics (correct, several
+ *       times slower: ~1000 blocks x 6912 atomics onto 6912 addresses). */
+size_t enerf_conv_wgrad_workspace_bytes(long long positions_a, int Ca, int Cb, int kd, int kh, int kw);
 int enerf_conv_wgrad(const float* a_cl, const float* b_cl, int n, int Da, int Ha, int Wa, int Ca, int Db, int Hb, int Wb, int Cb,
-                     int kd, int kh, int kw, int stride, int pad_d, int pad_h, int pad_w, float* grad_w, enerf_stream_t stream);
+                     int kd, int kh, int kw, int stride, int pad_d, int pad_h, int pad_w, float* grad_w, void* workspace,
+                     size_t workspace_bytes, enerf_stream_t stream);
 /*   Training-mode cost-regularisation layers (ConvBnReLU3D utils.py:22-33, cost_reg_net.py) — BatchNorm uses batch
  *   statistics, so it cannot be folded into the convolution:
  *   enerf_conv3d_layer[_pack]  one bias-free 3x3x3 layer on the inference path's MFMA kernels, identity epilogue (+ optional
@@ -342,6 +348,21 @@ int enerf_conv3d_layer(const float* packed, int cin, int cout, int kind, const f
                        int Di, int Hi, int Wi, const enerf_options_t* options, enerf_stream_t stream);
 int enerf_channel_sums(const float* a, const float* b, const float* z_mask, const float* mask_scale, const float* mask_shift,
                        long long n, int C, double* sums, enerf_stream_t stream);
+/*   enerf_bn_train_coeffs / enerf_bn_train_bwd_coeffs  (ABI v6) the C-sized arithmetic of a training-mode BatchNorm between the
+ *       statistics kernel (and, under SyncBatchNorm, its all-reduce) and the affine kernel, one launch each, fp64:
+ *       forward  sums = [sum z, sum z^2] (2C), position count (device scalar count_dev, or count_host when NULL) ->
+ *                mean_invstd (2C fp64), scale_shift (2C: gamma*invstd, beta - mean*gamma*invstd); running_mean/var (optional)
+ *                updated in place with the unbiased variance, momentum < 0 = cumulative average 1/num_batches_tracked
+ *                (int64 device scalar that already counts this batch; only read);
+ *       backward sums_local / sums_global = [sum g*m, sum g*m*z] of this rank / of all ranks (the same pointer without
+ *                SyncBatchNorm) -> dgamma_dbeta (2C, from the local sums: DDP averages parameter gradients) and k2k3 (2C):
+ *                d z = g*m*scale + z*k2 + k3 (enerf_channel_affine). */
+int enerf_bn_train_coeffs(const double* sums, const double* count_dev, double count_host, const float* gamma, const float* beta,
+                          double eps, double momentum, float* running_mean, float* running_var, const long long* num_batches_tracked,
+                          int C, double* mean_invstd, float* scale_shift, enerf_stream_t stream);
+int enerf_bn_train_bwd_coeffs(const double* sums_local, const double* sums_global, const double* count_dev, double count_host,
+                              const double* mean_invstd, const float* scale, int C, float* dgamma_dbeta, float* k2k3,
+                              enerf_stream_t stream);
 int enerf_channel_affine(const float* a, const float* b, const float* p, const float* q, const float* r, const float* z_mask,
                          const float* mask_scale, const float* mask_shift, const float* residual, int relu, long long n, int C,
                          float* out, enerf_stream_t stream);
@@ -383,8 +404,10 @@ typedef struct {
 } enerf_gather_args_t;
 int enerf_gather_fwd(const enerf_gather_args_t* args, enerf_stream_t stream);
 int enerf_gather_bwd(const enerf_gather_args_t* args, enerf_stream_t stream);
+size_t enerf_gemm_wgrad_workspace_bytes(long long P, int Ca, int Cb, int with_bias);   /* scratch of the two-stage commit, as above */
 int enerf_gemm_wgrad(const float* a, int lda, int Ca, const float* b, int ldb, int Cb, long long P, float* grad_w,
-                     float* grad_bias /* nullable: (Ca) = sum_p a[p][:] from the same pass */, enerf_stream_t stream);
+                     float* grad_bias /* nullable: (Ca) = sum_p a[p][:] from the same pass */, void* workspace,
+                     size_t workspace_bytes, enerf_stream_t stream);
 int enerf_build_feature_volume_bwd(const float* feat, const float* proj, const float* depth_values, const float* grad_vol, int B,
                                    int S, int C, int Hs, int Ws, int D, int h, int w, float* grad_feat, float* grad_depth_values,
                                    enerf_stream_t stream);

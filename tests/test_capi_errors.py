@@ -52,15 +52,15 @@ def test_training_entries_reject_bad_arguments(lib):
     with pytest.raises(EnerfError, match="unsupported"):                # only 3x3x3, 1x3x3, 1x5x5, 1x1x1 weight gradients
         gw = torch.empty(8, 8, 5, 5, 5)
         lib._check(lib.dll.enerf_conv_wgrad(x.data_ptr(), x.data_ptr(), 1, 4, 4, 4, 8, 4, 4, 4, 8, 5, 5, 5, 1, 2, 2, 2,
-                                            gw.data_ptr(), None), "conv_wgrad")
+                                            gw.data_ptr(), None, 0, None), "conv_wgrad")
     with pytest.raises(EnerfError, match="null pointer"):
-        lib._check(lib.dll.enerf_conv_wgrad(None, x.data_ptr(), 1, 4, 4, 4, 8, 4, 4, 4, 8, 3, 3, 3, 1, 1, 1, 1, x.data_ptr(), None),
+        lib._check(lib.dll.enerf_conv_wgrad(None, x.data_ptr(), 1, 4, 4, 4, 8, 4, 4, 4, 8, 3, 3, 3, 1, 1, 1, 1, x.data_ptr(), None, 0, None),
                    "conv_wgrad")
     a, b, gw = torch.zeros(10, 8), torch.zeros(10, 4), torch.zeros(8, 4)
     with pytest.raises(EnerfError, match="bad arguments"):              # row stride smaller than the used columns
-        lib._check(lib.dll.enerf_gemm_wgrad(a.data_ptr(), 4, 8, b.data_ptr(), 4, 4, 10, gw.data_ptr(), None, None), "gemm_wgrad")
+        lib._check(lib.dll.enerf_gemm_wgrad(a.data_ptr(), 4, 8, b.data_ptr(), 4, 4, 10, gw.data_ptr(), None, None, 0, None), "gemm_wgrad")
     with pytest.raises(EnerfError, match="P out of range"):
-        lib._check(lib.dll.enerf_gemm_wgrad(a.data_ptr(), 8, 8, b.data_ptr(), 4, 4, 0, gw.data_ptr(), None, None), "gemm_wgrad")
+        lib._check(lib.dll.enerf_gemm_wgrad(a.data_ptr(), 8, 8, b.data_ptr(), 4, 4, 0, gw.data_ptr(), None, None, 0, None), "gemm_wgrad")
     with pytest.raises(EnerfError, match="bad arguments"):              # channel count must be a multiple of 4
         s = torch.zeros(2, 6, dtype=torch.float64)
         t = torch.zeros(5, 6)

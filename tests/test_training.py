@@ -268,6 +268,24 @@ def _check_conv_wgrad(lib, dev):
         (ref,) = torch.autograd.grad(y, w, gy)
         got = lib.conv_wgrad(x, gy, (3, 3, 3), 2, (1, 1, 1))
         assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (cin, cout)
+    # the two-stage commit (workspace given: what the wrappers do) is deterministic; without a workspace the entry falls back to
+    # fp32 atomics onto a zeroed grad_w and must agree
+    a_cl, b_cl = rnd(1, 4, 6, 10, 16), rnd(1, 4, 6, 10, 32)
+    two = [lib.conv_wgrad_cl(a_cl, b_cl, 1) for _ in range(2)]
+    assert torch.equal(two[0], two[1])
+    gw = torch.full((16, 32, 3, 3, 3), 7.0, device=dev)
+    lib._check(lib.dll.enerf_conv_wgrad(a_cl.data_ptr(), b_cl.data_ptr(), 1, 4, 6, 10, 16, 4, 6, 10, 32, 3, 3, 3, 1, 1, 1, 1,
+                                        gw.data_ptr(), None, 0, lib.stream_of(a_cl)), "conv_wgrad")
+    assert float((gw - two[0]).abs().max()) <= 1e-5 * float(two[0].abs().max())
+    am, bm = rnd(1000, 40), rnd(1000, 24)
+    g1, gb1 = lib.gemm_wgrad(am, bm, bias=True)
+    assert torch.equal(g1, lib.gemm_wgrad(am, bm, bias=True)[0])
+    assert float((g1 - am.t() @ bm).abs().max()) <= 2e-5 * float((am.t() @ bm).abs().max())
+    assert float((gb1 - am.sum(0)).abs().max()) <= 2e-5 * float(am.sum(0).abs().max())
+    g2 = torch.full((40, 24), 7.0, device=dev)
+    lib._check(lib.dll.enerf_gemm_wgrad(am.data_ptr(), 40, 40, bm.data_ptr(), 24, 24, 1000, g2.data_ptr(), None, None, 0,
+                                        lib.stream_of(am)), "gemm_wgrad")
+    assert float((g2 - g1).abs().max()) <= 1e-5 * float(g1.abs().max())
 
 
 def _check_feature_net_train(lib, dev, H=32, W=64, n=3, tol=2e-4):
@@ -435,7 +453,7 @@ def _syncbn_worker(rank, world, port, q):
         net.load_state_dict(load_weights(), strict=False)
         net.train()
         # trainer.py:16 on the WHOLE network: every BatchNorm (FeatureNet 2-D, cost-reg 3-D) runs inside the HIP training
-        # functions, whose statistics exchange (autograd._sync_sums) works on any backend (torch's own SyncBatchNorm forward,
+        # functions, whose statistics exchange (autograd._BatchNormTrain) works on any backend (torch's own SyncBatchNorm forward,
         # which refuses CPU tensors, is never called on this path)
         net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
         assert isinstance(net.feature_net.conv0[0].bn, torch.nn.SyncBatchNorm)
