@@ -188,8 +188,11 @@ int enerf_channel_sums(const float* a, const float* b, const float* z_mask, cons
     if (z_mask) REQUIRE(mask_scale && mask_shift, "channel_sums: mask needs its scale/shift");
     zero_async(sums, (size_t)2 * C * sizeof(double), (hipStream_t)stream);
     const int ppb = 256 / (C / 4);
+    // every block ends with 2C fp64 atomics onto the same 2C addresses (~13 G atomics/s on one hot line: 2048 blocks x 64
+    // cost ~10 us, more than the streaming pass of most layers): two blocks per CU are enough to stream at full rate
     long long blocks = cdivl(n, (long long)ppb * 16);
-    if (blocks > 2048) blocks = 2048;
+    const long long cap = (long long)device_cu_count() * 2;
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     ENERF_LAUNCH(k_channel_sums, (unsigned)blocks, 256, 0, (hipStream_t)stream, a, b, z_mask, mask_scale, mask_shift, n, C, sums);
     return check_launch("channel_sums");
