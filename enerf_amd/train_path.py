@@ -224,8 +224,10 @@ def build_rays(cas, depth, std, rays, near_far, level):
         rn, rf = _clamp_pair(depth - std, depth + std, near_far[:, 0], near_far[:, 1], False)
     B, N = rays.shape[:2]
     uv = rays[:, :, 6:].long()
-    bi = torch.arange(B, device=rays.device)[:, None].expand(B, N)
-    pick = lambda m: m[bi, uv[..., 1], uv[..., 0]]
+    flat = uv[..., 1] * depth.shape[-1] + uv[..., 0]                     # (B,N) index into the flattened (h*w) maps
+    # m[b, v, u] as a gather on the flattened map: same values as the reference's advanced indexing (utils.py:414-417), but its
+    # backward is a scatter-add instead of index_put_(accumulate=True), which sorts the 327,680 indices of a full-image level
+    pick = lambda m: m.reshape(B, -1).gather(1, flat)
     return torch.cat([rays, pick(rn)[..., None], pick(rf)[..., None], pick(near_far[:, 0])[..., None],
                       pick(near_far[:, 1])[..., None]], -1)
 

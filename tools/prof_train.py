@@ -20,10 +20,25 @@ def step():
 for _ in range(3): step()
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], with_stack=True) as prof:
     step(); torch.cuda.synchronize()
-tab = prof.key_averages().table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=60)
+tab = prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=40, max_name_column_width=60)
 print(tab)
+# the torch-op glue by source line: which lines of enerf_amd/ launch the library (non-enerf) kernels
+import collections
+by_line, by_op = collections.Counter(), collections.Counter()
+for ev in prof.events():
+    t = getattr(ev, "self_device_time_total", 0)
+    if t > 0 and ev.name.startswith("aten::"):
+        by_op[ev.name] += t
+        fr = next((f for f in (ev.stack or []) if "enerf_amd/" in f), "?")
+        by_line[fr.split("enerf_amd/")[-1][:100]] += t
+print("== aten ops by self device time (us)")
+for k, v in by_op.most_common(25):
+    print(f"{v:9.1f}  {k}")
+print("== source lines by the self device time of the aten ops they launch (us)")
+for k, v in by_line.most_common(40):
+    print(f"{v:9.1f}  {k}")
 import time
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5): step()
