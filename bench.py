@@ -234,8 +234,11 @@ def train_bench(args, rank, world, dev, dist, emu_lib=None):
             step = lambda: gstep(batch)                                  # copies the batch in, camera tables, one replay
             launch_note = "one hipGraph replay per step (enerf_amd/train_graph.py; replays verified against eager steps)" + \
                 (": the flat gradient all-reduce and the SyncBatchNorm statistics exchanges are graph nodes" if dp else "")
-        except GraphMismatch as e:                                       # the verdict is collective: every rank lands here together
-            launch_note = f"eager (graph replay failed verification: {str(e)[:200]})"
+        except (GraphMismatch, RuntimeError) as e:                       # the verdict is collective: every rank lands here together
+            # (RuntimeError: a capture the stack refuses, e.g. a collective that cannot be captured — the same on every rank)
+            kind = "graph replay failed verification" if isinstance(e, GraphMismatch) else "capture failed"
+            launch_note = f"eager ({kind}: {str(e)[:200]})"
+            opt.zero_grad(set_to_none=True)
             if dp:
                 from enerf_amd.train_graph import FlatGradSync, train_step
                 sync = FlatGradSync(net)
