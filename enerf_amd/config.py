@@ -11,7 +11,7 @@ Defaults are ``configs/enerf/dtu_pretrain.yaml:17-43``.
 from __future__ import annotations
 
 from dataclasses import dataclass, field, replace
-from typing import Sequence, Tuple
+from typing import Tuple
 
 
 def _t(x) -> tuple:

@@ -12,7 +12,7 @@ from typing import Dict, List, Optional
 import torch
 
 from .config import EnerfConfig
-from .lib import EnerfLib, get_lib, stats_from_acc
+from .lib import EnerfLib, get_lib
 
 
 def nearest_resize_index(src: int, dst: int, device) -> torch.Tensor:

@@ -8,7 +8,7 @@ in the CPU tests.
 from __future__ import annotations
 
 import time
-from typing import Callable, Iterable, List, Optional, Tuple
+from typing import Callable, List, Optional, Tuple
 
 import torch
 
