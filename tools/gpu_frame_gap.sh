@@ -25,5 +25,19 @@ import statistics as st
 print("frames", len(frames), "kernels/frame", st.mean(len(f) for f in frames))
 print("GPU span per frame us: mean %.1f p50 %.1f" % (st.mean(busy)/1e3, st.median(busy)/1e3))
 print("GPU idle between frames us: mean %.1f p50 %.1f min %.1f" % (st.mean(gap)/1e3, st.median(gap)/1e3, min(gap)/1e3))
+# one steady-state frame as a timeline: start offset, duration, stream/queue, kernel
+f=frames[len(frames)//2]; t0=int(f[0]["Start_Timestamp"])
+keys=[k for k in f[0].keys() if "Stream" in k or "Queue" in k]
+print("columns:", list(f[0].keys()))
+for r in f:
+    s_,e_=int(r["Start_Timestamp"])-t0,int(r["End_Timestamp"])-t0
+    print("%8.1f %7.1f  %s  %s" % (s_/1e3,(e_-s_)/1e3," ".join(str(r[k]) for k in keys), r["Kernel_Name"].replace("void enerf::","").replace("enerf::","").split("(")[0][:60]))
+# time with NO kernel running inside the frame
+ev=sorted([(int(r["Start_Timestamp"]),1) for r in f]+[(int(r["End_Timestamp"]),-1) for r in f])
+idle=0; run=0; last=None
+for t,d in ev:
+    if run==0 and last is not None: idle+=t-last
+    run+=d; last=t
+print("in-frame time with no kernel running: %.1f us" % (idle/1e3))
 PY
 tail -1 $O/bench.log | cut -c1-200
