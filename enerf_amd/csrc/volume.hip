@@ -88,7 +88,14 @@ __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict_
             for (int c = 0; c < 4; ++c) {
                 const unsigned o = (unsigned)__shfl(my_o[c], lead + k) + (unsigned)(cq * 4);
                 const float wgt = __shfl(my_w[c], lead + k);
+                // ENERF_ABL_VOL: compile-time ablations behind profiles/r03_volume_ablation.txt (never defined in the product build)
+#if defined(ENERF_ABL_VOL) && (ENERF_ABL_VOL & 1)      /* one tap's load stands in for all four (gather traffic / 4) */
+                const float4 v = *reinterpret_cast<const float4*>(feat + ((unsigned)__shfl(my_o[0], lead + k) + (unsigned)(cq * 4)));
+#elif defined(ENERF_ABL_VOL) && (ENERF_ABL_VOL & 2)    /* no gathers at all (a lane-dependent constant) */
+                const float4 v = make_float4(wgt, 1.f, 2.f, (float)o);
+#else
                 const float4 v = *reinterpret_cast<const float4*>(feat + o);
+#endif
                 if (c == 0) { r.x = v.x * wgt; r.y = v.y * wgt; r.z = v.z * wgt; r.w = v.w * wgt; }
                 else { r.x += v.x * wgt; r.y += v.y * wgt; r.z += v.z * wgt; r.w += v.w * wgt; }
             }
@@ -110,7 +117,11 @@ __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict_
     // channels-last voxel would give it 16 useful bytes of every 64-128-byte line, re-fetched once per pass)
     const unsigned nvp = (unsigned)(D * h * w);
     const long long oidx = planar ? ((long long)((unsigned)b * CQ + cq) * nvp + (vox - (unsigned)b * nvp)) * 4 : (long long)vox * C + cq * 4;
+#if defined(ENERF_ABL_VOL) && (ENERF_ABL_VOL & 4)      /* (almost) no output writes */
+    if (live && o.x == 12345.678f) *reinterpret_cast<float4*>(vol + oidx) = o;
+#else
     if (live) *reinterpret_cast<float4*>(vol + oidx) = o;
+#endif
 }
 
 void launch_feature_volume(const float* feat_nhwc, const float* proj, const float* dv, int B, int S, int C, int Hs,
