@@ -30,6 +30,7 @@ semaphores with a memset) and gets wrong sums in about half of the replays.  Con
   * ``GraphedTrainStep(verify=True)`` (the default) replays a few steps against eager steps from the same state and
     compares every gradient before the graph is trusted; a mismatch raises ``GraphMismatch`` (bench.py then runs eager).
 """
+import time
 from typing import Callable, Dict, Iterable, Optional
 
 import torch
@@ -145,7 +146,19 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.opt.zero_grad(set_to_none=True)               # gradients are (re)allocated inside the graph's memory pool
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        capture_kw = {}
+        if self.sync is not None:
+            # The process group's watchdog thread polls the events of the collectives the warm-up enqueued until it has seen
+            # them complete; an event query from another thread while THIS thread captures in the default ("global") mode is
+            # an illegal call that takes the process down (seen once in ~10 runs on ROCm 7 / PyTorch 2.10: abort inside the
+            # capture).  Two guards: let the watchdog retire the finished work first (all ranks together), and capture in
+            # "thread_local" mode (only this thread's calls are policed; kernels other threads — the autograd engine's —
+            # launch into the capturing stream are captured all the same).
+            self.sync.dist.barrier(group=self.sync.group)
+            torch.cuda.synchronize()
+            time.sleep(0.5)
+            capture_kw["capture_error_mode"] = "thread_local"
+        with torch.cuda.graph(self.graph, **capture_kw):
             self.loss = self._eager_step(zero=False)
         net.invalidate_packed()
         if verify:
