@@ -369,9 +369,9 @@ def cost_reg_train(lib, m, vol):
 # inference path's MFMA kernel with an identity epilogue (enerf_conv2d_layer; the top-down `up2 + lateral` adds ride in the
 # lateral convolution's epilogue exactly as in inference), the input gradients of the stride-1 layers on the same kernel
 # (flipped, channel-transposed weights), BatchNorm2d on the channel kernels shared with the cost-volume networks, weight
-# gradients on the matrix cores.  Everything stays channels-last between the image and the three output maps.  Still
-# torch ops: the input gradients of the two stride-2 5x5 layers (a transposed 5x5 convolution: no kernel of ours) and the
-# adjoint of the 2x bilinear upsampling.
+# gradients on the matrix cores, the adjoint of the 2x upsampling as a gather kernel.  Everything stays channels-last
+# between the image and the three output maps.  Still torch ops: the input gradients of the two stride-2 5x5 layers (a
+# transposed 5x5 convolution: no kernel of ours).
 # ---------------------------------------------------------------------------------------------------------------------
 class _Conv2d:
     """One convolution of the FeatureNet on channels-last tensors (cin = 3: the NCHW image batch)."""
@@ -405,13 +405,6 @@ class _Conv2d:
         return gx, gw, gb
 
 
-def _up2_adjoint(g_cl):
-    """Adjoint of F.interpolate(scale_factor=2, bilinear, align_corners=True) (feature_net.py:24-25) on a channels-last map."""
-    N, H, W, C_ = g_cl.shape
-    g = torch.ops.aten.upsample_bilinear2d_backward(g_cl.permute(0, 3, 1, 2), [H, W], [N, C_, H // 2, W // 2], True, None, None)
-    return g.permute(0, 2, 3, 1).contiguous()
-
-
 _FEAT_ORDER = ("conv0.0", "conv0.1", "conv1.0", "conv1.1", "conv2.0", "conv2.1", "toplayer", "lat1", "lat0", "smooth1", "smooth0")
 
 
@@ -441,12 +434,12 @@ class FeatureNetTrainFn(torch.autograd.Function):
         f0 = plain("lat0", c0, up=f1)
         s1 = plain("smooth1", f1)
         s0 = plain("smooth0", f0)
-        ctx.conv, ctx.norm = conv, norm
+        ctx.conv, ctx.norm, ctx.lib = conv, norm, lib
         return f2.permute(0, 3, 1, 2), s1.permute(0, 3, 1, 2), s0.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, g_f2, g_s1, g_s0):
-        conv, norm = ctx.conv, ctx.norm
+        conv, norm, lib = ctx.conv, ctx.norm, ctx.lib
         grads = {}
         cl = lambda g: g.permute(0, 2, 3, 1).contiguous()       # (a no-op when the gradient arrives as a channels-last view)
 
@@ -462,9 +455,9 @@ class FeatureNetTrainFn(torch.autograd.Function):
             return gx
         g_f0 = plain_back("smooth0", cl(g_s0))
         g_c0 = plain_back("lat0", g_f0)
-        g_f1 = _up2_adjoint(g_f0) + plain_back("smooth1", cl(g_s1))
+        g_f1 = lib.up2_adjoint(g_f0, add=plain_back("smooth1", cl(g_s1)))       # up2^T(d f0) + d f1 through smooth1
         g_c1 = plain_back("lat1", g_f1)
-        g_top = _up2_adjoint(g_f1) + cl(g_f2)
+        g_top = lib.up2_adjoint(g_f1, add=cl(g_f2))
         g_c2 = plain_back("toplayer", g_top)
         g_c1 = g_c1 + cbr_back("conv2.0", cbr_back("conv2.1", g_c2))
         g_c0 = g_c0 + cbr_back("conv1.0", cbr_back("conv1.1", g_c1))

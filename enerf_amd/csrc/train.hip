@@ -127,6 +127,49 @@ __global__ void k_bn_train_bwd_coeffs(const double* __restrict__ local, const do
     k2k3[C + c] = (float)(-sc * sg / n - k2 * mean);
 }
 
+// ---- adjoint of the FeatureNet's 2x bilinear upsampling (feature_net.py:24-25: F.interpolate(scale_factor=2, bilinear,
+// align_corners=True)) on channels-last maps, in GATHER form: one thread per (coarse pixel, channel quad) sums w_y*w_x*g over the
+// <= 5 x 5 fine pixels whose taps touch it, with the forward's own ac_lerp weights (conv2d.hip epilogue).  No atomics, every
+// fine gradient is read by <= 4 coarse pixels (L2 hits); optional `add`: a second gradient of the coarse map summed in. ----
+__global__ __launch_bounds__(256) void k_up2_adjoint(const float* __restrict__ g, const float* __restrict__ add, int N, int Hc, int Wc,
+                                                     int CQ, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * Hc * Wc * CQ;
+    if (i >= total) return;
+    const int cq = (int)(i % CQ);
+    long long r = i / CQ;
+    const int xc = (int)(r % Wc); r /= Wc;
+    const int yc = (int)(r % Hc);
+    const int n = (int)(r / Hc);
+    const int Hf = 2 * Hc, Wf = 2 * Wc, C = CQ * 4;
+    const float sy = ac_scale(Hc, Hf), sx = ac_scale(Wc, Wf);
+    // fine rows whose source position falls in (yc - 1, yc + 1): a superset bounded by the reciprocal scale, then filtered
+    // with the exact forward tap indices
+    const int ylo = max(0, (int)floorf((float)(yc - 1) / sy)), yhi = min(Hf - 1, (int)ceilf((float)(yc + 1) / sy));
+    const int xlo = max(0, (int)floorf((float)(xc - 1) / sx)), xhi = min(Wf - 1, (int)ceilf((float)(xc + 1) / sx));
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* gb = g + (long long)n * Hf * Wf * C + cq * 4;
+    for (int y = ylo; y <= yhi; ++y) {
+        const Lerp1 ly = ac_lerp(y, sy, Hc);
+        const float wy = (ly.i0 == yc ? ly.l0 : 0.f) + (ly.i1 == yc ? ly.l1 : 0.f);
+        if (wy == 0.f) continue;
+        for (int x = xlo; x <= xhi; ++x) {
+            const Lerp1 lx = ac_lerp(x, sx, Wc);
+            const float wx = (lx.i0 == xc ? lx.l0 : 0.f) + (lx.i1 == xc ? lx.l1 : 0.f);
+            if (wx == 0.f) continue;
+            const float4 v = *reinterpret_cast<const float4*>(gb + ((long long)y * Wf + x) * C);
+            const float wgt = wy * wx;
+            acc.x += wgt * v.x; acc.y += wgt * v.y; acc.z += wgt * v.z; acc.w += wgt * v.w;
+        }
+    }
+    const long long o = (((long long)n * Hc + yc) * Wc + xc) * C + cq * 4;
+    if (add != nullptr) {
+        const float4 a = *reinterpret_cast<const float4*>(add + o);
+        acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+    }
+    *reinterpret_cast<float4*>(out + o) = acc;
+}
+
 }  // namespace enerf
 
 using namespace enerf;
@@ -181,6 +224,12 @@ int enerf_conv2d_layer(const float* packed, int cin, int cout, int k, int stride
     if (launch_conv2d(d, in, out, up, N, Hi, Wi, Ho / 2, Wo / 2, (hipStream_t)stream) != 0)
         return fail(ENERF_EINVAL, "conv2d_layer: no kernel for %d -> %d k %d stride %d", cin, cout, k, stride);
     return check_launch("conv2d_layer");
+}
+int enerf_up2_adjoint(const float* grad_fine, const float* add, int N, int Hc, int Wc, int C, float* grad_coarse, enerf_stream_t stream) {
+    REQUIRE(grad_fine && grad_coarse && N > 0 && Hc > 1 && Wc > 1 && C >= 4 && C % 4 == 0, "up2_adjoint: bad arguments");
+    const long long total = (long long)N * Hc * Wc * (C / 4);
+    ENERF_LAUNCH_SIMPLE(k_up2_adjoint, (unsigned)cdivl(total, 256), 256, 0, (hipStream_t)stream, grad_fine, add, N, Hc, Wc, C / 4, grad_coarse);
+    return check_launch("up2_adjoint");
 }
 int enerf_channel_sums(const float* a, const float* b, const float* z_mask, const float* mask_scale, const float* mask_shift,
                        long long n, int C, double* sums, enerf_stream_t stream) {

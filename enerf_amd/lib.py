@@ -169,6 +169,7 @@ _SIGNATURES = {
     "enerf_conv3d_layer_packed_floats": (_ll, [_i, _i, _i]),
     "enerf_conv3d_layer_pack": (_i, [_f, _i, _i, _i, _f, _f]),
     "enerf_conv3d_layer": (_i, [_f, _i, _i, _i, _f, _f, _f, _i, _i, _i, _i, C.POINTER(Options), _f]),
+    "enerf_up2_adjoint": (_i, [_f, _f, _i, _i, _i, _i, _f, _f]),
     "enerf_conv2d_layer_packed_floats": (_ll, [_i, _i, _i]),
     "enerf_conv2d_layer_pack": (_i, [_f, _f, _i, _i, _i, _f, _f]),
     "enerf_conv2d_layer": (_i, [_f, _i, _i, _i, _i, _f, _f, _f, _i, _i, _i, _f]),
@@ -492,6 +493,14 @@ class EnerfLib:
         self._check(self.dll.enerf_channel_sums(_ptr(a), _ptr(b), _ptr(z_mask), _ptr(mask_scale), _ptr(mask_shift),
                                                 a.numel() // Cc, Cc, sums.data_ptr(), self.stream_of(a)), "channel_sums")
         return sums[0], sums[1]
+
+    def up2_adjoint(self, g_fine, add=None):
+        """Adjoint of the 2x align-corners bilinear upsampling on a channels-last gradient (N,2h,2w,C) -> (N,h,w,C) (+ add)."""
+        N, Hf, Wf, Cc = g_fine.shape
+        out = torch.empty((N, Hf // 2, Wf // 2, Cc), dtype=torch.float32, device=g_fine.device)
+        self._check(self.dll.enerf_up2_adjoint(_ptr(g_fine), _ptr(add), N, Hf // 2, Wf // 2, Cc, _ptr(out), self.stream_of(g_fine)),
+                    "up2_adjoint")
+        return out
 
     def channel_sums_raw(self, a, b, z_mask=None, mask_scale=None, mask_shift=None):
         """channel_sums as ONE (2, C) fp64 tensor [sum a*m ; sum a*m*b] (what the all-reduce and the coefficient kernels take)."""

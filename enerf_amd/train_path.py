@@ -17,7 +17,7 @@ What runs where in training (state of this round, stated plainly):
     Agg + NeRF MLP (fused forward, fused recompute-backward, weight gradients as position reductions on the matrix cores)
     and alpha compositing;
   * still PyTorch-ROCm ops under autograd: the input gradients of the FeatureNet's two stride-2 5x5 convolutions (a
-    transposed 5x5 convolution), the adjoint of its 2x bilinear upsampling, and the per-ray geometry glue.  With frozen
+    transposed 5x5 convolution) and the per-ray geometry glue.  With frozen
     BatchNorm (``bn.eval()`` fine-tuning) the FeatureNet / cost-reg nets run through their modules instead (library
     convolutions, HIP weight gradients).  This is GPU code (no CPU fallback, nothing from ``oracle/``), checked against the
     reference's own gradients (tests/test_training.py, tests/golden/train_tiny.npz) with the HIP stages switched on and off.

@@ -338,6 +338,10 @@ int enerf_conv_wgrad(const float* a_cl, const float* b_cl, int n, int Da, int Ha
  *       upsampled 2x (bilinear, align_corners) and added (feature_net.py:24-25).  Supported (cin,cout,k,stride): the eleven
  *       FeatureNet layers and the input gradients of its stride-1 layers (dgrad = the stride-1 conv cout -> cin on the
  *       flipped, channel-transposed weights): 16->32 k3, 8->32 k3, 32->16 k1, 32->8 k1. */
+/*   enerf_up2_adjoint  (ABI v6) adjoint of the top-down 2x upsampling (feature_net.py:24-25: bilinear, align_corners=True):
+ *       grad_fine (N,2Hc,2Wc,C) channels-last -> grad_coarse (N,Hc,Wc,C) (+ add, an optional second gradient of the coarse
+ *       map), gather form with the forward's weights — no atomics. */
+int enerf_up2_adjoint(const float* grad_fine, const float* add, int N, int Hc, int Wc, int C, float* grad_coarse, enerf_stream_t stream);
 long long enerf_conv2d_layer_packed_floats(int cin, int cout, int k);
 int enerf_conv2d_layer_pack(const float* w, const float* bias, int cin, int cout, int k, float* packed, enerf_stream_t stream);
 int enerf_conv2d_layer(const float* packed, int cin, int cout, int k, int stride, const float* in, const float* up, float* out, int N,

@@ -289,39 +289,53 @@ def _check_conv_wgrad(lib, dev):
 
 
 def _check_feature_net_train(lib, dev, H=32, W=64, n=3, tol=2e-4):
-    """autograd.FeatureNetTrainFn (conv forward / input gradients / BatchNorm2d / weight gradients on the HIP kernels,
-    channels-last throughout) against the same FeatureNet through its torch modules: the three output maps, every
-    parameter gradient and the BatchNorm running statistics."""
+    """autograd.FeatureNetTrainFn (conv forward / input gradients / BatchNorm2d / weight gradients / upsampling adjoint on the
+    HIP kernels, channels-last throughout) against the same FeatureNet through its torch modules in fp32 AND in fp64: the
+    three output maps, every parameter gradient and the BatchNorm running statistics.  A parameter gradient must be within
+    ``tol`` of the fp32 module path, or — the gradients of the upstream layers amplify 1e-5-level differences between two
+    fp32 implementations of one op ~200x through the BatchNorm backward (batch statistics) — at least as close to the fp64
+    result as the fp32 module path is (3x slack)."""
     from enerf_amd.autograd import feature_net_train
     from enerf_amd.network import FeatureNet
     from enerf_amd.train_path import feature_net_forward
     torch.manual_seed(5)
-    nets = [FeatureNet().to(dev).train() for _ in range(2)]
-    nets[1].load_state_dict(nets[0].state_dict())
+    # the upsampling adjoint on its own: enerf_up2_adjoint vs autograd through F.interpolate(2x, bilinear, align_corners)
+    c = torch.randn(2, 16, H // 4, W // 4, device=dev, requires_grad=True)
+    gf = torch.randn(2, 16, H // 2, W // 2, device=dev)
+    extra = torch.randn(2, H // 4, W // 4, 16, device=dev)
+    F.interpolate(c, scale_factor=2, mode="bilinear", align_corners=True).backward(gf)
+    got = lib.up2_adjoint(gf.permute(0, 2, 3, 1).contiguous(), add=extra)
+    ref = c.grad.permute(0, 2, 3, 1) + extra
+    assert float((got - ref).abs().max()) <= 5e-5 * float(ref.abs().max())
+    nets = [FeatureNet().to(dev).train() for _ in range(3)]
     with torch.no_grad():
-        for net in nets:
-            for k, v in net.state_dict().items():
-                if k.endswith("bn.weight"):
-                    v.uniform_(0.5, 1.5)
-                elif k.endswith("bn.bias"):
-                    v.normal_(0.0, 0.1)
-        nets[1].load_state_dict(nets[0].state_dict())
+        for k, v in nets[0].state_dict().items():
+            if k.endswith("bn.weight"):
+                v.uniform_(0.5, 1.5)
+            elif k.endswith("bn.bias"):
+                v.normal_(0.0, 0.1)
+    nets[1].load_state_dict(nets[0].state_dict())
+    nets[2].load_state_dict(nets[0].state_dict())
+    nets[2].double()
     x = torch.randn(n, 3, H, W, device=dev)
     gen = torch.Generator().manual_seed(6)
     outs = []
-    for i, net in enumerate(nets):
-        o = feature_net_train(lib, net, x) if i == 0 else feature_net_forward(net, x, None)
+    for i, net in enumerate(nets):                       # 0: HIP fp32, 1: modules fp32, 2: modules fp64
+        o = feature_net_train(lib, net, x) if i == 0 else feature_net_forward(net, x.double() if i == 2 else x, None)
         if not outs:
             wts = [torch.randn(t.shape, generator=gen).to(dev) for t in o]
-        sum((t * w_).sum() for t, w_ in zip(o, wts)).backward()
+        sum((t * w_.to(t.dtype)).sum() for t, w_ in zip(o, wts)).backward()
         outs.append(o)
-    for a, b in zip(*outs):
+    for a, b in zip(outs[0], outs[1]):
         assert a.shape == b.shape
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), float((a - b).abs().max() / b.abs().max())
-    for (k, p0), (_, p1) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
-        assert p0.grad is not None and p1.grad is not None, k
-        err = float((p0.grad - p1.grad).abs().max()) / max(float(p1.grad.abs().max()), 1e-12)
-        assert err <= tol, (k, err)
+    named = [dict(net.named_parameters()) for net in nets]
+    for k, p0 in named[0].items():
+        g0, g1, g64 = p0.grad.double(), named[1][k].grad.double(), named[2][k].grad
+        scale = max(float(g64.abs().max()), 1e-12)
+        err_vs32 = float((g0 - g1).abs().max()) / scale
+        err_hip, err_mod = float((g0 - g64).abs().max()) / scale, float((g1 - g64).abs().max()) / scale
+        assert err_vs32 <= tol or err_hip <= max(tol, 3.0 * err_mod), (k, err_vs32, err_hip, err_mod)
     for (k, b0), (_, b1) in zip(nets[0].named_buffers(), nets[1].named_buffers()):
         if b1.dtype.is_floating_point:
             assert float((b0 - b1).abs().max()) <= 1e-5 + 1e-4 * float(b1.abs().max()), k
