@@ -83,6 +83,25 @@ __device__ __forceinline__ void block_barrier_raw() {
 }
 #endif
 
+// Raw buffer loads: a 128-bit resource (base, byte size) + a 32-bit byte offset per lane; an offset >= the size returns 0 —
+// padding taps and dead lanes cost ONE select on the offset instead of address clamps or a zero page, and the address is
+// `scalar base + 32-bit lane offset` (no 64-bit VALU address per load).  The emulator twin is the same bounds-checked read.
+#ifdef ENERF_EMU
+struct BufRsrc { const char* base; unsigned bytes; };
+__device__ __forceinline__ BufRsrc buf_rsrc(const void* p, unsigned bytes) { return BufRsrc{(const char*)p, bytes}; }
+__device__ __forceinline__ float buf_load_f32(const BufRsrc& r, unsigned byte_off) {
+    return byte_off < r.bytes ? *reinterpret_cast<const float*>(r.base + byte_off) : 0.f;
+}
+#else
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc buf_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);   // gfx9 raw buffer, dword data
+}
+__device__ __forceinline__ float buf_load_f32(const BufRsrc& r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+#endif
+
 constexpr int kWave = 64;
 
 // Pin a value in a VGPR at this program point: LLVM's Sink pass otherwise moves a pure arithmetic chain that is only consumed

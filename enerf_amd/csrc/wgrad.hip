@@ -32,10 +32,9 @@ struct WgradGeom {
     int chunks;                  // position chunks (blocks per tile pair)
     int lda, ldb;                // floats between consecutive positions of A / B (>= Ca / Cb: column slices of wider rows)
     int bias;                    // 1: B has a virtual column Cb of ones -> dbias[a] = sum_p A[a][p] (the layer's bias gradient)
+    unsigned abytes, bbytes;     // byte sizes of the A / B tensors (< 2^32: raw buffer loads, 32-bit lane offsets)
     long long npos;              // n * Da * Ha * Wa
 };
-
-__device__ float g_wgrad_zeros[4];          // the address padding taps and dead lanes load from
 
 // SPLIT: the taps are split (by their leading kernel dimension) over SPLIT waves of a block, PL position-lanes each: a wave keeps
 // NT/SPLIT accumulators (36 instead of 108 registers at 3x3x3) and 1 + NT/SPLIT loads per group in flight, so six to eight
@@ -59,25 +58,37 @@ __global__ __launch_bounds__(SPLIT * PL * 64) void k_conv_wgrad(const float* __r
     f32x4 acc[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // One group = 4 positions x (1 A value + NTW shifted B values per lane) -> NTW MFMAs.  Every load is UNCONDITIONAL: a padding
-    // tap / dead lane reads a zero page instead (`ok ? B[i] : 0` makes hipcc branch around each load and wait vmcnt(0) on it),
-    // and the loads of group i+1 are issued before the MFMAs of group i.
-    const float* const zero = g_wgrad_zeros;
+    // One group = 4 positions x (1 A value + NTW shifted B values per lane) -> NTW MFMAs.  Every load is an UNCONDITIONAL raw
+    // buffer load: `scalar base + 32-bit lane offset`, and a padding tap / dead lane sets its offset out of range, which reads 0.
+    // Per tap that is one add (uniform tap delta) + one select on the offset; the validity of a tap is the AND of three per-axis
+    // lane masks that live in scalar registers.  (History: `ok ? B[i] : 0` made hipcc branch around each load and wait on it — 27
+    // serial round trips per group; unconditional loads from 64-bit addresses with a zero page cost ~15 VALU of address math
+    // per tap, ~400 per group against 27 MFMAs = 864 cycles, and VALU and MFMA serialise on gfx950.)  The loads of group i+1 are
+    // issued before the MFMAs of group i.
+    const BufRsrc ra = buf_rsrc(A, q.abytes), rb = buf_rsrc(Bt, q.bbytes);
+    const int dw4 = q.ldb * 4, dh4 = q.Wb * dw4, dd4 = q.Hb * dh4;      // byte deltas of one step along w / h / d of the B grid (uniform)
     auto issue = [&](long long grp, float& av, float (&bv)[NTW]) {
-        const long long p = grp * 4 + g;
-        const bool pv = p < q.npos;
-        const unsigned pc = (unsigned)(pv ? p : q.npos - 1);           // npos < 2^31 (checked by the C entry)
+        const unsigned p = (unsigned)grp * 4u + (unsigned)g;            // npos < 2^31 (checked by the C entry)
+        const bool pv = p < (unsigned)q.npos;
+        const unsigned pc = pv ? p : (unsigned)q.npos - 1u;
         // p -> (b, od, oh, ow), 32-bit
         const unsigned r1 = pc / (unsigned)q.Wa;
         const int ow = (int)(pc - r1 * (unsigned)q.Wa);
         const unsigned r2 = r1 / (unsigned)q.Ha;
         const int oh = (int)(r1 - r2 * (unsigned)q.Ha);
         const int b = (int)(r2 / (unsigned)q.Da), od = (int)(r2 - (unsigned)b * (unsigned)q.Da);
-        const float* ap = (pv && ca_ok) ? A + ((long long)pc * q.lda + ca) : zero;
-        av = *ap;
+        av = buf_load_f32(ra, (pv && ca_ok) ? (pc * (unsigned)q.lda + (unsigned)ca) * 4u : 0xffffffffu);
         const int id0 = od * q.stride - q.pad_d, ih0 = oh * q.stride - q.pad_h, iw0 = ow * q.stride - q.pad_w;
-        const long long bbase = (long long)b * q.Db;
+        // byte offset of tap (0,0,0)'s element (may be "negative" at the borders: those taps are masked out below)
+        const int off0 = ((((b * q.Db + id0) * q.Hb + ih0) * q.Wb + iw0) * q.ldb + cb) * 4;
         const bool lane_ok = pv && cb_ok;
+        bool vd[KD], vh[KH], vw[KW];
+#pragma unroll
+        for (int k = 0; k < KD; ++k) vd[k] = lane_ok && (unsigned)(id0 + k) < (unsigned)q.Db;
+#pragma unroll
+        for (int k = 0; k < KH; ++k) vh[k] = (unsigned)(ih0 + k) < (unsigned)q.Hb;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) vw[k] = (unsigned)(iw0 + k) < (unsigned)q.Wb;
 #pragma unroll
         for (int k = 0; k < NTW; ++k) {
             // tap (kd, kh, kw) of this wave's k-th accumulator: the split is by the leading kernel dimension, so only that
@@ -86,16 +97,27 @@ __global__ __launch_bounds__(SPLIT * PL * 64) void k_conv_wgrad(const float* __r
             if (SPLIT == 1) { kd = k / (KH * KW); kh = (k / KW) % KH; kw = k % KW; }
             else if (KD > 1) { kd = ts; kh = k / KW; kw = k % KW; }          // SPLIT == KD
             else { kd = 0; kh = ts; kw = k; }                                // SPLIT == KH
-            const int id = id0 + kd, ih = ih0 + kh, iw = iw0 + kw;
-            const bool ok = lane_ok && (unsigned)id < (unsigned)q.Db && (unsigned)ih < (unsigned)q.Hb && (unsigned)iw < (unsigned)q.Wb;
-            const long long bi = ((bbase + id) * q.Hb + ih) * q.Wb + iw;
-            const float* bp = ok ? Bt + (bi * q.ldb + cb) : zero;
-            bv[k] = *bp;
+            bool ok;
+            if (SPLIT == 1) ok = vd[kd] && vh[kh] && vw[kw];
+            else if (KD > 1) ok = lane_ok && (unsigned)(id0 + kd) < (unsigned)q.Db && vh[kh] && vw[kw];
+            else ok = lane_ok && (unsigned)(ih0 + kh) < (unsigned)q.Hb && vw[kw];
+            const int off = off0 + kd * dd4 + kh * dh4 + kw * dw4;
+            bv[k] = buf_load_f32(rb, ok ? (unsigned)off : 0xffffffffu);
         }
         if (NT == 1 && q.bias && cb == q.Cb) bv[0] = pv ? 1.f : 0.f;
     };
     float av0, av1, bv0[NTW], bv1[NTW];
     long long grp = (long long)chunk * PL + pl;
+    // The unsplit 9- / 27-tap kernels run WITHOUT the cross-group prefetch: two groups in flight cost 182 registers next to the
+    // 108 accumulators (one wave per SIMD); one group at a time fits two to three waves, which hide the loads better
+    // (measured, 655k positions: 223 -> 130 us).  The tap-split and 1x1x1 kernels keep the prefetch (8 waves per SIMD anyway).
+    if (SPLIT == 1 && NT > 1) {
+        for (; grp < ngroups; grp += stride_g) {
+            issue(grp, av0, bv0);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[t] = ENERF_MFMA_W(av0, bv0[t], acc[t]);
+        }
+    }
     if (grp < ngroups) issue(grp, av0, bv0);
     for (; grp < ngroups; grp += 2 * stride_g) {
         const bool more1 = grp + stride_g < ngroups;                   // uniform
@@ -196,9 +218,13 @@ static void launch_wgrad_k(const float* A, const float* Bt, const WgradGeom& q, 
         launch_wgrad_reduce(scratch, q.tiles_a * q.tiles_b, q.chunks, KD * KH * KW, q.tiles_b, q.Ca, q.Cb, q.bias, 0, dW, dbias, st);
 }
 // position lanes per block for a kernel shape (the tap split is the leading kernel dimension; 1x1x1: four position lanes)
-// measured (MI355X, config-5 shapes): the tap split wins on the layers with few positions (32 -> 19 us) and loses on the 245k /
-// 655k-position ones (311 -> 358 us: three waves re-read every A value and row), which therefore keep one wave per group
-static bool wgrad_split(int taps, long long npos) { return taps == 25 || ((taps == 27 || taps == 9) && npos < 200000); }
+// measured (MI355X, config-5 shapes, tools/gpu_wgrad_variants.sh): the tap split wins on the layers with few positions
+// (<= 10k: 32 -> 16-20 us) and loses from 82k positions on (three waves re-read every A value and row), which keep one
+// wave per group
+#ifndef ENERF_WGRAD_SPLIT_BELOW
+#define ENERF_WGRAD_SPLIT_BELOW 50000           /* A/B builds: 0 = never split 3x3(x3), a huge value = always */
+#endif
+static bool wgrad_split(int taps, long long npos) { return taps == 25 || ((taps == 27 || taps == 9) && npos < (long long)ENERF_WGRAD_SPLIT_BELOW); }
 static int wgrad_pl(int taps, long long npos) { return taps == 25 ? 1 : (wgrad_split(taps, npos) ? 2 : 4); }
 // position chunks (= blocks per channel-tile pair): enough blocks to fill the chip, >= 8 position groups per wave
 static int wgrad_chunks(long long npos, int pairs, int taps, bool two_stage) {
@@ -223,6 +249,8 @@ bool launch_conv_wgrad(const float* A, const float* Bt, int n, int Da, int Ha, i
     q.stride = stride; q.pad_d = pad_d; q.pad_h = pad_h; q.pad_w = pad_w;
     q.tiles_a = cdiv(Ca, 16); q.tiles_b = cdiv(Cb + q.bias, 16);
     q.npos = (long long)n * Da * Ha * Wa;
+    q.abytes = (unsigned)(q.npos * q.lda * 4);                       // (< 2^32: checked by the C entries)
+    q.bbytes = (unsigned)((long long)n * Db * Hb * Wb * q.ldb * 4);
     const int taps = kd * kh * kw, pairs = q.tiles_a * q.tiles_b;
     float* scratch = (workspace != nullptr && workspace_bytes >= conv_wgrad_workspace_bytes(q.npos, Ca, Cb, taps, q.bias)) ? (float*)workspace : nullptr;
     q.chunks = wgrad_chunks(q.npos, pairs, taps, scratch != nullptr);
@@ -259,20 +287,23 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(const float* __restrict__ A,
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const long long ngroups = cdivl(P, 4);
+    // raw buffer loads (common.h): scalar base + 32-bit lane offset, rows past P / columns past C read 0 through an
+    // out-of-range offset — no branch around a load, no 64-bit address per load (P * ld < 2^30: checked by the C entry)
+    const BufRsrc ra = buf_rsrc(A, (unsigned)(P * lda * 4)), rb = buf_rsrc(Bt, (unsigned)(P * ldb * 4));
     for (long long grp = (long long)blockIdx.x * 4 + wave; grp < ngroups; grp += (long long)gridDim.x * 4) {
-        const long long p = grp * 4 + g;
-        const bool pv = p < P;
-        const long long pc = pv ? p : P - 1;
+        const unsigned p = (unsigned)grp * 4u + (unsigned)g;
+        const bool pv = p < (unsigned)P;
+        const unsigned arow = p * (unsigned)lda * 4u, brow = p * (unsigned)ldb * 4u;
         float av[TA], bv[TB];
 #pragma unroll
         for (int ta = 0; ta < TA; ++ta) {
             const int ca = ta * 16 + j;
-            av[ta] = (pv && ca < Ca) ? A[pc * lda + ca] : 0.f;
+            av[ta] = buf_load_f32(ra, (pv && ca < Ca) ? arow + (unsigned)ca * 4u : 0xffffffffu);
         }
 #pragma unroll
         for (int tb = 0; tb < TB; ++tb) {
             const int cb = tb * 16 + j;
-            bv[tb] = (pv && cb < Cb) ? Bt[pc * ldb + cb] : 0.f;
+            bv[tb] = buf_load_f32(rb, (pv && cb < Cb) ? brow + (unsigned)cb * 4u : 0xffffffffu);
             if (bias && cb == Cb) bv[tb] = pv ? 1.f : 0.f;           // virtual all-ones column -> bias gradient
         }
 #pragma unroll
@@ -375,6 +406,8 @@ int enerf_conv_wgrad(const float* a_cl, const float* b_cl, int n, int Da, int Ha
     REQUIRE(n > 0 && Da > 0 && Ha > 0 && Wa > 0 && Ca > 0 && Db > 0 && Hb > 0 && Wb > 0 && Cb > 0 && stride >= 1,
             "conv_wgrad: bad shape");
     REQUIRE((long long)n * Da * Ha * Wa < (1LL << 31) && (long long)n * Db * Hb * Wb < (1LL << 31), "conv_wgrad: more than 2^31 positions");
+    REQUIRE((long long)n * Da * Ha * Wa * Ca < (1LL << 30) && (long long)n * Db * Hb * Wb * Cb < (1LL << 30),
+            "conv_wgrad: a tensor of 4 GiB or more (32-bit byte offsets inside the kernel)");
     const bool two_stage = workspace != nullptr &&
                            workspace_bytes >= conv_wgrad_workspace_bytes((long long)n * Da * Ha * Wa, Ca, Cb, kd * kh * kw, 0);
     if (!two_stage) zero_async(grad_w, (size_t)Ca * Cb * kd * kh * kw * sizeof(float), (hipStream_t)stream);
@@ -391,6 +424,7 @@ int enerf_gemm_wgrad(const float* a, int lda, int Ca, const float* b, int ldb, i
                      float* grad_bias, void* workspace, size_t workspace_bytes, enerf_stream_t stream) {
     REQUIRE(a && b && grad_w && Ca > 0 && Cb > 0 && lda >= Ca && ldb >= Cb, "gemm_wgrad: bad arguments");
     REQUIRE(P > 0 && P < (1LL << 31), "gemm_wgrad: P out of range");
+    REQUIRE(P * lda < (1LL << 30) && P * ldb < (1LL << 30), "gemm_wgrad: a matrix of 4 GiB or more (32-bit byte offsets inside the kernel)");
     const bool two_stage = workspace != nullptr && workspace_bytes >= gemm_wgrad_workspace_bytes(P, Ca, Cb, grad_bias != nullptr);
     if (!two_stage) {
         zero_async(grad_w, (size_t)Ca * Cb * sizeof(float), (hipStream_t)stream);
