@@ -56,7 +56,10 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
         for (int s = 0; s < S; ++s) {
             const float* xp = a.x + (p * S + s) * XW;
 #pragma unroll
-            for (int r = 0; r < R; ++r) x[s][r] = (g * R + r < F) ? xp[g * R + r] : 0.f;
+            for (int r = 0; r < R; ++r) {     // unconditional load from a clamped index, then a select: `c ? p[i] : 0` makes hipcc
+                const float v = xp[min(g * R + r, F - 1)];       // branch around the load and wait on it (S*R serial round trips)
+                x[s][r] = (g * R + r < F) ? v : 0.f;
+            }
             dsel[s] = xp[F + g];
         }
         // ---------------- forward recompute (the render kernel's MLP phase) ----------------
@@ -432,7 +435,10 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const float* __restrict__ voxp,
         for (int s = 0; s < S; ++s) {
             const float* xp = a.x + (p * S + s) * XW;
 #pragma unroll
-            for (int r = 0; r < R; ++r) x[s][r] = (g * R + r < F) ? xp[g * R + r] : 0.f;
+            for (int r = 0; r < R; ++r) {     // unconditional load from a clamped index, then a select: `c ? p[i] : 0` makes hipcc
+                const float v = xp[min(g * R + r, F - 1)];       // branch around the load and wait on it (S*R serial round trips)
+                x[s][r] = (g * R + r < F) ? v : 0.f;
+            }
             dsel[s] = xp[F + g];
         }
         // ---------------- forward recompute (the render kernel's MLP phase) ----------------
