@@ -274,7 +274,7 @@ def train_bench(args, rank, world, dev, dist, emu_lib=None):
                                    "architecture with seeded random-init weights: no pretrained weights offline)" if perceptual is not None
                                    else " (the VGG perceptual term switched off)") + ", Adam, clip_grad_value_ 40", "parallelism": (f"data-parallel x{world} + SyncBatchNorm over {'gloo' if emu else 'RCCL'} (" + ("DistributedDataParallel" if model is not net else "one flat gradient all-reduce per step") + ")") if dp else "single GPU",
                        "step_launch": launch_note,
-                       "backward": "HIP forward+backward: FeatureNet (MFMA conv / stride-1 dgrad / wgrad, BN-train, channels-last), cost-reg nets (MFMA conv/dgrad/wgrad, BN-train), Agg+NeRF MLP (fused), warp+variance, depth regression, compositing, render-side fetches (bilinear texel + trilinear volume gathers, direction code); PyTorch-ROCm autograd: dgrad of the two stride-2 5x5 FeatureNet convolutions, the 2x-upsampling adjoint, geometry glue"}}))
+                       "backward": "HIP forward+backward: FeatureNet (MFMA conv / stride-1 dgrad / wgrad, BN-train, upsampling adjoint, channels-last), cost-reg nets (MFMA conv/dgrad/wgrad, BN-train), Agg+NeRF MLP (fused), warp+variance, depth regression, compositing, render-side fetches (bilinear texel + trilinear volume gathers, direction code); PyTorch-ROCm autograd: dgrad of the two stride-2 5x5 FeatureNet convolutions, geometry glue"}}))
 
 
 def main():
