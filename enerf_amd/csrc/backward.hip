@@ -87,13 +87,32 @@ __global__ __launch_bounds__(256) void k_feature_volume_bwd(const float* __restr
         const bool vx0 = fin && x0 >= 0 && x0 < Ws, vx1 = fin && x0 + 1 >= 0 && x0 + 1 < Ws;
         const bool vy0 = fin && y0 >= 0 && y0 < Hs, vy1 = fin && y0 + 1 >= 0 && y0 + 1 < Hs;
         float gu = 0.f, gv = 0.f;
+        // Neighbour merge: the voxel one to the right (lane + CQ, same channel quad) usually lands one texel to the right, so ITS
+        // left taps are MY right taps.  When the offsets agree, its two left contributions ride on my right atomics and it
+        // skips them: two atomics per voxel, view and channel instead of four where the warp is ~1:1 (level 1) — the kernel is
+        // bound by the L2 atomic rate.  (The order of fp32 atomic sums is arbitrary anyway.)
+        const int lane_ = threadIdx.x & 63;
+        const bool has_r = lane_ + CQ < 64, has_l = lane_ >= CQ;
+        const int rl = has_r ? lane_ + CQ : lane_, ll = has_l ? lane_ - CQ : lane_;
+        // (offsets compared as two 32-bit halves: lane broadcasts are 32-bit; every lane executes every broadcast)
+        const int r00lo = __shfl((int)(o00 & 0xffffffffLL), rl), r00hi = __shfl((int)(o00 >> 32), rl);
+        const int r10lo = __shfl((int)(o10 & 0xffffffffLL), rl), r10hi = __shfl((int)(o10 >> 32), rl);
+        const int r_ok0 = __shfl((int)(vx0 && vy0), rl), r_ok1 = __shfl((int)(vx0 && vy1), rl);
+        const bool same0 = r00lo == (int)(o01 & 0xffffffffLL) && r00hi == (int)(o01 >> 32);
+        const bool same1 = r10lo == (int)(o11 & 0xffffffffLL) && r10hi == (int)(o11 >> 32);
+        const bool m0 = has_r && r_ok0 && vx1 && vy0 && same0;      // right neighbour's (y0,x0) == my (y0,x1)
+        const bool m1 = has_r && r_ok1 && vx1 && vy1 && same1;      // right neighbour's (y1,x0) == my (y1,x1)
+        const int l_m0 = __shfl((int)m0, ll), l_m1 = __shfl((int)m1, ll);
+        const bool skip0 = has_l && l_m0, skip1 = has_l && l_m1;    // my left taps were taken by the left neighbour
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float df = live ? (2.f * inv_s) * gg[c] * (f[c] - mm[c]) : 0.f;
-            if (vx0 && vy0) { atomic_add_f32(gfeat + o00 + c, tp.w00 * df); gu -= a00[c] * ty0 * df; gv -= a00[c] * tx0 * df; }
-            if (vx1 && vy0) { atomic_add_f32(gfeat + o01 + c, tp.w01 * df); gu += a01[c] * ty0 * df; gv -= a01[c] * tx1 * df; }
-            if (vx0 && vy1) { atomic_add_f32(gfeat + o10 + c, tp.w10 * df); gu -= a10[c] * ty1 * df; gv += a10[c] * tx0 * df; }
-            if (vx1 && vy1) { atomic_add_f32(gfeat + o11 + c, tp.w11 * df); gu += a11[c] * ty1 * df; gv += a11[c] * tx1 * df; }
+            const float c00 = tp.w00 * df, c10 = tp.w10 * df;
+            const float r00 = __shfl(c00, rl), r10 = __shfl(c10, rl);
+            if (vx0 && vy0) { if (!skip0) atomic_add_f32(gfeat + o00 + c, c00); gu -= a00[c] * ty0 * df; gv -= a00[c] * tx0 * df; }
+            if (vx1 && vy0) { atomic_add_f32(gfeat + o01 + c, tp.w01 * df + (m0 ? r00 : 0.f)); gu += a01[c] * ty0 * df; gv -= a01[c] * tx1 * df; }
+            if (vx0 && vy1) { if (!skip1) atomic_add_f32(gfeat + o10 + c, c10); gu -= a10[c] * ty1 * df; gv += a10[c] * tx0 * df; }
+            if (vx1 && vy1) { atomic_add_f32(gfeat + o11 + c, tp.w11 * df + (m1 ? r10 : 0.f)); gu += a11[c] * ty1 * df; gv += a11[c] * tx1 * df; }
         }
         // (u, v) = p.xy / z ; z = max(p.z, 1e-6)
         const float gpx = gu / z, gpy = gv / z;
