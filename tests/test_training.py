@@ -341,6 +341,43 @@ def _check_feature_net_train(lib, dev, H=32, W=64, n=3, tol=2e-4):
             assert float((b0 - b1).abs().max()) <= 1e-5 + 1e-4 * float(b1.abs().max()), k
 
 
+def test_up2_adjoint_emulated_sizes():
+    """enerf_up2_adjoint against autograd through F.interpolate at even, odd and non-square coarse sizes, with and without the
+    summed-in second gradient; and the guards of the entry."""
+    from emu_lib import emu_lib
+    from enerf_amd.lib import EnerfError
+    lib = emu_lib()
+    g = torch.Generator().manual_seed(11)
+    for (N, C_, Hc, Wc) in ((1, 8, 8, 16), (2, 16, 15, 20), (1, 32, 5, 33), (1, 4, 2, 2)):
+        c = torch.randn(N, C_, Hc, Wc, generator=g, requires_grad=True)
+        gf = torch.randn(N, C_, 2 * Hc, 2 * Wc, generator=g)
+        F.interpolate(c, scale_factor=2, mode="bilinear", align_corners=True).backward(gf)
+        ref = c.grad.permute(0, 2, 3, 1)
+        got = lib.up2_adjoint(gf.permute(0, 2, 3, 1).contiguous())
+        assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), (N, C_, Hc, Wc)
+        extra = torch.randn(N, Hc, Wc, C_, generator=g)
+        got2 = lib.up2_adjoint(gf.permute(0, 2, 3, 1).contiguous(), add=extra)
+        assert float((got2 - (ref + extra)).abs().max()) <= 2e-6 * float((ref + extra).abs().max())
+    with pytest.raises(EnerfError, match="bad arguments"):           # channel count must be a multiple of 4
+        lib.up2_adjoint(torch.zeros(1, 4, 4, 6))
+
+
+def test_graphed_step_shape_key_and_flat_sync_guards():
+    """Host logic of train_graph that needs no device: the per-shape key of GraphedTrainSteps distinguishes what a captured
+    graph depends on (tensor shapes and dtypes, not values or non-tensor entries), and FlatGradSync refuses to exist without
+    a process group."""
+    from enerf_amd.train_graph import FlatGradSync, GraphedTrainSteps
+    _, b3 = _train_batch(seed=1, S=3)
+    _, b3b = _train_batch(seed=2, S=3)
+    _, b2 = _train_batch(seed=1, S=2)
+    k = GraphedTrainSteps.key
+    assert k(b3) == k(b3b) and k(b3) != k(b2)
+    assert k(dict(b3, meta={"scene": "x"})) == k(b3)
+    assert k(dict(b3, near_far=b3["near_far"].double())) != k(b3)
+    with pytest.raises(RuntimeError, match="process group"):
+        FlatGradSync(torch.nn.Linear(2, 2))
+
+
 def test_feature_net_train_emulated():
     from emu_lib import emu_lib
     _check_feature_net_train(emu_lib(), torch.device("cpu"))
