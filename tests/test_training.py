@@ -341,6 +341,41 @@ def _check_feature_net_train(lib, dev, H=32, W=64, n=3, tol=2e-4):
             assert float((b0 - b1).abs().max()) <= 1e-5 + 1e-4 * float(b1.abs().max()), k
 
 
+def test_batchnorm_train_kernels_match_torch_modules_emulated():
+    """autograd._BatchNormTrain (statistics + coefficient + affine kernels) against nn.BatchNorm in training mode: output,
+    input / gamma / beta gradients and the running statistics, with momentum 0.1 and with momentum=None (cumulative average),
+    with and without ReLU + skip."""
+    from emu_lib import emu_lib
+    from enerf_amd.autograd import _BatchNormTrain
+    lib = emu_lib()
+    torch.manual_seed(3)
+    for mom in (0.1, None):
+        for relu in (False, True):
+            bn, ref = torch.nn.BatchNorm1d(8, momentum=mom).train(), torch.nn.BatchNorm1d(8, momentum=mom).train()
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
+            ref.load_state_dict(bn.state_dict())
+            for it in range(2):
+                z = (torch.randn(60, 8) * 2 + 1).requires_grad_(True)
+                res = torch.randn(60, 8)
+                g = torch.randn(60, 8)
+                blk = _BatchNormTrain(lib, bn, relu)
+                out = blk.forward(z.detach(), residual=res if relu else None)
+                r = ref(z)
+                r = (torch.relu(r) + res) if relu else r
+                assert float((out - r).abs().max()) <= 2e-6 * float(r.abs().max())
+                r.backward(g)
+                dz, dgamma, dbeta = blk.backward(g)
+                assert float((dz - z.grad).abs().max()) <= 2e-5 * float(z.grad.abs().max())
+                assert float((dgamma - ref.weight.grad).abs().max()) <= 2e-5 * float(ref.weight.grad.abs().max())
+                assert float((dbeta - ref.bias.grad).abs().max()) <= 2e-5 * float(ref.bias.grad.abs().max())
+                ref.zero_grad()
+                for name in ("running_mean", "running_var"):
+                    a, b = getattr(bn, name), getattr(ref, name)
+                    assert float((a - b).abs().max()) <= 1e-6 + 1e-5 * float(b.abs().max()), (mom, relu, it, name)
+                assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == it + 1
+
+
 def test_up2_adjoint_emulated_sizes():
     """enerf_up2_adjoint against autograd through F.interpolate at even, odd and non-square coarse sizes, with and without the
     summed-in second gradient; and the guards of the entry."""
