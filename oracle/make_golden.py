@@ -46,6 +46,15 @@ CASES = {
 }
 
 
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from adversarial import ADV_CASES, regime_stats, tweak_batch, tweak_weights  # noqa: E402  (tests/adversarial.py: shared case table)
+
+# adversarial-regime cases: the base batch / weights plus the edits of tests/adversarial.py
+for _n, _c in ADV_CASES.items():
+    CASES[_n] = dict(H=_c["H"], W=_c["W"], S=_c["S"], planes=_c["planes"], render_if=_c["render_if"], seed=_c["seed"],
+                     textured=_c["textured"], human=False, inter="maps", adv=True, white_bkgd=bool(_c.get("white_bkgd")))
+
+
 def seeded_state_dict(net) -> dict:
     """Default init under seed 0 is done by the caller; here: non-trivial BN + biases (seed 1)."""
     g = torch.Generator().manual_seed(1)
@@ -76,7 +85,10 @@ def run_case(name: str) -> None:
     else:
         opts = ["enerf.cas_config.volume_planes", ",".join(map(str, c["planes"])),
                 "enerf.cas_config.render_if", ",".join(map(str, c["render_if"]))]
+        if c.get("white_bkgd"):
+            opts += ["enerf.white_bkgd", "True"]
         cfg, ref_network = load_reference("configs/enerf/dtu_pretrain.yaml", opts)
+        assert bool(cfg.enerf.white_bkgd) == bool(c.get("white_bkgd"))
     if c["human"]:
         from lib.networks.enerf import network_human as ref_network  # noqa: F811
     from lib.networks.enerf import utils as ref_utils
@@ -102,6 +114,9 @@ def run_case(name: str) -> None:
     else:
         batch_np = make_batch(c["H"], c["W"], c["S"], ecfg, seed=c["seed"], textured=c["textured"],
                               mask_box=c["human"])
+    if c.get("adv"):                               # edits on top of the pinned seeded weights / batch (tests/adversarial.py)
+        net.load_state_dict(tweak_weights({k: v.clone() for k, v in sd.items()}, name))
+        batch_np = tweak_batch(batch_np, name)
     batch = {k: torch.from_numpy(v) for k, v in batch_np.items()}
 
     # record stage boundaries by wrapping the reference's own functions (no reference code is edited)
@@ -156,6 +171,11 @@ def run_case(name: str) -> None:
             if k.split("_")[0] in ("depth", "std", "nf", "proj", "rays12"):
                 save[f"mid/{k}"] = v.detach().numpy()
     save["meta/torch_version"] = np.array(torch.__version__)
+    if c.get("adv"):                               # how deep into its regime the case is (asserted again by the tests)
+        import json
+        st = regime_stats(ecfg, {k: v.detach() for k, v in net.state_dict().items()}, batch)
+        save["meta/regime"] = np.array(json.dumps(st))
+        print(f"[golden] {name} regime: {st}")
     np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **save)
     rgb = out[[k for k in out if k.startswith("rgb")][-1]]
     print(f"[golden] {name}: {len(save)} arrays; rgb mean {rgb.mean():.4f} min {rgb.min():.4f} "
