@@ -4,11 +4,8 @@ of the UNMODIFIED reference on these inputs (``oracle/make_golden.py --case adv_
 
 CPU: the oracle and the lane-emulated kernel sources against the reference; GPU (-m gpu): the product library, 1e-4.
 
-Tolerance notes, measured: adv_onehot's cascade is discontinuous by construction — level 0's std sits on the 1e-10 variance
-clamp, level 1's depth planes span a ~1e-5-wide disparity interval, and the per-ray sample position divides by
-``max(vf - vn, 1e-6)`` (utils.py:433-436): a 1-ulp difference in level 0's depth moves ``depth_level1`` by more than 1e-4 of its
-range in the REFERENCE itself (1 vs 8 threads).  For that case the rendered colour / level-0 outputs keep the 1e-4 bound and the
-level-1 depth outputs are compared where the reference's own interval is not degenerate.
+Measured on the lane emulator: worst deviation 3.7e-5 of max|ref| (adv_clamp's std_level1); the oracle at 8 threads moves by
+up to 2e-5 against the reference's 1-thread run (adv_sigma's rgb_level1).
 """
 import json
 
@@ -62,7 +59,7 @@ def test_oracle_matches_reference_on_adversarial_inputs(case):
     sd = tweak_weights(load_weights(), case)
     with torch.no_grad():
         out = O.forward(cfg, sd, _tbatch(case))
-    _compare(case, out, gold, 2e-5 if case != "adv_onehot" else 2e-3)
+    _compare(case, out, gold, 5e-5)
 
 
 def _net(cfg, case, lib=None, dev=None):
@@ -72,21 +69,8 @@ def _net(cfg, case, lib=None, dev=None):
     return (net.to(dev) if dev is not None else net).eval()
 
 
-ONEHOT_LOOSE = ("depth_level1", "weights_level1", "depth_mvs_level1", "std_level1")
-
-
 def _check(case, out, gold):
-    if case != "adv_onehot":
-        return _compare(case, out, gold, REL_TOL)
-    # see the module docstring: level 1 of this case amplifies 1-ulp differences of level 0 by construction
-    strict = {k: v for k, v in out.items() if k not in ONEHOT_LOOSE}
-    w = _compare(case, strict, {k: v for k, v in gold.items() if k[4:] not in ONEHOT_LOOSE}, REL_TOL)
-    for k in ONEHOT_LOOSE:
-        a = out[k].detach().cpu().numpy()
-        assert np.isfinite(a).all(), k
-        w[k] = _rel(a, gold["out/" + k])
-        assert w[k] < 5e-3, (case, k, w[k])
-    return w
+    return _compare(case, out, gold, REL_TOL)
 
 
 @pytest.mark.parametrize("case", list(ADV_CASES))
