@@ -269,6 +269,8 @@ def train_bench(args, rank, world, dev, dist, emu_lib=None):
             "value": world * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not emu else "synthetic (CPU lane emulator, 32x64: launcher check, not a measurement)", "final_loss": float(loss.detach()),
+            "collective_ranks_seen": args.binding["ranks_seen"], "collective_backend": args.binding["backend"],
+            "rank_devices": [{k: b[k] for k in ("rank", "device", "visible", "hw")} for b in args.binding["bindings"]],
             "config": {"workload": "BASELINE config 5: DTU dtu_pretrain training, one sample per GPU per step, MSE loss "
                                    "(losses/enerf.py:21-24)" + (" + 0.01 x VGG16 perceptual L1 at both levels (losses/enerf.py:30-38; the "
                                    "architecture with seeded random-init weights: no pretrained weights offline)" if perceptual is not None
@@ -356,7 +358,17 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL
 
     from __graft_entry__ import _seeded_network
-    from enerf_amd.frame_parallel import render_sharded
+    from enerf_amd.frame_parallel import rank_bindings, render_sharded
+
+    # one process per GPU, checked: every rank's device binding is exchanged, duplicates are refused on all ranks, and the
+    # size of the communicator is counted on the devices (`collective_ranks_seen`, next to n_gpus in the line)
+    try:
+        args.binding = rank_bindings(rank, world, local, dev)
+    except RuntimeError as e:
+        raise SystemExit(f"rank {rank}: {e}: refusing to print an n_gpus={world} line")
+    print(f"[bench] rank {rank}/{world} local_rank {local} -> {args.binding['bindings'][rank if world > 1 else 0]}", file=sys.stderr, flush=True)
+    if args.binding["ranks_seen"] != world:
+        raise SystemExit(f"communicator holds {args.binding['ranks_seen']} ranks, --gpus says {world}")
 
     if args.train:
         return train_bench(args, rank, world, dev, dist, emu_lib)
@@ -434,6 +446,8 @@ def main():
             "vs_baseline": (fps / BASELINE_FPS_RTX3090) if args.workload == "dtu" else None,
             "dtype": "f32", "data": "synthetic" if not args.emu else "synthetic (CPU lane emulator: launcher check, not a measurement)",
             "per_rank_fps": [round(v, 2) for v in per_rank], "internal_warmup_frames": internal_warmup,
+            "collective_ranks_seen": args.binding["ranks_seen"], "collective_backend": args.binding["backend"],
+            "rank_devices": [{k: b[k] for k in ("rank", "device", "visible", "hw")} for b in args.binding["bindings"]],
             "config": {"workload": workload, "distinct_batches": nb, "feature_net": args.feature_backend, "hip_graph": bool(args.graph),
                        "single_stream": bool(args.single_stream), "options": opt_fields,
                        "protocol": "per-frame synchronize (run.py:62-76), one frame at a time, default kernel options "

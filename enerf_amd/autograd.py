@@ -192,10 +192,16 @@ class _BatchNormTrain:
         self.lib, self.bn, self.relu = lib, bn, relu
 
     @staticmethod
-    def _synced(bn):
+    def _group(bn):
+        """The module's own process group (``SyncBatchNorm(process_group=...)`` / ``convert_sync_batchnorm(m, group)``);
+        None = the default group — what torch's SyncBatchNorm uses as well."""
+        return getattr(bn, "process_group", None)
+
+    @classmethod
+    def _synced(cls, bn):
         import torch.distributed as dist
         return isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and \
-            (dist.get_world_size() > 1 or SYNC_SINGLE_RANK)
+            (dist.get_world_size(cls._group(bn)) > 1 or SYNC_SINGLE_RANK)
 
     def forward(self, z, residual=None):
         lib, bn = self.lib, self.bn
@@ -204,7 +210,7 @@ class _BatchNormTrain:
         if self._synced(bn):
             import torch.distributed as dist
             buf = torch.cat([sums.view(-1), sums.new_full((1,), float(n))])          # fill kernel, not a host copy: capture-safe
-            dist.all_reduce(buf)
+            dist.all_reduce(buf, group=self._group(bn))
             sums, n = buf[:2 * C_].view(2, C_), buf[2 * C_:]                         # the global count stays on the device
         self.mean_invstd, ss = lib.bn_train_coeffs(sums, n, bn)
         self.z, self.n, self.scale, self.shift = z, n, ss[0], ss[1]
@@ -219,7 +225,7 @@ class _BatchNormTrain:
         if self._synced(bn):                                                         # the input gradient needs the global sums;
             import torch.distributed as dist                                         # d gamma / d beta stay LOCAL (DDP averages
             glob = local.clone()                                                     # them), like torch's SyncBatchNorm
-            dist.all_reduce(glob)
+            dist.all_reduce(glob, group=self._group(bn))
         dgb, k23 = lib.bn_train_bwd_coeffs(local, glob, self.n, self.mean_invstd, self.scale)
         dz = lib.channel_affine(g, self.scale, k23[1], b=z, q=k23[0], **mask)
         return dz, dgb[0], dgb[1]

@@ -113,7 +113,7 @@ class GraphedTrainStep:
     Every batch passed later must have the tensors (keys, shapes, dtypes) of ``example_batch``.  The returned loss tensor is
     the graph's own output buffer: read it (``.item()``) before the next call.
 
-    Construction is side-effect free on the model: the warm-up, the capture and the verification steps DO run optimizer
+    Construction is side-effect free on the model (also when it FAILS — GraphMismatch, a refused capture): the warm-up, the capture and the verification steps DO run optimizer
     steps on ``example_batch`` (optimizer state must exist before the capture), but parameters, buffers (BatchNorm running
     statistics, ``num_batches_tracked``) are snapshotted first and restored in place afterwards, and the optimizer's state
     tensors are zeroed in place (step 0, zero moments: exactly a fresh Adam/AdamW; the graph keeps their addresses).  An
@@ -137,6 +137,30 @@ class GraphedTrainStep:
         self._params = [p for p in net.parameters() if p.requires_grad]
         pristine_net = [(t, t.clone()) for t in net.state_dict().values()]
         pristine_opt = {id(t): t.clone() for st in optimizer.state.values() for t in st.values() if torch.is_tensor(t)}
+        try:
+            self._construct(warmup, verify, verify_steps)
+        finally:
+            # undo the training the construction did (warm-up + capture + verification steps on example_batch) — on the
+            # failure paths too (GraphMismatch, a refused capture): a caller that falls back to eager steps (bench.py)
+            # must start from the weights, BatchNorm buffers and optimizer state it handed in
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                self._restore(pristine_net)
+                for st in optimizer.state.values():
+                    for t in st.values():
+                        if torch.is_tensor(t):
+                            t.copy_(pristine_opt[id(t)]) if id(t) in pristine_opt else t.zero_()
+            net.invalidate_packed()
+
+    def _agree(self, failed: bool) -> bool:
+        """One verdict for all ranks (MAX over the group): nobody is left alone inside a collective."""
+        if self.sync is None:
+            return failed
+        flag = torch.tensor([1.0 if failed else 0.0], device=next(iter(self.static.values())).device)
+        self.sync.dist.all_reduce(flag, op=self.sync.dist.ReduceOp.MAX, group=self.sync.group)
+        return bool(flag.item())
+
+    def _construct(self, warmup: int, verify: bool, verify_steps: int):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up on a side stream: lazy initialisation, caches, allocator
@@ -151,26 +175,26 @@ class GraphedTrainStep:
             # The process group's watchdog thread polls the events of the collectives the warm-up enqueued until it has seen
             # them complete; an event query from another thread while THIS thread captures in the default ("global") mode is
             # an illegal call that takes the process down (seen once in ~10 runs on ROCm 7 / PyTorch 2.10: abort inside the
-            # capture).  Two guards: let the watchdog retire the finished work first (all ranks together), and capture in
-            # "thread_local" mode (only this thread's calls are policed; kernels other threads — the autograd engine's —
-            # launch into the capturing stream are captured all the same).
+            # capture).  Two guards: let the watchdog retire the finished work first (all ranks together; the device is idle
+            # after the synchronize, the sleep covers the watchdog's polling period — a heuristic), and capture in
+            # "thread_local" mode, which is the LOAD-BEARING one: only this thread's calls are policed, so a late watchdog
+            # query cannot abort the capture (kernels other threads — the autograd engine's — launch into the capturing
+            # stream are captured all the same; the price: an illegal call from those threads is not diagnosed).
             self.sync.dist.barrier(group=self.sync.group)
             torch.cuda.synchronize()
             time.sleep(0.5)
             capture_kw["capture_error_mode"] = "thread_local"
-        with torch.cuda.graph(self.graph, **capture_kw):
-            self.loss = self._eager_step(zero=False)
-        net.invalidate_packed()
+        error = None
+        try:
+            with torch.cuda.graph(self.graph, **capture_kw):
+                self.loss = self._eager_step(zero=False)
+        except RuntimeError as e:                          # a refused capture executes nothing: every rank can still talk
+            error = e
+        if self._agree(error is not None):
+            raise error if error is not None else RuntimeError("GraphedTrainStep: the capture failed on another rank")
+        self.net.invalidate_packed()
         if verify:
             self._verify(verify_steps)
-        # undo the training the construction did (warm-up + capture + verification steps on example_batch)
-        with torch.no_grad():
-            self._restore(pristine_net)
-            for st in optimizer.state.values():
-                for t in st.values():
-                    if torch.is_tensor(t):
-                        t.copy_(pristine_opt[id(t)]) if id(t) in pristine_opt else t.zero_()
-        net.invalidate_packed()
 
     # ---- replay-vs-eager check (see MEMSET NODES above) ----
     def _snapshot(self):
@@ -204,11 +228,7 @@ class GraphedTrainStep:
                         bad.append((n, err, scale))
                 p.grad = grads_kept[n]
             failed = bool(bad) or not abs(loss_graph - loss_eager) <= 1e-3 * abs(loss_eager) + 1e-7
-            if self.sync is not None:                       # one verdict for all ranks: nobody leaves the collectives alone
-                flag = torch.tensor([1.0 if failed else 0.0], device=self.loss.device)
-                self.sync.dist.all_reduce(flag, op=self.sync.dist.ReduceOp.MAX, group=self.sync.group)
-                failed = bool(flag.item())
-            if failed:
+            if self._agree(failed):
                 raise GraphMismatch(f"replay {k}: loss {loss_graph} vs eager {loss_eager}; gradient mismatches "
                                     f"(name, max err, max |g|): {bad[:6]}")
         self.net.invalidate_packed()

@@ -52,6 +52,8 @@ def load_golden(name: str) -> dict:
 # ---- full-size frames pinned to the reference itself (oracle/make_golden.py::FULL_CASES; sparse digests, < 1 MB each) ----
 FULL_CASES = {
     "dtu_full": dict(H=512, W=640, S=3, planes=(48, 8), render_if=(False, True), seed=0, textured=True, human=False),
+    # BASELINE configs[0] (configs/enerf/dtu/scan114.yaml shape): 512x640, 3 views, planes 48,8, BOTH levels rendered
+    "dtu_full_tt": dict(H=512, W=640, S=3, planes=(48, 8), render_if=(True, True), seed=0, textured=True, human=False),
     "lego_full": dict(H=800, W=800, S=4, planes=(64, 8), render_if=(True, True), seed=5, human=False, rig="lego"),
     "zju_full": dict(H=1024, W=1024, S=4, planes=(32, 8), render_if=(False, True), seed=6, human=True, rig="zju"),
 }

@@ -245,6 +245,16 @@ def _full_size_check(cfg, b, human, keys_psnr, golden):
     return out, ref
 
 
+def test_full_size_dtu_both_levels_vs_oracle():
+    """BASELINE configs[0] (configs/enerf/dtu/scan114.yaml's shape; the configuration BASELINE.md's CPU figure is quoted on):
+    512x640, 3 views, planes 48,8, render_if True,True — k_render_rays<9,3,...> (level 0: C = 32, 8 samples per ray) on
+    20,480 rays and <3,3,...> on 327,680, pinned to the unmodified reference's digest (dtu_full_tt) and to the oracle."""
+    cfg = EnerfConfig().with_cas(volume_planes=(48, 8), render_if=(True, True))
+    out, ref = _full_size_check(cfg, make_batch(512, 640, 3, cfg, seed=0, textured=True), False, ("rgb_level0", "rgb_level1"),
+                                "dtu_full_tt")
+    assert out["rgb_level0"].shape == (1, 128 * 160, 3) and out["rgb_level1"].shape == (1, 512 * 640, 3)
+
+
 def test_full_size_lego_800x800_4views_both_levels_vs_oracle():
     """BASELINE config 3 at its real shape (configs/enerf/nerf/lego.yaml:4-8, lib/datasets/nerf/enerf.py:46-49,92):
     H=W=800, S=4, planes 64,8, render_if True,True — lego pinhole intrinsics, near_far [2.5, 5.5]; exercises
