@@ -68,22 +68,31 @@ class CompositeFn(torch.autograd.Function):
         rgb, depth, weights = lib.composite(raw2, z2, white_bkgd)
         ctx.lib, ctx.shape = lib, (B, N, Ns)
         ctx.save_for_backward(raw2, z2)
+        ctx.set_materialize_grads(False)                   # outputs the loss ignores arrive as None, not as zero tensors
         return rgb.view(B, N, 3), depth.view(B, N), weights.view(B, N, Ns)
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_weights):
         raw2, z2 = ctx.saved_tensors
         B, N, Ns = ctx.shape
-        g_raw, g_z = ctx.lib.composite_bwd(raw2, z2, _c(g_rgb).reshape(B * N, 3), _c(g_depth).reshape(B * N),
-                                           _c(g_weights).reshape(B * N, Ns))
+        opt = lambda g, *sh: None if g is None else _c(g).reshape(*sh)
+        g_raw, g_z = ctx.lib.composite_bwd(raw2, z2, opt(g_rgb, B * N, 3), opt(g_depth, B * N), opt(g_weights, B * N, Ns))
         # utils.py:595: depth_map = sum(weights * z_vals.detach()) — the sample depths never receive a gradient from the
         # composited depth (k_composite_bwd's g_z is the un-detached derivative: dropped here)
         return None, g_raw.view(B, N, Ns, 4), None, None
 
 
-def gather_cameras(batch, render_scale: float):
+def gather_cameras(batch, render_scale: float, lib=None):
     """The per-view constants of enerf_gather_*: cam (B,S,16) = K'E33 | K't | source centre | 0 and tcen (B,4), with
-    K' = K scaled to the level (utils.py:697-704); products in fp64, stored fp32 (as the inference kernel's table)."""
+    K' = K scaled to the level (utils.py:697-704); products in fp64, stored fp32 (as the inference kernel's table).
+    With the library: ONE launch on the device (enerf_camera_tables; no host synchronisation, capturable)."""
+    if lib is not None:
+        return lib.camera_tables(_c(batch["src_ixts"]), _c(batch["src_exts"]), _c(batch["tar_ext"]), render_scale)
+    return gather_cameras_torch(batch, render_scale)
+
+
+def gather_cameras_torch(batch, render_scale: float):
+    """gather_cameras as torch ops (torch.inverse synchronises): the twin the kernel is tested against."""
     E = batch["src_exts"].double()
     K = batch["src_ixts"].double().clone()
     K[:, :, :2] *= render_scale
@@ -100,13 +109,12 @@ def gather_cameras(batch, render_scale: float):
 
 class GatherFn(torch.autograd.Function):
     """get_img_feat + get_vox_feat (utils.py:689-722, 456-458) on the HIP kernels: xyz (B,P,3), dn (B,P), uv (B,P,2),
-    tex (B,S,F,Hr,Wr), feat_vol (B,8,D,h,w) -> x (B,P,S,F+4), vox (B,P,8).  Differentiable in xyz, dn, tex, feat_vol."""
+    tex_cl (B,S,Hr,Wr,F) and vol_cl (B,D,h,w,8) CHANNELS-LAST -> x (B,P,S,F+4), vox (B,P,8).  Differentiable in xyz, dn,
+    tex_cl, vol_cl (gradients in the same layouts)."""
 
     @staticmethod
-    def forward(ctx, lib: EnerfLib, xyz, dn, uv, tex, feat_vol, cam, tcen):
-        xyz, dn, uv = _c(xyz), _c(dn), _c(uv)
-        tex_cl = tex.permute(0, 1, 3, 4, 2).contiguous()
-        vol_cl = feat_vol.permute(0, 2, 3, 4, 1).contiguous()
+    def forward(ctx, lib: EnerfLib, xyz, dn, uv, tex_cl, vol_cl, cam, tcen):
+        xyz, dn, uv, tex_cl, vol_cl = _c(xyz), _c(dn), _c(uv), _c(tex_cl), _c(vol_cl)
         x, vox = lib.gather_fwd(xyz, dn, uv, tex_cl, vol_cl, cam, tcen)
         ctx.lib = lib
         ctx.save_for_backward(xyz, dn, uv, tex_cl, vol_cl, cam, tcen)
@@ -116,7 +124,95 @@ class GatherFn(torch.autograd.Function):
     def backward(ctx, g_x, g_vox):
         xyz, dn, uv, tex_cl, vol_cl, cam, tcen = ctx.saved_tensors
         g_tex, g_vol, g_xyz, g_dn = ctx.lib.gather_bwd(xyz, dn, uv, tex_cl, vol_cl, cam, tcen, _c(g_x), _c(g_vox))
-        return None, g_xyz, g_dn, None, g_tex.permute(0, 1, 4, 2, 3), g_vol.permute(0, 4, 1, 2, 3), None, None
+        return None, g_xyz, g_dn, None, g_tex, g_vol, None, None
+
+
+class DepthValuesFn(torch.autograd.Function):
+    """get_depth_values of a cascade level > 0 (utils.py:112-151): the previous level's depth, std (B,hp,wp; disparity space)
+    and near_far (B,2,hp,wp; detached) -> depth_values (B,D,h,w), near_far (B,2,h,w; detached, utils.py:148).  Forward = the
+    inference kernel; backward through the clamps, the reciprocals and the align-corners upsampling (enerf_get_depth_values_bwd)."""
+
+    @staticmethod
+    def forward(ctx, lib: EnerfLib, depth, std, near_far, batch_near_far, D: int, h: int, w: int, depth_inv: bool):
+        depth, std, near_far = _c(depth), _c(std), _c(near_far)
+        dv, nf = lib.get_depth_values(batch_near_far, (depth, std, near_far), depth.shape[0], D, h, w, depth_inv)
+        ctx.lib, ctx.depth_inv = lib, depth_inv
+        ctx.save_for_backward(depth, std, near_far)
+        ctx.mark_non_differentiable(nf)
+        ctx.set_materialize_grads(False)
+        return dv, nf
+
+    @staticmethod
+    def backward(ctx, g_dv, _g_nf):
+        depth, std, near_far = ctx.saved_tensors
+        if g_dv is None:
+            return (None,) * 9
+        g_d, g_s = ctx.lib.get_depth_values_bwd(depth, std, near_far, _c(g_dv), ctx.depth_inv)
+        return None, g_d, g_s, None, None, None, None, None, None
+
+
+class ReciprocalFn(torch.autograd.Function):
+    """1 / x (depth_mvs of a disparity-space level, network.py:105-108) as one library launch.  The trainer's loss never reads
+    depth_mvs; if something does, the backward is the two-op torch expression."""
+
+    @staticmethod
+    def forward(ctx, lib: EnerfLib, x):
+        y = lib.reciprocal(_c(x))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return None, -g * y * y
+
+
+class RaySamplesFn(torch.autograd.Function):
+    """build_rays + sample_along_depth (utils.py:390-441): depth, std (B,h,w), near_far (B,2,h,w; detached), rays (B,N,8)
+    -> z (B,N,Ns), xyz (B,N,Ns,3), dn (B,N,Ns), uv (B,N,Ns,2).  Differentiable in depth and std (through xyz and dn; z only
+    feeds the composited depth, which detaches it: utils.py:595)."""
+
+    @staticmethod
+    def forward(ctx, lib: EnerfLib, depth, std, near_far, rays8, Ns: int, Hr: int, Wr: int, depth_inv: bool):
+        depth, std, near_far, rays8 = _c(depth), _c(std), _c(near_far), _c(rays8[..., :8])
+        z, xyz, dn, uv = lib.ray_samples_fwd(rays8, depth, std, near_far, Ns, Hr, Wr, depth_inv)
+        ctx.lib, ctx.cfg = lib, (Ns, Hr, Wr, depth_inv)
+        ctx.save_for_backward(depth, std, near_far, rays8)
+        ctx.mark_non_differentiable(z, uv)
+        ctx.set_materialize_grads(False)
+        return z, xyz, dn, uv
+
+    @staticmethod
+    def backward(ctx, _g_z, g_xyz, g_dn, _g_uv):
+        depth, std, near_far, rays8 = ctx.saved_tensors
+        Ns, Hr, Wr, depth_inv = ctx.cfg
+        if g_xyz is None and g_dn is None:
+            return (None,) * 9
+        B, N = rays8.shape[:2]
+        g_xyz = g_xyz if g_xyz is not None else rays8.new_zeros(B, N, Ns, 3)
+        g_dn = g_dn if g_dn is not None else rays8.new_zeros(B, N, Ns)
+        g_d, g_s = ctx.lib.ray_samples_bwd(rays8, depth, std, near_far, _c(g_xyz), _c(g_dn), Ns, Hr, Wr, depth_inv)
+        return None, g_d, g_s, None, None, None, None, None, None
+
+
+class TexelsFn(torch.autograd.Function):
+    """The render-side gather source (network.py:28-33): im_feat (B,S,C,Hr,Wr) — an NCHW view of the FeatureNet's channels-last
+    map, already at the render resolution — and src_inps (B,S,3,H,W) -> tex_cl (B,S,Hr,Wr,C+3) = [features | unpreprocessed,
+    resized colours] channels-last.  Gradient: the feature channels of d tex (the images are inputs)."""
+
+    @staticmethod
+    def forward(ctx, lib: EnerfLib, im_feat, src_inps, Hr: int, Wr: int):
+        B, S, Cc = im_feat.shape[:3]
+        feat_cl = _c(im_feat.permute(0, 1, 3, 4, 2)).view(B * S, Hr, Wr, Cc)
+        H, W = src_inps.shape[-2:]
+        tex = lib.pack_texels_train(feat_cl, _c(src_inps).view(B * S, 3, H, W), Hr, Wr)
+        ctx.lib, ctx.C = lib, Cc
+        return tex.view(B, S, Hr, Wr, Cc + 3)
+
+    @staticmethod
+    def backward(ctx, g_tex):
+        g = ctx.lib.slice_channels(_c(g_tex), 0, ctx.C)                    # (B,S,Hr,Wr,C)
+        return None, g.permute(0, 1, 4, 2, 3), None, None, None
 
 
 class ConvFn(torch.autograd.Function):
@@ -256,7 +352,7 @@ class _Block:
         dz, dgamma, dbeta = self.norm.backward(g)
         w = self.w.detach()
         if self.kind == _S1:                                                         # dgrad: flipped, channel-transposed
-            wd = w.flip(2, 3, 4).transpose(0, 1).contiguous()
+            wd = lib.weights_flip_transpose(w.contiguous())
             pk = lib.conv3d_layer_pack(wd, self.cout, self.cin, _S1)
             gx = lib.conv3d_layer(pk, self.cout, self.cin, _S1, dz)
             gw = lib.conv_wgrad_cl(dz, self.x, 1)
@@ -299,21 +395,19 @@ class CostRegTrainFn(torch.autograd.Function):
         y = up(11).forward(y, residual=c0)
         # heads: feat_conv (8 -> 8) ++ depth_conv (8 -> 1) as one 8 -> 16 layer (rows 9..15 zero)
         wf, wd = m.feat_conv[0].weight.detach(), m.depth_conv[0].weight.detach()
-        w16 = torch.cat([wf, wd, wf.new_zeros(7, 8, 3, 3, 3)], 0).contiguous()
+        w16 = lib.concat2_pad(_c(wf), _c(wd), 16 * 8 * 27).view(16, 8, 3, 3, 3)
         heads = lib.conv3d_layer(lib.conv3d_layer_pack(w16, 8, 16, _S1), 8, 16, _S1, y)
         ctx.lib, ctx.m, ctx.blk, ctx.y, ctx.w16 = lib, m, blk, y, w16
-        feat = heads[..., :8].permute(0, 4, 1, 2, 3)
-        prob = heads[..., 8]
+        feat = lib.slice_channels(heads, 0, 8).permute(0, 4, 1, 2, 3)      # contiguous channels-last (what the render-side fetch reads)
+        prob = lib.slice_channels(heads, 8, 1)[..., 0]                     # contiguous (B,D,h,w)
         return feat, prob
 
     @staticmethod
     def backward(ctx, g_feat, g_prob):
         lib, m, blk, y = ctx.lib, ctx.m, ctx.blk, ctx.y
         B, D, h, w, _ = y.shape
-        g16 = torch.zeros((B, D, h, w, 16), dtype=torch.float32, device=y.device)
-        g16[..., :8] = g_feat.permute(0, 2, 3, 4, 1)
-        g16[..., 8] = g_prob
-        wd = ctx.w16.flip(2, 3, 4).transpose(0, 1).contiguous()
+        g16 = lib.concat_channels(_c(g_feat.permute(0, 2, 3, 4, 1)), _c(g_prob).unsqueeze(-1), 16)
+        wd = lib.weights_flip_transpose(ctx.w16)
         g = lib.conv3d_layer(lib.conv3d_layer_pack(wd, 16, 8, _S1), 16, 8, _S1, g16)     # d y11
         gw16 = lib.conv_wgrad_cl(g16, y, 1)
         grads = {"feat": gw16[:8], "depth": gw16[8:9]}
@@ -329,13 +423,13 @@ class CostRegTrainFn(torch.autograd.Function):
         if m.full:
             g_c4 = g
             g = back(5, back(6, back(7, g)))
-            g_c4 = g_c4 + g
+            g_c4 = lib.add(g_c4, g)
         else:
             g_c4 = g
         g = back(3, back(4, g_c4))
-        g_c2 = g_c2 + g
+        g_c2 = lib.add(g_c2, g)
         g = back(1, back(2, g_c2))
-        g_c0 = g_c0 + g
+        g_c0 = lib.add(g_c0, g)
         g_x = back(0, g_c0)
         out = []
         for i in ctx.order:
@@ -394,20 +488,24 @@ class _Conv2d:
         return lib.conv2d_layer(lib.conv2d_layer_pack(w.contiguous(), bias, self.cin, self.cout, self.k), self.cin, self.cout, self.k,
                                 self.stride, x, up)
 
-    def backward(self, dz, need_input=True):
-        """dz = gradient w.r.t. the convolution's output (channels-last) -> (grad_input or None, grad_weight, grad_bias or None)."""
+    def backward(self, dz, need_input=True, add=None):
+        """dz = gradient w.r.t. the convolution's output (channels-last) -> (grad_input (+ add) or None, grad_weight, grad_bias or None)."""
         lib, w = self.lib, self.conv.weight.detach()
-        x_cl = self.x if self.cin != 3 else self.x.permute(0, 2, 3, 1).contiguous()
+        if self.cin == 3:                                       # the NCHW image batch -> channels-last (the library's adapter kernel)
+            N, _, H, W = self.x.shape
+            x_cl = lib.channels_last(self.x.reshape(N, 3, H * W), N, 3, H * W).view(N, H, W, 3)
+        else:
+            x_cl = self.x
         gw = lib.conv_wgrad_cl2d(dz, x_cl, self.k, self.stride)
-        gb = None if self.conv.bias is None else lib.channel_sums(dz, dz)[0].float()
+        gb = None if self.conv.bias is None else lib.cast_f32(lib.channel_sums(dz, dz)[0])
         gx = None
         if need_input and self.stride == 1:                    # the stride-1 kernel on the flipped, channel-transposed weights
-            wd = w.flip(2, 3).transpose(0, 1).contiguous()
+            wd = lib.weights_flip_transpose(w.contiguous())
             gx = lib.conv2d_layer(lib.conv2d_layer_pack(wd, None, self.cout, self.cin, self.k), self.cout, self.cin, self.k, 1, dz)
-        elif need_input:                                        # transposed 5x5 stride-2 convolution: the library op
-            N, H, W, _ = self.x.shape
-            gx = torch.nn.grad.conv2d_input((N, self.cin, H, W), w, dz.permute(0, 3, 1, 2), self.stride, (self.k - 1) // 2)
-            gx = gx.permute(0, 2, 3, 1).contiguous()
+            if add is not None:
+                gx = lib.add(gx, add)
+        elif need_input:                                        # transposed 5x5 stride-2 convolution (feature_net.py:11,14): four
+            gx = lib.conv2d_s2k5_dgrad(w.contiguous(), dz, add=add)   # parity classes on the stride-1 MFMA kernel + depth-to-space
         return gx, gw, gb
 
 
@@ -454,9 +552,9 @@ class FeatureNetTrainFn(torch.autograd.Function):
             grads[name] = (gw, gb)
             return gx
 
-        def cbr_back(name, g, need_input=True):
+        def cbr_back(name, g, need_input=True, add=None):
             dz, dgamma, dbeta = norm[name].backward(g)
-            gx, gw, _ = conv[name].backward(dz, need_input)
+            gx, gw, _ = conv[name].backward(dz, need_input, add)
             grads[name] = (gw, dgamma, dbeta)
             return gx
         g_f0 = plain_back("smooth0", cl(g_s0))
@@ -465,8 +563,8 @@ class FeatureNetTrainFn(torch.autograd.Function):
         g_c1 = plain_back("lat1", g_f1)
         g_top = lib.up2_adjoint(g_f1, add=cl(g_f2))
         g_c2 = plain_back("toplayer", g_top)
-        g_c1 = g_c1 + cbr_back("conv2.0", cbr_back("conv2.1", g_c2))
-        g_c0 = g_c0 + cbr_back("conv1.0", cbr_back("conv1.1", g_c1))
+        g_c1 = cbr_back("conv2.0", cbr_back("conv2.1", g_c2), add=g_c1)         # the skip branch's gradient rides in the
+        g_c0 = cbr_back("conv1.0", cbr_back("conv1.1", g_c1), add=g_c0)         # depth-to-space pass of the stride-2 dgrad
         cbr_back("conv0.0", cbr_back("conv0.1", g_c0), need_input=False)
         out = []
         for name in _FEAT_ORDER:
@@ -494,18 +592,40 @@ def feature_net_train(lib, m, x):
 _IMAGE_INDEX_CACHE = {}
 
 
-def mlp_backward_images(m, S):
+def mlp_backward_images(m, S, lib=None):
     """Transposed-weight MFMA images of one ``NerfParams`` for enerf_nerf_mlp_bwd, in the kernel's unit / slot layouts
     (mlp_train.hip header).  Returns (flat image tensor, the 8 offsets b1, b2, b3, b4, b5, b6v, b6m, b7).  The index maps
-    only depend on (F, device) and are cached; per step this is eight gathers and one concatenation."""
+    only depend on (F, device) and are cached; per step this is ONE index-gather launch over the five weight tensors
+    (enerf_gather_images) — or, without the library, eight torch gathers and one concatenation."""
     key = (m.feat_ch, str(m.lr0[0].weight.device), hasattr(m.agg, "view_fc"))
     if key not in _IMAGE_INDEX_CACHE:
         _IMAGE_INDEX_CACHE[key] = _mlp_image_indices(m)
     specs = _IMAGE_INDEX_CACHE[key]
     F = m.feat_ch
     col0, glob = m.color[0].weight.detach(), m.agg.global_fc[0].weight.detach()
+    has_view = hasattr(m.agg, "view_fc")
+    if lib is not None:
+        fkey = key + ("flat",)
+        if fkey not in _IMAGE_INDEX_CACHE:
+            # (source tensor, first column, row length) of the eight matrices: element [k, r] of matrix e is
+            # srcs[src][k * ld + col0 + r]
+            ld_c, ld_g = col0.shape[1], glob.shape[1]
+            where = [(0, 88, ld_c), (0, 0, ld_c), (1, 0, 24), (2, 0, 32), (3, 0, ld_g), (3, F, ld_g), (3, 2 * F, ld_g), (4, 0, 4)]
+            which, idx, offs, o = [], [], [], 0
+            for e, ((rows, ks, valid), (src, c0, ld)) in enumerate(zip(specs, where)):
+                ok = valid if (e < 7 or has_view) else torch.zeros_like(valid)
+                flat = torch.where(ok, ks * ld + c0 + rows, -torch.ones_like(rows)).reshape(-1)
+                which.append(torch.full_like(flat, src))
+                idx.append(flat)
+                offs.append(o)
+                o += flat.numel()
+            _IMAGE_INDEX_CACHE[fkey] = (torch.cat(which).int().contiguous(), torch.cat(idx).int().contiguous(), offs)
+        which, idx, offs = _IMAGE_INDEX_CACHE[fkey]
+        srcs = [_c(col0), _c(m.lr0[0].weight.detach()), _c(m.agg.fc[0].weight.detach()), _c(glob)]
+        srcs.append(_c(m.agg.view_fc[0].weight.detach()) if has_view else srcs[0])
+        return lib.gather_images(srcs, which, idx), offs
     mats = [col0[:, 88:], col0[:, :88], m.lr0[0].weight.detach(), m.agg.fc[0].weight.detach(), glob[:, :F], glob[:, F:2 * F],
-            glob[:, 2 * F:], m.agg.view_fc[0].weight.detach() if hasattr(m.agg, "view_fc") else None]
+            glob[:, 2 * F:], m.agg.view_fc[0].weight.detach() if has_view else None]
     imgs, offs, o = [], [], 0
     for W, (rows, ks, valid) in zip(mats, specs):
         if W is None:
@@ -589,7 +709,7 @@ class NerfMlpFn(torch.autograd.Function):
         P, S, XW = x.shape
         F = XW - 4
         packed = ctx.packed
-        bimg, offs = mlp_backward_images(m, S)
+        bimg, offs = mlp_backward_images(m, S, lib)
         g_vox, g_x, sv = lib.nerf_mlp_bwd(vox.contiguous(), x.contiguous(), g_raw.contiguous(), packed, bimg, offs, S, F)
         hv, G, q, gs, a_, vm, d_c, d_q, d_p2, d_s, d_h, d_agg, d_u, d_g, d_gsum, d_v = sv
         PS = P * S
@@ -598,13 +718,13 @@ class NerfMlpFn(torch.autograd.Function):
         # color.2 (1,64) / color.0 (64, 88+F+4) / sigma (1,64) / lr0 (64,24) / fc (16,32) / agg_w (1,32) / global_fc (32,3F) / view_fc (F,4)
         gw["color.2.weight"], gw["color.2.bias"] = lib.gemm_wgrad(d_c.reshape(PS, 1), q.reshape(PS, 64), bias=True)
         w_hv, gw["color.0.bias"] = lib.gemm_wgrad(d_p2, hv, bias=True)
-        gw["color.0.weight"] = torch.cat([w_hv, lib.gemm_wgrad(d_q.reshape(PS, 64), x2)], 1)
+        gw["color.0.weight"] = lib.concat_channels(w_hv, lib.gemm_wgrad(d_q.reshape(PS, 64), x2), 88 + XW)
         gw["sigma.0.weight"], gw["sigma.0.bias"] = lib.gemm_wgrad(d_s.reshape(P, 1), hv, Cb=64, bias=True)
         gw["lr0.0.weight"], gw["lr0.0.bias"] = lib.gemm_wgrad(d_h, hv[:, 64:], bias=True)
         gw["agg.fc.0.weight"], gw["agg.fc.0.bias"] = lib.gemm_wgrad(d_agg, G, bias=True)
         gw["agg.agg_w_fc.0.weight"], gw["agg.agg_w_fc.0.bias"] = lib.gemm_wgrad(d_u.reshape(PS, 1), gs.reshape(PS, 32), bias=True)
         w_vm, gw["agg.global_fc.0.bias"] = lib.gemm_wgrad(d_gsum, vm, bias=True)
-        gw["agg.global_fc.0.weight"] = torch.cat([lib.gemm_wgrad(d_g.reshape(PS, 32), a_.reshape(PS, F)), w_vm], 1)
+        gw["agg.global_fc.0.weight"] = lib.concat_channels(lib.gemm_wgrad(d_g.reshape(PS, 32), a_.reshape(PS, F)), w_vm, 3 * F)
         if m.viewdir_agg:
             gw["agg.view_fc.0.weight"], gw["agg.view_fc.0.bias"] = lib.gemm_wgrad(d_v.reshape(PS, F), x2[:, F:], bias=True)
         grads = [gw.get(n) for n, _ in m.named_parameters()]

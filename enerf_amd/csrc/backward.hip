@@ -235,12 +235,13 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
     }
     float se = 0.f;
     for (int k = 0; k < Ns; ++k) { ws[k] = expf(wt[k] - m); se += ws[k]; }
-    const float gr[3] = {g_rgb[i * 3], g_rgb[i * 3 + 1], g_rgb[i * 3 + 2]};
-    const float gd = g_depth[i];
+    const bool has_rgb = g_rgb != nullptr;             // absent output gradients (nullptr) are zeros
+    const float gr[3] = {has_rgb ? g_rgb[i * 3] : 0.f, has_rgb ? g_rgb[i * 3 + 1] : 0.f, has_rgb ? g_rgb[i * 3 + 2] : 0.f};
+    const float gd = g_depth != nullptr ? g_depth[i] : 0.f;
     float gws[8], dot = 0.f;                            // gradient w.r.t. the softmaxed weights (white_bkgd adds 1 - sum = const)
     for (int k = 0; k < Ns; ++k) {
         ws[k] /= se;
-        gws[k] = g_weights[i * Ns + k] + gd * z[i * Ns + k];
+        gws[k] = (g_weights != nullptr ? g_weights[i * Ns + k] : 0.f) + gd * z[i * Ns + k];
         g_z[i * Ns + k] = gd * ws[k];
         dot += ws[k] * gws[k];
     }
@@ -307,7 +308,7 @@ int enerf_composite_bwd(const float* raw, const float* z, const float* grad_rgb,
                         long long n, int n_samples, float* grad_raw, float* grad_z, enerf_stream_t stream) {
     REQUIRE(n >= 0 && n_samples >= 1 && n_samples <= 8, "composite_bwd: n_samples must be in [1,8]");
     if (n == 0) return ENERF_OK;
-    REQUIRE(raw && z && grad_rgb && grad_depth && grad_weights && grad_raw && grad_z, "composite_bwd: null pointer");
+    REQUIRE(raw && z && grad_raw && grad_z, "composite_bwd: null pointer");        // grad_rgb / grad_depth / grad_weights: NULL = zeros
     launch_composite_bwd(raw, z, grad_rgb, grad_depth, grad_weights, n, n_samples, grad_raw, grad_z, (hipStream_t)stream);
     return check_launch("composite_bwd");
 }

@@ -87,11 +87,15 @@ __global__ __launch_bounds__(256) void k_channel_affine(const float* __restrict_
 __global__ void k_bn_train_coeffs(const double* __restrict__ sums, const double* __restrict__ count_dev, double count_host,
                                   const float* __restrict__ gamma, const float* __restrict__ beta, double eps, double momentum,
                                   float* __restrict__ running_mean, float* __restrict__ running_var,
-                                  const long long* __restrict__ nbt, int C, double* __restrict__ mean_invstd,
+                                  long long* __restrict__ nbt, int nbt_increment, int C, double* __restrict__ mean_invstd,
                                   float* __restrict__ scale_shift) {
     const int c = threadIdx.x;
     const double n = count_dev != nullptr ? *count_dev : count_host;
-    const long long tracked = nbt != nullptr ? *nbt : 1;   // already counts this batch (the caller increments it first)
+    // num_batches_tracked counts this batch: either the caller incremented it already (nbt_increment = 0) or this launch
+    // does (one block: every thread reads the old value, then thread 0 stores old + 1)
+    const long long tracked = nbt != nullptr ? *nbt + nbt_increment : 1;
+    __syncthreads();
+    if (c == 0 && nbt != nullptr && nbt_increment) *nbt = tracked;
     if (c >= C) return;
     const double mean = sums[c] / n;
     double var = sums[C + c] / n - mean * mean;            // biased (normalisation)
@@ -247,13 +251,13 @@ int enerf_channel_sums(const float* a, const float* b, const float* z_mask, cons
     return check_launch("channel_sums");
 }
 int enerf_bn_train_coeffs(const double* sums, const double* count_dev, double count_host, const float* gamma, const float* beta,
-                          double eps, double momentum, float* running_mean, float* running_var, const long long* num_batches_tracked,
-                          int C, double* mean_invstd, float* scale_shift, enerf_stream_t stream) {
+                          double eps, double momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
+                          int increment_num_batches_tracked, int C, double* mean_invstd, float* scale_shift, enerf_stream_t stream) {
     REQUIRE(sums && gamma && beta && mean_invstd && scale_shift && C >= 1 && C <= 256, "bn_train_coeffs: bad arguments (C in 1..256)");
     REQUIRE(count_dev || count_host > 0.0, "bn_train_coeffs: no position count");
     REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_coeffs: running_mean and running_var come together");
-    ENERF_LAUNCH_SIMPLE(k_bn_train_coeffs, 1, 256, 0, (hipStream_t)stream, sums, count_dev, count_host, gamma, beta, eps, momentum,
-                        running_mean, running_var, num_batches_tracked, C, mean_invstd, scale_shift);
+    ENERF_LAUNCH(k_bn_train_coeffs, 1, 256, 0, (hipStream_t)stream, sums, count_dev, count_host, gamma, beta, eps, momentum,
+                        running_mean, running_var, num_batches_tracked, increment_num_batches_tracked, C, mean_invstd, scale_shift);
     return check_launch("bn_train_coeffs");
 }
 int enerf_bn_train_bwd_coeffs(const double* sums_local, const double* sums_global, const double* count_dev, double count_host,

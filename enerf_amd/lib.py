@@ -14,7 +14,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libenerf_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _f = C.c_void_p     # device float*
 _i = C.c_int
@@ -174,10 +174,26 @@ _SIGNATURES = {
     "enerf_conv2d_layer_pack": (_i, [_f, _f, _i, _i, _i, _f, _f]),
     "enerf_conv2d_layer": (_i, [_f, _i, _i, _i, _i, _f, _f, _f, _i, _i, _i, _f]),
     "enerf_channel_sums": (_i, [_f, _f, _f, _f, _f, _ll, _i, C.c_void_p, _f]),
-    "enerf_bn_train_coeffs": (_i, [C.c_void_p, C.c_void_p, C.c_double, _f, _f, C.c_double, C.c_double, _f, _f, C.c_void_p, _i,
+    "enerf_bn_train_coeffs": (_i, [C.c_void_p, C.c_void_p, C.c_double, _f, _f, C.c_double, C.c_double, _f, _f, C.c_void_p, _i, _i,
                                    C.c_void_p, _f, _f]),
     "enerf_bn_train_bwd_coeffs": (_i, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, _f, _i, _f, _f, _f]),
     "enerf_channel_affine": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _ll, _i, _f, _f]),
+    "enerf_conv2d_s2k5_dgrad_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
+    "enerf_conv2d_s2k5_dgrad": (_i, [_f, _i, _i, _f, _f, _f, _i, _i, _i, C.c_void_p, C.c_size_t, _f]),
+    "enerf_resize_ac_adjoint": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f]),
+    "enerf_get_depth_values_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
+    "enerf_ray_samples_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
+    "enerf_ray_samples_bwd": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f]),
+    "enerf_camera_tables": (_i, [_f, _f, _f, _i, _i, _fl, _f, _f, _f]),
+    "enerf_weights_flip_transpose": (_i, [_f, _i, _i, _i, _f, _f]),
+    "enerf_concat2_pad": (_i, [_f, _ll, _f, _ll, _ll, _f, _f]),
+    "enerf_pack_texels_train": (_i, [_f, _i, _f, _i, _i, _i, _i, _i, _f, _f]),
+    "enerf_slice_channels": (_i, [_f, _ll, _i, _i, _i, _f, _f]),
+    "enerf_concat_channels": (_i, [_f, _i, _f, _i, _ll, _i, _f, _f]),
+    "enerf_gather_images": (_i, [C.c_void_p, _i, C.c_void_p, C.c_void_p, _ll, _f, _f]),
+    "enerf_add": (_i, [_f, _f, _ll, _f, _f]),
+    "enerf_cast_f64_f32": (_i, [C.c_void_p, _ll, _f, _f]),
+    "enerf_reciprocal": (_i, [_f, _ll, _f, _f]),
     "enerf_composite": (_i, [_f, _f, _ll, _i, _i, _f, _f, _f, _f]),
     "enerf_composite_bwd": (_i, [_f, _f, _f, _f, _f, _ll, _i, _f, _f, _f]),
     "enerf_gen_rays": (_i, [_f, _f, _i, _i, _i, _fl, _f, _f]),
@@ -516,15 +532,12 @@ class EnerfLib:
         Cc = sums.shape[1]
         mi = torch.empty((2, Cc), dtype=torch.float64, device=sums.device)
         ss = torch.empty((2, Cc), dtype=torch.float32, device=sums.device)
-        track = bn.track_running_stats and bn.running_mean is not None
-        if track:
-            with torch.no_grad():
-                bn.num_batches_tracked.add_(1)
+        track = bn.track_running_stats and bn.running_mean is not None      # (num_batches_tracked += 1 happens in the kernel)
         cd, ch = (count.data_ptr(), 0.0) if torch.is_tensor(count) else (None, float(count))
         self._check(self.dll.enerf_bn_train_coeffs(sums.data_ptr(), cd, ch, _ptr(bn.weight.detach()), _ptr(bn.bias.detach()), float(bn.eps),
                                                    -1.0 if bn.momentum is None else float(bn.momentum),
                                                    _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
-                                                   bn.num_batches_tracked.data_ptr() if track else None, Cc, mi.data_ptr(), _ptr(ss),
+                                                   bn.num_batches_tracked.data_ptr() if track else None, 1, Cc, mi.data_ptr(), _ptr(ss),
                                                    self.stream_of(sums)), "bn_train_coeffs")
         return mi, ss
 
@@ -658,6 +671,125 @@ class EnerfLib:
         gb = self.channel_sums(a_cl, a_cl)[0].float() if fits else a.sum(dim=[0] + list(range(2, a.dim())))
         return gw, gb
 
+    # -- ABI v7: the rest of the training step on the device (train_glue.hip) ----------------------------------------------
+    def conv2d_s2k5_dgrad(self, w, dz, add=None):
+        """Input gradient of Conv2d(cin -> cout, k5, s2, p2): w (cout,cin,5,5), dz (N,Ho,Wo,cout) -> (N,2Ho,2Wo,cin) (+ add)."""
+        cout, cin = w.shape[0], w.shape[1]
+        N, Ho, Wo, _ = dz.shape
+        gx = torch.empty((N, 2 * Ho, 2 * Wo, cin), dtype=torch.float32, device=dz.device)
+        ws = self._scratch(self.dll.enerf_conv2d_s2k5_dgrad_workspace_bytes(cin, cout, N, Ho, Wo), dz.device)
+        self._check(self.dll.enerf_conv2d_s2k5_dgrad(_ptr(w), cin, cout, _ptr(dz), _ptr(add), _ptr(gx), N, Ho, Wo, ws.data_ptr(),
+                                                     ws.numel(), self.stream_of(dz)), "conv2d_s2k5_dgrad")
+        return gx
+
+    def resize_ac_adjoint(self, g_fine, Hc, Wc, add=None):
+        """(..., Hf, Wf) planar gradient maps -> (..., Hc, Wc): adjoint of the align-corners bilinear resize."""
+        lead, (Hf, Wf) = g_fine.shape[:-2], g_fine.shape[-2:]
+        out = torch.empty(tuple(lead) + (Hc, Wc), dtype=torch.float32, device=g_fine.device)
+        self._check(self.dll.enerf_resize_ac_adjoint(_ptr(g_fine), _ptr(add), g_fine.numel() // (Hf * Wf), Hf, Wf, Hc, Wc, _ptr(out),
+                                                     self.stream_of(g_fine)), "resize_ac_adjoint")
+        return out
+
+    def get_depth_values_bwd(self, prev_depth, prev_std, prev_nf, g_dv, depth_inv):
+        """-> (g_depth, g_std) (B,hp,wp): views of one (2,B,hp,wp) buffer."""
+        B, D, h, w = g_dv.shape
+        hp, wp = prev_depth.shape[-2:]
+        g = torch.empty((2, B, hp, wp), dtype=torch.float32, device=g_dv.device)
+        scratch = torch.empty((2, B, h, w), dtype=torch.float32, device=g_dv.device)
+        self._check(self.dll.enerf_get_depth_values_bwd(_ptr(prev_depth), _ptr(prev_std), _ptr(prev_nf), _ptr(g_dv), B, D, h, w, hp, wp,
+                                                        int(depth_inv), _ptr(g), g[1].data_ptr(), _ptr(scratch), self.stream_of(g_dv)),
+                    "get_depth_values_bwd")
+        return g[0], g[1]
+
+    def ray_samples_fwd(self, rays8, depth, std, nf, Ns, Hr, Wr, depth_inv, want_rays12=False):
+        """build_rays + sample_along_depth -> z (B,N,Ns), xyz (B,N,Ns,3), dn (B,N,Ns), uv (B,N,Ns,2)[, rays12 (B,N,12)]."""
+        B, N = rays8.shape[:2]
+        h, w = depth.shape[-2:]
+        E = lambda *sh: torch.empty(sh, dtype=torch.float32, device=rays8.device)
+        z, xyz, dn, uv = E(B, N, Ns), E(B, N, Ns, 3), E(B, N, Ns), E(B, N, Ns, 2)
+        r12 = E(B, N, 12) if want_rays12 else None
+        self._check(self.dll.enerf_ray_samples_fwd(_ptr(rays8), _ptr(depth), _ptr(std), _ptr(nf), B, N, Ns, h, w, Hr, Wr, int(depth_inv),
+                                                   _ptr(z), _ptr(xyz), _ptr(dn), _ptr(uv), _ptr(r12), self.stream_of(rays8)),
+                    "ray_samples_fwd")
+        return (z, xyz, dn, uv, r12) if want_rays12 else (z, xyz, dn, uv)
+
+    def ray_samples_bwd(self, rays8, depth, std, nf, g_xyz, g_dn, Ns, Hr, Wr, depth_inv):
+        B, N = rays8.shape[:2]
+        h, w = depth.shape[-2:]
+        g = torch.empty((2, B, h, w), dtype=torch.float32, device=rays8.device)
+        self._check(self.dll.enerf_ray_samples_bwd(_ptr(rays8), _ptr(depth), _ptr(std), _ptr(nf), _ptr(g_xyz), _ptr(g_dn), B, N, Ns, h, w,
+                                                   Hr, Wr, int(depth_inv), _ptr(g), g[1].data_ptr(), self.stream_of(rays8)),
+                    "ray_samples_bwd")
+        return g[0], g[1]
+
+    def camera_tables(self, src_ixts, src_exts, tar_ext, render_scale):
+        B, S = src_exts.shape[:2]
+        cam = torch.empty((B, S, 16), dtype=torch.float32, device=src_exts.device)
+        tcen = torch.empty((B, 4), dtype=torch.float32, device=src_exts.device)
+        self._check(self.dll.enerf_camera_tables(_ptr(src_ixts), _ptr(src_exts), _ptr(tar_ext), B, S, float(render_scale), _ptr(cam),
+                                                 _ptr(tcen), self.stream_of(src_exts)), "camera_tables")
+        return cam, tcen
+
+    def weights_flip_transpose(self, w):
+        """w (cout,cin,*k) -> (cin,cout,*k) with every spatial axis reversed: the dgrad weights of a stride-1 convolution."""
+        cout, cin = w.shape[:2]
+        taps = w.numel() // (cout * cin)
+        out = torch.empty((cin, cout) + tuple(w.shape[2:]), dtype=torch.float32, device=w.device)
+        self._check(self.dll.enerf_weights_flip_transpose(_ptr(w), cout, cin, taps, _ptr(out), self.stream_of(w)), "weights_flip_transpose")
+        return out
+
+    def concat2_pad(self, a, b, n):
+        out = torch.empty((n,), dtype=torch.float32, device=a.device)
+        self._check(self.dll.enerf_concat2_pad(_ptr(a), a.numel(), _ptr(b), 0 if b is None else b.numel(), n, _ptr(out), self.stream_of(a)),
+                    "concat2_pad")
+        return out
+
+    def pack_texels_train(self, feat_cl, src_inps, Hr, Wr):
+        """feat_cl (n,Hr,Wr,C) channels-last, src_inps (n,3,H,W) -> tex (n,Hr,Wr,C+3)."""
+        n, _, _, Cc = feat_cl.shape
+        H, W = src_inps.shape[-2:]
+        tex = torch.empty((n, Hr, Wr, Cc + 3), dtype=torch.float32, device=feat_cl.device)
+        self._check(self.dll.enerf_pack_texels_train(_ptr(feat_cl), Cc, _ptr(src_inps), H, W, Hr, Wr, n, _ptr(tex), self.stream_of(tex)),
+                    "pack_texels_train")
+        return tex
+
+    def slice_channels(self, src, c0, Cc):
+        F = src.shape[-1]
+        dst = torch.empty(tuple(src.shape[:-1]) + (Cc,), dtype=torch.float32, device=src.device)
+        self._check(self.dll.enerf_slice_channels(_ptr(src), src.numel() // F, F, c0, Cc, _ptr(dst), self.stream_of(src)), "slice_channels")
+        return dst
+
+    def concat_channels(self, a, b, Cc):
+        """a (..., Ca), b (..., Cb) or None -> (..., Cc) = [a | b | 0]."""
+        Ca, Cb = a.shape[-1], 0 if b is None else b.shape[-1]
+        out = torch.empty(tuple(a.shape[:-1]) + (Cc,), dtype=torch.float32, device=a.device)
+        self._check(self.dll.enerf_concat_channels(_ptr(a), Ca, _ptr(b), Cb, a.numel() // Ca, Cc, _ptr(out), self.stream_of(a)),
+                    "concat_channels")
+        return out
+
+    def gather_images(self, srcs, which, idx):
+        """out[i] = idx[i] >= 0 ? srcs[which[i]].flatten()[idx[i]] : 0; srcs: <= 8 contiguous float tensors; which/idx int32."""
+        arr = (C.c_void_p * len(srcs))(*[_ptr(t) for t in srcs])
+        out = torch.empty((idx.numel(),), dtype=torch.float32, device=idx.device)
+        self._check(self.dll.enerf_gather_images(C.cast(arr, C.c_void_p), len(srcs), which.data_ptr(), idx.data_ptr(), idx.numel(), _ptr(out),
+                                                 self.stream_of(out)), "gather_images")
+        return out
+
+    def cast_f32(self, x64):
+        out = torch.empty(x64.shape, dtype=torch.float32, device=x64.device)
+        self._check(self.dll.enerf_cast_f64_f32(x64.data_ptr(), x64.numel(), _ptr(out), self.stream_of(out)), "cast_f64_f32")
+        return out
+
+    def reciprocal(self, x):
+        out = torch.empty_like(x)
+        self._check(self.dll.enerf_reciprocal(_ptr(x), x.numel(), _ptr(out), self.stream_of(x)), "reciprocal")
+        return out
+
+    def add(self, a, b):
+        out = torch.empty_like(a)
+        self._check(self.dll.enerf_add(_ptr(a), _ptr(b), a.numel(), _ptr(out), self.stream_of(a)), "add")
+        return out
+
     def composite(self, raw, z, white_bkgd=False):
         n, Ns = z.shape
         rgb = torch.empty((n, 3), dtype=torch.float32, device=raw.device)
@@ -670,7 +802,7 @@ class EnerfLib:
     def composite_bwd(self, raw, z, g_rgb, g_depth, g_weights):
         n, Ns = z.shape
         g_raw, g_z = torch.empty_like(raw), torch.empty_like(z)
-        self._check(self.dll.enerf_composite_bwd(_ptr(raw), _ptr(z), _ptr(g_rgb), _ptr(g_depth), _ptr(g_weights), n, Ns,
+        self._check(self.dll.enerf_composite_bwd(_ptr(raw), _ptr(z), _ptr(g_rgb), _ptr(g_depth), _ptr(g_weights), n, Ns,   # None = zeros
                                                  _ptr(g_raw), _ptr(g_z), self.stream_of(raw)), "composite_bwd")
         return g_raw, g_z
 

@@ -6,8 +6,9 @@ kernels, clip, Adam) whose GPU time (~35 ms) is no longer than the time Python +
 captured once — forward, loss, backward, gradient clip and optimizer update — and replayed with new batch contents copied
 into the captured input buffers.
 
-What stays outside the graph: the camera-only tables (train_path.camera_tables: 4x4 inverses — torch.inverse synchronises,
-which a capture does not allow); they are recomputed eagerly before every replay into the buffers the graph reads.
+Nothing of the step stays outside the graph: the camera-only tables (train_path.camera_tables: 4x4 inverses) are device
+kernels since ABI v7 (enerf_get_proj_mats, enerf_camera_tables).  Only with the HIP stages switched off
+(``net.hip_backward = False``: torch.inverse synchronises) are they recomputed eagerly before every replay.
 
 DATA-PARALLEL (trainer.py:15-22; ``distributed=True``): the same ONE graph per rank, with the collectives inside it.
 DistributedDataParallel's reducer (autograd hooks, bucket views, a host-side bookkeeping pass per step) is an eager-step
@@ -133,7 +134,11 @@ class GraphedTrainStep:
             self.sync.broadcast()
         self.static = {k: v.clone() for k, v in example_batch.items() if torch.is_tensor(v)}
         self.extra = {k: v for k, v in example_batch.items() if not torch.is_tensor(v)}
-        self.tables = {k: v.clone() for k, v in camera_tables(net.cfg.cas, self.static).items()}
+        # camera tables: with the HIP library the 4x4 inverses are device kernels inside the step (captured with it); without it
+        # (net.hip_backward = False) torch.inverse synchronises, so they are computed eagerly before each replay
+        from .train_path import _hip_lib
+        self._tables_in_graph = _hip_lib(net, next(iter(self.static.values()))) is not None
+        self.tables = None if self._tables_in_graph else {k: v.clone() for k, v in camera_tables(net.cfg.cas, self.static).items()}
         self._params = [p for p in net.parameters() if p.requires_grad]
         pristine_net = [(t, t.clone()) for t in net.state_dict().values()]
         pristine_opt = {id(t): t.clone() for st in optimizer.state.values() for t in st.values() if torch.is_tensor(t)}
@@ -234,7 +239,7 @@ class GraphedTrainStep:
         self.net.invalidate_packed()
 
     def _eager_step(self, zero: bool = True):
-        batch = dict(self.static, camera_tables=self.tables, **self.extra)
+        batch = dict(self.static, **self.extra) if self.tables is None else dict(self.static, camera_tables=self.tables, **self.extra)
         return train_step(self.net, self.opt, self.loss_fn, batch, self.clip, self.sync, zero, self._params)
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
@@ -242,8 +247,9 @@ class GraphedTrainStep:
             src = batch[k]
             if src.data_ptr() != dst.data_ptr():
                 dst.copy_(src, non_blocking=True)
-        for k, v in camera_tables(self.net.cfg.cas, self.static).items():
-            self.tables[k].copy_(v)
+        if self.tables is not None:
+            for k, v in camera_tables(self.net.cfg.cas, self.static).items():
+                self.tables[k].copy_(v)
         self.graph.replay()
         self.net.invalidate_packed()                       # the inference weight images are stale after every update
         return self.loss

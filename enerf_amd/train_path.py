@@ -290,43 +290,64 @@ def raw2outputs(raw, z, white_bkgd=False):
     return {"rgb": rgb, "depth": depth, "weights": w}
 
 
-def camera_tables(cas, batch) -> Dict[str, torch.Tensor]:
+def camera_tables(cas, batch, lib=None) -> Dict[str, torch.Tensor]:
     """Everything the step derives from the cameras alone (the matrix inverses live here): the warp matrices of each
     level and the per-view constants of the render-side fetches.  forward_train computes it unless the batch already
-    carries it under "camera_tables" — a captured training step (enerf_amd/train_graph.py) runs it eagerly before each
-    replay, because torch.inverse synchronises and cannot be captured."""
+    carries it under "camera_tables".  With the library the 4x4 inverses run on the device (enerf_get_proj_mats,
+    enerf_camera_tables: 2-4 launches, capturable); the torch twin (torch.inverse: synchronises) stays for lib=None."""
     from .autograd import gather_cameras
     t: Dict[str, torch.Tensor] = {}
     for i in range(cas.num):
-        t[f"proj_{i}"] = proj_mats(batch, cas.im_feat_scale[i], cas.volume_scale[i])
+        if lib is not None:      # the inference path's kernel (fp64 inverse on the device: no host synchronisation)
+            t[f"proj_{i}"] = lib.get_proj_mats(batch["src_ixts"], batch["src_exts"], batch["tar_ixt"], batch["tar_ext"],
+                                               cas.im_feat_scale[i], cas.volume_scale[i])
+        else:
+            t[f"proj_{i}"] = proj_mats(batch, cas.im_feat_scale[i], cas.volume_scale[i])
         if cas.render_if[i]:
-            t[f"cam_{i}"], t["tcen"] = gather_cameras(batch, cas.render_scale[i])
+            t[f"cam_{i}"], t["tcen"] = gather_cameras(batch, cas.render_scale[i], lib)
     return t
 
 
-def render_rays(net, rays, level, batch, im_feat, feat_vol, lib=None, tables=None):
-    """Network.render_rays (network.py:24-43), differentiable: rays (B,N,12), im_feat (B,S,C,Hf,Wf), feat_vol (B,8,D,h,w)."""
+def render_rays(net, rays, level, batch, im_feat, feat_vol, lib=None, tables=None, maps=None):
+    """Network.render_rays (network.py:24-43), differentiable: rays (B,N,12), im_feat (B,S,C,Hf,Wf), feat_vol (B,8,D,h,w).
+    ``maps`` = (depth, std, near_far) of the level: with the library, build_rays + sample_along_depth run as ONE kernel pair
+    (RaySamplesFn) on the 8-float rays and ``rays`` may be the batch's (B,N,8) list."""
     cas = net.cfg.cas
     Ns = cas.num_samples[level]
-    xyz, uvd, z = sample_along_depth(cas, rays, Ns, level)
     B, N = rays.shape[:2]
     src = batch["src_inps"]
     S, H, W = src.shape[1], src.shape[-2], src.shape[-1]
     rs = cas.render_scale[level]
-    rgbs = _resize_ac((src * 0.5 + 0.5).reshape(B * S, 3, H, W), rs, True)
     Hr, Wr = int(H * rs), int(W * rs)
-    rgbs = rgbs.reshape(B, S, 3, Hr, Wr)
     up = rs / cas.im_ibr_scale[level]
-    if up != 1.0:
-        b, s, c, h, w = im_feat.shape
-        im_feat = _resize_ac(im_feat.reshape(b * s, c, h, w), up).view(b, s, c, int(h * up), int(w * up))
-    tex = torch.cat([im_feat, rgbs], 2)
-    if lib is not None and getattr(net, "hip_gather", True):
-        from .autograd import GatherFn, gather_cameras
-        cam, tcen = (tables[f"cam_{level}"], tables["tcen"]) if tables is not None else gather_cameras(batch, rs)
-        x, vox = GatherFn.apply(lib, xyz.reshape(B, N * Ns, 3), uvd[..., 2].reshape(B, N * Ns),
-                                uvd[..., :2].reshape(B, N * Ns, 2), tex, feat_vol, cam, tcen)
+    hip_geo = lib is not None and maps is not None and getattr(net, "hip_geometry", True)
+    if hip_geo:
+        from .autograd import RaySamplesFn
+        z, xyz, dn, uv = RaySamplesFn.apply(lib, maps[0], maps[1], maps[2], rays, Ns, Hr, Wr, bool(cas.depth_inv[level]))
+        uvd = None
     else:
+        xyz, uvd, z = sample_along_depth(cas, rays, Ns, level)
+        dn, uv = uvd[..., 2], uvd[..., :2]
+    hip_gather = lib is not None and getattr(net, "hip_gather", True)
+    if hip_gather and hip_geo and up == 1.0 and tuple(im_feat.shape[-2:]) == (Hr, Wr):
+        from .autograd import TexelsFn
+        tex_cl = TexelsFn.apply(lib, im_feat, src, Hr, Wr)                 # channels-last texels, one launch
+        tex = None
+    else:
+        rgbs = _resize_ac((src * 0.5 + 0.5).reshape(B * S, 3, H, W), rs, True).reshape(B, S, 3, Hr, Wr)
+        if up != 1.0:
+            b, s, c, h, w = im_feat.shape
+            im_feat = _resize_ac(im_feat.reshape(b * s, c, h, w), up).view(b, s, c, int(h * up), int(w * up))
+        tex = torch.cat([im_feat, rgbs], 2)
+        tex_cl = tex.permute(0, 1, 3, 4, 2) if hip_gather else None
+    if hip_gather:
+        from .autograd import GatherFn, gather_cameras
+        cam, tcen = (tables[f"cam_{level}"], tables["tcen"]) if tables is not None else gather_cameras(batch, rs, lib)
+        x, vox = GatherFn.apply(lib, xyz.reshape(B, N * Ns, 3), dn.reshape(B, N * Ns), uv.reshape(B, N * Ns, 2), tex_cl,
+                                feat_vol.permute(0, 2, 3, 4, 1), cam, tcen)
+    else:
+        if uvd is None:
+            uvd = torch.cat([uv, dn[..., None]], -1)
         nd = torch.stack([uvd[..., 0] / (Wr - 1), uvd[..., 1] / (Hr - 1), uvd[..., 2]], -1)      # network.py:36-38
         g = nd.reshape(B, 1, 1, N * Ns, 3) * 2.0 - 1.0
         vox = F.grid_sample(feat_vol, g, align_corners=True)[:, :, 0, 0].permute(0, 2, 1)        # get_vox_feat utils.py:456-458
@@ -368,9 +389,21 @@ def forward_train(net, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor
     ret: Dict[str, torch.Tensor] = {}
     depth: Optional[torch.Tensor] = None
     std = near_far = None
-    tables = batch["camera_tables"] if "camera_tables" in batch else camera_tables(cas, batch)
+    tables = batch["camera_tables"] if "camera_tables" in batch else camera_tables(cas, batch, lib)
+    hip_geo = lib is not None and getattr(net, "hip_geometry", True)
     for i in range(cas.num):
-        dv, near_far = depth_values(cas, batch, i, cas.volume_planes[i], depth, std, near_far)
+        if hip_geo:      # get_depth_values on the inference kernel; level > 0 differentiable in the previous depth / std
+            from .autograd import DepthValuesFn
+            hv, wv = int(H * cas.volume_scale[i]), int(W * cas.volume_scale[i])
+            if depth is None:
+                dv, near_far = lib.get_depth_values(batch["near_far"], None, B, cas.volume_planes[i], hv, wv, cas.depth_inv[i])
+            else:
+                if not cas.depth_inv[i - 1]:
+                    raise RuntimeError("cascade levels after a depth-space level are undefined in the reference (utils.py:130)")
+                dv, near_far = DepthValuesFn.apply(lib, depth, std, near_far, batch["near_far"], cas.volume_planes[i], hv, wv,
+                                                   bool(cas.depth_inv[i]))
+        else:
+            dv, near_far = depth_values(cas, batch, i, cas.volume_planes[i], depth, std, near_far)
         P = tables[f"proj_{i}"]
         vol = FeatureVolumeFn.apply(lib, feats[f"level_{i}"], P, dv) if lib is not None else feature_volume(feats[f"level_{i}"], P, dv)
         reg = getattr(net, f"cost_reg_{i}")
@@ -386,10 +419,18 @@ def forward_train(net, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor
             else depth_regression(cas, prob, dv, i)
         if not cas.render_if[i]:
             continue
-        rays = build_rays(cas, depth, std, batch[f"rays_{i}"], near_far, i)
         # network_human.py:90 only compacts rays in eval mode (`not self.training`): training renders every ray
-        out = render_rays(net, rays, i, batch, feats[f"level_{cas.render_im_feat_level[i]}"], feat3d, lib, tables)
-        out["depth_mvs"] = 1.0 / depth if cas.depth_inv[i] else depth
+        if hip_geo:      # build_rays + sample_along_depth inside render_rays, as one kernel pair on the 8-float rays
+            out = render_rays(net, batch[f"rays_{i}"], i, batch, feats[f"level_{cas.render_im_feat_level[i]}"], feat3d, lib, tables,
+                              maps=(depth, std, near_far))
+        else:
+            rays = build_rays(cas, depth, std, batch[f"rays_{i}"], near_far, i)
+            out = render_rays(net, rays, i, batch, feats[f"level_{cas.render_im_feat_level[i]}"], feat3d, lib, tables)
+        if cas.depth_inv[i] and lib is not None:
+            from .autograd import ReciprocalFn
+            out["depth_mvs"] = ReciprocalFn.apply(lib, depth)
+        else:
+            out["depth_mvs"] = 1.0 / depth if cas.depth_inv[i] else depth
         out["std"] = std
         ret.update({f"{k}_level{i}": v for k, v in out.items()})
     return ret

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ENERF_ABI_VERSION 6
+#define ENERF_ABI_VERSION 7
 #define ENERF_OK 0
 #define ENERF_EINVAL (-1)   /* bad argument / unsupported shape */
 #define ENERF_ELAUNCH (-2)  /* HIP launch error */
@@ -357,13 +357,14 @@ int enerf_channel_sums(const float* a, const float* b, const float* z_mask, cons
  *       forward  sums = [sum z, sum z^2] (2C), position count (device scalar count_dev, or count_host when NULL) ->
  *                mean_invstd (2C fp64), scale_shift (2C: gamma*invstd, beta - mean*gamma*invstd); running_mean/var (optional)
  *                updated in place with the unbiased variance, momentum < 0 = cumulative average 1/num_batches_tracked
- *                (int64 device scalar that already counts this batch; only read);
+ *                (int64 device scalar; increment_num_batches_tracked = 1 (ABI v7): this launch adds the batch to it first,
+ *                0: the caller already did);
  *       backward sums_local / sums_global = [sum g*m, sum g*m*z] of this rank / of all ranks (the same pointer without
  *                SyncBatchNorm) -> dgamma_dbeta (2C, from the local sums: DDP averages parameter gradients) and k2k3 (2C):
  *                d z = g*m*scale + z*k2 + k3 (enerf_channel_affine). */
 int enerf_bn_train_coeffs(const double* sums, const double* count_dev, double count_host, const float* gamma, const float* beta,
-                          double eps, double momentum, float* running_mean, float* running_var, const long long* num_batches_tracked,
-                          int C, double* mean_invstd, float* scale_shift, enerf_stream_t stream);
+                          double eps, double momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
+                          int increment_num_batches_tracked, int C, double* mean_invstd, float* scale_shift, enerf_stream_t stream);
 int enerf_bn_train_bwd_coeffs(const double* sums_local, const double* sums_global, const double* count_dev, double count_host,
                               const double* mean_invstd, const float* scale, int C, float* dgamma_dbeta, float* k2k3,
                               enerf_stream_t stream);
@@ -422,6 +423,60 @@ int enerf_composite(const float* raw, const float* z, long long n, int n_samples
                     float* weights, enerf_stream_t stream);
 int enerf_composite_bwd(const float* raw, const float* z, const float* grad_rgb, const float* grad_depth, const float* grad_weights,
                         long long n, int n_samples, float* grad_raw, float* grad_z, enerf_stream_t stream);
+
+/* ---- ABI v7: the rest of the training step: what was still eager PyTorch after ABI v6 ----
+ *   enerf_conv2d_s2k5_dgrad   input gradient of Conv2d(cin->cout, k5, s2, p2) (feature_net.py:11,14; 8->16 and 16->32):
+ *       w (cout,cin,5,5) torch layout, dz (N,Ho,Wo,cout) channels-last -> gx (N,2Ho,2Wo,cin) (+ add, optional, same shape).
+ *       Four output-parity classes = one stride-1 3x3 launch of the inference MFMA kernel with 4*cin output channels + a
+ *       depth-to-space pass; scratch from the caller (enerf_conv2d_s2k5_dgrad_workspace_bytes).
+ *   enerf_resize_ac_adjoint   adjoint of F.interpolate(bilinear, align_corners=True) on planar maps (n_maps,Hf,Wf) ->
+ *       (n_maps,Hc,Wc) (+ add), gather form, any scale >= 1 (utils.py:115-117, 394-396).
+ *   enerf_get_depth_values_bwd  get_depth_values (utils.py:98-151), level > 0: grad_dv (B,D,h,w) -> grad_depth / grad_std
+ *       (the two halves of ONE (2,B,hp,wp) buffer) of the previous level's maps; clamped entries (utils.py:122-127) carry no
+ *       gradient, near_far is detached (utils.py:148).  scratch: 2*B*h*w floats.
+ *   enerf_ray_samples_fwd/bwd   build_rays + sample_along_depth (utils.py:390-441): rays8 (B,N,8), depth/std (B,h,w),
+ *       near_far (B,2,h,w) -> z (B,N,Ns), xyz (B,N,Ns,3), dn (B,N,Ns), uv (B,N,Ns,2), rays12 (B,N,12; optional).
+ *       bwd: grad_xyz, grad_dn -> grad_depth, grad_std (B,h,w) (zeroed here, scatter-added with the rays' bilinear taps).
+ *   enerf_camera_tables        the per-view constants of enerf_gather_* (utils.py:697-704, 712-715): cam (B,S,16) =
+ *       K'E[:3,:3] | K't | source camera centre | 0, tcen (B,4); fp64 products / 4x4 inverses on the device.
+ *   enerf_weights_flip_transpose  w (cout,cin,taps) -> (cin,cout,taps) with the taps reversed (dgrad weights, stride 1).
+ *   enerf_concat2_pad          out (n) = [a (na) | b (nb) | 0]  (feat_conv ++ depth_conv ++ zero rows).
+ *   enerf_pack_texels_train    tex (n,Hr,Wr,C+3) = [feat_cl (n,Hr,Wr,C) | bilinear_ac(src*0.5+0.5) (3)] (network.py:28-33).
+ *   enerf_slice_channels       dst (n,C) = src (n,F)[:, c0:c0+C].
+ *   enerf_concat_channels      out (n,C) = [a (n,Ca) | b (n,Cb) | 0]  (the fused heads' gradient from d feat and d prob).
+ *   enerf_gather_images        out[i] = idx[i] >= 0 ? srcs[which[i]][idx[i]] : 0 over <= 8 source tensors (the transposed-
+ *       weight images of enerf_nerf_mlp_bwd in one launch).
+ *   enerf_add                  out = a + b.
+ *   enerf_cast_f64_f32         out (n) fp32 = in (n) fp64 (bias gradients come out of enerf_channel_sums in fp64).
+ *   enerf_reciprocal           out = 1 / x  (depth_mvs of a disparity-space level, network.py:105-108).
+ *   enerf_composite_bwd        (changed) grad_rgb / grad_depth / grad_weights may be NULL = zeros (outputs the loss ignores). */
+size_t enerf_conv2d_s2k5_dgrad_workspace_bytes(int cin, int cout, int N, int Ho, int Wo);
+int enerf_conv2d_s2k5_dgrad(const float* w, int cin, int cout, const float* dz, const float* add, float* gx, int N, int Ho, int Wo,
+                            void* workspace, size_t workspace_bytes, enerf_stream_t stream);
+int enerf_resize_ac_adjoint(const float* grad_fine, const float* add, int n_maps, int Hf, int Wf, int Hc, int Wc, float* grad_coarse,
+                            enerf_stream_t stream);
+int enerf_get_depth_values_bwd(const float* prev_depth, const float* prev_std, const float* prev_near_far, const float* grad_dv, int B,
+                               int D, int h, int w, int hp, int wp, int depth_inv, float* grad_depth, float* grad_std, float* scratch,
+                               enerf_stream_t stream);
+int enerf_ray_samples_fwd(const float* rays8, const float* depth, const float* std, const float* near_far, int B, int N, int n_samples,
+                          int h, int w, int Hr, int Wr, int depth_inv, float* z, float* xyz, float* dn, float* uv, float* rays12,
+                          enerf_stream_t stream);
+int enerf_ray_samples_bwd(const float* rays8, const float* depth, const float* std, const float* near_far, const float* grad_xyz,
+                          const float* grad_dn, int B, int N, int n_samples, int h, int w, int Hr, int Wr, int depth_inv,
+                          float* grad_depth, float* grad_std, enerf_stream_t stream);
+int enerf_camera_tables(const float* src_ixts, const float* src_exts, const float* tar_ext, int B, int S, float render_scale, float* cam,
+                        float* tcen, enerf_stream_t stream);
+int enerf_weights_flip_transpose(const float* w, int cout, int cin, int taps, float* out, enerf_stream_t stream);
+int enerf_concat2_pad(const float* a, long long na, const float* b, long long nb, long long n, float* out, enerf_stream_t stream);
+int enerf_pack_texels_train(const float* feat_cl, int C, const float* src_inps, int H, int W, int Hr, int Wr, int n_img, float* tex,
+                            enerf_stream_t stream);
+int enerf_slice_channels(const float* src, long long n, int F, int c0, int C, float* dst, enerf_stream_t stream);
+int enerf_concat_channels(const float* a, int Ca, const float* b, int Cb, long long n, int C, float* out, enerf_stream_t stream);
+int enerf_gather_images(const float* const* srcs, int n_srcs, const int* which, const int* idx, long long n, float* out,
+                        enerf_stream_t stream);
+int enerf_add(const float* a, const float* b, long long n, float* out, enerf_stream_t stream);
+int enerf_cast_f64_f32(const double* in, long long n, float* out, enerf_stream_t stream);
+int enerf_reciprocal(const float* x, long long n, float* out, enerf_stream_t stream);
 
 /* ---- the steps before / after the path ----
  * Before (ray generation, view selection):

@@ -1,0 +1,164 @@
+"""ABI v7 (train_glue.hip): the parts of the training step that were eager PyTorch ops until round 3, each against its torch
+twin — the very expressions enerf_amd/train_path.py ran before (which restate utils.py:98-151, 390-441; feature_net.py:11,14).
+CPU: the kernel sources on the lane emulator.  GPU (-m gpu): the product library."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from enerf_amd import train_path as TP
+from enerf_amd.config import EnerfConfig
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-12))
+
+
+def _check_s2k5_dgrad(lib, dev):
+    g = torch.Generator().manual_seed(0)
+    for cin, cout, N, H, W in ((8, 16, 2, 24, 40), (16, 32, 3, 16, 36), (8, 16, 1, 64, 96)):
+        w = (torch.randn(cout, cin, 5, 5, generator=g) * 0.1).to(dev)
+        dz = torch.randn(N, H // 2, W // 2, cout, generator=g).to(dev)
+        add = torch.randn(N, H, W, cin, generator=g).to(dev)
+        ref = torch.nn.grad.conv2d_input((N, cin, H, W), w.cpu(), dz.cpu().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+        got = lib.conv2d_s2k5_dgrad(w, dz)
+        assert got.shape == (N, H, W, cin)
+        assert _rel(got, ref) < 2e-5, (cin, cout, _rel(got, ref))
+        got = lib.conv2d_s2k5_dgrad(w, dz, add=add)
+        assert _rel(got, ref + add.cpu()) < 2e-5
+
+
+def _check_resize_adjoint(lib, dev):
+    g = torch.Generator().manual_seed(1)
+    for (hc, wc), k in (((8, 10), 2), ((6, 9), 4), ((5, 7), 1), ((7, 3), 3)):
+        x = torch.randn(3, 2, hc, wc, generator=g, requires_grad=True)
+        y = F.interpolate(x, None, scale_factor=k, mode="bilinear", align_corners=True, recompute_scale_factor=True) if k != 1 else x * 1.0
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        add = torch.randn(3, 2, hc, wc, generator=g)
+        got = lib.resize_ac_adjoint(gy.to(dev).contiguous(), hc, wc)
+        assert _rel(got, x.grad) < 1e-5, (hc, wc, k, _rel(got, x.grad))
+        got = lib.resize_ac_adjoint(gy.to(dev).contiguous(), hc, wc, add=add.to(dev))
+        assert _rel(got, x.grad + add) < 1e-5
+
+
+def _level_inputs(g, B, hp, wp, clamp_share=0.4):
+    """Previous-level maps in disparity space with a share of the pixels on each clamp (utils.py:122-127)."""
+    nf0 = 1.0 / (425.0 + 20 * torch.rand(B, hp, wp, generator=g))
+    nf1 = 1.0 / (905.0 - 20 * torch.rand(B, hp, wp, generator=g))
+    depth = nf1 + (nf0 - nf1) * torch.rand(B, hp, wp, generator=g)
+    std = (nf0 - nf1) * (0.02 + clamp_share * torch.rand(B, hp, wp, generator=g))
+    return depth, std, torch.stack([nf0, nf1], 1)
+
+
+def _check_depth_values_bwd(lib, dev):
+    g = torch.Generator().manual_seed(2)
+    for depth_inv_level in (False, True):
+        cas = EnerfConfig().with_cas(depth_inv=(True, depth_inv_level), volume_planes=(8, 8)).cas
+        B, H, W = 2, 64, 96
+        hp, wp = int(H * cas.volume_scale[0]), int(W * cas.volume_scale[0])
+        depth, std, nf = _level_inputs(g, B, hp, wp)
+        depth.requires_grad_(True); std.requires_grad_(True)
+        batch = {"near_far": torch.tensor([[425.0, 905.0]] * B), "src_inps": torch.zeros(B, 3, 3, H, W)}
+        dv, out_nf = TP.depth_values(cas, batch, 1, 8, depth, std, nf)
+        gdv = torch.randn(dv.shape, generator=g)
+        dv.backward(gdv)
+        h, w = dv.shape[-2:]
+        # forward twin: the inference kernel
+        dv_k, nf_k = lib.get_depth_values(batch["near_far"].to(dev), (depth.detach().to(dev), std.detach().to(dev), nf.to(dev)), B, 8, h, w,
+                                          depth_inv_level)
+        assert _rel(dv_k, dv) < 1e-6 and _rel(nf_k, out_nf) < 1e-6
+        gd, gs = lib.get_depth_values_bwd(depth.detach().to(dev), std.detach().to(dev), nf.to(dev), gdv.to(dev), depth_inv_level)
+        clamped = float(((depth + std > nf[:, 0]) | (depth - std < nf[:, 1])).float().mean())
+        assert clamped > 0.1                                            # the case exercises the masked branches
+        assert _rel(gd, depth.grad) < 2e-5 and _rel(gs, std.grad) < 2e-5, (depth_inv_level, _rel(gd, depth.grad), _rel(gs, std.grad))
+
+
+def _check_ray_samples(lib, dev):
+    g = torch.Generator().manual_seed(3)
+    for level, Ns, same in ((0, 8, False), (1, 2, False), (1, 1, False), (0, 4, True)):
+        cas = EnerfConfig().cas
+        depth_inv = cas.depth_inv[level]
+        B, h, w = 2, 12, 20
+        k = 1 if same else 2
+        Hr, Wr = h * k, w * k
+        if depth_inv:
+            depth, std, nf = _level_inputs(g, B, h, w)
+        else:
+            nf0 = 425.0 + 50 * torch.rand(B, h, w, generator=g)
+            nf1 = nf0 + 100 + 50 * torch.rand(B, h, w, generator=g)
+            depth = nf0 + (nf1 - nf0) * torch.rand(B, h, w, generator=g)
+            std = (nf1 - nf0) * (0.02 + 0.4 * torch.rand(B, h, w, generator=g))
+            nf = torch.stack([nf0, nf1], 1)
+        depth.requires_grad_(True); std.requires_grad_(True)
+        N = 301
+        uu = torch.randint(0, Wr, (B, N), generator=g).float()
+        vv = torch.randint(0, Hr, (B, N), generator=g).float()
+        rays8 = torch.cat([torch.randn(B, N, 3, generator=g) * 10, torch.randn(B, N, 3, generator=g), uu[..., None], vv[..., None]], -1)
+        cas_l = EnerfConfig().with_cas(render_scale=(float(k) * cas.volume_scale[0], float(k) * cas.volume_scale[1])).cas
+        rays12 = TP.build_rays(cas_l, depth, std, rays8, nf, level)
+        xyz, uvd, z = TP.sample_along_depth(cas_l, rays12, Ns, level)
+        gx, gd = torch.randn(xyz.shape, generator=g), torch.randn(z.shape, generator=g)
+        (xyz * gx).sum().add((uvd[..., 2] * gd).sum()).backward()
+        a = lambda t: t.detach().to(dev).contiguous()
+        zk, xk, dnk, uvk, r12 = lib.ray_samples_fwd(a(rays8), a(depth), a(std), a(nf), Ns, Hr, Wr, depth_inv, want_rays12=True)
+        assert _rel(r12, rays12) < 1e-6 and _rel(zk, z) < 1e-6 and _rel(xk, xyz) < 2e-6 and _rel(dnk, uvd[..., 2]) < 1e-5
+        assert torch.equal(uvk.cpu(), uvd[..., :2].contiguous())
+        gdk, gsk = lib.ray_samples_bwd(a(rays8), a(depth), a(std), a(nf), a(gx), a(gd), Ns, Hr, Wr, depth_inv)
+        assert _rel(gdk, depth.grad) < 5e-5 and _rel(gsk, std.grad) < 5e-5, (level, Ns, same, _rel(gdk, depth.grad), _rel(gsk, std.grad))
+
+
+def _check_camera_tables_and_layout(lib, dev):
+    from enerf_amd.autograd import gather_cameras_torch
+    from enerf_amd.synth import make_batch
+    cfg = EnerfConfig()
+    b = {k: torch.from_numpy(v) for k, v in make_batch(32, 64, 3, cfg, seed=5, B=2).items()}
+    for rs in (0.25, 1.0):
+        cam_ref, tcen_ref = gather_cameras_torch(b, rs)
+        cam, tcen = lib.camera_tables(b["src_ixts"].to(dev), b["src_exts"].to(dev), b["tar_ext"].to(dev), rs)
+        assert _rel(cam, cam_ref) < 1e-6 and _rel(tcen, tcen_ref) < 1e-6
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(6, 5, 3, 3, 3, generator=g)
+    assert torch.equal(lib.weights_flip_transpose(w.to(dev)).cpu(), w.flip(2, 3, 4).transpose(0, 1).contiguous())
+    w2 = torch.randn(7, 4, 5, 5, generator=g)
+    assert torch.equal(lib.weights_flip_transpose(w2.to(dev)).cpu(), w2.flip(2, 3).transpose(0, 1).contiguous())
+    a, c = torch.randn(8, 8, 27, generator=g), torch.randn(1, 8, 27, generator=g)
+    out = lib.concat2_pad(a.to(dev), c.to(dev), 16 * 8 * 27).cpu().view(16, 8, 27)
+    assert torch.equal(out, torch.cat([a, c, torch.zeros(7, 8, 27)], 0))
+    feat = torch.randn(3, 16, 24, 8, generator=g)
+    src = torch.rand(3, 3, 64, 96, generator=g) * 2 - 1
+    for Hr, Wr in ((16, 24), ):
+        tex = lib.pack_texels_train(feat.to(dev), src.to(dev), Hr, Wr).cpu()
+        rgb = TP._resize_ac(src * 0.5 + 0.5, Hr / 64, True).permute(0, 2, 3, 1)
+        assert torch.equal(tex[..., :8], feat) and _rel(tex[..., 8:], rgb) < 1e-6
+    feat1 = torch.randn(2, 64, 96, 8, generator=g)
+    tex = lib.pack_texels_train(feat1.to(dev), src[:2].to(dev), 64, 96).cpu()
+    assert torch.equal(tex[..., 8:], (src[:2] * 0.5 + 0.5).permute(0, 2, 3, 1)) and torch.equal(tex[..., :8], feat1)
+    assert torch.equal(lib.slice_channels(tex.to(dev), 0, 8).cpu(), feat1)
+    assert torch.equal(lib.slice_channels(tex.to(dev), 8, 3).cpu(), tex[..., 8:].contiguous())
+    srcs = [torch.randn(n, generator=g) for n in (10, 33, 7)]
+    which = torch.randint(0, 3, (200,), generator=g).int()
+    idx = torch.stack([torch.randint(-1, srcs[int(q)].numel(), (1,), generator=g)[0] for q in which]).int()
+    ref = torch.stack([srcs[int(q)][int(i)] if i >= 0 else torch.tensor(0.0) for q, i in zip(which, idx)])
+    got = lib.gather_images([t.to(dev) for t in srcs], which.to(dev), idx.to(dev)).cpu()
+    assert torch.equal(got, ref)
+    x, y = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    assert torch.equal(lib.add(x.to(dev), y.to(dev)).cpu(), x + y)
+
+
+CHECKS = [_check_s2k5_dgrad, _check_resize_adjoint, _check_depth_values_bwd, _check_ray_samples, _check_camera_tables_and_layout]
+
+
+@pytest.mark.parametrize("check", CHECKS, ids=lambda f: f.__name__[7:])
+def test_train_glue_emulated(check):
+    from emu_lib import emu_lib
+    check(emu_lib(), torch.device("cpu"))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+@pytest.mark.parametrize("check", CHECKS, ids=lambda f: f.__name__[7:])
+def test_train_glue_gpu(check):
+    from enerf_amd.lib import get_lib
+    check(get_lib(), torch.device("cuda:0"))

@@ -228,7 +228,7 @@ def _check_hip_backward_stages(lib, dev):
         for t_ in (xyz, dn, tex, vol):
             t_.grad = None
         cam, tcen = gather_cameras(batch, rs)
-        x, vox = GatherFn.apply(lib, xyz, dn, uv, tex, vol, cam, tcen)
+        x, vox = GatherFn.apply(lib, xyz, dn, uv, tex.permute(0, 1, 3, 4, 2), vol.permute(0, 2, 3, 4, 1), cam, tcen)   # channels-last
         ((x * gx).sum() + (vox * gv).sum()).backward()
         assert float((x - x_ref).abs().max()) <= 2e-4 * float(x_ref.abs().max()), level
         assert float((vox - v_ref).abs().max()) <= 1e-5 * float(v_ref.abs().max()), level
