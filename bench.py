@@ -70,6 +70,16 @@ def render_mfma_tiles_per_16(S, R):
     return S * TR + 4 * R + 2 * S * R + 8 + 24 + 88 + 4 * S * (R + 1)
 
 
+def mlp_bwd_mfma_tiles_per_16(S, R):
+    """16x16x4 fp32 MFMA tiles k_mlp_bwd issues per 16 points (mlp_train.hip): the forward recompute (= the render kernel's
+    MLP), the colour layer's per-view half a second time, and the transposed-weight products b1..b7.  Equals the static
+    v_mfma count of the kernel's ISA (tools/isa_count.py: 482 at S=3,R=3; 940 at R=9)."""
+    TR, TX = (R + 3) // 4, (R + 4) // 4
+    fwd = render_mfma_tiles_per_16(S, R)
+    bwd = 4 * S * (R + 1) + 16 * S * TX + 96 + 32 + 8 + 16 * TR + 8 * S * TR + S * TX * R
+    return fwd + bwd
+
+
 def render_dense_flop_per_sample(S, F):
     """The reference's dense count of the same maths (SURVEY.md §8a derivation, nerf.py:29-89)."""
     return 2 * 4 * F * S + 2 * 3 * F * 32 * S + 2 * 32 * S + 2 * 32 * 16 + 2 * 24 * 64 + 2 * 64 + (2 * (88 + F + 4) * 64 + 2 * 64) * S
@@ -161,6 +171,74 @@ class _PerceptualVGG16(torch.nn.Module):
         return loss
 
 
+def train_extras(args, net, batch, loss_fn, cfg, dev, ms_per_step):
+    """`roofline` + `cpu_baseline` of the training line (rank 0, after the timed region).
+    roofline: the step's dominant kernel, k_mlp_bwd<R=3,S> of the last cascade level (MFMA-bound: fused recompute-forward +
+    backward of the Agg/NeRF MLP).  Its launch arguments are recorded from one eager step of this very batch and the kernel is
+    then re-launched alone on the bench's stream between HIP events (inside the captured step no event can bracket a node);
+    the per-step rocprofv3 table (profiles/r04_train_step_kernels_*.csv) holds the same kernel's duration inside the replays.
+    cpu_baseline: oracle.train_step (forward + MSE + backward of the reference-equivalent CPU restatement, BatchNorm batch
+    statistics; pinned to the reference's gradients by tests/test_oracle_golden.py) on the host cores, ONE step."""
+    lib = net.lib
+    rec = {}
+    orig = lib.nerf_mlp_bwd
+
+    def spy(vox, x, g_raw, packed, bimg, offsets, S, F):
+        rec[F] = (vox, x, g_raw, packed, bimg, offsets, S, F)
+        return orig(vox, x, g_raw, packed, bimg, offsets, S, F)
+    lib.nerf_mlp_bwd = spy
+    try:
+        for p_ in net.parameters():
+            p_.grad = None
+        loss_fn(net(batch), batch).backward()
+    finally:
+        lib.nerf_mlp_bwd = orig
+    for p_ in net.parameters():
+        p_.grad = None
+    out = {}
+    last = cfg.cas.num - 1
+    F = cfg.cas.nerf_model_feat_ch[last] + 3
+    if F in rec:
+        a = rec[F]
+        P, S, R = int(a[0].shape[0]), int(a[6]), (F + 3) // 4
+        for _ in range(3):
+            orig(*a)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+        ev[0].record()
+        for i in range(10):
+            orig(*a)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        t_ms = sum(ev[i].elapsed_time(ev[i + 1]) for i in range(10)) / 10
+        tiles = mlp_bwd_mfma_tiles_per_16(S, R)
+        flops = tiles * 2 * 16 * 16 * 4 * ((P + 15) // 16)
+        ach = flops / (t_ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "kernel": f"k_mlp_bwd<{R},{S}> (level-{last} Agg + NeRF MLP: fused recompute-forward + backward, {P} points)",
+            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(t_ms, 4),
+            "avg_launch_ms_source": "HIP events around 10 stand-alone launches on the bench's stream with the launch arguments "
+                                    "of this batch's step (a node inside the captured step cannot be bracketed)",
+            "algorithmic_flops_per_launch": flops, "mfma_tiles_per_16_points": tiles,
+            "share_of_step": round(t_ms / ms_per_step, 4),
+            "note": "issued fp32 16x16x4 MFMA work (static v_mfma count of the kernel = tiles per 16 points); one wave per SIMD at "
+                    "256 VGPRs + AGPR traffic is why the fraction is low (DESIGN.md)"}
+    if not args.no_cpu_baseline:
+        import numpy as np   # noqa: F401
+        from oracle import enerf_oracle as O
+        ncores = min(os.cpu_count() or 1, 32)
+        torch.set_num_threads(ncores)
+        sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        cb = {k: v.detach().cpu() for k, v in batch.items()}
+        t0 = time.perf_counter()
+        O.train_step(cfg, sd, cb)
+        cpu_s = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "samples/s", "cores": ncores, "kind": "port",
+                               "sample": f"1 training step (forward + MSE loss + backward, no optimizer update) of this batch through "
+                                         f"oracle/enerf_oracle.py::train_step (torch CPU, {ncores} of {os.cpu_count()} host threads)"}
+    return out
+
+
 def train_bench(args, rank, world, dev, dist, emu_lib=None):
     """Config 5: trainer.py:56-63 on the drop-in network — forward (train mode, BN batch statistics),
     the MSE part of losses/enerf.py:21-24, backward (DDP gradient all-reduce over RCCL when world > 1),
@@ -189,7 +267,13 @@ def train_bench(args, rank, world, dev, dist, emu_lib=None):
         if not graphed and not emu:                                      # trainer.py:17-22 as written: the eager DDP step
             from torch.nn.parallel import DistributedDataParallel as DDP
             model = DDP(net, device_ids=[dev.index], output_device=dev.index, find_unused_parameters=True)
-    opt = torch.optim.Adam(net.parameters(), lr=5e-4, capturable=graphed)
+    # torch.optim.Adam as the trainer builds it (lib/train/optimizer.py); on the GPU its fused multi-tensor implementation (the
+    # same update rule in ONE kernel per dtype/device group; the default capturable foreach path issues ~220 scalar-base pow
+    # kernels per step — 1 ms of a 19 ms step, profiles/r04_train_step_profile_run1.txt)
+    adam_kw = {"capturable": graphed}
+    if not emu and not args.adam_foreach:
+        adam_kw["fused"] = True
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4, **adam_kw)
     b = make_batch(H, W, 3, cfg, seed=rank, textured=True)
     rng = np.random.default_rng(rank)
     for i in range(2):
@@ -261,10 +345,13 @@ def train_bench(args, rank, world, dev, dist, emu_lib=None):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    extra = {}
+    if rank == 0 and not emu and not args.no_stages:
+        extra = train_extras(args, net, batch, loss_fn, cfg, dev, 1e3 * elapsed / args.steps)
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
-        emit_line(({
+        emit_line(({**extra,
             "metric": "training samples/sec (dtu_pretrain, 512x640, 3 src views, full-image rays at both levels)",
             "value": world * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -276,7 +363,8 @@ def train_bench(args, rank, world, dev, dist, emu_lib=None):
                                    "architecture with seeded random-init weights: no pretrained weights offline)" if perceptual is not None
                                    else " (the VGG perceptual term switched off)") + ", Adam, clip_grad_value_ 40", "parallelism": (f"data-parallel x{world} + SyncBatchNorm over {'gloo' if emu else 'RCCL'} (" + ("DistributedDataParallel" if model is not net else "one flat gradient all-reduce per step") + ")") if dp else "single GPU",
                        "step_launch": launch_note,
-                       "backward": "HIP forward+backward: FeatureNet (MFMA conv / stride-1 dgrad / wgrad, BN-train, upsampling adjoint, channels-last), cost-reg nets (MFMA conv/dgrad/wgrad, BN-train), Agg+NeRF MLP (fused), warp+variance, depth regression, compositing, render-side fetches (bilinear texel + trilinear volume gathers, direction code); PyTorch-ROCm autograd: dgrad of the two stride-2 5x5 FeatureNet convolutions, geometry glue"}}))
+                       "optimizer": "torch.optim.Adam(" + ", ".join(f"{k}={v}" for k, v in adam_kw.items()) + ")",
+                       "backward": "HIP forward+backward for every stage of the network: FeatureNet (MFMA conv / dgrad incl. the stride-2 5x5 layers / wgrad, BN-train, upsampling adjoint, channels-last), cost-reg nets (MFMA conv/dgrad/wgrad, BN-train), get_depth_values / build_rays / sample_along_depth, camera tables, Agg+NeRF MLP (fused), warp+variance, depth regression, compositing, render-side fetches; PyTorch ops left in a step: the trainer's loss, clip_grad_value_, Adam, and autograd's own gradient accumulation"}}))
 
 
 def main():
@@ -299,6 +387,7 @@ def main():
                          "dtu_pretrain (512x640, 3 views, full-image rays at both levels, bs 1 per GPU), DDP over RCCL for N > 1")
     ap.add_argument("--train-eager", action="store_true", help="--train: enqueue every step eagerly instead of one graph replay")
     ap.add_argument("--no-perceptual", action="store_true", help="--train: leave the VGG16 perceptual term out of the loss")
+    ap.add_argument("--adam-foreach", action="store_true", help="--train: torch.optim.Adam's foreach implementation instead of the fused one")
     ap.add_argument("--train-dp1", action="store_true",
                     help="--train --gpus 1: take the DATA-PARALLEL step on a 1-rank RCCL group (SyncBatchNorm conversion, statistics "
                          "exchanges and the flat gradient all-reduce captured as graph nodes) — what a 1-GPU box can measure of the N > 1 step")

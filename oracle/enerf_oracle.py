@@ -27,8 +27,13 @@ BN_EPS = 1e-5
 # --------------------------------------------------------------------------------------------------
 # small helpers
 # --------------------------------------------------------------------------------------------------
+_BN_TRAIN = False      # set by train_step(): BatchNorm with batch statistics (the reference network in .train() mode)
+
+
 def _bn(sd, p, x):
-    """Eval-mode BatchNorm{2,3}d with running statistics (torch default eps=1e-5)."""
+    """BatchNorm{2,3}d (torch default eps=1e-5): running statistics in eval mode, batch statistics inside train_step()."""
+    if _BN_TRAIN:
+        return F.batch_norm(x, None, None, sd[p + ".weight"], sd[p + ".bias"], training=True, eps=BN_EPS)
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"],
                         sd[p + ".bias"], training=False, eps=BN_EPS)
 
@@ -401,6 +406,26 @@ def forward(cfg, sd, batch, feats=None, intermediates=None):
         out["std"] = std
         ret.update({f"{k}_level{i}": v for k, v in out.items()})
     return ret
+
+
+def train_step(cfg, sd, batch, loss_weight=(0.1, 1.0)):
+    """One training step's forward + loss + backward on this restatement (BASELINE config 5): the reference network in
+    ``.train()`` mode (BatchNorm batch statistics, lib/networks/enerf/utils.py:10-33), the MSE part of
+    lib/train/losses/enerf.py:21-24 with ``loss_weight`` (dtu_pretrain.yaml:43), ``loss.backward()`` (trainer.py:56-63).
+    Returns (loss, {parameter name: gradient}).  Pinned to the reference's own gradients (tests/golden/train_tiny.npz) by
+    tests/test_oracle_golden.py; bench.py --train times it as the CPU baseline of the training step."""
+    global _BN_TRAIN
+    params = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v)
+              for k, v in sd.items()}
+    _BN_TRAIN = True
+    try:
+        out = forward(cfg, params, batch)
+        loss = sum(loss_weight[i] * F.mse_loss(batch[f"rgb_{i}"], out[f"rgb_level{i}"]) for i in range(cfg.cas.num)
+                   if cfg.cas.render_if[i])
+        loss.backward()
+    finally:
+        _BN_TRAIN = False
+    return loss.detach(), {k: v.grad for k, v in params.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None}
 
 
 def psnr(a, b):

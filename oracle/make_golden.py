@@ -279,13 +279,29 @@ def run_full_case(name: str) -> None:
 TRAIN_CASE = dict(H=32, W=64, S=3, planes=(8, 8), render_if=(True, True), seed=7, loss_weight=(0.1, 1.0))
 TRAIN_CASES = {"train_tiny": TRAIN_CASE,
                # a mid-size step: 128x160, 16 + 8 planes, 20,480 + 1,280 rays
-               "train_small": dict(H=128, W=160, S=3, planes=(16, 8), render_if=(True, True), seed=8, loss_weight=(0.1, 1.0))}
+               "train_small": dict(H=128, W=160, S=3, planes=(16, 8), render_if=(True, True), seed=8, loss_weight=(0.1, 1.0)),
+               # the same two steps with the reference's modules in float64 (net.double(), float64 batch): the arbiter between two
+               # fp32 implementations of an ill-conditioned step (VERDICT r03 next #1b) — full gradients
+               "train_tiny_fp64": dict(H=32, W=64, S=3, planes=(8, 8), render_if=(True, True), seed=7, loss_weight=(0.1, 1.0), fp64=True),
+               "train_small_fp64": dict(H=128, W=160, S=3, planes=(16, 8), render_if=(True, True), seed=8, loss_weight=(0.1, 1.0), fp64=True),
+               # BASELINE config 5 at its REAL shape (dtu_pretrain.yaml: 512x640, planes 64,8, both levels, full-image rays):
+               # sparse digests (every 97th element of every gradient + float64 norm), fp32 and fp64
+               "train_full": dict(H=512, W=640, S=3, planes=(64, 8), render_if=(True, True), seed=9, loss_weight=(0.1, 1.0), sparse=True),
+               "train_full_fp64": dict(H=512, W=640, S=3, planes=(64, 8), render_if=(True, True), seed=9, loss_weight=(0.1, 1.0), sparse=True,
+                                       fp64=True, threads=8)}
 
 
-def grad_digest(g: torch.Tensor) -> dict:
-    """The FULL gradient of every parameter (436,012 floats per case) + its float64 norm."""
+def grad_digest(g: torch.Tensor, sparse: bool = False) -> dict:
+    """The FULL gradient of every parameter (436,012 floats per case) + its float64 norm; sparse: every FULL_STRIDE-th element
+    and max|.| instead of the full tensor (the full-size cases)."""
     f = g.detach().reshape(-1)
-    return {"full": f.numpy(), "norm": np.array(float(f.double().norm()))}
+    d = {"norm": np.array(float(f.double().norm()))}
+    if sparse:
+        d["rows"] = f[::FULL_STRIDE].float().numpy().copy()
+        d["absmax"] = np.array(float(f.abs().max()))
+    else:
+        d["full"] = f.float().numpy()          # (a float64 run is stored rounded to float32: 6e-8, far below what it arbitrates)
+    return d
 
 
 def run_train_case(case: str = "train_tiny") -> None:
@@ -302,8 +318,9 @@ def run_train_case(case: str = "train_tiny") -> None:
             "enerf.cas_config.render_if", ",".join(map(str, c["render_if"]))]
     cfg, ref_network = load_reference("configs/enerf/dtu_pretrain.yaml", opts)
     assert tuple(cfg.enerf.cas_config.loss_weight) == c["loss_weight"]
+    import time
     torch.manual_seed(0)
-    torch.set_num_threads(1)
+    torch.set_num_threads(c.get("threads", 1))
     net = ref_network.Network()
     net.load_state_dict(seeded_state_dict(net))
     wnp = np.load(os.path.join(GOLDEN, "weights_seed0.npz"))
@@ -315,27 +332,44 @@ def run_train_case(case: str = "train_tiny") -> None:
     for i in range(2):
         b[f"rgb_{i}"] = rng.uniform(0, 1, size=(1, b[f"rays_{i}"].shape[1], 3)).astype(np.float32)
     batch = {k: torch.from_numpy(v) for k, v in b.items()}
+    if c.get("fp64"):                               # the SAME fp32 weights and inputs, every module and tensor in float64;
+        net = net.double()                          # (the reference builds its sampling grids with the default dtype:
+        torch.set_default_dtype(torch.float64)      #  linspace / create_meshgrid / ones — make that float64 too)
+        batch = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+        import functools
+        from lib.networks.enerf import utils as ref_utils
+        ref_utils.create_meshgrid = functools.partial(ref_utils.create_meshgrid, dtype=torch.float64)   # (kornia's default is float32)
+    t0 = time.perf_counter()
     out = net(batch)
     loss = sum(c["loss_weight"][i] * torch.nn.functional.mse_loss(batch[f"rgb_{i}"], out[f"rgb_level{i}"]) for i in range(2))
     loss.backward()
-    save = {"loss": np.array(float(loss))}
-    save.update({f"out/{k}": v.detach().numpy() for k, v in out.items()})
-    for i in range(2):
-        save[f"in/rgb_{i}"] = b[f"rgb_{i}"]
+    dt = time.perf_counter() - t0
+    sparse = bool(c.get("sparse"))
+    save = {"loss": np.array(float(loss)), "meta/reference_cpu_seconds": np.array(dt), "meta/threads": np.array(c.get("threads", 1)),
+            "meta/dtype": np.array("float64" if c.get("fp64") else "float32")}
+    if sparse:
+        for k, v in out.items():
+            sparse_digest(f"out/{k}", v, save)
+        save["meta/stride"] = np.array(FULL_STRIDE)
+    else:
+        save.update({f"out/{k}": v.detach().float().numpy() for k, v in out.items()})
+        for i in range(2):
+            save[f"in/rgb_{i}"] = b[f"rgb_{i}"]
     n_grad = 0
     for name, p_ in net.named_parameters():
         if p_.grad is None:
             save[f"nograd/{name}"] = np.array(1)
             continue
         n_grad += 1
-        for k, v in grad_digest(p_.grad).items():
+        for k, v in grad_digest(p_.grad, sparse).items():
             save[f"grad/{name}/{k}"] = v
     for name, buf in net.named_buffers():
         if name.endswith("running_mean") or name.endswith("running_var"):
             save[f"buf/{name}"] = buf.numpy()
     save["meta/torch_version"] = np.array(torch.__version__)
     np.savez_compressed(os.path.join(GOLDEN, f"{case}.npz"), **save)
-    print(f"[golden] {case}: loss {float(loss):.6f}; {n_grad} parameter gradients; {len(save)} arrays")
+    print(f"[golden] {case}: loss {float(loss):.6f}; {n_grad} parameter gradients; {len(save)} arrays; forward+backward {dt:.1f} s "
+          f"on {c.get('threads', 1)} thread(s), {'float64' if c.get('fp64') else 'float32'}")
 
 
 def main() -> None:

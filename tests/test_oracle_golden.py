@@ -85,3 +85,30 @@ def test_oracle_matches_reference_at_full_size(name, weights):
         out = O.forward(cfg, weights, batch, intermediates=mids)
     worst = check_sparse_golden(name, out, 1e-4, {k: v.reshape(-1, 1) for k, v in mids.items()})
     assert worst
+
+
+def test_oracle_training_step_matches_reference_gradients(weights):
+    """oracle.train_step (the CPU baseline of bench.py --train) against one training step of the UNMODIFIED reference network
+    (tests/golden/train_tiny.npz: loss + every element of all parameter gradients)."""
+    import os
+    from enerf_amd.config import EnerfConfig
+    from enerf_amd.synth import make_batch
+    from golden_cases import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "train_tiny.npz"))
+    cfg = EnerfConfig().with_cas(volume_planes=(8, 8), render_if=(True, True))
+    b = make_batch(32, 64, 3, cfg, seed=7, textured=True)
+    batch = {k: torch.from_numpy(v) for k, v in b.items()}
+    for i in range(2):
+        batch[f"rgb_{i}"] = torch.from_numpy(g[f"in/rgb_{i}"])
+    torch.set_num_threads(1)
+    loss, grads = O.train_step(cfg, weights, batch)
+    assert float(loss) == pytest.approx(float(g["loss"]), rel=1e-5)
+    checked = 0
+    for k in g.files:
+        if k.startswith("grad/") and k.endswith("/full"):
+            name = k[5:-5]
+            ref = g[k]
+            got = grads[name].reshape(-1).numpy()
+            assert np.abs(got - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-12) + 1e-9, name
+            checked += 1
+    assert checked >= 110

@@ -131,7 +131,7 @@ def _check_camera_tables_and_layout(lib, dev):
     for Hr, Wr in ((16, 24), ):
         tex = lib.pack_texels_train(feat.to(dev), src.to(dev), Hr, Wr).cpu()
         rgb = TP._resize_ac(src * 0.5 + 0.5, Hr / 64, True).permute(0, 2, 3, 1)
-        assert torch.equal(tex[..., :8], feat) and _rel(tex[..., 8:], rgb) < 1e-6
+        assert torch.equal(tex[..., :8], feat) and _rel(tex[..., 8:], rgb) < 1e-5       # (FMA contraction on the GPU: 3e-6)
     feat1 = torch.randn(2, 64, 96, 8, generator=g)
     tex = lib.pack_texels_train(feat1.to(dev), src[:2].to(dev), 64, 96).cpu()
     assert torch.equal(tex[..., 8:], (src[:2] * 0.5 + 0.5).permute(0, 2, 3, 1)) and torch.equal(tex[..., :8], feat1)

@@ -22,6 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LOSS_W = (0.1, 1.0)                                   # configs/enerf/dtu_pretrain.yaml:43
 # reference-generated training fixtures (oracle/make_golden.py::TRAIN_CASES): FULL gradients of all 115 parameters
 TRAIN_CASES = {"train_tiny": dict(seed=7, H=32, W=64, planes=(8, 8)), "train_small": dict(seed=8, H=128, W=160, planes=(16, 8))}
+FULL_TRAIN_CASE = dict(seed=9, H=512, W=640, planes=(64, 8))        # train_full / train_full_fp64: sparse digests (every 97th element)
 
 
 def _grad_errors(named_grads, g):
@@ -37,6 +38,41 @@ def _grad_errors(named_grads, g):
             # is zero and the reference value is rounding noise of the order 1e-10
             errs[name] = float(max(np.abs(f - ref).max() - 1e-8, 0.0) / max(np.abs(ref).max(), 1e-30))
     return errs
+
+
+def _distance_to_fp64(named_grads, g32, g64, sparse=False):
+    """Per parameter: (d_ours, d_ref) = max|. - fp64| / max|fp64| of OUR fp32 gradient and of the REFERENCE's fp32 gradient, against
+    the reference's own modules run in float64 on the same weights and inputs (oracle/make_golden.py --case *_fp64).  ``sparse``:
+    the full-size fixtures hold every 97th element (+ max|.|).  Parameters whose float64 gradient is numerically zero (the
+    shift-invariant agg_w_fc bias) are skipped."""
+    key, out = ("rows" if sparse else "full"), {}
+    for name, grad in named_grads:
+        k = f"grad/{name}/{key}"
+        if k not in g64.files:
+            continue
+        r64 = g64[k].astype(np.float64)
+        scale = float(g64[f"grad/{name}/absmax"]) if sparse else float(np.abs(r64).max())
+        if scale < 1e-9:
+            continue
+        f = grad.detach().reshape(-1).cpu().numpy().astype(np.float64)
+        f = f[::97] if sparse else f
+        out[name] = (float(np.abs(f - r64).max() / scale), float(np.abs(g32[k].astype(np.float64) - r64).max() / scale))
+    return out
+
+
+def _assert_as_close_to_fp64_as_the_reference(dist, slack=3.0, what=""):
+    """VERDICT r03 next #1b.  The step is ill-conditioned (BatchNorm statistics over few positions, floor() of sample positions):
+    two fp32 evaluations differ from each other by far more than fp32 epsilon, so 'equal to the reference's fp32 gradients' is
+    the wrong bar.  The right one: our fp32 result is (within ``slack``) as close to the float64 result as the reference's fp32
+    result is — per parameter against max(its own reference distance, the median reference distance), and in aggregate."""
+    ours = np.array([d[0] for d in dist.values()])
+    ref = np.array([d[1] for d in dist.values()])
+    floor = float(np.median(ref))
+    bad = {n: d for n, d in dist.items() if d[0] > slack * max(d[1], floor)}
+    assert len(dist) >= 105 and not bad, (what, floor, bad)
+    assert float(np.median(ours)) <= slack * floor and float(ours.max()) <= slack * float(ref.max()), \
+        (what, float(np.median(ours)), floor, float(ours.max()), float(ref.max()))
+    return float(np.median(ours)), floor, float(ours.max()), float(ref.max())
 
 
 def _train_batch(seed=7, H=32, W=64, S=3, planes=(8, 8)):
@@ -90,6 +126,20 @@ def test_training_step_matches_reference_gradients(case):
             np.testing.assert_allclose(buf.numpy(), g[f"buf/{name}"], rtol=1e-4, atol=1e-6, err_msg=name)
 
 
+def test_hip_training_step_is_as_close_to_fp64_as_the_reference_emulated():
+    """The fp64 arbitration on the lane emulator at 32x64 (the 128x160 and 512x640 steps run on the GPU: -m gpu)."""
+    from emu_lib import emu_lib
+    g32, g64 = np.load(os.path.join(GOLDEN, "train_tiny.npz")), np.load(os.path.join(GOLDEN, "train_tiny_fp64.npz"))
+    cfg, batch = _train_batch(**TRAIN_CASES["train_tiny"])
+    net = Network(cfg, lib=emu_lib())
+    net.load_state_dict(load_weights(), strict=False)
+    net.train()
+    _loss(net(batch), batch).backward()
+    dist = _distance_to_fp64([(n, p.grad) for n, p in net.named_parameters() if p.grad is not None], g32, g64)
+    med, floor, worst, worst_ref = _assert_as_close_to_fp64_as_the_reference(dist, what="32x64 emulator")
+    assert med < 1e-4                                                   # (measured: 2.1e-5 against the reference's 2.9e-5)
+
+
 def test_mid_size_step_is_ill_conditioned_in_the_reference():
     """Why the 128x160 fixture cannot carry the 5e-4 bound of the 32x64 one: the reference's OWN gradients (torch-op path = the
     reference's ops; bit-identical forward) are not reproducible beyond ~1e-3 at this size.  A 1e-6 relative perturbation of the
@@ -108,7 +158,7 @@ def test_mid_size_step_is_ill_conditioned_in_the_reference():
         T.feature_volume = orig
     errs = _grad_errors([(n, p.grad) for n, p in net.named_parameters() if p.grad is not None], g)
     assert max(errs.values()) > 1e-3, max(errs.values())          # (measured 7e-3; with 1 vs 8 CPU threads alone: 1.8e-3)
-    assert max(errs.values()) < GPU_GRAD_TOL_MID                   # ... and the bound used on the GPU has head-room over it
+    assert max(errs.values()) < 1.5e-1                             # (the element-wise bound round 3 needed at this size)
     # the same with the FeatureNet's three output maps perturbed by 1e-5 relative (two fp32 summation orders of its convolutions
     # differ by that much): the reference's own gradients move by > 1e-2 somewhere (measured: worst 1.0e-1, median 4.4e-3)
     orig_fn = T.feature_net_forward
@@ -579,7 +629,7 @@ def test_two_rank_syncbn_on_hip_training_path_equals_one_process_with_batch_two(
     for n, v in res[0][1].items():
         assert np.allclose(v, res[1][1][n], rtol=1e-5, atol=1e-9), n   # both ranks hold the averaged gradients
         r = ref[n].numpy()
-        tol = 1.5e-2      # two different summation orders of the same ill-conditioned step (see GPU_GRAD_TOL_MID's note)
+        tol = 1.5e-2      # two different summation orders of the same ill-conditioned step (see GPU_GRAD_TOL's note)
         assert np.abs(v - r).max() <= tol * max(np.abs(r).max(), 1e-12) + 1e-9, (n, float(np.abs(v - r).max() / max(np.abs(r).max(), 1e-12)))
         checked += 1
     assert checked > 80
@@ -669,18 +719,13 @@ def test_flat_gradient_sync_step_equals_distributed_data_parallel_step():
 
 
 GPU_GRAD_TOL = 5e-4            # max|grad - reference| / max|reference| per parameter, every element (fp32 atomics reorder sums)
-# The 128x160 step is ILL-CONDITIONED IN THE REFERENCE ITSELF: its own parameter gradients move by ~2e-3 between 1 and 8 CPU
-# threads, by ~7e-3 when the cost volume is perturbed by 1e-6 relative, and by 5e-2 (worst) / 2e-3 (median) to 1e-1 / 4e-3 when
-# the FeatureNet's output maps are perturbed by 3e-6 / 1e-5 relative — the size of the difference between two fp32 summation
-# orders of a convolution (test_mid_size_step_is_ill_conditioned_in_the_reference below: BatchNorm batch statistics over as few
-# as 80 positions in the deepest layers + the floor() of every bilinear sample position).  A different summation order anywhere
-# upstream (MFMA vs MKL convolutions, the HIP warp's 1e-6-level differences, atomics) is such a perturbation, so the end-to-end
-# bound at this size is 1.5e-1 worst / 1e-2 median (measured on MI355X with the whole FeatureNet on the HIP kernels: worst
-# 6.4e-2 on cost_reg_1.conv6 — BatchNorm over 80 voxels — median 5e-3; with the FeatureNet on MIOpen: 1.9e-2 / 1.2e-3).  The
-# 5e-4 bound holds at 32x64, and every HIP stage is pinned to its torch twin separately at 2e-4 or better
-# (_check_feature_net_train at 32x64 / 128x160 / 512x640, _check_hip_backward_stages: with the reference's forward values the
-# HIP warp backward reproduces the gradients to 4e-5).
-GPU_GRAD_TOL_MID = 1.5e-1
+# The 128x160 and 512x640 steps are ILL-CONDITIONED IN THE REFERENCE ITSELF: its own parameter gradients move by ~2e-3 between 1
+# and 8 CPU threads, by ~7e-3 when the cost volume is perturbed by 1e-6 relative, and by up to 1e-1 when the FeatureNet's output
+# maps are perturbed by 1e-5 relative (test_mid_size_step_is_ill_conditioned_in_the_reference: BatchNorm batch statistics over as
+# few as 80 positions + the floor() of every bilinear sample position).  An element-wise bound against the reference's fp32
+# gradients would have to be that loose (round 3 used 1.5e-1), so those sizes are judged by ARBITRATION instead: the
+# reference's own modules run in float64 (tests/golden/train_*_fp64.npz) are the truth, and our fp32 gradients must be as close
+# to it (x3) as the reference's fp32 gradients are (_assert_as_close_to_fp64_as_the_reference).  The 5e-4 bound holds at 32x64.
 
 
 @pytest.mark.gpu
@@ -709,25 +754,22 @@ def test_training_step_on_gpu_matches_reference_gradients():
     errs = _grad_errors([(n, p.grad) for n, p in net.named_parameters() if p.grad is not None], g)
     bad = {n: e for n, e in errs.items() if e > GPU_GRAD_TOL}
     assert len(errs) >= 110 and not bad, bad
-    # ... and the mid-size fixture (128x160, 16 + 8 planes, 20,480 + 1,280 rays): every element of every gradient
-    g2 = np.load(os.path.join(GOLDEN, "train_small.npz"))
+    # ... and the mid-size fixture (128x160, 16 + 8 planes, 20,480 + 1,280 rays), every element of every gradient.  This step
+    # is ill-conditioned in the reference itself (test_mid_size_step_is_ill_conditioned_in_the_reference), so the bar is the
+    # fp64 ARBITRATION: our fp32 gradients must be as close (x3) to the reference's float64 step as the reference's own fp32
+    # gradients are — with the whole FeatureNet on the HIP kernels, and with it on the library convolutions
+    g2, g2_64 = np.load(os.path.join(GOLDEN, "train_small.npz")), np.load(os.path.join(GOLDEN, "train_small_fp64.npz"))
     cfg2, batch2 = _train_batch(**TRAIN_CASES["train_small"])
     batch2 = {k: v.to(dev) for k, v in batch2.items()}
-    net2 = _net(cfg2).to(dev)
-    loss2 = _loss(net2(batch2), batch2)
-    assert float(loss2) == pytest.approx(float(g2["loss"]), rel=1e-4)
-    loss2.backward()
-    errs2 = _grad_errors([(n, p.grad) for n, p in net2.named_parameters() if p.grad is not None], g2)
-    bad2 = {n: e for n, e in errs2.items() if e > GPU_GRAD_TOL_MID}
-    assert len(errs2) >= 110 and not bad2, bad2
-    assert float(np.median(list(errs2.values()))) < 1e-2
-    # the same step with the FeatureNet on the library convolutions (MIOpen) instead of FeatureNetTrainFn: another draw from
-    # the same ill-conditioned problem (measured: worst 1.9e-2, median 1.2e-3)
-    net3 = _net(cfg2).to(dev)
-    net3.hip_feature_net_train = False
-    _loss(net3(batch2), batch2).backward()
-    errs3 = _grad_errors([(n, p.grad) for n, p in net3.named_parameters() if p.grad is not None], g2)
-    assert max(errs3.values()) < GPU_GRAD_TOL_MID and float(np.median(list(errs3.values()))) < 1e-2, max(errs3.values())
+    for hip_fnet in (True, False):
+        net2 = _net(cfg2).to(dev)
+        net2.hip_feature_net_train = hip_fnet
+        loss2 = _loss(net2(batch2), batch2)
+        assert float(loss2) == pytest.approx(float(g2["loss"]), rel=1e-4)
+        loss2.backward()
+        dist = _distance_to_fp64([(n, p.grad) for n, p in net2.named_parameters() if p.grad is not None], g2, g2_64)
+        print("128x160 fp64 arbitration (median ours, median ref, max ours, max ref), FeatureNet on HIP =", hip_fnet,
+              _assert_as_close_to_fp64_as_the_reference(dist, what=f"128x160 hip_fnet={hip_fnet}"))
     opt = torch.optim.Adam(net.parameters(), lr=5e-4)
     opt.step()
     net.eval()
@@ -738,6 +780,36 @@ def test_training_step_on_gpu_matches_reference_gradients():
         ref = O.forward(cfg, {k: v.detach().cpu() for k, v in net.state_dict().items()},
                         {k: v.cpu() for k, v in batch.items()})["rgb_level1"]
     assert float((img.cpu() - ref).abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_full_size_training_step_is_as_close_to_fp64_as_the_reference():
+    """BASELINE config 5 at its real shape (dtu_pretrain.yaml: 512x640, 3 views, planes 64,8, full-image rays at both levels:
+    327,680 + 20,480 rays) pinned to the REFERENCE: one training step of the unmodified reference network in fp32
+    (train_full.npz) and in float64 (train_full_fp64.npz), sparse digests.  Loss and outputs against the fp32 reference; every
+    parameter gradient by fp64 arbitration (see _assert_as_close_to_fp64_as_the_reference)."""
+    from golden_cases import check_sparse_golden
+    dev = torch.device("cuda:0")
+    g32, g64 = np.load(os.path.join(GOLDEN, "train_full.npz")), np.load(os.path.join(GOLDEN, "train_full_fp64.npz"))
+    cfg, batch = _train_batch(**FULL_TRAIN_CASE)
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    net = _net(cfg).to(dev)
+    out = net(batch)
+    loss = _loss(out, batch)
+    assert float(loss) == pytest.approx(float(g32["loss"]), rel=1e-4)
+    assert float(g64["loss"]) == pytest.approx(float(g32["loss"]), rel=1e-4)
+    worst = check_sparse_golden("train_full", {k: v.detach() for k, v in out.items()}, 2e-4)
+    loss.backward()
+    named = [(n, p.grad) for n, p in net.named_parameters() if p.grad is not None]
+    for n, gr in named:                                                # whole-tensor norms against the fp64 run
+        n64 = float(g64[f"grad/{n}/norm"])
+        if n64 > 1e-9:
+            assert abs(float(gr.double().norm()) - n64) <= 0.1 * n64, (n, float(gr.double().norm()), n64)
+    dist = _distance_to_fp64(named, g32, g64, sparse=True)
+    print("512x640 outputs vs reference fp32:", {k: f"{v:.1e}" for k, v in worst.items()})
+    print("512x640 fp64 arbitration (median ours, median ref, max ours, max ref):",
+          _assert_as_close_to_fp64_as_the_reference(dist, what="512x640"))
 
 
 @pytest.mark.gpu
