@@ -357,7 +357,7 @@ def render_rays(net, rays, level, batch, im_feat, feat_vol, lib=None, tables=Non
         raw = nerf_mlp(lib, getattr(net, f"nerf_{level}"), nerf_forward, vox, x).reshape(B, N, Ns, 4)   # fused HIP backward
     else:
         raw = nerf_forward(getattr(net, f"nerf_{level}"), vox, x).reshape(B, N, Ns, 4)
-    if lib is not None:
+    if lib is not None and getattr(net, "hip_composite", True):
         from .autograd import CompositeFn
         rgb, depth, weights = CompositeFn.apply(lib, raw, z, bool(net.cfg.white_bkgd))
         return {"rgb": rgb, "depth": depth, "weights": weights}
@@ -405,7 +405,8 @@ def forward_train(net, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor
         else:
             dv, near_far = depth_values(cas, batch, i, cas.volume_planes[i], depth, std, near_far)
         P = tables[f"proj_{i}"]
-        vol = FeatureVolumeFn.apply(lib, feats[f"level_{i}"], P, dv) if lib is not None else feature_volume(feats[f"level_{i}"], P, dv)
+        vol = FeatureVolumeFn.apply(lib, feats[f"level_{i}"], P, dv) if (lib is not None and getattr(net, "hip_volume", True)) \
+            else feature_volume(feats[f"level_{i}"], P, dv)
         reg = getattr(net, f"cost_reg_{i}")
         # the HIP training blocks normalise with BATCH statistics: only when every BatchNorm of the net is in training mode;
         # frozen-BN fine-tuning (bn.eval()) goes through the modules, which honour running statistics
@@ -415,7 +416,7 @@ def forward_train(net, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor
             feat3d, prob = cost_reg_train(lib, getattr(net, f"cost_reg_{i}"), vol)     # conv/BN forward + backward on HIP kernels
         else:
             feat3d, prob = cost_reg_forward(getattr(net, f"cost_reg_{i}"), vol, lib)
-        depth, std = DepthRegressionFn.apply(lib, prob, dv, bool(cas.depth_inv[i])) if lib is not None \
+        depth, std = DepthRegressionFn.apply(lib, prob, dv, bool(cas.depth_inv[i])) if (lib is not None and getattr(net, "hip_depth_regression", True)) \
             else depth_regression(cas, prob, dv, i)
         if not cas.render_if[i]:
             continue

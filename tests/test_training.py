@@ -60,19 +60,34 @@ def _distance_to_fp64(named_grads, g32, g64, sparse=False):
     return out
 
 
-def _assert_as_close_to_fp64_as_the_reference(dist, slack=3.0, what=""):
-    """VERDICT r03 next #1b.  The step is ill-conditioned (BatchNorm statistics over few positions, floor() of sample positions):
-    two fp32 evaluations differ from each other by far more than fp32 epsilon, so 'equal to the reference's fp32 gradients' is
-    the wrong bar.  The right one: our fp32 result is (within ``slack``) as close to the float64 result as the reference's fp32
-    result is — per parameter against max(its own reference distance, the median reference distance), and in aggregate."""
-    ours = np.array([d[0] for d in dist.values()])
-    ref = np.array([d[1] for d in dist.values()])
+def _assert_as_close_to_fp64_as_the_reference(dist, noise=None, slack=3.0, what=""):
+    """VERDICT r03 next #1b.  The step is ill-conditioned — worse, DISCONTINUOUS in its inputs (ReLU masks under BatchNorm batch
+    statistics, floor() of bilinear sample positions): two fp32 evaluations differ by far more than fp32 epsilon, so 'equal to
+    the reference's fp32 gradients' is the wrong bar.  The right one: our fp32 result is (within ``slack``) as close to the
+    float64 result as the reference's fp32 result is.  ``noise`` (tests/golden/train_*_noise.npz, oracle/make_golden.py
+    run_noise_case) calibrates what 'the reference's fp32 result' means per parameter: the UNMODIFIED reference re-run with its
+    input images perturbed by ONE ULP lands, in 2 of 8 draws at 128x160, 10-70x further from float64 on 37-56 of its 114
+    parameters (one flipped mask / floor moves a BatchNorm-bias-like gradient by a whole term).  Hence:
+      * bulk: median and 75th percentile of our distances <= slack x the reference's (robust to such jumps);
+      * per parameter: ours <= slack x max(reference single draw, reference 1-ulp noise, median reference distance), except for at
+        most as many parameters as the reference's own worst 1-ulp draw put beyond its single-draw distance;
+      * no parameter further than slack x the largest distance any reference draw produced."""
+    names = list(dist)
+    ours = np.array([dist[n][0] for n in names])
+    ref = np.array([dist[n][1] for n in names])
     floor = float(np.median(ref))
-    bad = {n: d for n, d in dist.items() if d[0] > slack * max(d[1], floor)}
-    assert len(dist) >= 105 and not bad, (what, floor, bad)
-    assert float(np.median(ours)) <= slack * floor and float(ours.max()) <= slack * float(ref.max()), \
-        (what, float(np.median(ours)), floor, float(ours.max()), float(ref.max()))
-    return float(np.median(ours)), floor, float(ours.max()), float(ref.max())
+    if noise is None:
+        per_param, allowed, ceiling = ref, 0, float(ref.max())
+    else:
+        per_param = np.maximum(ref, np.array([float(noise[f"noise/{n}"]) if f"noise/{n}" in noise.files else 0.0 for n in names]))
+        allowed, ceiling = int(noise["meta/draw_outliers"].max()), float(per_param.max())
+    outliers = {n: dist[n] for i, n in enumerate(names) if ours[i] > slack * max(per_param[i], floor)}
+    assert len(dist) >= 105 and len(outliers) <= allowed, (what, floor, allowed, outliers)
+    stats = dict(median=(float(np.median(ours)), floor), p75=(float(np.percentile(ours, 75)), float(np.percentile(ref, 75))),
+                 max=(float(ours.max()), ceiling), outliers=(len(outliers), allowed))
+    assert stats["median"][0] <= slack * stats["median"][1] and stats["p75"][0] <= slack * stats["p75"][1], (what, stats)
+    assert stats["max"][0] <= slack * ceiling, (what, stats, outliers)
+    return stats
 
 
 def _train_batch(seed=7, H=32, W=64, S=3, planes=(8, 8)):
@@ -136,8 +151,21 @@ def test_hip_training_step_is_as_close_to_fp64_as_the_reference_emulated():
     net.train()
     _loss(net(batch), batch).backward()
     dist = _distance_to_fp64([(n, p.grad) for n, p in net.named_parameters() if p.grad is not None], g32, g64)
-    med, floor, worst, worst_ref = _assert_as_close_to_fp64_as_the_reference(dist, what="32x64 emulator")
-    assert med < 1e-4                                                   # (measured: 2.1e-5 against the reference's 2.9e-5)
+    st = _assert_as_close_to_fp64_as_the_reference(dist, what="32x64 emulator")     # (no noise fixture needed at this size: every
+    assert st["median"][0] < 1e-4                                       #  parameter within 3x; measured median 2.1e-5 vs 2.9e-5)
+
+
+def test_reference_gradients_jump_under_one_ulp_input_perturbations():
+    """The calibration behind the arbitration bounds, read from the fixtures (generated by the UNMODIFIED reference,
+    oracle/make_golden.py run_noise_case): with the source images perturbed by one ulp, some draws put dozens of parameters
+    10x-70x further from the float64 step than the unperturbed fp32 draw — the gradients are discontinuous in the inputs."""
+    for name in ("train_small_noise", "train_full_noise"):
+        nz = np.load(os.path.join(GOLDEN, name + ".npz"))
+        counts, worst = nz["meta/draw_outliers"], nz["meta/draw_worst_ratio"]
+        assert len(counts) == int(nz["meta/draws"]) >= 6
+        assert counts.max() >= 5 and worst.max() >= 4.0, (name, counts, worst)
+    nz = np.load(os.path.join(GOLDEN, "train_small_noise.npz"))
+    assert nz["meta/draw_outliers"].max() >= 30 and (nz["meta/draw_outliers"] == 0).sum() >= 4      # all-or-nothing jumps at 128x160
 
 
 def test_mid_size_step_is_ill_conditioned_in_the_reference():
@@ -768,8 +796,9 @@ def test_training_step_on_gpu_matches_reference_gradients():
         assert float(loss2) == pytest.approx(float(g2["loss"]), rel=1e-4)
         loss2.backward()
         dist = _distance_to_fp64([(n, p.grad) for n, p in net2.named_parameters() if p.grad is not None], g2, g2_64)
-        print("128x160 fp64 arbitration (median ours, median ref, max ours, max ref), FeatureNet on HIP =", hip_fnet,
-              _assert_as_close_to_fp64_as_the_reference(dist, what=f"128x160 hip_fnet={hip_fnet}"))
+        noise2 = np.load(os.path.join(GOLDEN, "train_small_noise.npz"))
+        print("128x160 fp64 arbitration (ours, reference), FeatureNet on HIP =", hip_fnet,
+              _assert_as_close_to_fp64_as_the_reference(dist, noise2, what=f"128x160 hip_fnet={hip_fnet}"))
     opt = torch.optim.Adam(net.parameters(), lr=5e-4)
     opt.step()
     net.eval()
@@ -780,6 +809,50 @@ def test_training_step_on_gpu_matches_reference_gradients():
         ref = O.forward(cfg, {k: v.detach().cpu() for k, v in net.state_dict().items()},
                         {k: v.cpu() for k, v in batch.items()})["rgb_level1"]
     assert float((img.cpu() - ref).abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_cost_reg_training_stage_equals_its_float64_twin_on_the_steps_own_tensors():
+    """Stage-wise arbitration (what the end-to-end numbers cannot show, because a 1e-6 change of a stage's INPUT can flip a mask):
+    the cost volume entering cost_reg_i and the gradients arriving at its outputs are captured during one 128x160 step on the
+    GPU, the stage is replayed in float64 on the CPU with the network's own modules, and every parameter gradient of the HIP
+    stage (MFMA convolutions / dgrad / wgrad, BatchNorm-train kernels) must match it to 2e-5 of its largest element — measured
+    6e-7 median / 2e-6 worst, the same as the stage's torch fp32 twin on the CPU (tools/diag_cost_reg_fp64.py)."""
+    import copy
+    from enerf_amd import autograd as A, train_path as T
+    dev = torch.device("cuda:0")
+    cfg, batch = _train_batch(**TRAIN_CASES["train_small"])
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    net = _net(cfg).to(dev)
+    cap, orig = {}, A.cost_reg_train
+
+    def spy(lib, m, vol):
+        i = 1 if m.full else 0
+        feat, prob = orig(lib, m, vol)
+        cap[i] = {"vol": vol.detach().clone()}
+        feat.register_hook(lambda g, i=i: cap[i].__setitem__("g_feat", g.detach().clone()))
+        prob.register_hook(lambda g, i=i: cap[i].__setitem__("g_prob", g.detach().clone()))
+        return feat, prob
+    A.cost_reg_train = spy
+    try:
+        _loss(net(batch), batch).backward()
+    finally:
+        A.cost_reg_train = orig
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        m = getattr(net, f"cost_reg_{i}")
+        m64 = copy.deepcopy(m).cpu().double().train()
+        for p in m64.parameters():
+            p.grad = None
+        feat, prob = T.cost_reg_forward(m64, cap[i]["vol"].cpu().double())
+        torch.autograd.backward([feat, prob], [cap[i]["g_feat"].cpu().double(), cap[i]["g_prob"].cpu().double()])
+        worst = 0.0
+        for (n, p), (_, p64) in zip(m.named_parameters(), m64.named_parameters()):
+            err = float((p.grad.cpu().double() - p64.grad).abs().max()) / max(float(p64.grad.abs().max()), 1e-30)
+            worst = max(worst, err)
+            assert err < 2e-5, (i, n, err)
+        print(f"cost_reg_{i}: HIP stage vs float64 twin on the step's own tensors, worst parameter {worst:.1e}")
 
 
 @pytest.mark.gpu
@@ -808,8 +881,8 @@ def test_full_size_training_step_is_as_close_to_fp64_as_the_reference():
             assert abs(float(gr.double().norm()) - n64) <= 0.1 * n64, (n, float(gr.double().norm()), n64)
     dist = _distance_to_fp64(named, g32, g64, sparse=True)
     print("512x640 outputs vs reference fp32:", {k: f"{v:.1e}" for k, v in worst.items()})
-    print("512x640 fp64 arbitration (median ours, median ref, max ours, max ref):",
-          _assert_as_close_to_fp64_as_the_reference(dist, what="512x640"))
+    print("512x640 fp64 arbitration (ours, reference):",
+          _assert_as_close_to_fp64_as_the_reference(dist, np.load(os.path.join(GOLDEN, "train_full_noise.npz")), what="512x640"))
 
 
 @pytest.mark.gpu
