@@ -269,7 +269,7 @@ def train_bench(args, rank, world, dev, dist, emu_lib=None):
             model = DDP(net, device_ids=[dev.index], output_device=dev.index, find_unused_parameters=True)
     # torch.optim.Adam as the trainer builds it (lib/train/optimizer.py); on the GPU its fused multi-tensor implementation (the
     # same update rule in ONE kernel per dtype/device group; the default capturable foreach path issues ~220 scalar-base pow
-    # kernels per step — 1 ms of a 19 ms step, profiles/r04_train_step_profile_run1.txt)
+    # kernels per step — 1 ms of a 19 ms step, profiles/r04_train_step_profile_foreach_adam.txt)
     adam_kw = {"capturable": graphed}
     if not emu and not args.adam_foreach:
         adam_kw["fused"] = True
