@@ -206,8 +206,20 @@ void k_render_rays(RenderArgs a) {
     const float* rd_rec = stage + j * SST + g * R;       // + s*16*SST: channels [gR, gR+R) of view s, point j
     const float* rd_dir = stage + j * SST + TEX + g;     // + s*16*SST: direction-code component g of view s
 
-    // natural (round-robin) tile order: handing each XCD a contiguous run of tiles measured ~3 % slower
+    // Tile order (round 4, profiles/r04_ab_warp_variants_render_xcd_band.txt): XCD k (= block id % 8) renders the k-th eighth of
+    // the tile list = an image row band, round-robin over ITS blocks, so the texels its gathers touch stay in its own L2:
+    // FETCH_SIZE 241 -> 159 MB per launch at the same kernel time (190.2 vs 190.6 us).  (Round 3's variant — one contiguous run
+    // of tiles per BLOCK — measured ~3 % slower; ENERF_RENDER_XCD_BAND=0 is the plain round-robin order.)
+#ifndef ENERF_RENDER_XCD_BAND
+#define ENERF_RENDER_XCD_BAND 1
+#endif
+#if ENERF_RENDER_XCD_BAND
+    const long long xcd_ = blockIdx.x & 7, nb8 = ((long long)gridDim.x + 7 - xcd_) >> 3, bi_ = blockIdx.x >> 3;
+    const long long t_hi = ntiles * (xcd_ + 1) / 8;
+    for (long long tile = ntiles * xcd_ / 8 + bi_ * WAVES + wave_in_block; tile < t_hi; tile += nb8 * WAVES) {
+#else
     for (long long tile = (long long)blockIdx.x * WAVES + wave_in_block; tile < ntiles; tile += (long long)gridDim.x * WAVES) {
+#endif
         long long ray = tile * 16 + j;
         const bool rok = ray < nrays;
         const long long rc = rok ? ray : nrays - 1;

@@ -11,7 +11,18 @@
 // write D*h*w*C*4.  The 4-tap gathers re-read features from L2/MALL, not HBM.
 #include "kernels.h"
 
+#ifndef ENERF_VOL_PK
+#define ENERF_VOL_PK 0               // A/B: packed-fp32 blend + moments
+#endif
+#ifndef ENERF_VOL_BYTEOFF
+#define ENERF_VOL_BYTEOFF 0          // A/B (tools/build_variant.py): 32-bit byte offsets for the tap loads
+#endif
+
 namespace enerf {
+
+#ifndef ENERF_EMU
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#endif
 
 // The CQ lanes of a voxel share its geometry, so they also share the work: lane q projects the voxel into
 // view s0+q (homography, perspective divide, bilinear taps: ~130 VALU with the IEEE divides the reference
@@ -21,39 +32,39 @@ namespace enerf {
 template <int CQ>  // CQ = C/4 lanes per voxel
 __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict__ feat, const float* __restrict__ proj,
                                                         const float* __restrict__ dv, int B, int S, int Hs, int Ws,
-                                                        int D, int h, int w, float inv_w, int planar, float* __restrict__ vol) {
+                                                        int D, int h, int w, float inv_w, float inv_d, int planar,
+                                                        float* __restrict__ vol) {
     constexpr int C = CQ * 4;
     // Block -> voxels, XCD-aware: the dispatcher puts block i on XCD i % 8 and every XCD has a private 4 MiB L2, so
     // with the raster order every XCD gathers from the whole of every source image (PMC: 245 MB of fabric reads
     // per level-1 launch against 58 MB compulsory — at 7 TB/s that IS the kernel time).  Here XCD k owns the band
     // of rows [k*rb, (k+1)*rb) of every depth plane: its gathers stay inside a band of each source image that
     // fits its L2.  Within the band blocks walk plane-major.  Speed only; any placement is correct.
-    // Voxel -> (b, d, y, x) without per-lane divisions: the block's first voxel is decomposed once on the
-    // scalar unit, lanes add their offset and carry (launcher: B*D*h*w*CQ < 2^31, h*w < 2^23).
-    const int xcd = blockIdx.x & 7, kblk = blockIdx.x >> 3;
+    // (launcher: B*D*h*w*CQ < 2^31, D*h*w < 2^24)
+    // Round 4: the decomposition is carried by the GRID (x = XCD band, y = 256/CQ-voxel chunk of the band, z = depth plane of
+    // a batch element), so nothing is divided per lane or per block: the round-3 kernel spent a third of its ~400 VALU
+    // instructions (two emulated integer divisions + two carry loops) on turning a linear block id into (b, d, y, x), in a
+    // kernel that is VALU-issue bound (40 waves per SIMD x ~400 VALU x 4 cycles = its 27 us).
+    const int xcd = blockIdx.x;                                    // gridDim.x == 8: linear block id % 8 == blockIdx.x
     const int rb = (h + 7) >> 3;                                   // rows per band
     const int yb = xcd * rb, ny = min(rb, h - yb);
     if (ny <= 0) return;                                           // uniform
     const unsigned band = (unsigned)(ny * w);                      // voxels of the band in one plane
-    const unsigned nband = (unsigned)(B * D) * band;
-    const unsigned v0 = (unsigned)kblk * (256 / CQ);               // uniform
-    if (v0 >= nband) return;                                       // uniform
+    const unsigned p0 = blockIdx.y * (256 / CQ);                   // uniform
+    if (p0 >= band) return;                                        // uniform
     const int cq = threadIdx.x & (CQ - 1);
-    const unsigned v_raw = v0 + (threadIdx.x / CQ);
-    const bool live = v_raw < nband;
-    const unsigned vi = live ? v_raw : nband - 1;          // dead lanes shadow the last voxel (they take part in the broadcasts)
+    const unsigned p_raw = p0 + (threadIdx.x / CQ);
+    const bool live = p_raw < band;
+    const unsigned p = live ? p_raw : band - 1;            // dead lanes shadow the last voxel (they take part in the broadcasts)
     const int lane = threadIdx.x & 63, lead = lane & ~(CQ - 1);
-    const unsigned plane0 = v0 / band, p0 = v0 - plane0 * band;
-    unsigned p = p0 + (vi - v0), pl = plane0;
-    while (p >= band) { p -= band; ++pl; }
-    int b = (int)(plane0 / (unsigned)D);
-    while (pl >= (unsigned)(b + 1) * (unsigned)D) ++b;
+    const unsigned pl = blockIdx.z;                                // plane index b * D + d
+    const int b = (int)(((float)pl + 0.5f) * inv_d);               // uniform; exact for B * D < 2^22
     // row = p / w through a float reciprocal with an exact fix-up
-    int yr = (int)((float)p * inv_w), x = (int)p - yr * w;
+    int yr = (int)((float)p * inv_w), x = (int)p - mul24(yr, w);
     if (x < 0) { --yr; x += w; }
     if (x >= w) { ++yr; x -= w; }
     const int y = yb + yr;
-    const unsigned vox = (pl * (unsigned)h + (unsigned)y) * (unsigned)w + (unsigned)x;
+    const unsigned vox = (unsigned)mul24((int)(pl * (unsigned)h) + y, w) + (unsigned)x;
     const float depth = dv[vox];                      // (B,D,h,w) has the same linear index as the voxel
     const float fx = (float)x, fy = (float)y;
     // utils.py:82-83 divide by the Python scalars (W_S-1)/2, (H_S-1)/2: ATen's GPU kernel multiplies by the
@@ -61,6 +72,9 @@ __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict_
     const float inv_half_w = 1.f / (float)((Ws - 1) / 2.0), inv_half_h = 1.f / (float)((Hs - 1) / 2.0);
     const unsigned img = (unsigned)(Hs * Ws * C);      // floats per source view (launcher: B*S*img < 2^32)
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#if ENERF_VOL_PK && !defined(ENERF_EMU)
+    f32x2 s1a = {0.f, 0.f}, s1b = {0.f, 0.f}, s2a = {0.f, 0.f}, s2b = {0.f, 0.f};
+#endif
     for (int s0 = 0; s0 < S; s0 += CQ) {
         // ---- this lane's view ----
         const int sv = min(s0 + cq, S - 1);
@@ -68,31 +82,72 @@ __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict_
         // IEEE divisions, as the reference (utils.py:72,80-83).  Measured in round 3: two refined reciprocals instead (<= 1.5 ulp
         // off) save 0.7 us per launch but move the ill-conditioned BatchNorm-weight gradients of conv0 by 6e-3 relative in
         // the training path, which shares this arithmetic — not worth it.
+#if defined(ENERF_VOL_FASTDIV) && ENERF_VOL_FASTDIV && !defined(ENERF_EMU)   /* A/B only: what the five IEEE divisions cost (1-ulp reciprocals) */
+        const float rdep = __builtin_amdgcn_rcpf(depth);
+        const float px = P[0] * fx + P[1] * fy + P[2] + P[3] * rdep;
+        const float py = P[4] * fx + P[5] * fy + P[6] + P[7] * rdep;
+        const float pz = P[8] * fx + P[9] * fy + P[10] + P[11] * rdep;
+        const float z = clamp_min(pz, 1e-6f);
+        const float rz = __builtin_amdgcn_rcpf(z);
+        const float gx = (px * rz) * inv_half_w - 1.f, gy = (py * rz) * inv_half_h - 1.f;
+#else
         const float px = P[0] * fx + P[1] * fy + P[2] + P[3] / depth;       // utils.py:72
         const float py = P[4] * fx + P[5] * fy + P[6] + P[7] / depth;
         const float pz = P[8] * fx + P[9] * fy + P[10] + P[11] / depth;
         const float z = clamp_min(pz, 1e-6f);                                // utils.py:80
         const float gx = (px / z) * inv_half_w - 1.f, gy = (py / z) * inv_half_h - 1.f;
+#endif
         const Taps2 t = gs_taps2<false>(gs_unnorm(gx, Ws), gs_unnorm(gy, Hs), Ws, Hs);
         const unsigned vb = (unsigned)(b * S + sv) * img;
         const int r0 = mul24(t.y0, Ws), r1 = mul24(t.y1, Ws);
+#if ENERF_VOL_BYTEOFF    /* 32-bit BYTE offsets: `scalar base + lane offset` loads, no 64-bit address add per tap (launcher: < 2^30 floats) */
+        const int my_o[4] = {(int)((vb + (unsigned)mul24(r0 + t.x0, C)) * 4u), (int)((vb + (unsigned)mul24(r0 + t.x1, C)) * 4u),
+                             (int)((vb + (unsigned)mul24(r1 + t.x0, C)) * 4u), (int)((vb + (unsigned)mul24(r1 + t.x1, C)) * 4u)};
+#else
         const int my_o[4] = {(int)(vb + (unsigned)mul24(r0 + t.x0, C)), (int)(vb + (unsigned)mul24(r0 + t.x1, C)),
                              (int)(vb + (unsigned)mul24(r1 + t.x0, C)), (int)(vb + (unsigned)mul24(r1 + t.x1, C))};
+#endif
         const float my_w[4] = {t.w00, t.w01, t.w10, t.w11};
         // ---- the group's views in turn ----
 #pragma unroll
         for (int k = 0; k < CQ; ++k) {
             if (s0 + k >= S) break;                                          // uniform
+#if ENERF_VOL_PK && !defined(ENERF_EMU)
+            // packed-fp32 form of the blend and the moments (v_pk_mul/fma/add_f32: two channels per instruction)
+            f32x2 ra = {0.f, 0.f}, rb = {0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const unsigned o = (unsigned)__shfl(my_o[c], lead + k) + (unsigned)(cq * (ENERF_VOL_BYTEOFF ? 16 : 4));
+                const float wgt = __shfl(my_w[c], lead + k);
+#if ENERF_VOL_BYTEOFF
+                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(feat) + o);
+#else
+                const float4 v = *reinterpret_cast<const float4*>(feat + o);
+#endif
+                const f32x2 va = {v.x, v.y}, vb2 = {v.z, v.w}, w2 = {wgt, wgt};
+                if (c == 0) { ra = va * w2; rb = vb2 * w2; }
+                else { ra = __builtin_elementwise_fma(va, w2, ra); rb = __builtin_elementwise_fma(vb2, w2, rb); }
+            }
+            s1a += ra; s1b += rb;
+            s2a = __builtin_elementwise_fma(ra, ra, s2a); s2b = __builtin_elementwise_fma(rb, rb, s2b);
+            continue;
+#endif
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+#if ENERF_VOL_BYTEOFF
+                const unsigned o = (unsigned)__shfl(my_o[c], lead + k) + (unsigned)(cq * 16);
+#else
                 const unsigned o = (unsigned)__shfl(my_o[c], lead + k) + (unsigned)(cq * 4);
+#endif
                 const float wgt = __shfl(my_w[c], lead + k);
                 // ENERF_ABL_VOL: compile-time ablations behind profiles/r03_volume_ablation.txt (never defined in the product build)
 #if defined(ENERF_ABL_VOL) && (ENERF_ABL_VOL & 1)      /* one tap's load stands in for all four (gather traffic / 4) */
                 const float4 v = *reinterpret_cast<const float4*>(feat + ((unsigned)__shfl(my_o[0], lead + k) + (unsigned)(cq * 4)));
 #elif defined(ENERF_ABL_VOL) && (ENERF_ABL_VOL & 2)    /* no gathers at all (a lane-dependent constant) */
                 const float4 v = make_float4(wgt, 1.f, 2.f, (float)o);
+#elif ENERF_VOL_BYTEOFF
+                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(feat) + o);
 #else
                 const float4 v = *reinterpret_cast<const float4*>(feat + o);
 #endif
@@ -106,6 +161,9 @@ __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict_
     // utils.py:345 `div_(S)`: with a Python scalar divisor ATen's GPU kernel multiplies by the reciprocal
     // (BinaryDivTrueKernel: is_cpu_scalar -> MulFunctor(1/b)), so this is the reference's device arithmetic;
     // the CPU oracle divides, which differs by <= 1 ulp of the mean.
+#if ENERF_VOL_PK && !defined(ENERF_EMU)
+    s1 = make_float4(s1a.x, s1a.y, s1b.x, s1b.y); s2 = make_float4(s2a.x, s2a.y, s2b.x, s2b.y);
+#endif
     const float inv_s = 1.f / (float)S;
     float4 o;
     float m;
@@ -126,14 +184,15 @@ __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict_
 
 void launch_feature_volume(const float* feat_nhwc, const float* proj, const float* dv, int B, int S, int C, int Hs,
                            int Ws, int D, int h, int w, float* vol, hipStream_t st, int planar) {
-    // 8 row bands (one per XCD), each padded to a whole number of blocks: grid = 8 x blocks-per-band
+    // grid = 8 row bands (one per XCD) x chunks of 256/CQ voxels of a band x (B * D) planes
     const int rb = (h + 7) / 8;
-    const long long band_threads = (long long)B * D * rb * w * (C / 4);
-    unsigned grid = 8u * (unsigned)cdivl(band_threads, 256);
+    const int vpb = 256 / (C / 4);
+    const dim3 grid(8, (unsigned)cdiv(rb * w, vpb), (unsigned)(B * D));
+    const float inv_w = 1.f / (float)w, inv_d = 1.f / (float)D;
     switch (C) {
-        case 32: ENERF_LAUNCH(k_feature_volume<8>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, 1.f / (float)w, planar, vol); break;
-        case 16: ENERF_LAUNCH(k_feature_volume<4>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, 1.f / (float)w, planar, vol); break;
-        case 8: ENERF_LAUNCH(k_feature_volume<2>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, 1.f / (float)w, planar, vol); break;
+        case 32: ENERF_LAUNCH(k_feature_volume<8>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, inv_w, inv_d, planar, vol); break;
+        case 16: ENERF_LAUNCH(k_feature_volume<4>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, inv_w, inv_d, planar, vol); break;
+        case 8: ENERF_LAUNCH(k_feature_volume<2>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, inv_w, inv_d, planar, vol); break;
         default: break;   // validated by the C-ABI layer
     }
 }

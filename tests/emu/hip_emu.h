@@ -175,8 +175,8 @@ inline void run_block_lockstep(BlockCtx& c) {
 
 template <class F>
 inline void launch(bool lockstep, dim3 grid, dim3 block, size_t shmem, F&& kernel_call) {
-    if (grid.y != 1 || grid.z != 1 || block.y != 1 || block.z != 1) die("emu supports 1-D launches only");
-    unsigned nblk = grid.x;
+    if (block.y != 1 || block.z != 1) die("emu supports 1-D blocks only");
+    unsigned nblk = grid.x * grid.y * grid.z;                     // x fastest, like the hardware's dispatch order
     unsigned nthreads = std::min<unsigned>(nblk, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* e = getenv("ENERF_EMU_THREADS")) nthreads = std::max(1, atoi(e));
     nthreads = std::min(nthreads, nblk);
@@ -190,7 +190,7 @@ inline void launch(bool lockstep, dim3 grid, dim3 block, size_t shmem, F&& kerne
         for (;;) {
             unsigned b = next.fetch_add(1);
             if (b >= nblk) break;
-            c.blockIdx = dim3(b);
+            c.blockIdx = dim3(b % grid.x, (b / grid.x) % grid.y, b / (grid.x * grid.y));
             if (!lockstep) {
                 for (unsigned t = 0; t < block.x; ++t) { c.tid = t; kernel_call(); }
             } else {
@@ -208,9 +208,17 @@ inline void launch(bool lockstep, dim3 grid, dim3 block, size_t shmem, F&& kerne
 }
 
 struct TidProxy { unsigned y = 0, z = 0; struct X { operator unsigned() const { return ctx()->tid; } } x; };
-struct BidProxy { unsigned y = 0, z = 0; struct X { operator unsigned() const { return ctx()->blockIdx.x; } } x; };
+struct BidProxy {
+    struct X { operator unsigned() const { return ctx()->blockIdx.x; } } x;
+    struct Y { operator unsigned() const { return ctx()->blockIdx.y; } } y;
+    struct Z { operator unsigned() const { return ctx()->blockIdx.z; } } z;
+};
 struct BdimProxy { unsigned y = 1, z = 1; struct X { operator unsigned() const { return ctx()->blockDim.x; } } x; };
-struct GdimProxy { unsigned y = 1, z = 1; struct X { operator unsigned() const { return ctx()->gridDim.x; } } x; };
+struct GdimProxy {
+    struct X { operator unsigned() const { return ctx()->gridDim.x; } } x;
+    struct Y { operator unsigned() const { return ctx()->gridDim.y; } } y;
+    struct Z { operator unsigned() const { return ctx()->gridDim.z; } } z;
+};
 
 }  // namespace emu
 
