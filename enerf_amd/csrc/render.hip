@@ -214,9 +214,10 @@ void k_render_rays(RenderArgs a) {
 #define ENERF_RENDER_XCD_BAND 1
 #endif
 #if ENERF_RENDER_XCD_BAND
-    const long long xcd_ = blockIdx.x & 7, nb8 = ((long long)gridDim.x + 7 - xcd_) >> 3, bi_ = blockIdx.x >> 3;
-    const long long t_hi = ntiles * (xcd_ + 1) / 8;
-    for (long long tile = ntiles * xcd_ / 8 + bi_ * WAVES + wave_in_block; tile < t_hi; tile += nb8 * WAVES) {
+    const long long nbands = gridDim.x < 8 ? gridDim.x : 8;                      // (small launches: fewer blocks than XCDs)
+    const long long xcd_ = blockIdx.x % nbands, nb8 = ((long long)gridDim.x + nbands - 1 - xcd_) / nbands, bi_ = blockIdx.x / nbands;
+    const long long t_hi = ntiles * (xcd_ + 1) / nbands;
+    for (long long tile = ntiles * xcd_ / nbands + bi_ * WAVES + wave_in_block; tile < t_hi; tile += nb8 * WAVES) {
 #else
     for (long long tile = (long long)blockIdx.x * WAVES + wave_in_block; tile < ntiles; tile += (long long)gridDim.x * WAVES) {
 #endif
