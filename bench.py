@@ -95,6 +95,50 @@ def cost_reg_gflop(C, full, D, h, w):
     return f / 1e9
 
 
+def live_pmc(workload, kernel_prefix="k_render_rays<3"):
+    """HBM traffic + matrix-pipe busy fraction of the dominant kernel, measured NOW: three short rocprofv3 --pmc passes
+    (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE; separate passes, --kernel-trace only — the
+    MI355X_MICROARCH.md recipe, as tools/collect_profiles.sh) over a child run of this script (3 frames, kernels alone on one
+    stream).  Returns None when rocprofv3 is missing or a pass fails: the caller then replays the committed figures."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+             "--no-stages", "--no-sync-per-frame", "--single-stream", "--no-live-pmc"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    means = {}
+    for counters in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"):
+        d = tempfile.mkdtemp(prefix="enerf_pmc_", dir="/tmp")
+        try:
+            subprocess.run([rocprof, "--pmc", *counters.split(), "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", *child],
+                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            acc = {}
+            for r in csv.DictReader(open(files[0])):
+                k = r["Kernel_Name"].replace("void enerf::", "").replace("enerf::", "")
+                if k.startswith(kernel_prefix):
+                    acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            for c, v in acc.items():
+                means[c] = sum(v) / len(v)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if not all(c in means for c in ("FETCH_SIZE", "WRITE_SIZE")):
+        return None
+    out = {"hbm_bytes_per_launch": (2.0 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024.0,      # gfx950: FETCH_SIZE doubled
+           "fetch_size_kb": means["FETCH_SIZE"], "write_size_kb": means["WRITE_SIZE"]}
+    if means.get("GRBM_GUI_ACTIVE"):
+        out["mfma_busy_frac"] = round(means.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * means["GRBM_GUI_ACTIVE"] / 8.0), 4)
+    return out
+
+
 def make_workload(name, seed):
     from enerf_amd.config import EnerfConfig
     from enerf_amd.synth import make_batch, make_lego_batch, make_zju_batch
@@ -375,6 +419,8 @@ def main():
     ap.add_argument("--workload", choices=["dtu", "lego", "zju"], default="dtu")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="skip everything after the timed region (profiling runs)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not run the rocprofv3 --pmc child passes for roofline.traffic (replay profiles/pmc_render_<workload>.json)")
     ap.add_argument("--no-sync-per-frame", action="store_true",
                     help="profiling runs: enqueue the timed frames back to back (value is then sequential_fps)")
     ap.add_argument("--in-flight", type=int, default=6, help="frames in flight for the pipelined_fps extra")
@@ -702,7 +748,15 @@ def main():
             from enerf_amd.build import source_digest
             traffic, pmc_note, busy, pmc_digest = None, None, None, None
             lib_digest = source_digest()
-            for cand in (f"pmc_render_{args.workload}.json", f"r02_pmc_render_{args.workload}.json"):
+            live = None
+            if world == 1 and not args.no_live_pmc and dom == f"render_{last}" and cas.num_samples[last] <= 2:
+                torch.cuda.synchronize()
+                live = live_pmc(args.workload)
+            if live is not None:
+                traffic, busy, pmc_digest = live["hbm_bytes_per_launch"], live.get("mfma_busy_frac"), lib_digest
+                pmc_note = ("measured by this run: rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE) "
+                            "over a 3-frame child run of bench.py --single-stream; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB")
+            for cand in (() if live is not None else (f"pmc_render_{args.workload}.json", f"r02_pmc_render_{args.workload}.json")):
                 pmc_path = os.path.join(ROOT, "profiles", cand)
                 if os.path.exists(pmc_path):
                     pmc = json.load(open(pmc_path))
@@ -719,7 +773,7 @@ def main():
                 "reference_dense_flops_per_launch": d["reference_dense_flops_per_launch"],
                 "note": f"achieved = {d['mfma_tiles_per_16_samples']} fp32 16x16x4 MFMA tiles per 16 samples (the MLP with the "
                         "view-independent halves of global_fc/color.0 evaluated once per point) x samples / launch time",
-                "traffic_measured_live": False, "mfma_pipe_busy_frac_pmc": busy, "pmc_measured_live": False,
+                "traffic_measured_live": live is not None, "mfma_pipe_busy_frac_pmc": busy, "pmc_measured_live": live is not None,
                 "traffic_source": pmc_note, "library_source_digest": lib_digest, "pmc_source_digest": pmc_digest,
                 "pmc_stale": pmc_digest != lib_digest}
 

@@ -7,4 +7,4 @@ timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu_$TAG.log 2>&1; 
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke_$TAG.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke_$TAG.log
 bash tools/collect_profiles.sh ${TAG}_dtu dtu 1
 bash tools/collect_profiles.sh ${TAG}_lego lego 1
-bash tools/collect_profiles.sh ${TAG}_zju zju 0
+bash tools/collect_profiles.sh ${TAG}_zju zju 1
