@@ -176,9 +176,10 @@ class P: name = "fake"; uuid = None; pci_bus_id = None
 fp.torch.cuda.get_device_properties = lambda d: P()
 try:
     fp.rank_bindings(rank, world, 0, torch.device("cuda", 0))       # both ranks claim cuda:0 of the same visible list
-    print("NOT REFUSED")
+    sys.stdout.write("NOT-REFUSED\n")
 except RuntimeError as e:
-    print("refused:", "share a device" in str(e))
+    sys.stdout.write("refused-%s\n" % ("share a device" in str(e)))          # one write per rank: the two ranks share the pipe
+sys.stdout.flush()
 dist.destroy_process_group()
 ''' % ROOT
     env = dict(os.environ, OMP_NUM_THREADS="1")
@@ -193,7 +194,7 @@ dist.destroy_process_group()
     finally:
         os.unlink(f.name)
     assert p.returncode == 0, p.stderr[-2000:]
-    assert p.stdout.count("refused: True") == 2 and "NOT REFUSED" not in p.stdout, p.stdout
+    assert p.stdout.count("refused-True") == 2 and "NOT-REFUSED" not in p.stdout, p.stdout
 
 
 def _bench(args, timeout):
