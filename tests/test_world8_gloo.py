@@ -178,7 +178,7 @@ try:
     fp.rank_bindings(rank, world, 0, torch.device("cuda", 0))       # both ranks claim cuda:0 of the same visible list
     sys.stdout.write("NOT-REFUSED\n")
 except RuntimeError as e:
-    sys.stdout.write("refused-%s\n" % ("share a device" in str(e)))          # one write per rank: the two ranks share the pipe
+    sys.stdout.write("refused-" + str("share a device" in str(e)) + "\n")     # one write per rank: the two ranks share the pipe
 sys.stdout.flush()
 dist.destroy_process_group()
 ''' % ROOT
