@@ -700,6 +700,36 @@ def main():
             except Exception as e:                      # an extra: never let it take the line down
                 result["feature_backend_torch"] = {"error": str(e)[:200]}
 
+        # ---- the opt-in fast precision of the render MLP (enerf_options_t.render_precision = 2, "bf16x3": every fp32 operand as two
+        #      bf16 pieces on the bf16 matrix cores; ~7e-6 of max|ref| on ordinary inputs, NOT robust to large head gains —
+        #      tests/test_adversarial.py): an extra key, never `value` ----
+        if not args.graph:
+            try:
+                from enerf_amd.lib import Options as _O
+                saved = net.options
+                net.options = _O(render_precision=2, **{k: v for k, v in opt_fields.items()})
+                for _ in range(20):
+                    step()
+                torch.cuda.synchronize()
+                lt = []
+                for _ in range(200):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    o_fast = step()
+                    torch.cuda.synchronize()
+                    lt.append(time.perf_counter() - t1)
+                key = f"rgb_level{last}"
+                o_fast = {key: o_fast[key].clone()}
+                net.options = saved
+                o_exact = net(batches[frame_no[0] % nb])
+                torch.cuda.synchronize()
+                result["render_bf16x3"] = {"value": round(len(lt) / sum(lt), 1), "unit": "frames/s",
+                                           "max_abs_rgb_vs_exact_kernel": float((o_fast[key] - o_exact[key]).abs().max()),
+                                           "note": "same protocol, 200 frames, render_precision = 2 (opt-in: ~1e-5 operand error, "
+                                                   "amplified by large head gains); the default and `value` are the exact fp32 kernel"}
+            except Exception as e:
+                result["render_bf16x3"] = {"error": str(e)[:200]}
+
         # ---- rooflines: per stage, and the dominant kernel as the contract's `roofline` object ----
         sr = {}
         for i in range(cas.num):

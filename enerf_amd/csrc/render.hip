@@ -36,7 +36,10 @@
 
 namespace enerf {
 
-long long nerf_packed_floats(int F) { return nerf_layout(F).total; }
+// fp32 image (nerf_layout) + for F = 11 the bf16x3 tiles of the level-1 render (bx_layout: 44 tiles x 64 lanes x 16 bytes)
+// three planes (hi, mid, lo) of [pair-tile][lane] 16 bytes = bx_layout().tiles * 256 floats each
+__host__ __device__ __forceinline__ int bx_image_floats(int F, int pieces = 3) { return F == 11 ? bx_layout().tiles * 256 * pieces : 0; }
+long long nerf_packed_floats(int F) { return nerf_layout(F).total + bx_image_floats(F); }
 
 // slot (g, r) of the channel layout -> channel index (or -1)
 __host__ __device__ __forceinline__ int slot_channel(int g, int r, int R, int F) {
@@ -44,10 +47,54 @@ __host__ __device__ __forceinline__ int slot_channel(int g, int r, int R, int F)
     return (r < R && c < F) ? c : -1;
 }
 
+// one weight of the bf16 image: pair-tile e, lane (g, j), k-slot q = 0..7 (q < 4: first 16-unit group of the pair, slot r = q;
+// q >= 4: second group, r = q - 4); see bx_layout / the BX branches of k_render_rays
+__device__ __forceinline__ float bx_weight(const NerfRaw& w, int F, int e, int g, int j, int q) {
+    const int R = (F + 3) / 4, CI = 88 + F + 4;
+    const BxLayout B = bx_layout();
+    const int half = q >> 2, r = q & 3;
+    const int c = (r < R && g * R + r < F) ? g * R + r : -1;          // feature channel of slot (g, r)
+    if (e < B.ga) return c >= 0 ? w.glob_w[(16 * e + j) * 3 * F + (1 + half) * F + c] : 0.f;       // [variance | mean] columns, tile u = e
+    if (e < B.fc) return (half == 0 && c >= 0) ? w.glob_w[(16 * (e - B.ga) + j) * 3 * F + c] : 0.f;  // per-view a_s columns | 0
+    if (e < B.lr0) return w.fc_w[j * 32 + 16 * half + 4 * g + r];                                    // agg.fc: [G tile 0 | G tile 1]
+    if (e < B.c0p) {                         // lr0: [voxel pair (slots 0, 1) | agg]; tile v
+        const int unit = 16 * (e - B.lr0) + j;
+        if (half == 0) return r < 2 ? w.lr0_w[unit * 24 + 2 * g + r] : 0.f;
+        return w.lr0_w[unit * 24 + 8 + 4 * g + r];
+    }
+    if (e < B.c0v) {                         // color.0, shared columns: pair 0 [h0 | h1], 1 [h2 | h3], 2 [voxel pair | agg]; tile = pair*4 + v
+        const int pr = (e - B.c0p) >> 2, unit = 16 * ((e - B.c0p) & 3) + j;
+        if (pr < 2) return w.col0_w[unit * CI + 16 * (2 * pr + half) + 4 * g + r];
+        if (half == 0) return r < 2 ? w.col0_w[unit * CI + 64 + 2 * g + r] : 0.f;
+        return w.col0_w[unit * CI + 72 + 4 * g + r];
+    }
+    if (half) return 0.f;                    // color.0, per-view columns | 0: slots r < R = texel channels, slot R = direction code g
+    const int unit = 16 * (e - B.c0v) + j;
+    if (c >= 0) return w.col0_w[unit * CI + 88 + c];
+    return r == R ? w.col0_w[unit * CI + 88 + F + g] : 0.f;
+}
+__device__ __forceinline__ unsigned bf16_bits_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
 __global__ __launch_bounds__(256) void k_nerf_pack(NerfRaw w, int F, int viewdir_agg, float* __restrict__ out) {
     const NerfLayout L = nerf_layout(F);
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L.total) return;
+    if (i >= L.total + bx_image_floats(F)) return;
+    if (i >= L.total) {                      // bf16 image: plane (hi, mid, lo) x [pair-tile][lane] x 4 words, word = slots (2w, 2w+1)
+        const int idx = i - L.total, n_plane = bx_layout().tiles * 256;
+        const int piece = idx / n_plane, k = idx - piece * n_plane;
+        const int e = k >> 8, lane = (k >> 2) & 63, wq = k & 3;
+        unsigned word = 0;
+        for (int h = 0; h < 2; ++h) {
+            float rem = bx_weight(w, F, e, lane >> 4, lane & 15, 2 * wq + h);
+            unsigned bits = 0;
+            for (int pc = 0; pc <= piece; ++pc) { bits = bf16_bits_rne(rem); rem -= __uint_as_float(bits << 16); }
+            word |= (bits & 0xffffu) << (16 * h);
+        }
+        out[i] = __uint_as_float(word);
+        return;
+    }
     const int R = L.R;
     const int CI = 88 + F + 4;    // color.0 fan-in
     float v = 0.f;
@@ -107,7 +154,7 @@ __global__ __launch_bounds__(256) void k_nerf_pack(NerfRaw w, int F, int viewdir
     out[i] = v;
 }
 void launch_nerf_pack(const NerfRaw& raw, int F, int viewdir_agg, float* packed, hipStream_t st) {
-    int total = nerf_layout(F).total;
+    int total = (int)nerf_packed_floats(F);
     ENERF_LAUNCH_SIMPLE(k_nerf_pack, cdiv(total, 256), 256, 0, st, raw, F, viewdir_agg, packed);
 }
 
@@ -127,37 +174,56 @@ template <int R> struct Stage { static constexpr int kTex = 4 * R, kStride = 4 *
 //   MLP phase, lane (g, j): channels [gR, gR+R) of every view come back from the LDS records as MFMA B operands; the
 //     rest is the k-ordered MFMA chain described at the top of this file.
 // WPE = waves per SIMD the register budget is sized for (512 / WPE VGPRs): blocks per CU x WAVES / 4
-template <int R, int S, int WAVES, int WPE, bool PFK = false, bool LEANK = false>
+// BX = 3 / 6 (R = 3 only): the dense layers of the MLP on the bf16 matrix cores with operands split into 2 / 3 bf16 pieces
+// (nerf_layout.h "bf16x3" / "bf16x6"); view_fc (k = 4) and the width-1 heads stay as they are.  BX = 0: fp32 MFMAs.
+template <int R, int S, int WAVES, int WPE, bool PFK = false, bool LEANK = false, int BX = 0>
 __global__ __launch_bounds__(64 * WAVES)
 #ifndef ENERF_EMU
 __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #endif
 void k_render_rays(RenderArgs a) {
+    static_assert(BX == 0 || R == 3, "the bf16 image exists for F = 11 only");
+    constexpr bool BX3 = BX != 0;                        // (name kept: "the MLP runs on bf16 pieces")
+    constexpr int NP = BX == 6 ? 3 : 2;                  // bf16 pieces per operand
     constexpr int TR = (R + 3) / 4;
     constexpr int TEX = Stage<R>::kTex, SST = Stage<R>::kStride;
-    const NerfLayout L = nerf_layout(a.F);
+    const NerfLayout LF = nerf_layout(a.F);              // the image in global memory
+    const NerfLayout L = nerf_layout(a.F, BX3);          // what is staged: without the fp32 MFMA tiles in the bf16 variants
+    constexpr int BXP = 25 * 256;                        // floats of one bf16 plane (bx_layout().tiles pair-tiles x 64 lanes x 16 B)
+    constexpr int BXF = BX3 ? BXP * NP : 0;              // the planes staged behind it (hi, mid[, lo])
     ENERF_DYN_SMEM(float, smem);
     float* wl = smem;                                    // packed weights
-    float* cam = smem + L.total;                         // B*S*16
+    const float* bx = smem + L.total;                    // bf16 planes
+    auto bxplane = [&](int q) { return bx + q * BXP; };
+    float* cam = smem + L.total + BXF;                   // B*S*16
     float* tcen = cam + a.B * S * kCamStride;            // B*4
     float* stage_all = tcen + ((a.B * 4 + 15) & ~15);    // WAVES * S * 16 * SST
 
     // ---- prologue: stage weights + camera table ----
     {   // weight image (42-56 KB) -> LDS with every load in flight before the first store: the plain copy loop compiles to
         // load -> s_waitcnt vmcnt(0) -> ds_write per iteration (11-14 serial L2 round trips at the head of every block)
-        constexpr int MAXW4 = (R == 3 ? 10560 : 14528) / 4;                 // nerf_layout(11 | 35).total / 4 (the launcher checks)
+        constexpr int MAXW4 = (BX3 ? BXF : (R == 3 ? 10560 : 14528)) / 4;    // nerf_layout(11 | 35).total / 4 (the launcher checks)
         constexpr int NWI = (MAXW4 + 64 * WAVES - 1) / (64 * WAVES);
         float4 wq[NWI];
-        const int n4 = L.total / 4;
+        const int n4 = (BX3 ? BXF : L.total) / 4;
+        const float* src = a.packed + (BX3 ? LF.total : 0);
+        float* dst = BX3 ? smem + L.total : wl;
 #pragma unroll
         for (int it = 0; it < NWI; ++it) {
             const int i = (int)threadIdx.x + it * 64 * WAVES;
-            wq[it] = *reinterpret_cast<const float4*>(a.packed + (i < n4 ? i : n4 - 1) * 4);
+            wq[it] = *reinterpret_cast<const float4*>(src + (i < n4 ? i : n4 - 1) * 4);
         }
 #pragma unroll
         for (int it = 0; it < NWI; ++it) {
             const int i = (int)threadIdx.x + it * 64 * WAVES;
-            if (i < n4) *reinterpret_cast<float4*>(wl + i * 4) = wq[it];
+            if (i < n4) *reinterpret_cast<float4*>(dst + i * 4) = wq[it];
+        }
+        if (BX3) {   // the small fp32 arrays (view_fc, biases, width-1 heads): nine short copies from their places in the full image
+            const int so[9] = {LF.view, LF.viewb, LF.globb, LF.aggw, LF.fcb, LF.lr0b, LF.sigma, LF.c0b, LF.col2};
+            const int dd[9] = {L.view, L.viewb, L.globb, L.aggw, L.fcb, L.lr0b, L.sigma, L.c0b, L.col2};
+            const int nn[9] = {L.TR * 64, L.TR * 16, 32, 33, 16, 64, 65, 64, 65};
+            for (int q = 0; q < 9; ++q)
+                for (int i = threadIdx.x; i < nn[q]; i += blockDim.x) wl[dd[q] + i] = a.packed[so[q] + i];
         }
     }
     for (int i = threadIdx.x; i < a.B * (S + 1); i += blockDim.x) {
@@ -465,13 +531,36 @@ void k_render_rays(RenderArgs a) {
             f32x4 P[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) P[u] = lds4(wl + L.globb + u * 16 + 4 * g);
-            // k-steps 0..R-1: variance slots, R..2R-1: mean slots (tiles (1*R + r)*2 + u and (2*R + r)*2 + u)
-            mfma_chain<2 * R, 2>(P, [&](int e) { return A_GLOB(2 * R + e); },
-                                 [&](int ks) { return ks < R ? var[ks < R ? ks : 0] : mean[ks >= R ? ks - R : 0]; });
             f32x4 gf[S][2];
             float aw[S];
             const f32x4 aggw0 = lds4(wl + L.aggw + 4 * g), aggw1 = lds4(wl + L.aggw + 16 + 4 * g);
             const float aggb = wl[L.aggw + 32];
+            if constexpr (BX3) {
+                // global_fc on the bf16 cores: one 16-deep chunk each for the variance, the mean and a view's a_s slots
+                const BxLayout BL = bx_layout();
+                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                {
+                    bfx8 vm[NP];
+                    bx_split<NP>(f32x4{var[0], var[1], var[2], 0.f}, f32x4{mean[0], mean[1], mean[2], 0.f}, vm);
+                    bx_mma_n<NP, 2>(bxplane, BL.gvm, lane, vm, P);
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    bfx8 ap[NP];
+                    bx_split<NP>(f32x4{av[s][0], av[s][1], av[s][2], 0.f}, zero4, ap);
+                    gf[s][0] = P[0]; gf[s][1] = P[1];
+                    bx_mma_n<NP, 2>(bxplane, BL.ga, lane, ap, gf[s]);
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    gf[s][0] = relu4(gf[s][0]); gf[s][1] = relu4(gf[s][1]);
+                    float part = dot4(gf[s][1], aggw1, dot4(gf[s][0], aggw0, 0.f));
+                    aw[s] = relu1(group_sum(part) + aggb);
+                }
+            } else {
+            // k-steps 0..R-1: variance slots, R..2R-1: mean slots (tiles (1*R + r)*2 + u and (2*R + r)*2 + u)
+            mfma_chain<2 * R, 2>(P, [&](int e) { return A_GLOB(2 * R + e); },
+                                 [&](int ks) { return ks < R ? var[ks < R ? ks : 0] : mean[ks >= R ? ks - R : 0]; });
             {
                 float ag[R * 2];                          // the per-view tiles are the same for every view: read them once
 #pragma unroll
@@ -492,6 +581,7 @@ void k_render_rays(RenderArgs a) {
                     aw[s] = relu1(group_sum(part) + aggb);
                 }
             }
+            }
             {   // softmax over views
                 float m = aw[0];
 #pragma unroll
@@ -511,7 +601,12 @@ void k_render_rays(RenderArgs a) {
                 for (int s = 1; s < S; ++s) G[u] += gf[s][u] * aw[s];
             }
             f32x4 aggv[1] = {lds4(wl + L.fcb + 4 * g)};
-            {
+            if constexpr (BX3) {
+                const BxLayout BL = bx_layout();
+                bfx8 gp[NP];
+                bx_split<NP>(G[0], G[1], gp);
+                bx_mma_n<NP, 1>(bxplane, BL.fc, lane, gp, aggv);
+            } else {
                 float afc[8];                             // one accumulator, eight dependent k-steps: all A values up front
 #pragma unroll
                 for (int e = 0; e < 8; ++e) afc[e] = A_FC(e);
@@ -527,6 +622,12 @@ void k_render_rays(RenderArgs a) {
             f32x4 hid[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) hid[v] = lds4(wl + L.lr0b + v * 16 + 4 * g);
+            bfx8 vap[NP];                                // (bf16 variants) [voxel pair | agg] feeds lr0 AND color.0: split once
+            if constexpr (BX3) {
+                const BxLayout BL = bx_layout();
+                bx_split<NP>(f32x4{vox[0], vox[1], 0.f, 0.f}, agg, vap);
+                bx_mma_n<NP, 4>(bxplane, BL.lr0, lane, vap, hid);
+            } else
             mfma_chain<6, 4>(hid, [&](int e) { return A_LR0(e); }, [&](int ks) { return ks < 2 ? vox[ks < 2 ? ks : 0] : agg[ks >= 2 ? ks - 2 : 0]; });
             float sig = 0.f;
 #pragma unroll
@@ -541,11 +642,39 @@ void k_render_rays(RenderArgs a) {
             f32x4 P2[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) P2[v] = lds4(wl + L.c0b + v * 16 + 4 * g);
+            if constexpr (BX3) {
+                const BxLayout BL = bx_layout();
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    bfx8 hp[NP];
+                    bx_split<NP>(hid[2 * pr], hid[2 * pr + 1], hp);
+                    bx_mma_n<NP, 4>(bxplane, BL.c0p + 4 * pr, lane, hp, P2);
+                }
+                bx_mma_n<NP, 4>(bxplane, BL.c0p + 8, lane, vap, P2);
+            } else
             mfma_chain<22, 4>(P2, [&](int e) { return A_C0P(e); },
                               [&](int ks) { return ks < 16 ? hid[(ks < 16 ? ks : 0) >> 2][ks & 3]
                                                            : (ks < 18 ? vox[ks < 18 ? ks - 16 : 0] : agg[ks >= 18 ? ks - 18 : 0]); });
             float cl[S];
             const float c2b = wl[L.col2 + 64];
+            if constexpr (BX3) {
+                const BxLayout BL = bx_layout();
+                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                f32x4 c2w[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) c2w[v] = lds4(wl + L.col2 + v * 16 + 4 * g);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    bfx8 xp[NP];
+                    bx_split<NP>(f32x4{x[s][0], x[s][1], x[s][2], dsel[s]}, zero4, xp);
+                    f32x4 cc[4] = {P2[0], P2[1], P2[2], P2[3]};
+                    bx_mma_n<NP, 4>(bxplane, BL.c0v, lane, xp, cc);
+                    float part = 0.f;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) part = dot4(relu4(cc[v]), c2w[v], part);
+                    cl[s] = relu1(group_sum(part) + c2b);
+                }
+            } else
             {
                 float acv[(R + 1) * 4];                   // the per-view tiles of color.0, shared by the S views
 #pragma unroll
@@ -636,19 +765,19 @@ void k_render_rays(RenderArgs a) {
     }
 }
 
-template <int R, int WAVES, int OCC, bool PFK = false, bool LEANK = false>
+template <int R, int WAVES, int OCC, bool PFK = false, bool LEANK = false, int BX3 = 0>
 static int dispatch_s(const RenderArgs& a, unsigned grid, size_t shmem, hipStream_t st) {
     constexpr int WPE = (WAVES * OCC + 3) / 4;
     switch (a.S) {
-        case 2: ENERF_LAUNCH((k_render_rays<R, 2, WAVES, WPE, PFK, LEANK>), grid, 64 * WAVES, shmem, st, a); return 0;
-        case 3: ENERF_LAUNCH((k_render_rays<R, 3, WAVES, WPE, PFK, LEANK>), grid, 64 * WAVES, shmem, st, a); return 0;
-        case 4: ENERF_LAUNCH((k_render_rays<R, 4, WAVES, WPE, PFK, LEANK>), grid, 64 * WAVES, shmem, st, a); return 0;
+        case 2: ENERF_LAUNCH((k_render_rays<R, 2, WAVES, WPE, PFK, LEANK, BX3>), grid, 64 * WAVES, shmem, st, a); return 0;
+        case 3: ENERF_LAUNCH((k_render_rays<R, 3, WAVES, WPE, PFK, LEANK, BX3>), grid, 64 * WAVES, shmem, st, a); return 0;
+        case 4: ENERF_LAUNCH((k_render_rays<R, 4, WAVES, WPE, PFK, LEANK, BX3>), grid, 64 * WAVES, shmem, st, a); return 0;
         default: return -3;
     }
 }
 template <int R, int WAVES>
-static size_t render_shmem(const RenderArgs& a, int record_buffers = 1) {
-    return ((size_t)nerf_layout(a.F).total + (size_t)a.B * a.S * kCamStride + (size_t)((a.B * 4 + 15) & ~15) +
+static size_t render_shmem(const RenderArgs& a, int record_buffers = 1, int bx = 0) {
+    return ((size_t)nerf_layout(a.F, bx != 0).total + (size_t)(bx ? bx_image_floats(a.F, bx == 6 ? 3 : 2) : 0) + (size_t)a.B * a.S * kCamStride + (size_t)((a.B * 4 + 15) & ~15) +
             (size_t)WAVES * record_buffers * a.S * 16 * Stage<R>::kStride) * sizeof(float);
 }
 int launch_render_rays(const RenderArgs& a, hipStream_t st) {
@@ -685,10 +814,15 @@ int launch_render_rays(const RenderArgs& a, hipStream_t st) {
         // Measured (profiles/r03_render_waves.txt, S = 3): 4-wave blocks x 2 per CU at 184 VGPRs 199.5 us; the same with the lean
         // register set (157) 196.5; 12-wave blocks x 1 (THREE waves per SIMD, 159 VGPRs, no spills) 190.7; 6-wave blocks x 2 254.8
         // (uneven over the SIMDs).  Round 2's 12-wave attempt spilled at 168 VGPRs (215 us).
-        const size_t shmem = render_shmem<3, 12>(a);
+        // enerf_options_t.render_precision: 0 / 1 = exact fp32 MFMAs (default), 2 = bf16x3 (opt-in fast mode), 3 = bf16x6 (A/B)
+        const int prec = a.options != nullptr ? a.options->render_precision : 0;
+        const int bx = prec == 2 ? 3 : (prec == 3 ? 6 : 0);
+        const size_t shmem = render_shmem<3, 12>(a, 1, bx);
         if (shmem <= 160 * 1024) {
             const unsigned grid = grid_for(12, 1);
             if (grid == 0) return 0;
+            if (bx == 6) return dispatch_s<3, 12, 1, false, true, 6>(a, grid, shmem, st);
+            if (bx == 3) return dispatch_s<3, 12, 1, false, true, 3>(a, grid, shmem, st);
             return dispatch_s<3, 12, 1, false, true>(a, grid, shmem, st);
         }
     }

@@ -44,7 +44,8 @@ class Options(C.Structure):
     """``enerf_options_t``: explicit kernel-variant choices, passed per call (all zero = defaults)."""
     _fields_ = [("conv3d_global_only", _i), ("conv3d_lds_min_voxels", _ll), ("conv3d_pk8", _i),
                 ("featnet_unfused", _i), ("featnet_smooth0_plain", _i), ("conv3d_b4", _i), ("single_stream", _i),
-                ("side_gate", _i), ("fuse_depth_prep", _i), ("conv3d_t2_variant", _i), ("conv3d_small_variant", _i)]
+                ("side_gate", _i), ("fuse_depth_prep", _i), ("conv3d_t2_variant", _i), ("conv3d_small_variant", _i),
+                ("render_precision", _i)]
 
     def __repr__(self):
         return "Options(" + ", ".join(f"{n}={getattr(self, n)}" for n, _ in self._fields_ if getattr(self, n)) + ")"

@@ -71,6 +71,16 @@ typedef struct {
                                         1 = taps split over 3 waves + LDS reduce, one tile per wave (the round-2 default);
                                         2 = no tap split, 2 row tiles x 2 column tiles per wave (operand reuse over wave count);
                                         3 = no tap split, 1 row tile x 4 column tiles */
+    int render_precision;            /* enerf_render_rays / enerf_forward, ABI >= 7, the cascade's last level (F = 11, <= 2 samples per
+                                        ray): how the dense layers of the Agg/NeRF MLP are multiplied.
+                                        0 / 1 (default) = exact fp32 16x16x4 MFMAs;
+                                        2 = "bf16x3": every fp32 operand split into two bf16 pieces, three v_mfma_f32_16x16x32_bf16
+                                            per 32-deep k-chunk, fp32 accumulation: kernel 192 -> 128 us, dtu +7 % frames/s, outputs
+                                            within 7e-6 of max|ref| at 512x640 (profiles/r04_ab_render_precision_k32.txt) — but a
+                                            head with a large gain amplifies the ~1e-5 operand error (tests/test_adversarial.py
+                                            adv_sigma: 1.3e-3), so it is an opt-in, not the default;
+                                        3 = "bf16x6": three pieces, six MFMAs: fp32-level accuracy, measured SLOWER than the exact
+                                            kernel (203 us: the operand splits are VALU work, which does not overlap the MFMAs) */
 } enerf_options_t;
 
 /* ---- layout adapters at the PyTorch boundary (FeatureNet output is NCHW, network.py:58-67) ---- */

@@ -286,6 +286,8 @@ inline void __builtin_amdgcn_sched_barrier(int) {}
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only ever applied to wave-uniform values
 inline void __builtin_amdgcn_s_sleep(int) {}
 inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
+inline unsigned __float_as_uint(float f) { unsigned v; memcpy(&v, &f, 4); return v; }
+inline float __uint_as_float(unsigned v) { float f; memcpy(&f, &v, 4); return f; }
 inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
 inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
 inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }

@@ -45,19 +45,29 @@ def test_gfx950_code_object_contains_mfma(tmp_path):
     assert "gfx950" in out
     cos = sorted(p for p in os.listdir(tmp_path) if "gfx950" in p)
     assert cos, "no gfx950 code object in the library"
-    n_mfma, n_b4, other = 0, 0, set()
+    n_mfma, n_b4, other, bf16_in = 0, 0, set(), set()
     for co in cos:
         dis = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(tmp_path / co)], capture_output=True, text=True).stdout
-        for m in re.findall(r"\bv_mfma_[a-z0-9_]+", dis):
-            if m == "v_mfma_f32_16x16x4_f32":
-                n_mfma += 1
-            elif m == "v_mfma_f32_4x4x1_16b_f32":            # batched 4x4 fp32 shape of conv3d_b4.hip (Cout = 8 layers)
-                n_b4 += 1
-            else:
-                other.add(m)
+        sym = ""
+        for line in dis.splitlines():
+            ms = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if ms:
+                sym = ms.group(1)
+                continue
+            for m in re.findall(r"\bv_mfma_[a-z0-9_]+", line):
+                if m == "v_mfma_f32_16x16x4_f32":
+                    n_mfma += 1
+                elif m == "v_mfma_f32_4x4x1_16b_f32":        # batched 4x4 fp32 shape of conv3d_b4.hip (Cout = 8 layers)
+                    n_b4 += 1
+                elif m == "v_mfma_f32_16x16x32_bf16":        # the OPT-IN bf16x3 / bf16x6 render variants (enerf_options_t.render_precision)
+                    bf16_in.add(sym)
+                else:
+                    other.add(m)
     assert n_mfma > 5000, n_mfma                             # render + conv2d + conv3d kernels (17 k in round 1)
     assert n_b4 > 5000, n_b4                                 # 27 taps x Cin x 2 halves x voxels-per-lane per b4 kernel
-    assert not other, other                                  # exact-fp32 path: no reduced-precision MFMA shapes
+    assert not other, other                                  # no other MFMA shape anywhere
+    # the default path is exact fp32: bf16 MFMAs live ONLY in the render kernels instantiated with BX = 3 / 6
+    assert bf16_in and all(re.search(r"k_render_raysILi3ELi[234]ELi12ELi3ELb0ELb1ELi[36]E", f) for f in bf16_in), bf16_in
     assert not [p for p in os.listdir(os.path.dirname(LIB_PATH)) if "hipv4" in p], "code objects leaked into the package"
 
 

@@ -36,6 +36,25 @@ def test_emulated_kernels_match_reference_goldens(name):
         _close(v.numpy(), gold["out/" + k], 2e-5, k)
 
 
+def test_render_precision_variants_match_reference_goldens():
+    """enerf_options_t.render_precision: default = exact fp32 MFMAs; 2 = bf16x3 (every operand as two bf16 pieces on the bf16
+    matrix cores, ~1e-5), 3 = bf16x6 (three pieces: fp32-level accuracy): all against the reference's outputs; bf16x6 must be
+    as close as the exact kernel (within fp32 re-association noise), bf16x3 within 2e-5."""
+    from enerf_amd.lib import Options
+    for name in ("tiny_s3", "tiny_s4_mask"):
+        cfg, batch, gold = case_config(name), case_batch(name), load_golden(name)
+        net = _net(cfg, CASES[name]["human"])
+        err = {}
+        for tag, opt in (("fp32", None), ("bf16x3", Options(render_precision=2)), ("bf16x6", Options(render_precision=3))):
+            net.options = opt
+            out = net(batch)
+            for k, v in out.items():
+                _close(v.numpy(), gold["out/" + k], 2e-5, k)
+            err[tag] = float(np.abs(out["rgb_level1"].numpy() - gold["out/rgb_level1"]).max()) / float(np.abs(gold["out/rgb_level1"]).max())
+        print(name, err)
+        assert err["bf16x6"] <= max(3.0 * err["fp32"], 2e-6) and err["fp32"] <= err["bf16x3"] < 2e-5, err
+
+
 def test_state_dict_names_match_reference():
     sd = load_weights()
     net = Network(EnerfConfig())

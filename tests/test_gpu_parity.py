@@ -160,7 +160,9 @@ def test_full_size_dtu_eval_vs_oracle_and_properties():
                 "t2_round2": Options(conv3d_t2_variant=1), "t2_all": Options(conv3d_t2_variant=2),
                 "small_rt2ct2": Options(conv3d_small_variant=2), "small_ct4": Options(conv3d_small_variant=3),
                 "small_split3": Options(conv3d_small_variant=1), "b4_round2": Options(conv3d_b4=3), "separate_depth_prep": Options(fuse_depth_prep=1),
-                "side_gate": Options(side_gate=2)}
+                "side_gate": Options(side_gate=2),
+                # the opt-in bf16 variants of the render MLP (two / three bf16 pieces per fp32 operand on the bf16 matrix cores)
+                "render_bf16x3": Options(render_precision=2), "render_bf16x6": Options(render_precision=3)}
     for name, opt in variants.items():
         o = net._forward(_to(batch), opt)
         for k in ref:
