@@ -25,10 +25,18 @@ struct MlpBwdArgs {
     float *sv_hv, *sv_G, *sv_q, *sv_g, *sv_a, *sv_vm;                       // (P,88) (P,32) (P,S,64) (P,S,32) (P,S,F) (P,2F)
     float *d_cpre, *d_qpre, *d_p2, *d_spre, *d_hpre, *d_aggpre, *d_upre, *d_gpre, *d_gsum, *d_vpre;
     long long P;
-    int F;
+    int F, n_bimg;                       // floats of the backward images (staged in LDS behind the forward image)
     int o_b1, o_b2, o_b3, o_b4, o_b5, o_b6v, o_b6m, o_b7;                  // float offsets of the backward images
 };
 
+// A/B switches (tools/build_variant.py): backward images from LDS (default) or from global memory as until round 3; the
+// per-layer saves switched off (timing ablation only: the weight gradients are then garbage).
+#ifndef ENERF_MLPB_LDS_BIMG
+#define ENERF_MLPB_LDS_BIMG 1
+#endif
+#ifndef ENERF_MLPB_NOSTORE
+#define ENERF_MLPB_NOSTORE 0
+#endif
 template <int R, int S>
 __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
     constexpr int TR = (R + 3) / 4;             // slot tiles of the F channels
@@ -39,15 +47,28 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
     float* wl = smem;
     for (int i = threadIdx.x * 4; i < L.total; i += blockDim.x * 4)
         *reinterpret_cast<float4*>(wl + i) = *reinterpret_cast<const float4*>(a.packed + i);
+#if ENERF_MLPB_LDS_BIMG
+    // the transposed-weight images too (R = 3: 46 KB, R = 9: 72 KB; with the forward image 88 / 130 KB, one block per CU — which
+    // the 512 registers per lane dictate anyway): a backward A operand was a 256-B global load per MFMA, 233 of them per 16
+    // points with one wave per SIMD to hide them behind
+    float* wb = wl + L.total;
+    for (int i = threadIdx.x * 4; i < a.n_bimg; i += blockDim.x * 4)
+        *reinterpret_cast<float4*>(wb + i) = *reinterpret_cast<const float4*>(a.bimg + i);
+#endif
     __syncthreads();
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const float* wlane = wl + lane;
+#if ENERF_MLPB_LDS_BIMG
+    const float* bl = wb + lane;
+#else
     const float* bl = a.bimg + lane;
+#endif
     const long long ntiles = cdivl(a.P, 16);
     const int waves = blockDim.x >> 6;
     for (long long tile = (long long)blockIdx.x * waves + (threadIdx.x >> 6); tile < ntiles; tile += (long long)gridDim.x * waves) {
         const long long pr = tile * 16 + j;
         const bool ok = pr < a.P;
+        const bool sv = ok && !ENERF_MLPB_NOSTORE;          // write the per-layer saves
         const long long p = ok ? pr : a.P - 1;
         // ---------------- inputs ----------------
         float vox[2], x[S][R], dsel[S];
@@ -197,7 +218,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
             for (int s = 0; s < S; ++s) cl[s] /= se;
         }
         // ---------------- save the layer inputs ----------------
-        if (ok) {
+        if (sv) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(a.sv_hv + p * 88 + 16 * v + 4 * g) = hid[v];
             a.sv_hv[p * 88 + 64 + 2 * g] = vox[0]; a.sv_hv[p * 88 + 64 + 2 * g + 1] = vox[1];
@@ -258,12 +279,12 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gq[v][r] = cc[v][r] > 0.f ? c2w[v][r] * gcpre[s] : 0.f;
                 dP2[v] += gq[v];
-                if (ok) {
+                if (sv) {
                     *reinterpret_cast<f32x4*>(a.sv_q + (p * S + s) * 64 + 16 * v + 4 * g) = relu4(cc[v]);
                     *reinterpret_cast<f32x4*>(a.d_qpre + (p * S + s) * 64 + 16 * v + 4 * g) = gq[v];
                 }
             }
-            if (ok && g == 0) a.d_cpre[p * S + s] = gcpre[s];
+            if (sv && g == 0) a.d_cpre[p * S + s] = gcpre[s];
             // B1: d [x_s | dir_s] = W_v^T gq
 #pragma unroll
             for (int t = 0; t < TX; ++t) {
@@ -290,19 +311,19 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
             for (int kk = 0; kk < 16; ++kk) acc = ENERF_MFMA(bl[a.o_b2 + (t * 16 + kk) * 64], dP2[kk >> 2][kk & 3], acc);
             if (t < 4) dh[t] = acc; else if (t == 4) dvox = acc; else dagg = acc;
         }
-        if (ok) {
+        if (sv) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(a.d_p2 + p * 64 + 16 * v + 4 * g) = dP2[v];
         }
         // sigma = softplus(spre) (beta 1, threshold 20)
         const float gspre = gsig * (spre > 20.f ? 1.f : 1.f / (1.f + expf(-spre)));
-        if (ok && g == 0) a.d_spre[p] = gspre;
+        if (sv && g == 0) a.d_spre[p] = gspre;
         f32x4 ghpre[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) ghpre[v][r] = hid[v][r] > 0.f ? dh[v][r] + sigw[v][r] * gspre : 0.f;
-            if (ok) *reinterpret_cast<f32x4*>(a.d_hpre + p * 64 + 16 * v + 4 * g) = ghpre[v];
+            if (sv) *reinterpret_cast<f32x4*>(a.d_hpre + p * 64 + 16 * v + 4 * g) = ghpre[v];
         }
         // B3: d [vox | agg] += W_0^T ghpre
 #pragma unroll
@@ -315,7 +336,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
         f32x4 gaggpre;
 #pragma unroll
         for (int r = 0; r < 4; ++r) gaggpre[r] = agg[r] > 0.f ? dagg[r] : 0.f;
-        if (ok) *reinterpret_cast<f32x4*>(a.d_aggpre + p * 16 + 4 * g) = gaggpre;
+        if (sv) *reinterpret_cast<f32x4*>(a.d_aggpre + p * 16 + 4 * g) = gaggpre;
         // B4: dG = W_f^T gaggpre
         f32x4 dG[2];
 #pragma unroll
@@ -338,17 +359,17 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
         for (int s = 0; s < S; ++s) {
             const float du = aw[s] * (daw[s] - dot2);
             const float dup = (ok && upre[s] > 0.f) ? du : 0.f;
-            if (ok && g == 0) a.d_upre[p * S + s] = dup;
+            if (sv && g == 0) a.d_upre[p * S + s] = dup;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const f32x4 wv = u == 0 ? aggw0 : aggw1;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dgp[s][u][r] = gf[s][u][r] > 0.f ? aw[s] * dG[u][r] + wv[r] * dup : 0.f;
                 dgsum[u] += dgp[s][u];
-                if (ok) *reinterpret_cast<f32x4*>(a.d_gpre + (p * S + s) * 32 + 16 * u + 4 * g) = dgp[s][u];
+                if (sv) *reinterpret_cast<f32x4*>(a.d_gpre + (p * S + s) * 32 + 16 * u + 4 * g) = dgp[s][u];
             }
         }
-        if (ok) {
+        if (sv) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) *reinterpret_cast<f32x4*>(a.d_gsum + p * 32 + 16 * u + 4 * g) = dgsum[u];
         }
@@ -384,7 +405,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
                                 dvar[r >> 2][r & 3] * (2.f / (float)(S - 1)) * (av[s][r] - mean[r]);
                 dx2[r >> 2][r & 3] += d;                                     // a_s = x_s + relu(view_fc(dir_s))
                 dvp[r] = vmask[s][r] ? d : 0.f;
-                if (ok && g * R + r < F) a.d_vpre[(p * S + s) * F + g * R + r] = dvp[r];
+                if (sv && g * R + r < F) a.d_vpre[(p * S + s) * F + g * R + r] = dvp[r];
                 // the rgb channels also feed the colour blend directly: col = sum_s cw_s rgb_s
                 const int c = g * R + r - (F - 3);
                 if (c >= 0 && c < 3) dx2[r >> 2][r & 3] += cl[s] * gcol[c];
@@ -609,12 +630,21 @@ extern "C" int enerf_nerf_mlp_bwd(const enerf_mlp_bwd_args_t* u, enerf_stream_t 
     a.d_cpre = u->save[6]; a.d_qpre = u->save[7]; a.d_p2 = u->save[8]; a.d_spre = u->save[9]; a.d_hpre = u->save[10];
     a.d_aggpre = u->save[11]; a.d_upre = u->save[12]; a.d_gpre = u->save[13]; a.d_gsum = u->save[14]; a.d_vpre = u->save[15];
     a.P = u->P; a.F = u->F;
+    {
+        const int Rr = (u->F + 3) / 4, TXr = (Rr + 1 + 3) / 4;
+        a.n_bimg = u->image_offsets[7] + TXr * Rr * 64;      // b7 is the last image (autograd.py:mlp_backward_images)
+    }
     a.o_b1 = u->image_offsets[0]; a.o_b2 = u->image_offsets[1]; a.o_b3 = u->image_offsets[2]; a.o_b4 = u->image_offsets[3];
     a.o_b5 = u->image_offsets[4]; a.o_b6v = u->image_offsets[5]; a.o_b6m = u->image_offsets[6]; a.o_b7 = u->image_offsets[7];
-    const size_t shmem = (size_t)nerf_layout(u->F).total * sizeof(float);
+    REQUIRE(a.n_bimg % 4 == 0 && nerf_layout(u->F).total % 4 == 0, "nerf_mlp_bwd: image sizes not float4-aligned");
+    const size_t shmem = ((size_t)nerf_layout(u->F).total + (ENERF_MLPB_LDS_BIMG ? a.n_bimg : 0)) * sizeof(float);
+    REQUIRE(shmem <= 160 * 1024, "nerf_mlp_bwd: images do not fit LDS");
     const long long ntiles = cdivl(u->P, 16);
     long long blocks = cdivl(ntiles, 4);
-    const long long resident = (long long)device_cu_count() * 2;
+#ifndef ENERF_MLPB_RESIDENT
+#define ENERF_MLPB_RESIDENT 2
+#endif
+    const long long resident = (long long)device_cu_count() * ENERF_MLPB_RESIDENT;
     if (blocks > resident) blocks = resident;
     const unsigned grid = (unsigned)blocks;
     hipStream_t st = (hipStream_t)stream;

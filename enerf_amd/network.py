@@ -446,7 +446,10 @@ class Network(nn.Module):
             rays_of = [batch.get(f"rays_{i}") if cas.render_if[i] else None for i in range(cas.num)]
             sig = (B, S, H, W, hip_feats, masked) + tuple(
                 -1 if not cas.render_if[i] else (-2 if rays_of[i] is None else rays_of[i].shape[1]) for i in range(cas.num))
-            static_key = (sig, self._packed_gen, options)
+            # (ctypes structures compare by identity: key on the option VALUES, so that a fresh-but-equal Options does not
+            # refresh every frame and an Options mutated in place does)
+            okey = None if options is None else tuple(getattr(options, f[0]) for f in options._fields_)
+            static_key = (sig, self._packed_gen, okey, dev)
             if st.get("static_key") != static_key:            # shapes / weights / options changed: the shape-only fields
                 a.B, a.S, a.H, a.W = B, S, H, W
                 pk = st.get("packed")
@@ -521,10 +524,10 @@ class Network(nn.Module):
                 a.stage_events = C.cast(arr, C.POINTER(C.c_void_p))
                 st["static_key"] = None                          # (the next untimed frame clears the event slots again)
             if st.get("plan"):                                   # after a static refresh: (re)plan the workspace for these shapes
-                if st["sig"] != sig:
+                if st["sig"] != (sig, okey):                          # some options change the plan's workspace needs
                     a.workspace, a.workspace_bytes = None, 0
-                    st["need"], st["sig"] = lib.forward_workspace_bytes(a), sig
-                if st["ws"] is None or st["ws"].numel() * 4 < st["need"]:
+                    st["need"], st["sig"] = lib.forward_workspace_bytes(a), (sig, okey)
+                if st["ws"] is None or st["ws"].numel() * 4 < st["need"] or st["ws"].device != dev:
                     st["ws"] = torch.empty(((st["need"] + 3) // 4,), dtype=torch.float32, device=dev)
                 a.workspace, a.workspace_bytes = st["ws"].data_ptr(), st["ws"].numel() * 4
                 st["plan"] = False

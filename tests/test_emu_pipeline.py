@@ -53,6 +53,17 @@ def test_render_precision_variants_match_reference_goldens():
             err[tag] = float(np.abs(out["rgb_level1"].numpy() - gold["out/rgb_level1"]).max()) / float(np.abs(gold["out/rgb_level1"]).max())
         print(name, err)
         assert err["bf16x6"] <= max(3.0 * err["fp32"], 2e-6) and err["fp32"] <= err["bf16x3"] < 2e-5, err
+        # the frame's cached static fields are keyed on the option VALUES: an Options mutated in place takes effect, a fresh but
+        # equal one is the same frame
+        net.options = Options(render_precision=2)
+        a = net(batch)["rgb_level1"].clone()
+        net.options.render_precision = 0
+        b = net(batch)["rgb_level1"].clone()
+        net.options = None
+        c = net(batch)["rgb_level1"].clone()
+        net.options = Options(render_precision=2)
+        d = net(batch)["rgb_level1"].clone()
+        assert torch.equal(b, c) and torch.equal(a, d) and not torch.equal(a, b)
 
 
 def test_state_dict_names_match_reference():
