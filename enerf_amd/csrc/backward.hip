@@ -104,15 +104,48 @@ __global__ __launch_bounds__(256) void k_feature_volume_bwd(const float* __restr
         const bool m1 = has_r && r_ok1 && vx1 && vy1 && same1;      // right neighbour's (y1,x0) == my (y1,x1)
         const int l_m0 = __shfl((int)m0, ll), l_m1 = __shfl((int)m1, ll);
         const bool skip0 = has_l && l_m0, skip1 = has_l && l_m1;    // my left taps were taken by the left neighbour
+        // The four taps' contributions of this lane's channel quad.  They are NOT added from here: the L2 executes fp32 atomics
+        // per 64-byte LINE REQUEST of a wave instruction (tools/micro/atomic_rate.hip: 20.8 G requests/s whatever the lanes
+        // carry — 334 G adds/s when 16 lanes share a line, 82 G/s in this kernel's natural layout, where an instruction holds one
+        // channel of every quad: 16-byte stride, a texel's line requested four times per tap).  The wave transposes them through
+        // LDS so that an instruction carries whole texels: lane = channel, 64 / C texels per instruction, one request per line.
+        float4 t00 = make_float4(0.f, 0.f, 0.f, 0.f), t01 = t00, t10 = t00, t11 = t00;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float df = live ? (2.f * inv_s) * gg[c] * (f[c] - mm[c]) : 0.f;
             const float c00 = tp.w00 * df, c10 = tp.w10 * df;
             const float r00 = __shfl(c00, rl), r10 = __shfl(c10, rl);
-            if (vx0 && vy0) { if (!skip0) atomic_add_f32(gfeat + o00 + c, c00); gu -= a00[c] * ty0 * df; gv -= a00[c] * tx0 * df; }
-            if (vx1 && vy0) { atomic_add_f32(gfeat + o01 + c, tp.w01 * df + (m0 ? r00 : 0.f)); gu += a01[c] * ty0 * df; gv -= a01[c] * tx1 * df; }
-            if (vx0 && vy1) { if (!skip1) atomic_add_f32(gfeat + o10 + c, c10); gu -= a10[c] * ty1 * df; gv += a10[c] * tx0 * df; }
-            if (vx1 && vy1) { atomic_add_f32(gfeat + o11 + c, tp.w11 * df + (m1 ? r10 : 0.f)); gu += a11[c] * ty1 * df; gv += a11[c] * tx1 * df; }
+            if (vx0 && vy0) { (&t00.x)[c] = c00; gu -= a00[c] * ty0 * df; gv -= a00[c] * tx0 * df; }
+            if (vx1 && vy0) { (&t01.x)[c] = tp.w01 * df + (m0 ? r00 : 0.f); gu += a01[c] * ty0 * df; gv -= a01[c] * tx1 * df; }
+            if (vx0 && vy1) { (&t10.x)[c] = c10; gu -= a10[c] * ty1 * df; gv += a10[c] * tx0 * df; }
+            if (vx1 && vy1) { (&t11.x)[c] = tp.w11 * df + (m1 ? r10 : 0.f); gu += a11[c] * ty1 * df; gv += a11[c] * tx1 * df; }
+        }
+        {
+            constexpr int NVW = 64 / CQ;                        // voxels per wave
+            __shared__ __attribute__((aligned(16))) float xval[4][4][256];       // [wave][tap][voxel-in-wave * C + channel]
+            __shared__ int xoff[4][4][NVW];                                      // [wave][tap][voxel-in-wave]: texel offset or -1
+            const int wv = threadIdx.x >> 6, vin = lane_ / CQ;
+            *reinterpret_cast<float4*>(&xval[wv][0][lane_ * 4]) = t00;
+            *reinterpret_cast<float4*>(&xval[wv][1][lane_ * 4]) = t01;
+            *reinterpret_cast<float4*>(&xval[wv][2][lane_ * 4]) = t10;
+            *reinterpret_cast<float4*>(&xval[wv][3][lane_ * 4]) = t11;
+            if (cq == 0) {                                      // (offsets fit 32 bits: the C entry rejects larger maps)
+                xoff[wv][0][vin] = (live && vx0 && vy0 && !skip0) ? (int)(o00 - cq * 4) : -1;
+                xoff[wv][1][vin] = (live && vx1 && vy0) ? (int)(o01 - cq * 4) : -1;
+                xoff[wv][2][vin] = (live && vx0 && vy1 && !skip1) ? (int)(o10 - cq * 4) : -1;
+                xoff[wv][3][vin] = (live && vx1 && vy1) ? (int)(o11 - cq * 4) : -1;
+            }
+            wave_sync();
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {                   // 256 floats of the wave's voxels, 64 per instruction
+                    const int e = i * 64 + lane_, v = e / C, ch = e - v * C;
+                    const int off = xoff[wv][tap][v];
+                    const float val = xval[wv][tap][e];
+                    if (off >= 0) atomic_add_f32(gfeat + off + ch, val);
+                }
+            wave_sync();                                        // before the next view overwrites the staging arrays
         }
         // (u, v) = p.xy / z ; z = max(p.z, 1e-6)
         const float gpx = gu / z, gpy = gv / z;
@@ -282,6 +315,8 @@ int enerf_build_feature_volume_bwd(const float* feat, const float* proj, const f
     REQUIRE(feat && proj && depth_values && grad_vol && grad_feat && grad_depth_values, "build_feature_volume_bwd: null pointer");
     REQUIRE(C == 8 || C == 16 || C == 32, "build_feature_volume_bwd: C=%d unsupported (8/16/32)", C);
     REQUIRE(B > 0 && S > 0 && Hs > 1 && Ws > 1 && D > 0 && h > 0 && w > 0, "build_feature_volume_bwd: bad shape");
+    REQUIRE((long long)B * S * Hs * Ws * C < (1LL << 31), "build_feature_volume_bwd: feature maps of %lld floats (limit 2^31)",
+            (long long)B * S * Hs * Ws * C);
     zero_async(grad_feat, (size_t)B * S * Hs * Ws * C * sizeof(float), (hipStream_t)stream);
     launch_feature_volume_bwd(feat, proj, depth_values, grad_vol, B, S, C, Hs, Ws, D, h, w, grad_feat, grad_depth_values,
                               (hipStream_t)stream);

@@ -266,6 +266,8 @@ __device__ __forceinline__ float clamp_min(float v, float lo) { return v < lo ? 
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
 #ifdef ENERF_EMU
     atomicAdd(p, v);
+#elif defined(ENERF_ABL_NOATOMIC)
+    *p = v;                         // timing ablation only (tools/build_variant.py): what the scatter kernels cost without the L2 atomics
 #else
     unsafeAtomicAdd(p, v);          // global_atomic_add_f32 (hipMalloc memory is coarse-grained)
 #endif
