@@ -113,18 +113,18 @@ class GatherFn(torch.autograd.Function):
     tex_cl, vol_cl (gradients in the same layouts)."""
 
     @staticmethod
-    def forward(ctx, lib: EnerfLib, xyz, dn, uv, tex_cl, vol_cl, cam, tcen):
+    def forward(ctx, lib: EnerfLib, xyz, dn, uv, tex_cl, vol_cl, cam, tcen, n_samples=0, ray_w=0):
         xyz, dn, uv, tex_cl, vol_cl = _c(xyz), _c(dn), _c(uv), _c(tex_cl), _c(vol_cl)
         x, vox = lib.gather_fwd(xyz, dn, uv, tex_cl, vol_cl, cam, tcen)
-        ctx.lib = lib
+        ctx.lib, ctx.hints = lib, (int(n_samples), int(ray_w))
         ctx.save_for_backward(xyz, dn, uv, tex_cl, vol_cl, cam, tcen)
         return x, vox
 
     @staticmethod
     def backward(ctx, g_x, g_vox):
         xyz, dn, uv, tex_cl, vol_cl, cam, tcen = ctx.saved_tensors
-        g_tex, g_vol, g_xyz, g_dn = ctx.lib.gather_bwd(xyz, dn, uv, tex_cl, vol_cl, cam, tcen, _c(g_x), _c(g_vox))
-        return None, g_xyz, g_dn, None, g_tex, g_vol, None, None
+        g_tex, g_vol, g_xyz, g_dn = ctx.lib.gather_bwd(xyz, dn, uv, tex_cl, vol_cl, cam, tcen, _c(g_x), _c(g_vox), *ctx.hints)
+        return None, g_xyz, g_dn, None, g_tex, g_vol, None, None, None, None
 
 
 class DepthValuesFn(torch.autograd.Function):

@@ -148,6 +148,20 @@ __device__ __forceinline__ float group_sum4(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 #endif
 }
+// sum over the 16 lanes of a row (lanes with the same lane >> 4), left in every lane of the row: four DPP row rotations (VALU;
+// __shfl_xor would be four ds_bpermute round trips through the LDS pipe)
+__device__ __forceinline__ float row_sum16(float v) {
+#ifdef ENERF_EMU
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+    return v;
+#else
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));    // row_ror:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));    // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));    // row_ror:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));    // row_ror:1
+    return v;
+#endif
+}
 __device__ __forceinline__ float group_max4(float v) {
 #ifdef ENERF_EMU
     v = fmaxf(v, __shfl_xor(v, 16));
@@ -270,6 +284,16 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
     *p = v;                         // timing ablation only (tools/build_variant.py): what the scatter kernels cost without the L2 atomics
 #else
     unsafeAtomicAdd(p, v);          // global_atomic_add_f32 (hipMalloc memory is coarse-grained)
+#endif
+}
+
+// fp32 add onto an LDS word (ds_add_f32).  Through the generic atomic_add_f32 the compiler merges an `LDS or global` pair of
+// branches into one FLAT atomic on a selected pointer; this keeps the LDS side a DS instruction.
+__device__ __forceinline__ void lds_add_f32(float* p, float v) {
+#ifdef ENERF_EMU
+    atomicAdd(p, v);
+#else
+    __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)p, v, 0, 0, false);
 #endif
 }
 

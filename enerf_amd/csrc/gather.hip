@@ -22,6 +22,7 @@ struct GatherArgs {
     float *g_tex, *g_vol, *g_xyz, *g_dn; // backward outputs (g_tex, g_vol zeroed by the C entry; g_xyz (B,P,3), g_dn (B,P))
     int B, S, F, Hr, Wr, D, h, w;
     long long P;
+    int ray_w, n_samples;                // raster hints of the backward (enerf_gather_args_t)
 };
 
 struct ViewGeom {
@@ -127,17 +128,14 @@ __device__ __forceinline__ float sum16(float v) {          // sum over the 16 la
 
 // Backward: 16 lanes per (point, view), lane = channel (c, c+16, c+32): the scatter-add of a tap is ONE coalesced run of F
 // floats (the thread-per-point form issued 64 scattered cache lines per atomic instruction and ran 2.5x slower than the
-// library grid_sampler backward; this form is bounded by the L2 atomic rate of 4*F*P*S adds).
-__global__ __launch_bounds__(256) void k_gather_bwd(GatherArgs a) {
-    const int lane = threadIdx.x & 15;
-    const long long i_raw = (long long)blockIdx.x * (blockDim.x / 16) + (threadIdx.x >> 4);
-    const long long total = (long long)a.B * a.P * a.S;
-    const bool live = i_raw < total;                        // dead groups follow along (uniform shuffles), write nothing
-    const long long i = live ? i_raw : total - 1;
-    const int s = (int)(i % a.S);
-    const long long bp = i / a.S;
-    const int b = (int)(bp / a.P);
+// library grid_sampler backward).  The body is shared by the two kernels below, which differ in WHERE a contribution is added:
+//   tex_add(y, x, element offset of the texel, channel, value), vol_add(z, y, x, element offset of the voxel + channel, value),
+//   xyz_add(b * P + p, gX, gY, gZ).
+template <class TexAdd, class VolAdd, class XyzAdd>
+__device__ __forceinline__ void gather_bwd_pair(const GatherArgs& a, long long bp, int b, int s, bool live, int lane, TexAdd tex_add,
+                                                VolAdd vol_add, XyzAdd xyz_add) {
     const int F = a.F, XW = F + 4;
+    const long long i = bp * a.S + s;
     const float X = a.xyz[bp * 3], Y = a.xyz[bp * 3 + 1], Z = a.xyz[bp * 3 + 2];
     const float* c = a.cam + ((long long)b * a.S + s) * 16;
     const ViewGeom q = view_geom(c, a.tcen + b * 4, X, Y, Z, a.Wr, a.Hr);
@@ -150,8 +148,8 @@ __global__ __launch_bounds__(256) void k_gather_bwd(GatherArgs a) {
     for (int ch = lane; live && ch < F; ch += 16) {
         const float g = gx[ch];
         const float v00 = a.tex[o00 + ch], v01 = a.tex[o01 + ch], v10 = a.tex[o10 + ch], v11 = a.tex[o11 + ch];
-        atomic_add_f32(a.g_tex + o00 + ch, q.w00 * g); atomic_add_f32(a.g_tex + o01 + ch, q.w01 * g);
-        atomic_add_f32(a.g_tex + o10 + ch, q.w10 * g); atomic_add_f32(a.g_tex + o11 + ch, q.w11 * g);
+        tex_add(q.y0, q.x0, o00, ch, q.w00 * g); tex_add(q.y0, q.x1, o01, ch, q.w01 * g);
+        tex_add(q.y1, q.x0, o10, ch, q.w10 * g); tex_add(q.y1, q.x1, o11, ch, q.w11 * g);
         gix += g * ((v01 - v00) * ty0 + (v11 - v10) * q.ty1);
         giy += g * ((v10 - v00) * tx0 + (v11 - v01) * q.tx1);
     }
@@ -168,7 +166,7 @@ __global__ __launch_bounds__(256) void k_gather_bwd(GatherArgs a) {
                 if (!(v.vx[cx] && v.vy[cy] && v.vz[cz])) continue;
                 const long long o = (vb + ((long long)v.zo[cz] * a.h + v.yo[cy]) * a.w + v.xo[cx]) * 8 + lane;
                 const float wxy = v.wx[cx] * v.wy[cy];
-                atomic_add_f32(a.g_vol + o, wxy * v.wz[cz] * g);
+                vol_add(v.zo[cz], v.yo[cy], v.xo[cx], o, wxy * v.wz[cz] * g);
                 giz += (cz ? 1.f : -1.f) * a.vol[o] * wxy * g;
             }
         }
@@ -201,7 +199,355 @@ __global__ __launch_bounds__(256) void k_gather_bwd(GatherArgs a) {
         const float pr = (q.sdx * gsx + q.sdy * gsy + q.sdz * gsz), k = q.ns > 0.f ? pr * is * is / q.ns : 0.f;
         gX += gsx * is - q.sdx * k; gY += gsy * is - q.sdy * k; gZ += gsz * is - q.sdz * k;
     }
-    atomic_add_f32(a.g_xyz + bp * 3, gX); atomic_add_f32(a.g_xyz + bp * 3 + 1, gY); atomic_add_f32(a.g_xyz + bp * 3 + 2, gZ);
+    xyz_add(bp, gX, gY, gZ);
+}
+
+// Points in any order: every contribution is a global atomic (bounded by the L2's atomic request rate).
+__global__ __launch_bounds__(256) void k_gather_bwd(GatherArgs a) {
+    const int lane = threadIdx.x & 15;
+    const long long i_raw = (long long)blockIdx.x * (blockDim.x / 16) + (threadIdx.x >> 4);
+    const long long total = (long long)a.B * a.P * a.S;
+    const bool live = i_raw < total;                        // dead groups follow along (uniform shuffles), write nothing
+    const long long i = live ? i_raw : total - 1;
+    const int s = (int)(i % a.S);
+    const long long bp = i / a.S;
+    const int b = (int)(bp / a.P);
+    gather_bwd_pair(a, bp, b, s, live, lane,
+                    [&](int, int, long long o, int ch, float v) { atomic_add_f32(a.g_tex + o + ch, v); },
+                    [&](int, int, int, long long o, float v) { atomic_add_f32(a.g_vol + o, v); },
+                    [&](long long q, float gX, float gY, float gZ) {
+                        atomic_add_f32(a.g_xyz + q * 3, gX); atomic_add_f32(a.g_xyz + q * 3 + 1, gY); atomic_add_f32(a.g_xyz + q * 3 + 2, gZ);
+                    });
+}
+
+// Raster-ordered rays (enerf_gather_args_t.ray_w / n_samples): a block owns a th x tw tile of rays (x kg samples: <= 256 points)
+// of one batch element and walks the source views.  Per view the tile's texel taps land in a compact patch of the view (the
+// image of the tile under the view's projection), so they are accumulated in LDS patches [PH][PW][F] whose rows are contiguous
+// runs of the gradient map and flushed ONCE with lane = consecutive floats; the same for the trilinear volume taps of view 0
+// ([VZ][VH][VW][8]).  A patch's origin is the minimum tap coordinate over its points; a tap that does not fit goes to the
+// global map as before.  fp32 atomics cost one L2 request per 64-byte line and instruction (tools/micro/atomic_rate.hip:
+// 20.8 G requests/s): ~90 line requests per 64 points and view instead of ~420.
+// Three phases per view: (1) one THREAD per point: the view's geometry once (the any-order kernel computes it in all 16 lanes of
+// a group), taps + fractions to LDS, patch origin by min-reduction; (2) the scatter and the coordinate gradients' channel sums;
+// (3) one thread per point again: the chain rule through projection and direction code, accumulated over the views in
+// registers — g_xyz is stored once, no atomics.
+// Two forms of phase 2, because LDS float atomics are no way out: ds_add_f32 runs at ~3 cycles PER LANE per CU on gfx950
+// (tools/micro/lds_atomic_rate.hip: 133-193 cycles per wave instruction against 12.7 for a plain read-add-write), and an LDS
+// instruction costs its issue slot whatever its lane count, so taking turns between the four 16-lane point groups of an
+// instruction is as slow (both measured: profiles/r04_gather_bwd_tiled.txt).
+//   WP ("wave-private", F <= 16): a wave owns an 8-row x cw-column strip of the tile (64 points) and ITS OWN patches, and handles
+//     ONE point per instruction: lane = (tap, channel) for the texel — the four taps of a bilinear footprint are four different
+//     texels, duplicates created by the border clamp carry weight 0 and are skipped — and lane = (tap, channel) of the eight
+//     trilinear taps for the volume: 64 different words, so a plain read-add-write is exact (a wave's LDS operations execute in
+//     order).  The sums over the 64 lanes are register permutes (group_sum4 + a DPP row rotation), not LDS traffic.
+//   block-shared (F = 35: four private patches of 35-float texels do not fit): 16 lanes per point, LDS atomics.
+struct GatherTile { int th, tw, kg, PW, PH, VW, VH, VZ, tiles_x, tiles_y, groups; };
+
+__device__ __forceinline__ int wave_min_i(int v) {
+    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_sum64(float v) { return row_sum16(group_sum4(v)); }
+
+#ifndef ENERF_GT_ABL
+#define ENERF_GT_ABL 0                  // timing ablations (tools/build_variant.py): 1 no scatter passes, 2 passes without adds, 3 no flush, 4 no phase 3
+#endif
+template <int NCH, bool WP>             // NCH: channel rounds of a 16-lane group: ceil(F / 16)
+__global__ __launch_bounds__(256) void k_gather_bwd_tiled(GatherArgs a, GatherTile T) {
+    ENERF_DYN_SMEM(float, smem);
+    __shared__ int mn[5];                                   // minimum tap x, y of the view; minimum voxel x, y, z (block-shared form)
+    __shared__ int geo[WP ? 1 : 256][4];                    // x0 | x1 << 16, y0 | y1 << 16, tx1, ty1 (float bits); WP: in registers
+    __shared__ int gpt[WP ? 1 : 256];                       // the point's index p inside its batch element, -1: outside the image
+    __shared__ float gij[256][3];                           // d loss / d (ix, iy, iz) of the point for this view
+    const int F = a.F, XW = F + 4, Ns = a.n_samples, tid = threadIdx.x, lane = tid & 15, grp = tid >> 4, wave = tid >> 6, l64 = tid & 63;
+    const int ntex = T.PH * T.PW * F, nvol = T.VZ * T.VH * T.VW * 8;
+    float* ptex = smem + (WP ? wave * (ntex + nvol) : 0);
+    float* pvol = ptex + ntex;
+    for (int i = tid; i < (ntex + nvol) * (WP ? 4 : 1); i += 256) smem[i] = 0.f;
+    int bid = blockIdx.x;
+    const int sg = bid % T.groups; bid /= T.groups;
+    const int txi = bid % T.tiles_x, tyi = (bid / T.tiles_x) % T.tiles_y, b = bid / (T.tiles_x * T.tiles_y);
+    const int rows = (int)(a.P / Ns / a.ray_w);
+    const int ry0 = tyi * T.th, rx0 = txi * T.tw;
+    const int npts = T.th * T.tw * T.kg;                    // <= 256
+    auto point_of = [&](int pi, long long& bp) {            // point pi of the tile -> (inside the image, b * P + p)
+        int kk, rx, ry;
+        if (WP) {                                           // wave w = pi >> 6 owns columns [w cw, (w + 1) cw) of the tile: cw = tw / 4
+            const int l = pi & 63, cw = T.tw >> 2, r = l / T.kg;
+            kk = l - r * T.kg; ry = r / cw; rx = (pi >> 6) * cw + (r - ry * cw);
+        } else {
+            const int r = pi / T.kg;
+            kk = pi - r * T.kg; ry = r / T.tw; rx = r - ry * T.tw;
+        }
+        const int gy = ry0 + ry, gx = rx0 + rx;
+        const bool ok = pi < npts && gy < rows && gx < a.ray_w;
+        bp = (long long)b * a.P + (ok ? ((long long)gy * a.ray_w + gx) * Ns + sg * T.kg + kk : 0);
+        return ok;
+    };
+    long long bp;
+    const bool live = point_of(tid, bp);
+    const int rpp = live ? (int)(bp - (long long)b * a.P) : -1;  // (P < 2^31: the C entry)
+    if (!WP) gpt[tid] = rpp;
+    const float X = a.xyz[bp * 3], Y = a.xyz[bp * 3 + 1], Z = a.xyz[bp * 3 + 2];
+    float gX = 0.f, gY = 0.f, gZ = 0.f;
+    for (int s = 0; s < a.S; ++s) {
+        // ---- (1) geometry of (point, view s), one thread per point ----
+        __syncthreads();                                    // the previous view's flush is done
+        if (tid < 5) mn[tid] = 0x7fffffff;
+        __syncthreads();
+        const float* c = a.cam + ((long long)b * a.S + s) * 16;
+        int m0, m1, m2 = 0x7fffffff, m3 = m2, m4 = m2;
+        int rg0, rg1, rg2, rg3, rv0 = 0, rv1 = 0, rv2 = 0, rv3 = 0, rv4 = 0, rv5 = 0;   // WP: this lane's point, read by v_readlane in phase 2
+        {
+            const ViewGeom q = view_geom(c, a.tcen + b * 4, X, Y, Z, a.Wr, a.Hr);
+            rg0 = q.x0 | (q.x1 << 16); rg1 = q.y0 | (q.y1 << 16); rg2 = __float_as_int(q.tx1); rg3 = __float_as_int(q.ty1);
+            if (!WP) { geo[tid][0] = rg0; geo[tid][1] = rg1; geo[tid][2] = rg2; geo[tid][3] = rg3; }
+            m0 = live ? q.x0 : 0x7fffffff; m1 = live ? q.y0 : 0x7fffffff;
+        }
+        if (s == 0) {
+            const VoxGeom v = vox_geom(a.uv[bp * 2], a.uv[bp * 2 + 1], a.dn[bp], a.Wr, a.Hr, a.D, a.h, a.w);
+            if (live) { m2 = v.xo[0]; m3 = v.yo[0]; m4 = v.zo[0]; }
+            if (WP) {
+                const int valid = (int)v.vx[0] | ((int)v.vx[1] << 1) | ((int)v.vy[0] << 2) | ((int)v.vy[1] << 3) | ((int)v.vz[0] << 4) | ((int)v.vz[1] << 5);
+                rv0 = v.xo[0] | (v.xo[1] << 16); rv1 = v.yo[0] | (v.yo[1] << 16);
+                rv2 = v.zo[0] | (v.zo[1] << 8) | (valid << 16);
+                rv3 = __float_as_int(v.wx[1]); rv4 = __float_as_int(v.wy[1]); rv5 = __float_as_int(v.wz[1]);
+            }
+        }
+        m0 = wave_min_i(m0); m1 = wave_min_i(m1);
+        if (s == 0) { m2 = wave_min_i(m2); m3 = wave_min_i(m3); m4 = wave_min_i(m4); }
+        if (!WP && (tid & 63) == 0) {
+            atomicMin(&mn[0], m0); atomicMin(&mn[1], m1);
+            if (s == 0) { atomicMin(&mn[2], m2); atomicMin(&mn[3], m3); atomicMin(&mn[4], m4); }
+        }
+        __syncthreads();
+        // (the butterfly leaves a wave's minimum in all of its lanes: the wave-private patches take that)
+        const int x0p = WP ? m0 : mn[0], y0p = WP ? m1 : mn[1], vx0 = WP ? m2 : mn[2], vy0 = WP ? m3 : mn[3], vz0 = WP ? m4 : mn[4];
+        const long long img = ((long long)b * a.S + s) * a.Hr * a.Wr;
+        const long long vb = (long long)b * a.D * a.h * a.w;
+        // ---- (2) scatter.  Two-stage software pipeline over two NAMED stages (no copies, no conditional fetch: hipcc otherwise
+        //      waits vmcnt(0) before every pass' scatter, i.e. for the prefetch it has just issued; the last prefetch re-reads the
+        //      last pass): the loads of pass it + 1 are in flight while pass it blends and scatters ----
+        if constexpr (WP) {
+            struct Stage {
+                long long bq, goff, voff; bool ok, von; int slot, vslot; float w, cx, cy, g, v, vwxy, vwz, vsign, gvox, vv;
+            };
+            const int tap = l64 >> 4, chl = l64 & 15, vtap = l64 >> 3, vch = l64 & 7;
+            auto fetch = [&](int j, Stage& P) {
+                // (point j of the wave is lane j of phase 1: its geometry comes over v_readlane, not through LDS)
+                const int pp = __builtin_amdgcn_readlane(rpp, j);
+                P.ok = pp >= 0;
+                P.bq = (long long)b * a.P + (P.ok ? pp : 0);
+                const int gxw = __builtin_amdgcn_readlane(rg0, j), gyw = __builtin_amdgcn_readlane(rg1, j);
+                const float tx1 = __int_as_float(__builtin_amdgcn_readlane(rg2, j)), ty1 = __int_as_float(__builtin_amdgcn_readlane(rg3, j));
+                const float tx0 = 1.f - tx1, ty0 = 1.f - ty1;
+                // (view_geom forms tx0 as (fx + 1) - ix; 1 - tx1 differs from that by one rounding at most)
+                const int x = (tap & 1) ? (gxw >> 16) & 0xffff : gxw & 0xffff, y = (tap & 2) ? (gyw >> 16) & 0xffff : gyw & 0xffff;
+                P.w = ((tap & 1) ? tx1 : tx0) * ((tap & 2) ? ty1 : ty0);
+                P.cx = ((tap & 1) ? 1.f : -1.f) * ((tap & 2) ? ty1 : ty0);       // d ix: (v01 - v00) ty0 + (v11 - v10) ty1
+                P.cy = ((tap & 2) ? 1.f : -1.f) * ((tap & 1) ? tx1 : tx0);       // d iy: (v10 - v00) tx0 + (v11 - v01) tx1
+                const unsigned dy = (unsigned)(y - y0p), dx = (unsigned)(x - x0p);
+                P.slot = (dy < (unsigned)T.PH && dx < (unsigned)T.PW) ? (int)((dy * T.PW + dx) * F) + chl : -1;
+                const int ch = min(chl, F - 1);                                  // clamped: always loads, masked when used
+                P.goff = (img + (P.ok ? y * a.Wr + x : 0)) * F + chl;
+                P.g = a.g_x[(P.bq * a.S + s) * XW + ch];
+                P.v = a.tex[(img + (P.ok ? y * a.Wr + x : 0)) * F + ch];
+                if (s == 0) {
+                    const int w0 = __builtin_amdgcn_readlane(rv0, j), w1 = __builtin_amdgcn_readlane(rv1, j), w2 = __builtin_amdgcn_readlane(rv2, j);
+                    const float wx1 = __int_as_float(__builtin_amdgcn_readlane(rv3, j)), wy1 = __int_as_float(__builtin_amdgcn_readlane(rv4, j));
+                    const float wz1 = __int_as_float(__builtin_amdgcn_readlane(rv5, j));
+                    const int cx = vtap & 1, cy = (vtap >> 1) & 1, cz = vtap >> 2;
+                    const int xo = cx ? (w0 >> 16) & 0xffff : w0 & 0xffff, yo = cy ? (w1 >> 16) & 0xffff : w1 & 0xffff;
+                    const int zo = cz ? (w2 >> 8) & 0xff : w2 & 0xff, valid = w2 >> 16;
+                    P.von = P.ok && ((valid >> cx) & 1) && ((valid >> (2 + cy)) & 1) && ((valid >> (4 + cz)) & 1);
+                    P.vwxy = (cx ? wx1 : 1.f - wx1) * (cy ? wy1 : 1.f - wy1);
+                    P.vwz = cz ? wz1 : 1.f - wz1;
+                    P.vsign = cz ? 1.f : -1.f;
+                    const unsigned dz = (unsigned)(zo - vz0), dyv = (unsigned)(yo - vy0), dxv = (unsigned)(xo - vx0);
+                    P.vslot = (dz < (unsigned)T.VZ && dyv < (unsigned)T.VH && dxv < (unsigned)T.VW) ? (int)(((dz * T.VH + dyv) * T.VW + dxv) * 8) + vch : -1;
+                    P.voff = (vb + (P.ok ? ((long long)zo * a.h + yo) * a.w + xo : 0)) * 8 + vch;
+                    P.gvox = a.g_vox[P.bq * 8 + vch];
+                    P.vv = a.vol[P.voff];
+                }
+            };
+            auto process = [&](const Stage& P, int j) {
+                const int pj = wave * 64 + j;
+                const bool on = P.ok && chl < F;
+                const float g = on ? P.g : 0.f;
+                if (ENERF_GT_ABL != 2 && on && P.w != 0.f) {                     // (weight 0: among others the clamp's duplicate taps)
+                    if (P.slot >= 0) { const float r = ptex[P.slot]; ptex[P.slot] = r + P.w * g; }
+                    else atomic_add_f32(a.g_tex + P.goff, P.w * g);
+                }
+                const float gix = wave_sum64(g * P.v * P.cx), giy = wave_sum64(g * P.v * P.cy);
+                float giz = 0.f;
+                if (s == 0) {
+                    const float val = P.vwxy * P.vwz * P.gvox;
+                    if (ENERF_GT_ABL != 2 && P.von) {
+                        if (P.vslot >= 0) { const float r = pvol[P.vslot]; pvol[P.vslot] = r + val; }
+                        else atomic_add_f32(a.g_vol + P.voff, val);
+                    }
+                    giz = wave_sum64(P.von ? P.vsign * P.vv * P.vwxy * P.gvox : 0.f);
+                }
+                if (l64 == 0) { gij[pj][0] = gix; gij[pj][1] = giy; gij[pj][2] = giz; }
+            };
+            const int passes = ENERF_GT_ABL == 1 ? 0 : 64;
+            Stage sa, sb;
+            fetch(0, sa);
+            for (int it = 0; it < passes; it += 2) {
+                fetch(it + 1, sb);
+                __builtin_amdgcn_sched_barrier(0);
+                process(sa, it);
+                fetch(min(it + 2, 63), sa);
+                __builtin_amdgcn_sched_barrier(0);
+                process(sb, it + 1);
+            }
+        } else {
+            struct Stage {
+                long long bq; bool ok; int x0, x1, y0, y1; float tx1, ty1;
+                float g[NCH], v00[NCH], v01[NCH], v10[NCH], v11[NCH];
+                VoxGeom vg; float gvox, vv[4];                      // view 0 only: the point's volume taps, its d vox channel, tap values
+            };
+            auto fetch = [&](int it, Stage& P) {
+                const int pj = it * 16 + grp;
+                const int pp = pj < 256 ? gpt[pj] : -1;
+                P.ok = pp >= 0;
+                P.bq = (long long)b * a.P + (P.ok ? pp : 0);
+                if (s == 0) {
+                    // lanes 0-7 / 8-15 of the group: channel = lane & 7, the taps with cz = 0 / 1 (the any-order kernel leaves half of
+                    // the group idle); coordinates are clamped, so the four values are always loadable
+                    P.gvox = a.g_vox[P.bq * 8 + (lane & 7)];
+                    P.vg = vox_geom(a.uv[P.bq * 2], a.uv[P.bq * 2 + 1], a.dn[P.bq], a.Wr, a.Hr, a.D, a.h, a.w);
+                    const int zoc = (lane >> 3) ? P.vg.zo[1] : P.vg.zo[0];  // (selects, not a runtime array index: that would be scratch)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) P.vv[t] = a.vol[(vb + ((long long)zoc * a.h + P.vg.yo[t >> 1]) * a.w + P.vg.xo[t & 1]) * 8 + (lane & 7)];
+                }
+                const int gxw = geo[pj & 255][0], gyw = geo[pj & 255][1];
+                P.tx1 = __int_as_float(geo[pj & 255][2]); P.ty1 = __int_as_float(geo[pj & 255][3]);
+                P.x0 = gxw & 0xffff; P.x1 = (gxw >> 16) & 0xffff; P.y0 = gyw & 0xffff; P.y1 = (gyw >> 16) & 0xffff;
+                if (!P.ok) { P.x0 = P.x1 = P.y0 = P.y1 = 0; }
+                const float* gx = a.g_x + (P.bq * a.S + s) * XW;
+                const long long t00 = (img + P.y0 * a.Wr + P.x0) * F, t01 = (img + P.y0 * a.Wr + P.x1) * F;
+                const long long t10 = (img + P.y1 * a.Wr + P.x0) * F, t11 = (img + P.y1 * a.Wr + P.x1) * F;
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const int ch = min(lane + 16 * k, F - 1);               // clamped: always loads, masked when used
+                    P.g[k] = gx[ch];
+                    P.v00[k] = a.tex[t00 + ch]; P.v01[k] = a.tex[t01 + ch]; P.v10[k] = a.tex[t10 + ch]; P.v11[k] = a.tex[t11 + ch];
+                }
+            };
+            auto process = [&](const Stage& cur, int it) {
+                const int pj = it * 16 + grp;
+                const bool ok = cur.ok;
+                const int x0 = cur.x0, x1 = cur.x1, y0 = cur.y0, y1 = cur.y1;
+                const float tx1 = cur.tx1, ty1 = cur.ty1, tx0 = 1.f - tx1, ty0 = 1.f - ty1;
+                const float w00 = tx0 * ty0, w01 = tx1 * ty0, w10 = tx0 * ty1, w11 = tx1 * ty1;
+                const int t00 = y0 * a.Wr + x0, t01 = y0 * a.Wr + x1, t10 = y1 * a.Wr + x0, t11 = y1 * a.Wr + x1;
+                auto tex_add = [&](int y, int x, int t, int ch, float v) {
+                    if (ENERF_GT_ABL == 2) return;
+                    const unsigned dy = (unsigned)(y - y0p), dx = (unsigned)(x - x0p);
+                    if (dy < (unsigned)T.PH && dx < (unsigned)T.PW) lds_add_f32(ptex + (dy * T.PW + dx) * F + ch, v);
+                    else atomic_add_f32(a.g_tex + (img + t) * F + ch, v);
+                };
+                float gix = 0.f, giy = 0.f, giz = 0.f;
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const int ch = lane + 16 * k;
+                    if (!ok || ch >= F) continue;
+                    const float g = cur.g[k], v00 = cur.v00[k], v01 = cur.v01[k], v10 = cur.v10[k], v11 = cur.v11[k];
+                    tex_add(y0, x0, t00, ch, w00 * g); tex_add(y0, x1, t01, ch, w01 * g);
+                    tex_add(y1, x0, t10, ch, w10 * g); tex_add(y1, x1, t11, ch, w11 * g);
+                    gix += g * ((v01 - v00) * ty0 + (v11 - v10) * ty1);
+                    giy += g * ((v10 - v00) * tx0 + (v11 - v01) * tx1);
+                }
+                if (s == 0) {
+                    const VoxGeom& v = cur.vg;
+                    const int cz = lane >> 3, chn = lane & 7;
+                    const int zoc = cz ? v.zo[1] : v.zo[0];
+                    const float wzc = cz ? v.wz[1] : v.wz[0];
+                    const bool vzc = cz ? v.vz[1] : v.vz[0];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int cx = t & 1, cy = t >> 1;
+                        if (!(ok && v.vx[cx] && v.vy[cy] && vzc) || ENERF_GT_ABL == 2) continue;
+                        const float wxy = v.wx[cx] * v.wy[cy];
+                        const unsigned dz = (unsigned)(zoc - vz0), dy = (unsigned)(v.yo[cy] - vy0), dx = (unsigned)(v.xo[cx] - vx0);
+                        if (dz < (unsigned)T.VZ && dy < (unsigned)T.VH && dx < (unsigned)T.VW)
+                            lds_add_f32(pvol + ((dz * T.VH + dy) * T.VW + dx) * 8 + chn, wxy * wzc * cur.gvox);
+                        else atomic_add_f32(a.g_vol + (vb + ((long long)zoc * a.h + v.yo[cy]) * a.w + v.xo[cx]) * 8 + chn, wxy * wzc * cur.gvox);
+                        giz += (cz ? 1.f : -1.f) * cur.vv[t] * wxy * cur.gvox;
+                    }
+                }
+                gix = sum16(gix); giy = sum16(giy);
+                if (s == 0) giz = sum16(giz);
+                if (lane == 0 && pj < 256) { gij[pj][0] = gix; gij[pj][1] = giy; gij[pj][2] = giz; }
+            };
+            const int passes = ENERF_GT_ABL == 1 ? 0 : (npts + 15) / 16;
+            Stage sa, sb;
+            fetch(0, sa);
+            for (int it = 0; it < passes; it += 2) {
+                fetch(min(it + 1, passes - 1), sb);
+                __builtin_amdgcn_sched_barrier(0);
+                process(sa, it);
+                fetch(min(it + 2, passes - 1), sa);
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + 1 < passes) process(sb, it + 1);
+            }
+        }
+        __syncthreads();
+        // ---- (3) chain rule of (point, view s), one thread per point (the geometry again: 16 x cheaper than in the any-order
+        //      kernel, and not held in registers across the scatter) ----
+        if (live && ENERF_GT_ABL != 4) {
+            const ViewGeom q = view_geom(c, a.tcen + b * 4, X, Y, Z, a.Wr, a.Hr);
+            float gix = gij[tid][0], giy = gij[tid][1];
+            if (s == 0) a.g_dn[bp] = gij[tid][2] * (float)(a.D - 1);   // iz = dn (D-1): unnormalise (D-1)/2 x d(2 dn - 1)/d dn
+            if (!q.gx_on) gix = 0.f;
+            if (!q.gy_on) giy = 0.f;
+            const float gpx = gix / q.zc, gpy = giy / q.zc;
+            const float gpz = q.pz >= 1e-6f ? -(gix * q.px + giy * q.py) / (q.zc * q.zc) : 0.f;
+            gX += c[0] * gpx + c[3] * gpy + c[6] * gpz; gY += c[1] * gpx + c[4] * gpy + c[7] * gpz; gZ += c[2] * gpx + c[5] * gpy + c[8] * gpz;
+            const float* gx = a.g_x + (bp * a.S + s) * XW;
+            const float gd0 = gx[F], gd1 = gx[F + 1], gd2 = gx[F + 2], gdot = gx[F + 3];
+            const float it = 1.f / (q.nt + 1e-6f), is = 1.f / (q.ns + 1e-6f);
+            const float tx = q.tdx * it, ty = q.tdy * it, tz = q.tdz * it, sx = q.sdx * is, sy = q.sdy * is, sz = q.sdz * is;
+            float gex, gey, gez;
+            if (q.ne > 1e-6f) {
+                const float in = 1.f / q.ne, hx = q.ex * in, hy = q.ey * in, hz = q.ez * in, pr = hx * gd0 + hy * gd1 + hz * gd2;
+                gex = (gd0 - hx * pr) * in; gey = (gd1 - hy * pr) * in; gez = (gd2 - hz * pr) * in;
+            } else { gex = gd0 * 1e6f; gey = gd1 * 1e6f; gez = gd2 * 1e6f; }
+            const float gtx = gex + gdot * sx, gty = gey + gdot * sy, gtz = gez + gdot * sz;
+            const float gsx = -gex + gdot * tx, gsy = -gey + gdot * ty, gsz = -gez + gdot * tz;
+            {   // t_hat = dt / (|dt| + eps)
+                const float pr = (q.tdx * gtx + q.tdy * gty + q.tdz * gtz), k = q.nt > 0.f ? pr * it * it / q.nt : 0.f;
+                gX += gtx * it - q.tdx * k; gY += gty * it - q.tdy * k; gZ += gtz * it - q.tdz * k;
+            }
+            {
+                const float pr = (q.sdx * gsx + q.sdy * gsy + q.sdz * gsz), k = q.ns > 0.f ? pr * is * is / q.ns : 0.f;
+                gX += gsx * is - q.sdx * k; gY += gsy * is - q.sdy * k; gZ += gsz * is - q.sdz * k;
+            }
+        }
+        // ---- flush: a patch row is a contiguous run of the gradient map ----
+        if (ENERF_GT_ABL != 3) {
+            const int rowf = T.PW * F;
+            for (int i = WP ? l64 : tid; i < ntex; i += WP ? 64 : 256) {
+                const float v = ptex[i];
+                if (v == 0.f) continue;
+                ptex[i] = 0.f;
+                const int row = i / rowf, e = i - row * rowf;              // (an entry is only ever non-zero inside the image)
+                atomic_add_f32(a.g_tex + (img + (long long)(y0p + row) * a.Wr + x0p) * F + e, v);
+            }
+        }
+        if (s == 0 && ENERF_GT_ABL != 3) {
+            const int rowf = T.VW * 8;
+            for (int i = WP ? l64 : tid; i < nvol; i += WP ? 64 : 256) {
+                const float v = pvol[i];
+                if (v == 0.f) continue;
+                pvol[i] = 0.f;
+                const int r = i / rowf, e = i - r * rowf, dz = r / T.VH, dy = r - dz * T.VH;
+                atomic_add_f32(a.g_vol + (vb + ((long long)(vz0 + dz) * a.h + vy0 + dy) * a.w + vx0) * 8 + e, v);
+            }
+        }
+    }
+    if (live) { a.g_xyz[bp * 3] = gX; a.g_xyz[bp * 3 + 1] = gY; a.g_xyz[bp * 3 + 2] = gZ; }
 }
 
 }  // namespace enerf
@@ -217,6 +563,7 @@ static int gather_check(const enerf_gather_args_t* u, GatherArgs* a, const char*
     a->x = u->x; a->vox = u->vox; a->g_x = u->g_x; a->g_vox = u->g_vox; a->g_tex = u->g_tex; a->g_vol = u->g_vol;
     a->g_xyz = u->g_xyz; a->g_dn = u->g_dn;
     a->B = u->B; a->S = u->S; a->F = u->F; a->Hr = u->Hr; a->Wr = u->Wr; a->D = u->D; a->h = u->h; a->w = u->w; a->P = u->P;
+    a->ray_w = 0; a->n_samples = 0;
     return ENERF_OK;
 }
 int enerf_gather_fwd(const enerf_gather_args_t* u, enerf_stream_t stream) {
@@ -240,6 +587,32 @@ int enerf_gather_bwd(const enerf_gather_args_t* u, enerf_stream_t stream) {
     if (u->P == 0) return ENERF_OK;
     zero_async(a.g_xyz, (size_t)a.B * a.P * 3 * sizeof(float), st);
     const long long total = (long long)a.B * a.P * a.S;
+    a.ray_w = u->ray_w; a.n_samples = u->n_samples;
+    REQUIRE(a.ray_w >= 0 && a.n_samples >= 0, "gather_bwd: negative raster hint");
+    const bool raster = a.ray_w > 0 && a.n_samples > 0 && a.n_samples <= 8 && a.P % ((long long)a.ray_w * a.n_samples) == 0 &&
+                        (long long)a.B * a.S * a.Hr * a.Wr * a.F < (1LL << 31) && a.F <= 48 && a.Wr < 65535 && a.Hr < 65535;
+    if (raster) {
+        GatherTile T;
+        const bool wp = a.F <= 16;                            // wave-private patches (see the kernel)
+        T.kg = a.n_samples <= 2 ? a.n_samples : 1;            // the fine level's samples share a patch; the coarse level's span the
+        T.groups = a.n_samples / T.kg;                        // whole depth range: one block per sample index
+        T.th = 8; T.tw = wp ? 4 * (64 / (8 * T.kg)) : 16;     // x kg <= 256 points: one thread per point in phases 1 and 3
+        const int pw = wp ? T.tw / 4 : T.tw;                  // columns of rays behind one patch
+        T.PW = pw + (wp ? 6 : 12); T.PH = T.th + (wp ? 4 : 6);
+        while (T.PH > T.th + 2 && (size_t)T.PH * T.PW * a.F * sizeof(float) > 40 * 1024) --T.PH;
+        T.VW = (int)((float)pw * (float)(a.w - 1) / (float)(a.Wr - 1)) + 3;
+        T.VH = (int)((float)T.th * (float)(a.h - 1) / (float)(a.Hr - 1)) + 3;
+        T.VZ = a.D < 4 ? a.D : 4;
+        const int rows = (int)(a.P / a.n_samples / a.ray_w);
+        T.tiles_x = cdiv(a.ray_w, T.tw); T.tiles_y = cdiv(rows, T.th);
+        const size_t shmem = ((size_t)T.PH * T.PW * a.F + (size_t)T.VZ * T.VH * T.VW * 8) * sizeof(float) * (wp ? 4 : 1);
+        const long long blocks = (long long)a.B * T.tiles_x * T.tiles_y * T.groups;
+        if (shmem <= 64 * 1024 && blocks < (1LL << 31)) {
+            if (wp) ENERF_LAUNCH((k_gather_bwd_tiled<1, true>), (unsigned)blocks, 256, shmem, st, a, T);
+            else ENERF_LAUNCH((k_gather_bwd_tiled<3, false>), (unsigned)blocks, 256, shmem, st, a, T);
+            return check_launch("gather_bwd");
+        }
+    }
     ENERF_LAUNCH(k_gather_bwd, (unsigned)cdivl(total, 16), 256, 0, st, a);
     return check_launch("gather_bwd");
 }

@@ -72,7 +72,7 @@ class GatherArgs(C.Structure):
     """``enerf_gather_args_t``."""
     _fields_ = ([(n, _f) for n in ("xyz", "dn", "uv", "tex", "vol", "cam", "tcen", "x", "vox", "g_x", "g_vox", "g_tex",
                                    "g_vol", "g_xyz", "g_dn")]
-                + [("P", _ll)] + [(n, _i) for n in ("B", "S", "F", "Hr", "Wr", "D", "h", "w")])
+                + [("P", _ll)] + [(n, _i) for n in ("B", "S", "F", "Hr", "Wr", "D", "h", "w", "ray_w", "n_samples")])
 
 
 class RenderArgs(C.Structure):
@@ -615,9 +615,10 @@ class EnerfLib:
         self._check(self.dll.enerf_gather_fwd(C.byref(a), self.stream_of(xyz)), "gather_fwd")
         return x, vox
 
-    def gather_bwd(self, xyz, dn, uv, tex_cl, vol_cl, cam, tcen, g_x, g_vox):
-        """-> (g_tex_cl, g_vol_cl, g_xyz, g_dn)."""
+    def gather_bwd(self, xyz, dn, uv, tex_cl, vol_cl, cam, tcen, g_x, g_vox, n_samples=0, ray_w=0):
+        """-> (g_tex_cl, g_vol_cl, g_xyz, g_dn).  ``n_samples`` / ``ray_w``: raster hints (enerf_gather_args_t)."""
         a = self._gather_args(xyz, dn, uv, tex_cl, vol_cl, cam, tcen)
+        a.n_samples, a.ray_w = int(n_samples), int(ray_w)
         E = lambda ref: torch.empty_like(ref)
         g_tex, g_vol, g_xyz, g_dn = E(tex_cl), E(vol_cl), E(xyz), E(dn)
         a.g_x, a.g_vox, a.g_tex, a.g_vol, a.g_xyz, a.g_dn = (_ptr(g_x), _ptr(g_vox), _ptr(g_tex), _ptr(g_vol), _ptr(g_xyz),

@@ -343,8 +343,10 @@ def render_rays(net, rays, level, batch, im_feat, feat_vol, lib=None, tables=Non
     if hip_gather:
         from .autograd import GatherFn, gather_cameras
         cam, tcen = (tables[f"cam_{level}"], tables["tcen"]) if tables is not None else gather_cameras(batch, rs, lib)
+        # a full image of rays (train_img, dtu_pretrain.yaml:41; enerf_utils.py:61-71 emits them row-major): the backward owns
+        # 2-D ray tiles (a hint: a permuted list of Hr * Wr rays is still scattered correctly, only slower)
         x, vox = GatherFn.apply(lib, xyz.reshape(B, N * Ns, 3), dn.reshape(B, N * Ns), uv.reshape(B, N * Ns, 2), tex_cl,
-                                feat_vol.permute(0, 2, 3, 4, 1), cam, tcen)
+                                feat_vol.permute(0, 2, 3, 4, 1), cam, tcen, Ns, Wr if N == Hr * Wr else 0)
     else:
         if uvd is None:
             uvd = torch.cat([uv, dn[..., None]], -1)

@@ -416,6 +416,12 @@ typedef struct {
     float *g_tex, *g_vol, *g_xyz, *g_dn;
     long long P;
     int B, S, F, Hr, Wr, D, h, w;
+    /* optional hints for enerf_gather_bwd (0 = none): the points are n_samples consecutive samples of each ray and the rays are
+     * a row-major raster of ray_w rays per row (config 5 trains on full images, dtu_pretrain.yaml:41): p = (y * ray_w + x) *
+     * n_samples + k.  With both set, a block owns a 2-D ray tile and accumulates its texel / volume scatter in LDS patches that
+     * are flushed once (fp32 atomics cost one L2 request per 64-byte line and instruction, tools/micro/atomic_rate.hip); taps
+     * outside a patch fall back to global atomics, so a wrong hint costs time, never correctness. */
+    int ray_w, n_samples;
 } enerf_gather_args_t;
 int enerf_gather_fwd(const enerf_gather_args_t* args, enerf_stream_t stream);
 int enerf_gather_bwd(const enerf_gather_args_t* args, enerf_stream_t stream);

@@ -284,6 +284,7 @@ inline emu_f32x4 __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, emu_f32x4 
 
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only ever applied to wave-uniform values
+inline int __builtin_amdgcn_readlane(int v, int lane) { return __shfl(v, lane); }   // uniform lane index, uniform control flow
 inline void __builtin_amdgcn_s_sleep(int) {}
 inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
 inline unsigned __float_as_uint(float f) { unsigned v; memcpy(&v, &f, 4); return v; }
@@ -307,6 +308,12 @@ inline float atomicAdd(float* p, float v) {            // blocks run on several 
     do { memcpy(&of, &old, 4); float nf = of + v; memcpy(&neu, &nf, 4);
     } while (!__atomic_compare_exchange_n(u, &old, neu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
     return of;
+}
+
+inline int atomicMin(int* p, int v) {
+    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
 }
 
 #define ENERF_LAUNCH(kern, grid, block, shmem, stream, ...) \

@@ -147,7 +147,49 @@ def _check_camera_tables_and_layout(lib, dev):
     assert torch.equal(lib.add(x.to(dev), y.to(dev)).cpu(), x + y)
 
 
-CHECKS = [_check_s2k5_dgrad, _check_resize_adjoint, _check_depth_values_bwd, _check_ray_samples, _check_camera_tables_and_layout]
+def _check_gather_bwd_tiled(lib, dev):
+    """enerf_gather_bwd with the raster hints (a block per 2-D ray tile, texel / volume scatter accumulated in LDS patches) against
+    the same entry without them (every contribution a global atomic; pinned to torch's grid_sample backward in
+    tests/test_training.py): partial tiles in both directions, the one-patch-per-sample-index form of the coarse level, taps that
+    do not fit a patch (random depths: the projections of a tile cover the whole source image), and a WRONG hint (permuted
+    points) — all the same sums."""
+    from enerf_amd.autograd import gather_cameras_torch
+    from enerf_amd.synth import make_batch
+    g = torch.Generator().manual_seed(9)
+    for Hr, Wr, Ns, Fc, wild, permute in ((20, 44, 2, 11, False, False), (12, 40, 4, 35, False, False), (9, 35, 2, 11, True, False),
+                                          (16, 32, 1, 11, False, True)):
+        cfg = EnerfConfig().with_cas(render_scale=(1.0, 1.0))
+        b = {k: torch.from_numpy(v) for k, v in make_batch(Hr, Wr, 3, cfg, seed=3 + Ns, B=2).items()}
+        rays = b["rays_1"]                                               # (B, Hr*Wr, 8+): row-major full-image rays
+        B, N = rays.shape[0], rays.shape[1]
+        assert N == Hr * Wr
+        near, far = float(b["near_far"].min()), float(b["near_far"].max())
+        if wild:
+            t = near + (far - near) * torch.rand(B, N, Ns, generator=g) * 3.0 - (far - near)
+        else:                                                            # a smooth depth map + the samples of a ray close together
+            yy, xx = torch.meshgrid(torch.linspace(0, 1, Hr), torch.linspace(0, 1, Wr), indexing="ij")
+            base = near + (far - near) * (0.3 + 0.4 * torch.sin(3 * xx + 2 * yy).abs()).reshape(1, N, 1)
+            t = base + (far - near) * 0.02 * torch.arange(Ns).reshape(1, 1, Ns) + (far - near) * 0.005 * torch.rand(B, N, Ns, generator=g)
+        xyz = (rays[:, :, None, :3] + rays[:, :, None, 3:6] * t[..., None]).reshape(B, N * Ns, 3).contiguous()
+        dn = (torch.rand(B, N * Ns, generator=g) * 1.2 - 0.1).contiguous()
+        uv = rays[:, :, None, 6:8].expand(B, N, Ns, 2).reshape(B, N * Ns, 2).contiguous()
+        if permute:
+            perm = torch.randperm(N * Ns, generator=g)
+            xyz, dn, uv = xyz[:, perm].contiguous(), dn[:, perm].contiguous(), uv[:, perm].contiguous()
+        tex = torch.randn(B, 3, Hr, Wr, Fc, generator=g)
+        vol = torch.randn(B, 8, max(Hr // 2, 2), max(Wr // 2, 2), 8, generator=g)
+        gx, gv = torch.randn(B, N * Ns, 3, Fc + 4, generator=g), torch.randn(B, N * Ns, 8, generator=g)
+        cam, tcen = gather_cameras_torch(b, 1.0)
+        T = lambda *ts: [t_.to(dev).contiguous() for t_ in ts]
+        args = T(xyz, dn, uv, tex, vol, cam, tcen, gx, gv)
+        ref = lib.gather_bwd(*args)
+        got = lib.gather_bwd(*args, n_samples=Ns, ray_w=Wr)
+        for name, r, o in zip(("tex", "vol", "xyz", "dn"), ref, got):
+            assert float(r.abs().max()) > 0
+            assert _rel(o, r) < 2e-5, (Hr, Wr, Ns, Fc, wild, permute, name, _rel(o, r))
+
+
+CHECKS = [_check_gather_bwd_tiled, _check_s2k5_dgrad, _check_resize_adjoint, _check_depth_values_bwd, _check_ray_samples, _check_camera_tables_and_layout]
 
 
 @pytest.mark.parametrize("check", CHECKS, ids=lambda f: f.__name__[7:])

@@ -31,7 +31,7 @@ import csv, glob
 f=glob.glob("/tmp/pt_$v/**/*kernel_stats.csv", recursive=True)
 for r in csv.DictReader(open(f[0])):
     if "mlp_bwd" in r["Name"] or "gemm_wgrad" in r["Name"] or "gather_bwd" in r["Name"] or "feature_volume_bwd" in r["Name"]:
-        print("$v", r["Name"][:60], "calls", r["Calls"], "avg us", round(float(r["AverageNs"])/1e3,1))
+        print("$v", r["Name"][:60], "calls", r["Calls"], "avg us", round(float(r["AverageNs"])/1e3,1), "min", round(float(r["MinNs"])/1e3,1), "max", round(float(r["MaxNs"])/1e3,1))
 PY
 done
 cp /tmp/lib_keep3.so $R/enerf_amd/libenerf_hip.so
