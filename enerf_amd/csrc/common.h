@@ -162,6 +162,14 @@ __device__ __forceinline__ float row_sum16(float v) {
     return v;
 #endif
 }
+// v + the value of lane ^ 8 (one DPP row rotation by 8: inside a row of 16 lanes, +8 mod 16 is ^ 8)
+__device__ __forceinline__ float add_xor8(float v) {
+#ifdef ENERF_EMU
+    return v + __shfl_xor(v, 8);
+#else
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+#endif
+}
 __device__ __forceinline__ float group_max4(float v) {
 #ifdef ENERF_EMU
     v = fmaxf(v, __shfl_xor(v, 16));

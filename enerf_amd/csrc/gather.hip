@@ -121,6 +121,79 @@ __global__ __launch_bounds__(256) void k_gather_fwd(GatherArgs a) {
     for (int ch = 0; ch < 8; ++ch) a.vox[bp * 8 + ch] = acc[ch];
 }
 
+// Forward, the form the C entry launches: a wave owns 64 consecutive points.  Per view, lane l computes the geometry of point l
+// ONCE (the thread-per-(point, view) kernel above then walks 4 F scattered 4-byte loads per thread: 64 different cache lines per
+// load instruction); the 64 points are then fetched one per pass with lane = (tap, channel): 4 taps x 16 channels (64 lanes, the
+// four taps' weighted values summed across the lane groups by register permutes) for the texel, 8 taps x 8 channels for the
+// volume — every load and store instruction touches whole texels.  No LDS, no barriers.
+template <int NCH>                      // channel rounds: ceil(F / 16)
+__global__ __launch_bounds__(256) void k_gather_fwd_w(GatherArgs a) {
+    const int F = a.F, XW = F + 4, l64 = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;     // first point (b * P + p) of the wave
+    const long long total = (long long)a.B * a.P;
+    if (wave0 >= total) return;
+    const long long bp_raw = wave0 + l64;
+    const bool live = bp_raw < total;
+    const long long bp = live ? bp_raw : total - 1;
+    const int b = (int)(bp / a.P);
+    const float X = a.xyz[bp * 3], Y = a.xyz[bp * 3 + 1], Z = a.xyz[bp * 3 + 2];
+    const int tap = l64 >> 4, chl = l64 & 15, vtap = l64 >> 3, vch = l64 & 7;
+    const int npass = (int)(total - wave0 < 64 ? total - wave0 : 64);
+    // ---- the volume sample (once per point) ----
+    {
+        const VoxGeom v = vox_geom(a.uv[bp * 2], a.uv[bp * 2 + 1], a.dn[bp], a.Wr, a.Hr, a.D, a.h, a.w);
+        const int valid = (int)v.vx[0] | ((int)v.vx[1] << 1) | ((int)v.vy[0] << 2) | ((int)v.vy[1] << 3) | ((int)v.vz[0] << 4) | ((int)v.vz[1] << 5);
+        const int r0 = v.xo[0] | (v.xo[1] << 16), r1 = v.yo[0] | (v.yo[1] << 16), r2 = v.zo[0] | (v.zo[1] << 8) | (valid << 16), rb = b;
+        const int r3 = __float_as_int(v.wx[0]), r4 = __float_as_int(v.wx[1]), r5 = __float_as_int(v.wy[0]), r6 = __float_as_int(v.wy[1]);
+        const int r7 = __float_as_int(v.wz[0]), r8 = __float_as_int(v.wz[1]);
+        const int cx = vtap & 1, cy = (vtap >> 1) & 1, cz = vtap >> 2;
+#pragma unroll 2
+        for (int j = 0; j < npass; ++j) {
+            const int w0 = __builtin_amdgcn_readlane(r0, j), w1 = __builtin_amdgcn_readlane(r1, j), w2 = __builtin_amdgcn_readlane(r2, j);
+            const int bj = __builtin_amdgcn_readlane(rb, j);
+            // (every lane executes every v_readlane — they are wave-level operations; the selects come after)
+            const int x3 = __builtin_amdgcn_readlane(r3, j), x4 = __builtin_amdgcn_readlane(r4, j), x5 = __builtin_amdgcn_readlane(r5, j);
+            const int x6 = __builtin_amdgcn_readlane(r6, j), x7 = __builtin_amdgcn_readlane(r7, j), x8 = __builtin_amdgcn_readlane(r8, j);
+            const float wx = __int_as_float(cx ? x4 : x3), wy = __int_as_float(cy ? x6 : x5), wz = __int_as_float(cz ? x8 : x7);
+            const int xo = cx ? (w0 >> 16) & 0xffff : w0 & 0xffff, yo = cy ? (w1 >> 16) & 0xffff : w1 & 0xffff;
+            const int zo = cz ? (w2 >> 8) & 0xff : w2 & 0xff, vld = w2 >> 16;
+            const bool on = ((vld >> cx) & 1) && ((vld >> (2 + cy)) & 1) && ((vld >> (4 + cz)) & 1);
+            const float val = a.vol[(((long long)bj * a.D + zo) * a.h + yo) * a.w * 8 + (long long)xo * 8 + vch];
+            float acc = on ? val * (wx * wy * wz) : 0.f;
+            acc = group_sum4(add_xor8(acc));                      // over the 8 taps: lane bits 3 | 4, 5
+            if (l64 < 8) a.vox[(wave0 + j) * 8 + vch] = acc;
+        }
+    }
+    // ---- the texel of every view ----
+    for (int s = 0; s < a.S; ++s) {
+        const float* c = a.cam + ((long long)b * a.S + s) * 16;
+        const ViewGeom q = view_geom(c, a.tcen + b * 4, X, Y, Z, a.Wr, a.Hr);
+        if (live) {
+            float* xo = a.x + (bp * a.S + s) * XW + F;
+            xo[0] = q.dir[0]; xo[1] = q.dir[1]; xo[2] = q.dir[2]; xo[3] = q.dir[3];
+        }
+        const int r0 = q.x0 | (q.x1 << 16), r1 = q.y0 | (q.y1 << 16), rb = b;
+        const int r2 = __float_as_int(q.w00), r3 = __float_as_int(q.w01), r4 = __float_as_int(q.w10), r5 = __float_as_int(q.w11);
+#pragma unroll 2
+        for (int j = 0; j < npass; ++j) {
+            const int gxw = __builtin_amdgcn_readlane(r0, j), gyw = __builtin_amdgcn_readlane(r1, j), bj = __builtin_amdgcn_readlane(rb, j);
+            const int x2 = __builtin_amdgcn_readlane(r2, j), x3 = __builtin_amdgcn_readlane(r3, j);   // (all lanes, then select)
+            const int x4 = __builtin_amdgcn_readlane(r4, j), x5 = __builtin_amdgcn_readlane(r5, j);
+            const float w = __int_as_float((tap & 2) ? ((tap & 1) ? x5 : x4) : ((tap & 1) ? x3 : x2));
+            const int x = (tap & 1) ? (gxw >> 16) & 0xffff : gxw & 0xffff, y = (tap & 2) ? (gyw >> 16) & 0xffff : gyw & 0xffff;
+            const long long t = ((((long long)bj * a.S + s) * a.Hr + y) * a.Wr + x) * F;
+            float* xrow = a.x + ((wave0 + j) * a.S + s) * XW;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int ch = chl + 16 * k;
+                const float v = a.tex[t + min(ch, F - 1)];                 // clamped: always loads
+                const float acc = group_sum4(v * w);
+                if (l64 < 16 && ch < F) xrow[ch] = acc;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ float sum16(float v) {          // sum over the 16 lanes of a group (lane ^ 1, 2, 4, 8)
     v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
     return v;
@@ -572,8 +645,14 @@ int enerf_gather_fwd(const enerf_gather_args_t* u, enerf_stream_t stream) {
     if (rc != ENERF_OK) return rc;
     REQUIRE(u->x && u->vox, "gather_fwd: null output");
     if (u->P == 0) return ENERF_OK;
-    const long long total = (long long)a.B * a.P * a.S;
-    ENERF_LAUNCH_SIMPLE(k_gather_fwd, (unsigned)cdivl(total, 256), 256, 0, (hipStream_t)stream, a);
+    const long long waves = cdivl((long long)a.B * a.P, 64);
+    REQUIRE(a.Wr < 65535 && a.Hr < 65535 && a.w < 65535 && a.h < 65535 && a.D < 256, "gather_fwd: map sizes beyond the packed tap coordinates");
+    if (a.F <= 16) ENERF_LAUNCH(k_gather_fwd_w<1>, (unsigned)cdivl(waves, 4), 256, 0, (hipStream_t)stream, a);
+    else if (a.F <= 48) ENERF_LAUNCH(k_gather_fwd_w<3>, (unsigned)cdivl(waves, 4), 256, 0, (hipStream_t)stream, a);
+    else {
+        const long long total = (long long)a.B * a.P * a.S;
+        ENERF_LAUNCH_SIMPLE(k_gather_fwd, (unsigned)cdivl(total, 256), 256, 0, (hipStream_t)stream, a);
+    }
     return check_launch("gather_fwd");
 }
 int enerf_gather_bwd(const enerf_gather_args_t* u, enerf_stream_t stream) {
@@ -585,7 +664,6 @@ int enerf_gather_bwd(const enerf_gather_args_t* u, enerf_stream_t stream) {
     zero_async(a.g_tex, (size_t)a.B * a.S * a.Hr * a.Wr * a.F * sizeof(float), st);
     zero_async(a.g_vol, (size_t)a.B * a.D * a.h * a.w * 8 * sizeof(float), st);
     if (u->P == 0) return ENERF_OK;
-    zero_async(a.g_xyz, (size_t)a.B * a.P * 3 * sizeof(float), st);
     const long long total = (long long)a.B * a.P * a.S;
     a.ray_w = u->ray_w; a.n_samples = u->n_samples;
     REQUIRE(a.ray_w >= 0 && a.n_samples >= 0, "gather_bwd: negative raster hint");
@@ -613,6 +691,7 @@ int enerf_gather_bwd(const enerf_gather_args_t* u, enerf_stream_t stream) {
             return check_launch("gather_bwd");
         }
     }
+    zero_async(a.g_xyz, (size_t)a.B * a.P * 3 * sizeof(float), st);     // (the tiled kernel stores every point's g_xyz itself)
     ENERF_LAUNCH(k_gather_bwd, (unsigned)cdivl(total, 16), 256, 0, st, a);
     return check_launch("gather_bwd");
 }

@@ -12,38 +12,89 @@
 namespace enerf {
 
 // sums[c] = sum_p a[p][c]*m ;  sums[C + c] = sum_p a[p][c]*m*b[p][c] ;  m = (zm[p][c]*ms[c] + mh[c] > 0) or 1
+template <bool SAME, bool MASK>          // a == b (the forward statistics: read once); a ReLU mask from zm
 __global__ __launch_bounds__(256) void k_channel_sums(const float* __restrict__ a, const float* __restrict__ b,
                                                       const float* __restrict__ zm, const float* __restrict__ ms,
                                                       const float* __restrict__ mh, long long n, int C,
-                                                      double* __restrict__ sums) {
+                                                      double* __restrict__ sums, double* __restrict__ partials) {
     __shared__ double red[2][256][4];
     const int CQ = C >> 2;                                 // float4 channel groups
     const int cq = threadIdx.x % CQ, lane_p = threadIdx.x / CQ, ppb = 256 / CQ;   // positions per block step
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {1.f, 1.f, 1.f, 1.f};
-    if (zm != nullptr)
+    if (MASK)
         for (int k = 0; k < 4; ++k) { sc[k] = ms[cq * 4 + k]; sh[k] = mh[cq * 4 + k]; }
-    for (long long p = (long long)blockIdx.x * ppb + lane_p; p < n; p += (long long)gridDim.x * ppb) {
-        const float4 av = *reinterpret_cast<const float4*>(a + p * C + cq * 4);
-        const float4 bv = *reinterpret_cast<const float4*>(b + p * C + cq * 4);
-        float am[4] = {av.x, av.y, av.z, av.w};
-        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-        if (zm != nullptr) {
-            const float4 zv = *reinterpret_cast<const float4*>(zm + p * C + cq * 4);
-            const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
-            for (int k = 0; k < 4; ++k) am[k] = (zz[k] * sc[k] + sh[k] > 0.f) ? am[k] : 0.f;
+    // four positions per thread and iteration, all their loads requested before the first is used (one 16-byte load in flight per
+    // thread streamed at 0.6 TB/s: two blocks per CU cannot hide a memory round trip per iteration — and with the two optional
+    // tensors as RUNTIME conditions hipcc put a branch and an s_waitcnt vmcnt(0) between any two loads: compile-time variants)
+    constexpr int U = 4;
+    for (long long p0 = (long long)blockIdx.x * ppb * U + lane_p; p0 < n; p0 += (long long)gridDim.x * ppb * U) {
+        float4 av[U], bv[U], zv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long p = p0 + (long long)u * ppb, pc = p < n ? p : n - 1;     // clamped: always loads, masked when used
+            av[u] = *reinterpret_cast<const float4*>(a + pc * C + cq * 4);
+            if (!SAME) bv[u] = *reinterpret_cast<const float4*>(b + pc * C + cq * 4);
+            if (MASK) zv[u] = *reinterpret_cast<const float4*>(zm + pc * C + cq * 4);
         }
-        for (int k = 0; k < 4; ++k) { s1[k] += (double)am[k]; s2[k] += (double)am[k] * (double)bb[k]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p0 + (long long)u * ppb >= n) continue;
+            float am[4] = {av[u].x, av[u].y, av[u].z, av[u].w};
+            const float4 bq = SAME ? av[u] : bv[u];
+            const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+            if (MASK) {
+                const float zz[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w};
+                for (int k = 0; k < 4; ++k) am[k] = (zz[k] * sc[k] + sh[k] > 0.f) ? am[k] : 0.f;
+            }
+            for (int k = 0; k < 4; ++k) { s1[k] += (double)am[k]; s2[k] += (double)am[k] * (double)bb[k]; }
+        }
     }
-    for (int k = 0; k < 4; ++k) { red[0][threadIdx.x][k] = s1[k]; red[1][threadIdx.x][k] = s2[k]; }
+    // block sums: butterfly over the lanes of a wave that share a channel quad (lane bits >= log2 CQ), then the four waves through
+    // LDS.  (Before: thread cq walked all 256 / CQ position lanes in LDS serially — 1024 dependent fp64 reads for C = 8, ~40 us
+    // at the end of EVERY block: the kernel streamed its 31 MB layers at 0.5 TB/s.)
+    for (int m = 32; m >= CQ; m >>= 1)
+        for (int k = 0; k < 4; ++k) { s1[k] += __shfl_xor(s1[k], m); s2[k] += __shfl_xor(s2[k], m); }
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    if (ln < CQ)
+        for (int k = 0; k < 4; ++k) { red[0][wv * 64 + ln][k] = s1[k]; red[1][wv * 64 + ln][k] = s2[k]; }
     __syncthreads();
-    if (threadIdx.x < CQ) {                                // thread cq sums the ppb position lanes of its channel group
+    if (threadIdx.x < CQ) {
+        // (CQ <= 64 divides 64: lane ln of a wave holds quad ln % CQ = ln for ln < CQ)
         for (int k = 0; k < 4; ++k) {
             double t1 = 0, t2 = 0;
-            for (int q = 0; q < ppb; ++q) { t1 += red[0][q * CQ + cq][k]; t2 += red[1][q * CQ + cq][k]; }
-            atomicAdd(sums + cq * 4 + k, t1);
-            atomicAdd(sums + C + cq * 4 + k, t2);
+            for (int q = 0; q < 4; ++q) { t1 += red[0][q * 64 + cq][k]; t2 += red[1][q * 64 + cq][k]; }
+            if (partials != nullptr) {                     // one row of 2C sums per block, summed by k_channel_sums_finish
+                partials[(long long)blockIdx.x * 2 * C + cq * 4 + k] = t1;
+                partials[(long long)blockIdx.x * 2 * C + C + cq * 4 + k] = t2;
+            } else {
+                atomicAdd(sums + cq * 4 + k, t1);
+                atomicAdd(sums + C + cq * 4 + k, t2);
+            }
         }
+    }
+}
+
+// sums[c] = sum over the nb block rows of partials[blk][c], c < 2C <= 128: thread t adds the rows t / 2C, t / 2C + 1024 / 2C, ...
+// (fixed order: deterministic), the row groups are combined through LDS.
+__global__ __launch_bounds__(1024) void k_channel_sums_finish(const double* __restrict__ partials, int nb, int C2,
+                                                              double* __restrict__ sums) {
+    __shared__ double red[1024];
+    const int c = threadIdx.x % C2, r0 = threadIdx.x / C2, nr = 1024 / C2;
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0;                  // four rows in flight per thread (the sum order stays fixed)
+    int blk = r0;
+    for (; blk + 3 * nr < nb; blk += 4 * nr) {
+        const double v0 = partials[(long long)blk * C2 + c], v1 = partials[(long long)(blk + nr) * C2 + c];
+        const double v2 = partials[(long long)(blk + 2 * nr) * C2 + c], v3 = partials[(long long)(blk + 3 * nr) * C2 + c];
+        t0 += v0; t1 += v1; t2 += v2; t3 += v3;
+    }
+    for (; blk < nb; blk += nr) t0 += partials[(long long)blk * C2 + c];
+    red[threadIdx.x] = (t0 + t1) + (t2 + t3);
+    __syncthreads();
+    if (threadIdx.x < C2) {
+        double tot = 0;
+        for (int q = 0; q < nr; ++q) tot += red[q * C2 + c];
+        sums[c] = tot;
     }
 }
 
@@ -235,20 +286,44 @@ int enerf_up2_adjoint(const float* grad_fine, const float* add, int N, int Hc, i
     ENERF_LAUNCH_SIMPLE(k_up2_adjoint, (unsigned)cdivl(total, 256), 256, 0, (hipStream_t)stream, grad_fine, add, N, Hc, Wc, C / 4, grad_coarse);
     return check_launch("up2_adjoint");
 }
-int enerf_channel_sums(const float* a, const float* b, const float* z_mask, const float* mask_scale, const float* mask_shift,
-                       long long n, int C, double* sums, enerf_stream_t stream) {
+static long long channel_sums_blocks(long long n, int C) {
+    const int ppb = 256 / (C / 4);
+    long long blocks = cdivl(n, (long long)ppb * 16);
+    const long long cap = (long long)device_cu_count() * 2;        // two blocks per CU stream at full rate
+    if (blocks > cap) blocks = cap;
+    return blocks < 1 ? 1 : blocks;
+}
+size_t enerf_channel_sums_workspace_bytes(long long n, int C) {
+    if (n <= 0 || C < 4 || C > 64 || C % 4 != 0 || (256 % (C / 4)) != 0) return 0;
+    return (size_t)channel_sums_blocks(n, C) * 2 * C * sizeof(double);
+}
+// Without a workspace every block ends with 2C fp64 atomics onto the same 2C addresses of the zeroed `sums`: ~1.3 ns each,
+// SERIALISED across blocks — 21 us for 256 blocks at C = 32, more than streaming a 31 MB layer (tools/bench_channel_sums.py,
+// profiles/r04_channel_sums.txt).  With one (enerf_channel_sums_workspace_bytes) the blocks store a row of partial sums each and
+// a second small launch adds the rows: no atomics, no zeroing launch, deterministic.
+int enerf_channel_sums_ws(const float* a, const float* b, const float* z_mask, const float* mask_scale, const float* mask_shift,
+                          long long n, int C, double* sums, void* workspace, size_t workspace_bytes, enerf_stream_t stream) {
     REQUIRE(a && b && sums && n > 0 && C >= 4 && C <= 64 && C % 4 == 0 && (256 % (C / 4)) == 0, "channel_sums: bad arguments (C in 4..64, power-of-two quads)");
     if (z_mask) REQUIRE(mask_scale && mask_shift, "channel_sums: mask needs its scale/shift");
-    zero_async(sums, (size_t)2 * C * sizeof(double), (hipStream_t)stream);
-    const int ppb = 256 / (C / 4);
-    // every block ends with 2C fp64 atomics onto the same 2C addresses (~13 G atomics/s on one hot line: 2048 blocks x 64
-    // cost ~10 us, more than the streaming pass of most layers): two blocks per CU are enough to stream at full rate
-    long long blocks = cdivl(n, (long long)ppb * 16);
-    const long long cap = (long long)device_cu_count() * 2;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    ENERF_LAUNCH(k_channel_sums, (unsigned)blocks, 256, 0, (hipStream_t)stream, a, b, z_mask, mask_scale, mask_shift, n, C, sums);
+    const long long blocks = channel_sums_blocks(n, C);
+    double* partials = nullptr;
+    if (workspace != nullptr) {
+        REQUIRE(workspace_bytes >= (size_t)blocks * 2 * C * sizeof(double), "channel_sums: workspace of %zu bytes, need %zu", workspace_bytes,
+                (size_t)blocks * 2 * C * sizeof(double));
+        partials = (double*)workspace;
+    } else {
+        zero_async(sums, (size_t)2 * C * sizeof(double), (hipStream_t)stream);
+    }
+#define ENERF_CS(SAME, MASK) ENERF_LAUNCH((k_channel_sums<SAME, MASK>), (unsigned)blocks, 256, 0, (hipStream_t)stream, a, b, z_mask, mask_scale, mask_shift, n, C, sums, partials)
+    if (a == b) { if (z_mask) ENERF_CS(true, true); else ENERF_CS(true, false); }
+    else { if (z_mask) ENERF_CS(false, true); else ENERF_CS(false, false); }
+#undef ENERF_CS
+    if (partials != nullptr) ENERF_LAUNCH(k_channel_sums_finish, 1, 1024, 0, (hipStream_t)stream, partials, (int)blocks, 2 * C, sums);
     return check_launch("channel_sums");
+}
+int enerf_channel_sums(const float* a, const float* b, const float* z_mask, const float* mask_scale, const float* mask_shift,
+                       long long n, int C, double* sums, enerf_stream_t stream) {
+    return enerf_channel_sums_ws(a, b, z_mask, mask_scale, mask_shift, n, C, sums, nullptr, 0, stream);
 }
 int enerf_bn_train_coeffs(const double* sums, const double* count_dev, double count_host, const float* gamma, const float* beta,
                           double eps, double momentum, float* running_mean, float* running_var, long long* num_batches_tracked,

@@ -175,6 +175,8 @@ _SIGNATURES = {
     "enerf_conv2d_layer_pack": (_i, [_f, _f, _i, _i, _i, _f, _f]),
     "enerf_conv2d_layer": (_i, [_f, _i, _i, _i, _i, _f, _f, _f, _i, _i, _i, _f]),
     "enerf_channel_sums": (_i, [_f, _f, _f, _f, _f, _ll, _i, C.c_void_p, _f]),
+    "enerf_channel_sums_workspace_bytes": (C.c_size_t, [_ll, _i]),
+    "enerf_channel_sums_ws": (_i, [_f, _f, _f, _f, _f, _ll, _i, C.c_void_p, C.c_void_p, C.c_size_t, _f]),
     "enerf_bn_train_coeffs": (_i, [C.c_void_p, C.c_void_p, C.c_double, _f, _f, C.c_double, C.c_double, _f, _f, C.c_void_p, _i, _i,
                                    C.c_void_p, _f, _f]),
     "enerf_bn_train_bwd_coeffs": (_i, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, _f, _i, _f, _f, _f]),
@@ -507,8 +509,11 @@ class EnerfLib:
         """(sum_p a*m, sum_p a*m*b) per channel in fp64; tensors channels-last (..., C)."""
         Cc = a.shape[-1]
         sums = torch.empty((2, Cc), dtype=torch.float64, device=a.device)
-        self._check(self.dll.enerf_channel_sums(_ptr(a), _ptr(b), _ptr(z_mask), _ptr(mask_scale), _ptr(mask_shift),
-                                                a.numel() // Cc, Cc, sums.data_ptr(), self.stream_of(a)), "channel_sums")
+        n = a.numel() // Cc
+        nb = self.dll.enerf_channel_sums_workspace_bytes(n, Cc)
+        ws = self._scratch(nb, a.device)
+        self._check(self.dll.enerf_channel_sums_ws(_ptr(a), _ptr(b), _ptr(z_mask), _ptr(mask_scale), _ptr(mask_shift),
+                                                   n, Cc, sums.data_ptr(), ws.data_ptr(), nb, self.stream_of(a)), "channel_sums")
         return sums[0], sums[1]
 
     def up2_adjoint(self, g_fine, add=None):
@@ -523,8 +528,11 @@ class EnerfLib:
         """channel_sums as ONE (2, C) fp64 tensor [sum a*m ; sum a*m*b] (what the all-reduce and the coefficient kernels take)."""
         Cc = a.shape[-1]
         sums = torch.empty((2, Cc), dtype=torch.float64, device=a.device)
-        self._check(self.dll.enerf_channel_sums(_ptr(a), _ptr(b), _ptr(z_mask), _ptr(mask_scale), _ptr(mask_shift),
-                                                a.numel() // Cc, Cc, sums.data_ptr(), self.stream_of(a)), "channel_sums")
+        n = a.numel() // Cc
+        nb = self.dll.enerf_channel_sums_workspace_bytes(n, Cc)
+        ws = self._scratch(nb, a.device)
+        self._check(self.dll.enerf_channel_sums_ws(_ptr(a), _ptr(b), _ptr(z_mask), _ptr(mask_scale), _ptr(mask_shift),
+                                                   n, Cc, sums.data_ptr(), ws.data_ptr(), nb, self.stream_of(a)), "channel_sums")
         return sums
 
     def bn_train_coeffs(self, sums, count, bn):

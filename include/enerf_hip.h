@@ -362,6 +362,12 @@ int enerf_conv3d_layer(const float* packed, int cin, int cout, int kind, const f
                        int Di, int Hi, int Wi, const enerf_options_t* options, enerf_stream_t stream);
 int enerf_channel_sums(const float* a, const float* b, const float* z_mask, const float* mask_scale, const float* mask_shift,
                        long long n, int C, double* sums, enerf_stream_t stream);
+/*   the same with caller-provided scratch (ABI v7): the blocks store partial rows and a second launch adds them — no atomics (the
+ *   2C fp64 atomics per block of the form above serialise on their 2C addresses: 21 us for 256 blocks at C = 32), no zeroing
+ *   launch, deterministic.  workspace == NULL is the form above. */
+size_t enerf_channel_sums_workspace_bytes(long long n, int C);
+int enerf_channel_sums_ws(const float* a, const float* b, const float* z_mask, const float* mask_scale, const float* mask_shift,
+                          long long n, int C, double* sums, void* workspace, size_t workspace_bytes, enerf_stream_t stream);
 /*   enerf_bn_train_coeffs / enerf_bn_train_bwd_coeffs  (ABI v6) the C-sized arithmetic of a training-mode BatchNorm between the
  *       statistics kernel (and, under SyncBatchNorm, its all-reduce) and the affine kernel, one launch each, fp64:
  *       forward  sums = [sum z, sum z^2] (2C), position count (device scalar count_dev, or count_host when NULL) ->

@@ -248,6 +248,13 @@ inline int __shfl(int v, int src, int width = 64) {
     memcpy(&v, &f, 4);
     return v;
 }
+inline double __shfl_xor(double v, int mask, int width = 64) {      // two 32-bit exchanges, as the hardware does it
+    int w[2]; memcpy(w, &v, 8);
+    float f0, f1; memcpy(&f0, &w[0], 4); memcpy(&f1, &w[1], 4);
+    f0 = __shfl_xor(f0, mask, width); f1 = __shfl_xor(f1, mask, width);
+    memcpy(&w[0], &f0, 4); memcpy(&w[1], &f1, 4); memcpy(&v, w, 8);
+    return v;
+}
 inline int __shfl_xor(int v, int mask, int width = 64) {
     float f; memcpy(&f, &v, 4);
     f = __shfl_xor(f, mask, width);

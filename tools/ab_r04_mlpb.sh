@@ -30,7 +30,7 @@ for v in "$@"; do
 import csv, glob
 f=glob.glob("/tmp/pt_$v/**/*kernel_stats.csv", recursive=True)
 for r in csv.DictReader(open(f[0])):
-    if "mlp_bwd" in r["Name"] or "gemm_wgrad" in r["Name"] or "gather_bwd" in r["Name"] or "feature_volume_bwd" in r["Name"]:
+    if any(k in r["Name"] for k in ("mlp_bwd", "gather", "feature_volume_bwd", "channel_sums", "channel_affine", "k_zero", "conv_wgrad", "wgrad_reduce")):
         print("$v", r["Name"][:60], "calls", r["Calls"], "avg us", round(float(r["AverageNs"])/1e3,1), "min", round(float(r["MinNs"])/1e3,1), "max", round(float(r["MaxNs"])/1e3,1))
 PY
 done
