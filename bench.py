@@ -95,7 +95,7 @@ def cost_reg_gflop(C, full, D, h, w):
     return f / 1e9
 
 
-def live_pmc(workload, kernel_prefix="k_render_rays<3"):
+def live_pmc(workload, kernel_prefix="k_render_rays<3", child_flags=None):
     """HBM traffic + matrix-pipe busy fraction of the dominant kernel, measured NOW: three short rocprofv3 --pmc passes
     (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE; separate passes, --kernel-trace only — the
     MI355X_MICROARCH.md recipe, as tools/collect_profiles.sh) over a child run of this script (3 frames, kernels alone on one
@@ -110,6 +110,8 @@ def live_pmc(workload, kernel_prefix="k_render_rays<3"):
         return None
     child = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
              "--no-stages", "--no-sync-per-frame", "--single-stream", "--no-live-pmc"]
+    if child_flags is not None:                           # (the training line: eager steps of the same loss, kernels alone)
+        child = [sys.executable, os.path.abspath(__file__), *child_flags, "--no-cpu-baseline", "--no-live-pmc"]
     env = dict(os.environ, TMPDIR="/tmp")
     env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     means = {}
@@ -267,6 +269,17 @@ def train_extras(args, net, batch, loss_fn, cfg, dev, ms_per_step):
             "share_of_step": round(t_ms / ms_per_step, 4),
             "note": "issued fp32 16x16x4 MFMA work (static v_mfma count of the kernel = tiles per 16 points); one wave per SIMD at "
                     "256 VGPRs + AGPR traffic is why the fraction is low (DESIGN.md)"}
+        if not args.no_live_pmc and not args.emu:
+            # HBM bytes of one launch, measured now: rocprofv3 --pmc passes over two EAGER steps of a child run (the same kernels
+            # as the captured step; counters serialise the kernels either way)
+            flags = ["--train", "--train-eager", "--steps", "2", "--warmup", "1"] + (["--no-perceptual"] if args.no_perceptual else [])
+            live = live_pmc(args.workload, kernel_prefix=f"k_mlp_bwd<{R}, {S}>", child_flags=flags)
+            if live is not None:
+                out["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = ("live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over a child run of "
+                                                     "bench.py --train --train-eager; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB")
+                if "mfma_busy_frac" in live:
+                    out["roofline"]["mfma_busy_frac"] = live["mfma_busy_frac"]
     if not args.no_cpu_baseline:
         import numpy as np   # noqa: F401
         from oracle import enerf_oracle as O
