@@ -162,6 +162,43 @@ __device__ __forceinline__ float row_sum16(float v) {
     return v;
 #endif
 }
+// Broadcast inside aligned groups of CQ (2, 4, 8) consecutive lanes: every lane gets the value of lane K of ITS group.  DPP
+// register permutes (quad_perm; for 8-lane groups one row shift by 4 on top) — `__shfl` lowers to ds_bpermute_b32, a round trip
+// through the LDS pipe (~100+ cycles of latency each), and the warp kernel does eight of them per source view.
+template <int CQ, int K>
+__device__ __forceinline__ int group_bcast_i(int v) {
+#ifdef ENERF_EMU
+    return __shfl(v, (int)((threadIdx.x & 63) & ~(CQ - 1)) + K);
+#else
+    static_assert(CQ == 2 || CQ == 4 || CQ == 8, "group width");
+    if (CQ == 2) return __builtin_amdgcn_update_dpp(0, v, K | (K << 2) | ((2 + K) << 4) | ((2 + K) << 6), 0xf, 0xf, true);
+    constexpr int q = K & 3, bc = q | (q << 2) | (q << 4) | (q << 6);                  // quad_perm: [q, q, q, q]
+    const int y = __builtin_amdgcn_update_dpp(0, v, bc, 0xf, 0xf, true);
+    if (CQ == 4) return y;
+    // CQ == 8: the source quad's value has to reach the other quad of the group: a row shift by 4 lanes (0x114 = row_shr:4, lane
+    // i <- i - 4; 0x104 = row_shl:4, lane i <- i + 4); the quads that shift in a neighbour GROUP's value keep their own y
+    const bool upper = (threadIdx.x & 4) != 0;
+    if (K < 4) { const int t = __builtin_amdgcn_update_dpp(0, y, 0x114, 0xf, 0xf, true); return upper ? t : y; }
+    const int u = __builtin_amdgcn_update_dpp(0, y, 0x104, 0xf, 0xf, true);
+    return upper ? y : u;
+#endif
+}
+template <int CQ>
+__device__ __forceinline__ int group_bcast_i(int v, int k) {      // k: loop-unrolled (folds to one case)
+    switch (k) {
+        case 0: return group_bcast_i<CQ, 0>(v);
+        case 1: return group_bcast_i<CQ, 1 % CQ>(v);
+        case 2: return group_bcast_i<CQ, 2 % CQ>(v);
+        case 3: return group_bcast_i<CQ, 3 % CQ>(v);
+        case 4: return group_bcast_i<CQ, 4 % CQ>(v);
+        case 5: return group_bcast_i<CQ, 5 % CQ>(v);
+        case 6: return group_bcast_i<CQ, 6 % CQ>(v);
+        default: return group_bcast_i<CQ, 7 % CQ>(v);
+    }
+}
+template <int CQ>
+__device__ __forceinline__ float group_bcast_f(float v, int k) { return __int_as_float(group_bcast_i<CQ>(__float_as_int(v), k)); }
+
 // v + the value of lane ^ 8 (one DPP row rotation by 8: inside a row of 16 lanes, +8 mod 16 is ^ 8)
 __device__ __forceinline__ float add_xor8(float v) {
 #ifdef ENERF_EMU

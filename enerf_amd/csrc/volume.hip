@@ -29,6 +29,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // rounding needs) and the group then walks the views, each lane fetching the taps of the view in turn from
 // its owner with one lane broadcast per value.  Before, every lane projected every view — 4x (level 1) and
 // 8x (level 0) redundant VALU in a kernel that is VALU- not HBM-bound (48+37 us against a 16 us HBM floor).
+// The group's broadcasts: DPP register permutes (default) or, for A/B, the ds_bpermute round trips of rounds 1-3
+#ifndef ENERF_VOL_DPP
+#define ENERF_VOL_DPP 1
+#endif
+#if ENERF_VOL_DPP
+#define ENERF_VOL_BCAST_I(v, k) group_bcast_i<CQ>((v), (k))
+#define ENERF_VOL_BCAST_F(v, k) group_bcast_f<CQ>((v), (k))
+#else
+#define ENERF_VOL_BCAST_I(v, k) __shfl((v), lead + (k))
+#define ENERF_VOL_BCAST_F(v, k) __shfl((v), lead + (k))
+#endif
 template <int CQ>  // CQ = C/4 lanes per voxel
 __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict__ feat, const float* __restrict__ proj,
                                                         const float* __restrict__ dv, int B, int S, int Hs, int Ws,
@@ -117,8 +128,8 @@ __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict_
             f32x2 ra = {0.f, 0.f}, rb = {0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const unsigned o = (unsigned)__shfl(my_o[c], lead + k) + (unsigned)(cq * (ENERF_VOL_BYTEOFF ? 16 : 4));
-                const float wgt = __shfl(my_w[c], lead + k);
+                const unsigned o = (unsigned)ENERF_VOL_BCAST_I(my_o[c], k) + (unsigned)(cq * (ENERF_VOL_BYTEOFF ? 16 : 4));
+                const float wgt = ENERF_VOL_BCAST_F(my_w[c], k);
 #if ENERF_VOL_BYTEOFF
                 const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(feat) + o);
 #else
@@ -136,14 +147,14 @@ __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict_
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
 #if ENERF_VOL_BYTEOFF
-                const unsigned o = (unsigned)__shfl(my_o[c], lead + k) + (unsigned)(cq * 16);
+                const unsigned o = (unsigned)ENERF_VOL_BCAST_I(my_o[c], k) + (unsigned)(cq * 16);
 #else
-                const unsigned o = (unsigned)__shfl(my_o[c], lead + k) + (unsigned)(cq * 4);
+                const unsigned o = (unsigned)ENERF_VOL_BCAST_I(my_o[c], k) + (unsigned)(cq * 4);
 #endif
-                const float wgt = __shfl(my_w[c], lead + k);
+                const float wgt = ENERF_VOL_BCAST_F(my_w[c], k);
                 // ENERF_ABL_VOL: compile-time ablations behind profiles/r03_volume_ablation.txt (never defined in the product build)
 #if defined(ENERF_ABL_VOL) && (ENERF_ABL_VOL & 1)      /* one tap's load stands in for all four (gather traffic / 4) */
-                const float4 v = *reinterpret_cast<const float4*>(feat + ((unsigned)__shfl(my_o[0], lead + k) + (unsigned)(cq * 4)));
+                const float4 v = *reinterpret_cast<const float4*>(feat + ((unsigned)ENERF_VOL_BCAST_I(my_o[0], k) + (unsigned)(cq * 4)));
 #elif defined(ENERF_ABL_VOL) && (ENERF_ABL_VOL & 2)    /* no gathers at all (a lane-dependent constant) */
                 const float4 v = make_float4(wgt, 1.f, 2.f, (float)o);
 #elif ENERF_VOL_BYTEOFF
