@@ -193,13 +193,128 @@ __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict_
 #endif
 }
 
+// Two depth planes per wave (the default when D is even): the same pixel at two consecutive hypotheses — one set of projection
+// matrices, two independent chains `depth -> projection -> 4 gathers per view -> moments`, and the gathers of BOTH planes of a
+// view are requested before either is consumed (eight 16-byte loads in flight per lane instead of four).  A wave of the
+// one-plane form above lives for two dependent memory round trips and there are ~40 of them per SIMD: neither its VALU count
+// (round 4: -30 % VALU, < 3 % time) nor its lane broadcasts (DPP instead of ds_bpermute: nothing) is what it waits for.
+// Same arithmetic per voxel, bit-identical output.
+template <int CQ>
+__global__ __launch_bounds__(256) void k_feature_volume_mp(const float* __restrict__ feat, const float* __restrict__ proj,
+                                                           const float* __restrict__ dv, int B, int S, int Hs, int Ws,
+                                                           int D, int h, int w, float inv_w, float inv_d, int planar,
+                                                           float* __restrict__ vol) {
+    constexpr int C = CQ * 4, NPL = 2;
+    const int xcd = blockIdx.x;                                    // gridDim.x == 8: one row band per XCD (see above)
+    const int rb = (h + 7) >> 3;
+    const int yb = xcd * rb, ny = min(rb, h - yb);
+    if (ny <= 0) return;                                           // uniform
+    const unsigned band = (unsigned)(ny * w);
+    const unsigned p0 = blockIdx.y * (256 / CQ);
+    if (p0 >= band) return;                                        // uniform
+    const int cq = threadIdx.x & (CQ - 1);
+    const unsigned p_raw = p0 + (threadIdx.x / CQ);
+    const bool live = p_raw < band;
+    const unsigned p = live ? p_raw : band - 1;                    // dead lanes shadow the last voxel (they take part in the broadcasts)
+    const unsigned pl0 = blockIdx.z * NPL;                         // plane index b * D + d of the first plane (launcher: D even)
+    const int b = (int)(((float)pl0 + 0.5f) * inv_d);              // uniform; exact for B * D < 2^22
+    int yr = (int)((float)p * inv_w), x = (int)p - mul24(yr, w);
+    if (x < 0) { --yr; x += w; }
+    if (x >= w) { ++yr; x -= w; }
+    const int y = yb + yr;
+    unsigned vox[NPL];
+    float depth[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        vox[q] = (unsigned)mul24((int)((pl0 + q) * (unsigned)h) + y, w) + (unsigned)x;
+        depth[q] = dv[vox[q]];
+    }
+    const float fx = (float)x, fy = (float)y;
+    const float inv_half_w = 1.f / (float)((Ws - 1) / 2.0), inv_half_h = 1.f / (float)((Hs - 1) / 2.0);
+    const unsigned img = (unsigned)(Hs * Ws * C);
+    float4 s1[NPL], s2[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) { s1[q] = make_float4(0.f, 0.f, 0.f, 0.f); s2[q] = s1[q]; }
+    for (int s0 = 0; s0 < S; s0 += CQ) {
+        // ---- this lane's view, both planes ----
+        const int sv = min(s0 + cq, S - 1);
+        const float* P = proj + (b * S + sv) * 12;
+        const float P0 = P[0], P1 = P[1], P2 = P[2], P3 = P[3], P4 = P[4], P5 = P[5], P6 = P[6], P7 = P[7], P8 = P[8], P9 = P[9], P10 = P[10], P11 = P[11];
+        const unsigned vb = (unsigned)(b * S + sv) * img;
+        int my_o[NPL][4];
+        float my_w[NPL][4];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const float px = P0 * fx + P1 * fy + P2 + P3 / depth[q];        // utils.py:72 (IEEE divisions, as the reference)
+            const float py = P4 * fx + P5 * fy + P6 + P7 / depth[q];
+            const float pz = P8 * fx + P9 * fy + P10 + P11 / depth[q];
+            const float z = clamp_min(pz, 1e-6f);                           // utils.py:80
+            const float gx = (px / z) * inv_half_w - 1.f, gy = (py / z) * inv_half_h - 1.f;
+            const Taps2 t = gs_taps2<false>(gs_unnorm(gx, Ws), gs_unnorm(gy, Hs), Ws, Hs);
+            const int r0 = mul24(t.y0, Ws), r1 = mul24(t.y1, Ws);
+            my_o[q][0] = (int)(vb + (unsigned)mul24(r0 + t.x0, C)); my_o[q][1] = (int)(vb + (unsigned)mul24(r0 + t.x1, C));
+            my_o[q][2] = (int)(vb + (unsigned)mul24(r1 + t.x0, C)); my_o[q][3] = (int)(vb + (unsigned)mul24(r1 + t.x1, C));
+            my_w[q][0] = t.w00; my_w[q][1] = t.w01; my_w[q][2] = t.w10; my_w[q][3] = t.w11;
+        }
+        // ---- the group's views in turn: all eight gathers of a view first, then the blends ----
+#pragma unroll
+        for (int k = 0; k < CQ; ++k) {
+            if (s0 + k >= S) break;                                          // uniform
+            float4 v[NPL][4];
+            float wgt[NPL][4];
+#pragma unroll
+            for (int q = 0; q < NPL; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned o = (unsigned)group_bcast_i<CQ>(my_o[q][c], k) + (unsigned)(cq * 4);
+                    wgt[q][c] = group_bcast_f<CQ>(my_w[q][c], k);
+                    v[q][c] = *reinterpret_cast<const float4*>(feat + o);
+                }
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                float4 r;
+                r.x = v[q][0].x * wgt[q][0]; r.y = v[q][0].y * wgt[q][0]; r.z = v[q][0].z * wgt[q][0]; r.w = v[q][0].w * wgt[q][0];
+#pragma unroll
+                for (int c = 1; c < 4; ++c) { r.x += v[q][c].x * wgt[q][c]; r.y += v[q][c].y * wgt[q][c]; r.z += v[q][c].z * wgt[q][c]; r.w += v[q][c].w * wgt[q][c]; }
+                s1[q].x += r.x; s1[q].y += r.y; s1[q].z += r.z; s1[q].w += r.w;
+                s2[q].x += r.x * r.x; s2[q].y += r.y * r.y; s2[q].z += r.z * r.z; s2[q].w += r.w * r.w;
+            }
+        }
+    }
+    const float inv_s = 1.f / (float)S;                                      // utils.py:345 (see the one-plane kernel)
+    const unsigned nvp = (unsigned)(D * h * w);
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        float4 o;
+        float m;
+        m = s1[q].x * inv_s; o.x = s2[q].x * inv_s - m * m;
+        m = s1[q].y * inv_s; o.y = s2[q].y * inv_s - m * m;
+        m = s1[q].z * inv_s; o.z = s2[q].z * inv_s - m * m;
+        m = s1[q].w * inv_s; o.w = s2[q].w * inv_s - m * m;
+        const long long oidx = planar ? ((long long)((unsigned)b * CQ + cq) * nvp + (vox[q] - (unsigned)b * nvp)) * 4 : (long long)vox[q] * C + cq * 4;
+        if (live) *reinterpret_cast<float4*>(vol + oidx) = o;
+    }
+}
+
 void launch_feature_volume(const float* feat_nhwc, const float* proj, const float* dv, int B, int S, int C, int Hs,
                            int Ws, int D, int h, int w, float* vol, hipStream_t st, int planar) {
     // grid = 8 row bands (one per XCD) x chunks of 256/CQ voxels of a band x (B * D) planes
     const int rb = (h + 7) / 8;
     const int vpb = 256 / (C / 4);
-    const dim3 grid(8, (unsigned)cdiv(rb * w, vpb), (unsigned)(B * D));
     const float inv_w = 1.f / (float)w, inv_d = 1.f / (float)D;
+#ifndef ENERF_VOL_NPL
+#define ENERF_VOL_NPL 2
+#endif
+    if (ENERF_VOL_NPL == 2 && D % 2 == 0) {                       // two planes per wave
+        const dim3 grid2(8, (unsigned)cdiv(rb * w, vpb), (unsigned)(B * D / 2));
+        switch (C) {
+            case 32: ENERF_LAUNCH(k_feature_volume_mp<8>, grid2, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, inv_w, inv_d, planar, vol); return;
+            case 16: ENERF_LAUNCH(k_feature_volume_mp<4>, grid2, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, inv_w, inv_d, planar, vol); return;
+            case 8: ENERF_LAUNCH(k_feature_volume_mp<2>, grid2, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, inv_w, inv_d, planar, vol); return;
+            default: return;   // validated by the C-ABI layer
+        }
+    }
+    const dim3 grid(8, (unsigned)cdiv(rb * w, vpb), (unsigned)(B * D));
     switch (C) {
         case 32: ENERF_LAUNCH(k_feature_volume<8>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, inv_w, inv_d, planar, vol); break;
         case 16: ENERF_LAUNCH(k_feature_volume<4>, grid, 256, 0, st, feat_nhwc, proj, dv, B, S, Hs, Ws, D, h, w, inv_w, inv_d, planar, vol); break;
