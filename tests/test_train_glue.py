@@ -189,7 +189,65 @@ def _check_gather_bwd_tiled(lib, dev):
             assert _rel(o, r) < 2e-5, (Hr, Wr, Ns, Fc, wild, permute, name, _rel(o, r))
 
 
-CHECKS = [_check_gather_bwd_tiled, _check_s2k5_dgrad, _check_resize_adjoint, _check_depth_values_bwd, _check_ray_samples, _check_camera_tables_and_layout]
+def _check_round4_kernel_pairs(lib, dev):
+    """Round-4 kernel pairs that must agree with the form they replace.
+    * the warp kernel with two depth planes per wave (even D) and the one-plane kernel (odd D): the same planes, bit for bit;
+    * enerf_channel_sums with scratch (partial rows + finish launch) and without (fp64 atomics): the same sums up to the fp64
+      summation order, for every channel width, ragged position counts, all three input forms;
+    * the wave-per-64-points gather forward on point counts that are not a multiple of 64 and straddle batch elements."""
+    from enerf_amd.autograd import gather_cameras_torch
+    from enerf_amd.synth import make_batch
+    g = torch.Generator().manual_seed(21)
+    # ---- warp: D = 6 (two planes per wave) vs its first five planes as a D = 5 volume (one plane per wave) ----
+    cfg = EnerfConfig()
+    b = {k: torch.from_numpy(v) for k, v in make_batch(32, 64, 3, cfg, seed=2, B=2).items()}
+    for Cc, (h, w) in ((32, (9, 14)), (16, (13, 22)), (8, (8, 16))):
+        feat = torch.randn(2, 3, 16, 32, Cc, generator=g)
+        P = lib.get_proj_mats(b["src_ixts"].to(dev), b["src_exts"].to(dev), b["tar_ixt"].to(dev), b["tar_ext"].to(dev), 16 / 32, h / 32).cpu()
+        dv6 = 425.0 + 480.0 * torch.rand(2, 6, h, w, generator=g)
+        v6 = lib.build_feature_volume(feat.to(dev), P.to(dev), dv6.to(dev), Cc).cpu()
+        v5 = lib.build_feature_volume(feat.to(dev), P.to(dev), dv6[:, :5].contiguous().to(dev), Cc).cpu()
+        assert torch.equal(v6[:, :5], v5), Cc
+    # ---- BatchNorm statistics: scratch form vs atomic form ----
+    for n, Cc in ((1000, 8), (4099, 16), (777, 32), (1, 64), (30000, 4)):
+        a_, b_, z_ = (torch.randn(n, Cc, generator=g).to(dev) for _ in range(3))
+        ms, mh = torch.rand(Cc, generator=g).to(dev) + 0.5, torch.randn(Cc, generator=g).to(dev) * 0.1
+        for args in ((a_, a_, None, None, None), (a_, b_, None, None, None), (a_, b_, z_, ms, mh)):
+            new = lib.channel_sums_raw(*args).cpu()
+            old = torch.empty((2, Cc), dtype=torch.float64, device=dev)
+            p_ = lambda t: None if t is None else t.data_ptr()
+            lib._check(lib.dll.enerf_channel_sums(p_(args[0]), p_(args[1]), p_(args[2]), p_(args[3]), p_(args[4]), n, Cc, old.data_ptr(),
+                                                  lib.stream_of(a_)), "channel_sums")
+            old = old.cpu()
+            m = (z_.cpu().double() * ms.cpu().double() + mh.cpu().double() > 0) if args[2] is not None else torch.ones(n, Cc, dtype=torch.bool)
+            # (the kernels evaluate the mask in fp32: build the reference from the same comparison)
+            if args[2] is not None:
+                m = (z_.cpu() * ms.cpu() + mh.cpu()) > 0
+            ref = torch.stack([(args[0].cpu().double() * m).sum(0), (args[0].cpu().double() * m * args[1].cpu().double()).sum(0)])
+            scale = float(ref.abs().max()) + 1e-30
+            assert float((new - ref).abs().max()) <= 1e-12 * scale * n and float((old - ref).abs().max()) <= 1e-12 * scale * n, (n, Cc)
+    # ---- gather forward: B * P = 2 * 77 points (three waves, the middle one straddles the batch elements, the last is ragged) ----
+    Hr, Wr, Fc = 12, 20, 11
+    cfg1 = EnerfConfig().with_cas(render_scale=(1.0, 1.0))
+    bb = {k: torch.from_numpy(v) for k, v in make_batch(Hr, Wr, 3, cfg1, seed=5, B=2).items()}
+    rays = bb["rays_1"][:, :77]
+    t = 500.0 + 300.0 * torch.rand(2, 77, 1, generator=g)
+    xyz = (rays[..., :3] + rays[..., 3:6] * t).contiguous()
+    dn, uv = torch.rand(2, 77, generator=g), rays[..., 6:8].contiguous()
+    tex, vol = torch.randn(2, 3, Hr, Wr, Fc, generator=g), torch.randn(2, 4, 6, 10, 8, generator=g)
+    cam, tcen = gather_cameras_torch(bb, 1.0)
+    T = lambda *ts: [t_.to(dev).contiguous() for t_ in ts]
+    x, vox = lib.gather_fwd(*T(xyz, dn, uv, tex, vol, cam, tcen))
+    # per batch element on its own (one wave each, no straddling): the same rows
+    for e in range(2):
+        xe, ve = lib.gather_fwd(*T(xyz[e:e + 1], dn[e:e + 1], uv[e:e + 1], tex[e:e + 1], vol[e:e + 1], cam[e:e + 1], tcen[e:e + 1]))
+        assert torch.equal(x[e].cpu(), xe[0].cpu()) and torch.equal(vox[e].cpu(), ve[0].cpu()), e
+    nd = torch.stack([uv[..., 0] / (Wr - 1), uv[..., 1] / (Hr - 1), dn], -1).reshape(2, 1, 1, 77, 3) * 2.0 - 1.0
+    v_ref = F.grid_sample(vol.permute(0, 4, 1, 2, 3), nd, align_corners=True)[:, :, 0, 0].permute(0, 2, 1)
+    assert _rel(vox, v_ref) < 1e-5
+
+
+CHECKS = [_check_round4_kernel_pairs, _check_gather_bwd_tiled, _check_s2k5_dgrad, _check_resize_adjoint, _check_depth_values_bwd, _check_ray_samples, _check_camera_tables_and_layout]
 
 
 @pytest.mark.parametrize("check", CHECKS, ids=lambda f: f.__name__[7:])
