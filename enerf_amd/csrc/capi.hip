@@ -323,7 +323,9 @@ extern "C" {
 long long enerf_feature_net_packed_floats(void) {
     long long t = 0;
     for (int i = 0; i < 11; ++i) t += flayer_floats(kFeat[i]);
-    return t + 320 + 3072;   // tail: raw lat0 weight (32x8) + bias (32) for the fused smooth0 kernel, then smooth0's P/Q image
+    // tail: raw lat0 weight (32x8) + bias (32) for the fused smooth0 kernel, smooth0's P/Q image (3072), smooth0's broadcast-A image
+    // (round 5: 2 passes x 18 registers x 64 lanes), conv0.0's (4 x 64) and conv0.1's (9 x 64)
+    return t + 320 + 3072 + 2304 + 256 + 576;
 }
 int enerf_feature_net_pack(const enerf_featnet_raw_t* raw, float* packed, enerf_stream_t stream) {
     REQUIRE(raw && packed, "feature_net_pack: null pointer");
@@ -349,6 +351,10 @@ int enerf_feature_net_pack(const enerf_featnet_raw_t* raw, float* packed, enerf_
     hipMemcpyAsync(p, raw->lat0_w, 256 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
     hipMemcpyAsync(p + 256, raw->lat0_b, 32 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
     launch_conv2d_pq_pack(raw->smooth0_w, 32, p + 320, (hipStream_t)stream);             // tap-packed smooth0 (conv2d.hip PK)
+    launch_conv2d_cb_pack(raw->smooth0_w, 32, 0, 16, p + 320 + 3072, (hipStream_t)stream);          // broadcast-A images (conv2d.hip
+    launch_conv2d_cb_pack(raw->smooth0_w, 32, 16, 16, p + 320 + 3072 + 1152, (hipStream_t)stream);  //  k_smooth0_cb, k_conv0_fused_cb)
+    launch_conv2d_cb_pack(raw->conv[0].w, 3, 0, 3, p + 320 + 3072 + 2304, (hipStream_t)stream);
+    launch_conv2d_cb_pack(raw->conv[1].w, 8, 0, 8, p + 320 + 3072 + 2304 + 256, (hipStream_t)stream);
     return check_launch("feature_net_pack");
 }
 size_t enerf_feature_net_workspace_bytes(int n_img, int H, int W) {
@@ -395,7 +401,7 @@ int enerf_feature_net_stage(const float* packed, const float* src_inps, int n_im
     int rc = 0;
     if (trunk) {
         if (!opt.featnet_unfused) {
-            launch_conv0_fused(d[0], d[1], src_inps, c0, n_img, H, W, st);             // conv0.1(conv0.0(image))
+            launch_conv0_fused(d[0], d[1], p + 320 + 3072 + 2304, p + 320 + 3072 + 2304 + 256, src_inps, c0, n_img, H, W, st);   // conv0.1(conv0.0(image))
         } else {
             rc |= launch_conv2d(d[0], src_inps, c0a, nullptr, n_img, H, W, 0, 0, st);  // conv0.0 (NCHW image in)
             rc |= launch_conv2d(d[1], c0a, c0, nullptr, n_img, H, W, 0, 0, st);        // conv0.1
@@ -421,8 +427,8 @@ int enerf_feature_net_stage(const float* packed, const float* src_inps, int n_im
         d[10].rgb_src = (l2_stride == 12) ? src_inps : nullptr;
         if (!opt.featnet_unfused) {
             // smooth0(up2(feat1) + lat0(conv0)) in one kernel: the 32-channel full-res sum never touches HBM
-            launch_smooth0_fused(d[10], c0, f1pre, p, p + 256, opt.featnet_smooth0_plain ? nullptr : p + 320, feat_l2, n_img,
-                                 H, W, st);
+            launch_smooth0_fused(d[10], c0, f1pre, p, p + 256, opt.featnet_smooth0_plain ? nullptr : p + 320, p + 320 + 3072, feat_l2,
+                                 n_img, H, W, st);
         } else {
             rc |= launch_conv2d(d[8], c0, f0pre, f1pre, n_img, H, W, H1, W1, st);      // up2(feat1) + lat0(conv0)
             rc |= launch_conv2d(d[10], f0pre, feat_l2, nullptr, n_img, H, W, 0, 0, st);  // smooth0 -> level_2 / texels

@@ -104,6 +104,34 @@ __device__ __forceinline__ float buf_load_f32(const BufRsrc& r, unsigned byte_of
 
 constexpr int kWave = 64;
 
+// v_mfma_f32_4x4x1_16b_f32 with the A-operand BROADCAST controls (cbsz:4 abid:K): the 4x1 A column of block K — lanes 4K..4K+3 of
+// the A register — multiplies the B value of EVERY lane (all 16 blocks).  With lane = pixel (conv3d_b4.hip) this turns one VGPR
+// into sixteen different weight columns (4 output channels x 1 input channel each), addressed by an immediate: a Cout = 8
+// convolution then needs no LDS broadcast read (2 of the 3 ds_read_b128 per 8 MFMAs in round 4's kernels) and no per-block
+// weight re-layout at all.  Semantics + issue rate: tools/micro/mfma_cbsz.hip.  K must fold to a constant (unrolled loops).
+template <int K>
+__device__ __forceinline__ f32x4 mfma4_bc_k(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, K, 0); }
+__device__ __forceinline__ f32x4 mfma4_bc(float a, float b, f32x4 c, int k) {
+    switch (k) {
+        case 0: return mfma4_bc_k<0>(a, b, c);
+        case 1: return mfma4_bc_k<1>(a, b, c);
+        case 2: return mfma4_bc_k<2>(a, b, c);
+        case 3: return mfma4_bc_k<3>(a, b, c);
+        case 4: return mfma4_bc_k<4>(a, b, c);
+        case 5: return mfma4_bc_k<5>(a, b, c);
+        case 6: return mfma4_bc_k<6>(a, b, c);
+        case 7: return mfma4_bc_k<7>(a, b, c);
+        case 8: return mfma4_bc_k<8>(a, b, c);
+        case 9: return mfma4_bc_k<9>(a, b, c);
+        case 10: return mfma4_bc_k<10>(a, b, c);
+        case 11: return mfma4_bc_k<11>(a, b, c);
+        case 12: return mfma4_bc_k<12>(a, b, c);
+        case 13: return mfma4_bc_k<13>(a, b, c);
+        case 14: return mfma4_bc_k<14>(a, b, c);
+        default: return mfma4_bc_k<15>(a, b, c);
+    }
+}
+
 // Pin a value in a VGPR at this program point: LLVM's Sink pass otherwise moves a pure arithmetic chain that is only consumed
 // under a late condition (an epilogue store) down into that branch, keeping every operand of the chain alive until then.
 #ifdef ENERF_EMU

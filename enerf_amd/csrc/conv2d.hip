@@ -599,12 +599,141 @@ __global__ __launch_bounds__(256) void k_conv0_fused_b4(const float* __restrict_
                     relu1(acc1[2] * scale1[6] + shift1[6]), relu1(acc1[3] * scale1[7] + shift1[7]));
 }
 
+// Round 5: the same two layers with their weights in REGISTERS (A-operand broadcast, common.h mfma4_bc): 54 + 144 weight columns =
+// 4 + 9 VGPRs, loaded with 13 coalesced loads from images packed once (k_conv2d_cb_pack).  The per-block re-layout of both
+// layers' weights into LDS (four gather loads + stores per thread, in front of the first barrier) and two of the three
+// ds_read_b128 per 6-8 MFMAs go away; a block is 17.8 KB of LDS.  Same arithmetic as k_conv0_fused_b4: bit-identical outputs.
+__global__ __launch_bounds__(256) void k_conv0_fused_cb(const float* __restrict__ wc0, const float* __restrict__ scale0,
+                                                        const float* __restrict__ shift0, const float* __restrict__ wc1,
+                                                        const float* __restrict__ scale1, const float* __restrict__ shift1,
+                                                        const float* __restrict__ img, float* __restrict__ out, int N, int H,
+                                                        int W, int tiles_y, int tiles_x) {
+    constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, NPX = IH * IW;      // conv0.1 input tile (10 x 34)
+    constexpr int PH = IH + 2, PW = IW + 2, NPP = PH * PW;                        // image patch (12 x 36)
+    ENERF_DYN_SMEM(float, lds);
+    float* pat = lds;                   // [NPP] float4 image texels (4th channel 0)
+    float* til = pat + NPP * 4;         // [2 quads][NPX] float4: conv0.0 output planes
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+    const int oy0 = ty * TH, ox0 = tx * TW;
+
+    float w0r[4], w1r[9];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w0r[r] = wc0[r * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) w1r[r] = wc1[r * 64 + lane];
+    {   // ---- image patch -> LDS: one thread per patch pixel, three coalesced plane reads, zero outside ----
+        constexpr int NIT = (NPP + 255) / 256;
+        float v0[NIT], v1[NIT], v2[NIT];
+        bool sk[NIT];
+        const float* base = img + (long long)n * 3 * H * W;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256, ic = i < NPP ? i : NPP - 1;
+            const int ly = ic / PW, lx = ic - ly * PW, gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
+            sk[it] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int off = sk[it] ? gy * W + gx : 0;
+            v0[it] = base[off]; v1[it] = base[H * W + off]; v2[it] = base[2 * H * W + off];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            if (i < NPP)
+                *reinterpret_cast<float4*>(pat + i * 4) =
+                    sk[it] ? make_float4(v0[it], v1[it], v2[it], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 1: conv0.0 + BN + ReLU for the haloed tile, lane = haloed pixel (flat order) -> LDS planes ----
+#pragma unroll 1
+    for (int base = wv * 64; base < NPX; base += 256) {                    // wave-uniform
+        const int p = base + lane, pc = p < NPX ? p : NPX - 1;
+        const int ly = pc / IW, lx = pc - ly * IW;
+        const float* pb = pat + (ly * PW + lx) * 4;
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4 tex = *reinterpret_cast<const float4*>(pb + ((t / 3) * PW + (t % 3)) * 4);
+            const int c = t * 6;                                            // column (t*3 + ch)*2 + half
+            acc0 = mfma4_bc(w0r[(c + 0) >> 4], tex.x, acc0, (c + 0) & 15);
+            acc1 = mfma4_bc(w0r[(c + 1) >> 4], tex.x, acc1, (c + 1) & 15);
+            acc0 = mfma4_bc(w0r[(c + 2) >> 4], tex.y, acc0, (c + 2) & 15);
+            acc1 = mfma4_bc(w0r[(c + 3) >> 4], tex.y, acc1, (c + 3) & 15);
+            acc0 = mfma4_bc(w0r[(c + 4) >> 4], tex.z, acc0, (c + 4) & 15);
+            acc1 = mfma4_bc(w0r[(c + 5) >> 4], tex.z, acc1, (c + 5) & 15);
+        }
+        const int gy = oy0 - 1 + ly, gx = ox0 - 1 + lx;
+        const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        if (p < NPX) {
+            float4 o0, o1;
+            o0.x = inside ? relu1(acc0[0] * scale0[0] + shift0[0]) : 0.f; o0.y = inside ? relu1(acc0[1] * scale0[1] + shift0[1]) : 0.f;
+            o0.z = inside ? relu1(acc0[2] * scale0[2] + shift0[2]) : 0.f; o0.w = inside ? relu1(acc0[3] * scale0[3] + shift0[3]) : 0.f;
+            o1.x = inside ? relu1(acc1[0] * scale0[4] + shift0[4]) : 0.f; o1.y = inside ? relu1(acc1[1] * scale0[5] + shift0[5]) : 0.f;
+            o1.z = inside ? relu1(acc1[2] * scale0[6] + shift0[6]) : 0.f; o1.w = inside ? relu1(acc1[3] * scale0[7] + shift0[7]) : 0.f;
+            *reinterpret_cast<float4*>(til + p * 4) = o0;
+            *reinterpret_cast<float4*>(til + (NPX + p) * 4) = o1;
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 2: conv0.1 (8 -> 8), lane = output pixel; service group k of a wave = 16 consecutive pixels of one row ----
+    const int m = lane & 31;
+    const bool g1 = (m >= 4 && m < 12) || (m >= 16 && m < 20) || m >= 28;
+    const int pos = g1 ? (m < 12 ? m - 4 : m < 20 ? m - 8 : m - 16) : (m < 4 ? m : m < 16 ? m - 8 : m - 12);
+    const int kgrp = 2 * (lane >> 5) + (g1 ? 1 : 0);
+    const int row = 2 * wv + (kgrp >> 1), col = (kgrp & 1) * 16 + pos;
+    const float* tb = til + (row * IW + col) * 4;
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bq[2];
+    bq[0] = *reinterpret_cast<const float4*>(tb);
+#pragma unroll
+    for (int tq = 0; tq < 18; ++tq) {                                       // (tap, quad)
+        if (tq + 1 < 18) {
+            const int t1 = (tq + 1) >> 1, q1 = (tq + 1) & 1;
+            bq[(tq + 1) & 1] = *reinterpret_cast<const float4*>(tb + q1 * NPX * 4 + ((t1 / 3) * IW + (t1 % 3)) * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 bb = bq[tq & 1];
+        const float a = w1r[tq >> 1];                                       // columns tq*8 .. tq*8 + 7
+        const int kb = (tq & 1) * 8;
+        acc0 = mfma4_bc(a, bb.x, acc0, kb + 0); acc1 = mfma4_bc(a, bb.x, acc1, kb + 1);
+        acc0 = mfma4_bc(a, bb.y, acc0, kb + 2); acc1 = mfma4_bc(a, bb.y, acc1, kb + 3);
+        acc0 = mfma4_bc(a, bb.z, acc0, kb + 4); acc1 = mfma4_bc(a, bb.z, acc1, kb + 5);
+        acc0 = mfma4_bc(a, bb.w, acc0, kb + 6); acc1 = mfma4_bc(a, bb.w, acc1, kb + 7);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue: BN + ReLU, channels-last store (cout = 8: 32 contiguous bytes per pixel) ----
+    const int oy = oy0 + row, ox = ox0 + col;
+    if (oy >= H || ox >= W) return;
+    const long long o = ((long long)n * H + oy) * W + ox;
+    *reinterpret_cast<float4*>(out + o * 8) =
+        make_float4(relu1(acc0[0] * scale1[0] + shift1[0]), relu1(acc0[1] * scale1[1] + shift1[1]),
+                    relu1(acc0[2] * scale1[2] + shift1[2]), relu1(acc0[3] * scale1[3] + shift1[3]));
+    *reinterpret_cast<float4*>(out + o * 8 + 4) =
+        make_float4(relu1(acc1[0] * scale1[4] + shift1[4]), relu1(acc1[1] * scale1[5] + shift1[5]),
+                    relu1(acc1[2] * scale1[6] + shift1[6]), relu1(acc1[3] * scale1[7] + shift1[7]));
+}
+
 #ifndef ENERF_CONV0_B4
 #define ENERF_CONV0_B4 1
 #endif
-void launch_conv0_fused(const Conv2dDesc& L0, const Conv2dDesc& L1, const float* img, float* out, int N, int H, int W,
-                        hipStream_t st) {
+#ifndef ENERF_CONV0_CB
+#define ENERF_CONV0_CB 1            // 1: k_conv0_fused_cb (weights in registers); 0: k_conv0_fused_b4
+#endif
+void launch_conv0_fused(const Conv2dDesc& L0, const Conv2dDesc& L1, const float* w_cb0, const float* w_cb1, const float* img,
+                        float* out, int N, int H, int W, hipStream_t st) {
     const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
+    if (ENERF_CONV0_CB && ENERF_CONV0_B4 && w_cb0 != nullptr && w_cb1 != nullptr) {
+        const size_t shmem = (size_t)(12 * 36 * 4 + 2 * 10 * 34 * 4) * sizeof(float);
+        ENERF_LAUNCH(k_conv0_fused_cb, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, w_cb0, L0.scale, L0.shift, w_cb1,
+                     L1.scale, L1.shift, img, out, N, H, W, tiles_y, tiles_x);
+        return;
+    }
     if (ENERF_CONV0_B4) {
         const size_t shmem = (size_t)(12 * 36 * 4 + 2 * 10 * 34 * 4 + 9 * 32 + 9 * 64) * sizeof(float);
         ENERF_LAUNCH(k_conv0_fused_b4, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, L0.w, L0.scale, L0.shift, L1.w,
@@ -1018,13 +1147,215 @@ __global__ __launch_bounds__(256, 3) void k_smooth0_b4(const float* __restrict__
     }
 }
 
+// ---- round 5: the same fusion with the weights in REGISTERS (A-operand broadcast, common.h mfma4_bc) -------------------------
+// k_smooth0_b4's three co-resident blocks per CU spent half of the CU's LDS cycles (PMC r04: LDS busy 0.51, matrix pipe 0.38)
+// and two of every three ds_read_b128 of the tap loop were broadcast reads of weights that a per-pass re-layout had put there.
+// With cbsz:4 abid:K ONE VGPR holds sixteen 4x1 weight columns: a 16-channel pass of the 3x3 32 -> 8 layer is 288 columns = 18
+// VGPRs, loaded with 18 coalesced 256-byte loads from an image packed once (k_conv2d_cb_pack) — the tap loop is one ds_read_b128
+// (the lane's own pixel, 4 channels) per 8 MFMAs.  What else left LDS: the conv0 tile (a lane's six float2 build operands are
+// loaded ONCE into registers and serve both passes), the lat0 weights (one float2 + one float4 per lane and pass, from global),
+// the re-laid-out conv weights; the f1pre patch arrives by LDS-DMA (no VGPRs; pass 1's copy lands during pass 0's MFMAs).
+// 31 KB of LDS per block instead of 47.6: FIVE blocks per CU, so that one block's build phase (VALU + LDS) runs beside four
+// others' matrix phases.  Arithmetic (operation order included) is k_smooth0_b4's: the outputs are bit-identical.
+// Broadcast-A image of a 3x3 layer with Cout = 8 for `cinp` of its input channels (ci0 .. ci0 + cinp - 1):
+// packed[r*64 + l]: column c = 16r + (l >> 2) = (t*cinp + cil)*2 + half  ->  W[4*half + (l & 3)][ci0 + cil][tap t]; 0 beyond 18*cinp
+// columns.  ceil(18*cinp / 16) registers: 4 (conv0.0, cinp = 3), 9 (conv0.1, 8), 18 per 16-channel pass of smooth0.
+__host__ __device__ __forceinline__ int cb_regs(int cinp) { return (18 * cinp + 15) / 16; }
+__global__ __launch_bounds__(256) void k_conv2d_cb_pack(const float* __restrict__ w, int cin, int ci0, int cinp,
+                                                        float* __restrict__ packed) {
+    const int total = cb_regs(cinp) * 64, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int l = i & 63, c = (i >> 6) * 16 + (l >> 2);
+    const int half = c & 1, cc = c >> 1, cil = cc % cinp, t = cc / cinp;
+    packed[i] = c < 18 * cinp ? w[((4 * half + (l & 3)) * cin + ci0 + cil) * 9 + t] : 0.f;
+}
+void launch_conv2d_cb_pack(const float* w, int cin, int ci0, int cinp, float* packed, hipStream_t st) {
+    ENERF_LAUNCH_SIMPLE(k_conv2d_cb_pack, (unsigned)cdiv(cb_regs(cinp) * 64, 256), 256, 0, st, w, cin, ci0, cinp, packed);
+}
+
+#ifndef ENERF_S0_CB_BLOCKS
+#define ENERF_S0_CB_BLOCKS 5         // co-resident blocks per CU the register budget is set for (LDS allows 5)
+#endif
+__global__ __launch_bounds__(256, ENERF_S0_CB_BLOCKS) void k_smooth0_cb(
+    const float* __restrict__ wcb, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ c0,
+    const float* __restrict__ f1pre, const float* __restrict__ lat_w, const float* __restrict__ lat_b, float* __restrict__ out,
+    const float* __restrict__ rgb_src, int out_stride, int N, int H, int W, int tiles_y, int tiles_x) {
+    constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, NPX = IH * IW;             // 10 x 34 halo tile
+    constexpr int PH = 7, PW = 20, NPP = PH * PW;                                       // f1pre patch (half res)
+    constexpr int NPCH = (NPP * 4 + 63) / 64;                                           // 64-float4 chunks of a pass's patch (9)
+    constexpr int NT16 = (NPX + 15) / 16, NBI = (NT16 + 3) / 4;                         // build items (16 px x 16 ch): 22, <= 6 per wave
+    ENERF_DYN_SMEM(float, lds);
+    float* pat = lds;                       // [NPCH * 64] float4: [patch pixel][16 channels of the pass], DMA destination
+    float* til = pat + NPCH * 256;          // [4 quads][NPX] float4 planes (16 channels of the current pass)
+    float* tabs = til + 4 * NPX * 4;        // bilinear tables of the x2 upsample (see k_smooth0_b4)
+
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+    const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int H1 = H / 2, W1 = W / 2;
+    const float sy = ac_scale(H1, H), sx = ac_scale(W1, W);
+    const int py0 = (int)(sy * (float)max(iy0, 0)), px0 = (int)(sx * (float)max(ix0, 0));
+
+    // ---- everything the block reads from memory is requested here, before the first wait ----
+    float wr[2][18];                                                  // the passes' weight columns (16 per register)
+#pragma unroll
+    for (int r = 0; r < 18; ++r) wr[0][r] = wcb[r * 64 + lane];
+    float2 a_lat[2];
+    float4 bias4[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        a_lat[cb] = *reinterpret_cast<const float2*>(lat_w + (cb * 16 + j) * 8 + 2 * g);    // lat0 A operand: row j, k = channel 2g + r
+        bias4[cb] = *reinterpret_cast<const float4*>(lat_b + cb * 16 + 4 * g);
+    }
+    float2 cvr[NBI];                                                  // conv0 values of this lane's build items (both passes)
+#pragma unroll
+    for (int it = 0; it < NBI; ++it) {
+        const int t = wv + 4 * it;
+        cvr[it] = make_float2(0.f, 0.f);
+        if (t < NT16) {                                               // wave-uniform
+            const int px = t * 16 + j, pxc = px < NPX ? px : NPX - 1;
+            const int ly = (pxc * 241) >> 13, lx = pxc - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const long long off = ok ? ((long long)n * H + gy) * W + gx : 0;
+            const float2 v = *reinterpret_cast<const float2*>(c0 + off * 8 + 2 * g);
+            cvr[it] = ok ? v : make_float2(0.f, 0.f);
+        }
+    }
+    unsigned psrc[(NPCH + 3) / 4];                                    // this lane's source (float offset, channel 0) per patch chunk
+#pragma unroll
+    for (int k = 0; k < (NPCH + 3) / 4; ++k) {
+        const int i = (wv + 4 * k) * 64 + lane, ic = i < NPP * 4 ? i : NPP * 4 - 1;
+        const int pp = ic >> 2, q = ic & 3, pr = pp / PW, pc = pp - pr * PW;
+        const int gy = min(py0 + pr, H1 - 1), gx = min(px0 + pc, W1 - 1);
+        psrc[k] = (unsigned)((((long long)n * H1 + gy) * W1 + gx) * 32 + q * 4);
+    }
+    auto issue_pat = [&](int cb) {
+#pragma unroll
+        for (int k = 0; k < (NPCH + 3) / 4; ++k)
+            if (wv + 4 * k < NPCH) glds16(f1pre + psrc[k] + cb * 16, pat + (wv + 4 * k) * 256, lane);
+    };
+    issue_pat(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < IH + IW) {                                              // upsample tables, once per block (see k_smooth0_b4)
+        const bool isrow = tid < IH;
+        const int k = isrow ? tid : tid - IH, gq = (isrow ? iy0 : ix0) + k, lim = isrow ? H : W;
+        const Lerp1 v = ac_lerp(min(max(gq, 0), lim - 1), isrow ? sy : sx, isrow ? H1 : W1);
+        const int unit = isrow ? PW * 16 : 16, org = isrow ? py0 : px0;
+        const bool ok = gq >= 0 && gq < lim;
+        float4 e;
+        e.x = __int_as_float(ok ? (v.i0 - org) * unit : -1);
+        e.y = __int_as_float(ok ? (v.i1 - org) * unit : -1);
+        e.z = v.l0; e.w = v.l1;
+        *reinterpret_cast<float4*>(tabs + tid * 4) = e;
+    }
+    // stage-2 lane -> pixel map: service group k of a wave = 16 consecutive pixels of one tile row
+    const int m = lane & 31;
+    const bool g1 = (m >= 4 && m < 12) || (m >= 16 && m < 20) || m >= 28;
+    const int pos = g1 ? (m < 12 ? m - 4 : m < 20 ? m - 8 : m - 16) : (m < 4 ? m : m < 16 ? m - 8 : m - 12);
+    const int kgrp = 2 * (lane >> 5) + (g1 ? 1 : 0);
+    const int row = 2 * wv + (kgrp >> 1), col = (kgrp & 1) * 16 + pos;
+    const float* tb = til + (row * IW + col) * 4;
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    glds_wait_all();
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        // ---- build the FPN-sum tile of this pass (lat0 on the matrix cores + bilinear x2 of the patch) into the quad planes ----
+#pragma unroll
+        for (int it = 0; it < NBI; ++it) {
+            const int t = wv + 4 * it;
+            if (t < NT16) {                                           // wave-uniform
+                const int px = t * 16 + j, pxc = px < NPX ? px : NPX - 1;
+                const int ly = (pxc * 241) >> 13, lx = pxc - ly * IW;
+                const float4 rt = *reinterpret_cast<const float4*>(tabs + ly * 4);
+                const float4 ct = *reinterpret_cast<const float4*>(tabs + (IH + lx) * 4);
+                const int ro0 = __float_as_int(rt.x), ro1 = __float_as_int(rt.y), co0 = __float_as_int(ct.x), co1 = __float_as_int(ct.y);
+                const bool inside = (ro0 | co0) >= 0;
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat[cb].x, cvr[it].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat[cb].y, cvr[it].y, acc, 0, 0, 0);
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (inside) {
+                    Lerp1 vy, vx;
+                    vy.l0 = rt.z; vy.l1 = rt.w; vx.l0 = ct.z; vx.l1 = ct.w; vy.i0 = vy.i1 = vx.i0 = vx.i1 = 0;
+                    const float* pb = pat + g * 4;
+                    const float4 u00 = *reinterpret_cast<const float4*>(pb + ro0 + co0), u01 = *reinterpret_cast<const float4*>(pb + ro0 + co1);
+                    const float4 u10 = *reinterpret_cast<const float4*>(pb + ro1 + co0), u11 = *reinterpret_cast<const float4*>(pb + ro1 + co1);
+                    o.x = ac_blend(vy, vx, u00.x, u01.x, u10.x, u11.x) + (acc[0] + bias4[cb].x);
+                    o.y = ac_blend(vy, vx, u00.y, u01.y, u10.y, u11.y) + (acc[1] + bias4[cb].y);
+                    o.z = ac_blend(vy, vx, u00.z, u01.z, u10.z, u11.z) + (acc[2] + bias4[cb].z);
+                    o.w = ac_blend(vy, vx, u00.w, u01.w, u10.w, u11.w) + (acc[3] + bias4[cb].w);
+                }
+                if (px < NPX) *reinterpret_cast<float4*>(til + (g * NPX + px) * 4) = o;
+            }
+        }
+        __syncthreads();                                              // tile complete; nobody reads the patch any more
+        if (cb == 0) {                                                // pass 1's patch + weights travel during pass 0's MFMAs
+            issue_pat(1);
+#pragma unroll
+            for (int r = 0; r < 18; ++r) wr[1][r] = wcb[(18 + r) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- 3x3 conv over the pass's 16 channels: per (tap, quad) ONE ds_read_b128 and 8 broadcast-A MFMAs ----
+        float4 bq[2];
+        bq[0] = *reinterpret_cast<const float4*>(tb);
+#pragma unroll
+        for (int tq = 0; tq < 36; ++tq) {
+            if (tq + 1 < 36) {
+                const int t1 = (tq + 1) >> 2, q1 = (tq + 1) & 3;
+                bq[(tq + 1) & 1] = *reinterpret_cast<const float4*>(tb + q1 * NPX * 4 + ((t1 / 3) * IW + (t1 % 3)) * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 bb = bq[tq & 1];
+            const float a = wr[cb][tq >> 1];
+            const int kb = (tq & 1) * 8;
+            acc0 = mfma4_bc(a, bb.x, acc0, kb + 0); acc1 = mfma4_bc(a, bb.x, acc1, kb + 1);
+            acc0 = mfma4_bc(a, bb.y, acc0, kb + 2); acc1 = mfma4_bc(a, bb.y, acc1, kb + 3);
+            acc0 = mfma4_bc(a, bb.z, acc0, kb + 4); acc1 = mfma4_bc(a, bb.z, acc1, kb + 5);
+            acc0 = mfma4_bc(a, bb.w, acc0, kb + 6); acc1 = mfma4_bc(a, bb.w, acc1, kb + 7);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (cb == 0) {
+            glds_wait_all();                                          // this wave's share of pass 1's patch has landed
+            __syncthreads();                                          // everyone's has; everyone is done reading the tile
+        }
+    }
+    // ---- epilogue: bias, channels-last / texel store (cout = 8): a pixel's 8 features (+ rgb texel) from its own lane ----
+    const int oy = oy0 + row, ox = ox0 + col;
+    if (oy >= H || ox >= W) return;
+    const long long o = ((long long)n * H + oy) * W + ox;
+    *reinterpret_cast<float4*>(out + o * out_stride) =
+        make_float4(acc0[0] * scale[0] + shift[0], acc0[1] * scale[1] + shift[1], acc0[2] * scale[2] + shift[2], acc0[3] * scale[3] + shift[3]);
+    *reinterpret_cast<float4*>(out + o * out_stride + 4) =
+        make_float4(acc1[0] * scale[4] + shift[4], acc1[1] * scale[5] + shift[5], acc1[2] * scale[6] + shift[6], acc1[3] * scale[7] + shift[7]);
+    if (rgb_src != nullptr) {
+        const float* sp = rgb_src + (long long)n * 3 * H * W + (long long)oy * W + ox;
+        *reinterpret_cast<float4*>(out + o * out_stride + 8) =
+            make_float4(sp[0] * 0.5f + 0.5f, sp[(long long)H * W] * 0.5f + 0.5f, sp[2LL * H * W] * 0.5f + 0.5f, 0.f);
+    }
+}
+
+
 #ifndef ENERF_SMOOTH0_B4
 #define ENERF_SMOOTH0_B4 1
 #endif
+#ifndef ENERF_SMOOTH0_CB
+#define ENERF_SMOOTH0_CB 1           // 1: k_smooth0_cb (weights in registers through the A-operand broadcast); 0: k_smooth0_b4
+#endif
 void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1pre, const float* lat_w, const float* lat_b,
-                          const float* w_pq, float* out, int N, int H, int W, hipStream_t st) {
+                          const float* w_pq, const float* w_cb, float* out, int N, int H, int W, hipStream_t st) {
     const int out_stride = L.out_stride > 0 ? L.out_stride : 8;
-    if (ENERF_SMOOTH0_B4 && w_pq != nullptr) {                         // default: batched-4x4 convolution, 8x32 tiles
+    if (ENERF_SMOOTH0_CB && ENERF_SMOOTH0_B4 && w_pq != nullptr && w_cb != nullptr) {   // default (round 5): weights in registers
+        const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
+        const size_t shmem = (size_t)(9 * 256 + 4 * 340 * 4 + 44 * 4) * sizeof(float);
+        ENERF_LAUNCH(k_smooth0_cb, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, w_cb, L.scale, L.shift, c0, f1pre, lat_w,
+                     lat_b, out, L.rgb_src, out_stride, N, H, W, tiles_y, tiles_x);
+        return;
+    }
+    if (ENERF_SMOOTH0_B4 && w_pq != nullptr) {                         // round 3/4: batched-4x4 convolution, weights through LDS
         const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
         const size_t shmem = (size_t)(340 * 8 + 140 * 16 + 4 * 340 * 4 + 288 + 9 * 4 * 32 + 44 * 4) * sizeof(float);
         ENERF_LAUNCH(k_smooth0_b4, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, L.w, L.scale, L.shift, c0, f1pre, lat_w,

@@ -128,13 +128,16 @@ void launch_conv2d_pack(const float* w, const float* bias, const float* bn_w, co
 int launch_conv2d(const Conv2dDesc& L, const float* in, float* out, const float* up, int N, int Hi, int Wi, int Hc,
                   int Wc, hipStream_t st);
 // conv0.1(conv0.0(image)) fused (feature_net.py:7-9): L0/L1 = the two layers' descriptors, img (N,3,H,W) -> out (N,H,W,8)
-void launch_conv0_fused(const Conv2dDesc& L0, const Conv2dDesc& L1, const float* img, float* out, int N, int H, int W,
-                        hipStream_t st);
+void launch_conv0_fused(const Conv2dDesc& L0, const Conv2dDesc& L1, const float* w_cb0, const float* w_cb1, const float* img,
+                        float* out, int N, int H, int W, hipStream_t st);
 // smooth0(up2(f1pre) + lat0(c0)) fused (feature_net.py:32-35); L = smooth0's descriptor, lat_w/lat_b raw (32,8)/(32)
 // w_pq: the layer's P/Q tap-packed image (launch_conv2d_pq_pack) or nullptr for the plain 8x32 tiling
+// w_cb: the layer's broadcast-A image (launch_conv2d_cb_pack; round 5 default kernel) or nullptr
 void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1pre, const float* lat_w, const float* lat_b,
-                          const float* w_pq, float* out, int N, int H, int W, hipStream_t st);   // w_pq == nullptr: plain tiling
+                          const float* w_pq, const float* w_cb, float* out, int N, int H, int W, hipStream_t st);   // w_pq == nullptr: plain tiling
 void launch_conv2d_pq_pack(const float* w, int cin, float* packed, hipStream_t st);   // 3*(cin/4)*2*64 floats
+// broadcast-A image (common.h mfma4_bc) of input channels ci0 .. ci0+cinp-1 of a 3x3, Cout = 8 layer: ceil(18*cinp/16)*64 floats
+void launch_conv2d_cb_pack(const float* w, int cin, int ci0, int cinp, float* packed, hipStream_t st);
 // texels from channels-last features at the render resolution + resized colours (general case)
 void launch_pack_texels_cl(const float* feat_cl, int C, const float* src_inps, int H, int W, int Hr, int Wr, int tex,
                            int n_img, float* out, hipStream_t st);

@@ -280,10 +280,13 @@ inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x
 
 // v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 blocks, k = 1.  Lane l = 4b + i supplies A_b[i] and B_b[i]; lane 4b + j
 // receives D_b[0..3][j] in its four accumulator registers.
-inline emu_f32x4 __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, emu_f32x4 c, int, int, int) {
+// cbsz / abid (the A-operand broadcast controls): the 16 blocks form groups of 2^cbsz consecutive blocks and every block of a group
+// takes the A column of the group's block `abid` (cbsz = 4: ONE block's weights for all 16).
+inline emu_f32x4 __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, emu_f32x4 c, int cbsz, int abid, int) {
     unsigned lane = emu::ctx()->cur->tid % emu::kWave;
     auto buf = emu::wave_exchange(a, b);
     unsigned blk = lane & ~3u;
+    if (cbsz > 0) blk = ((((lane >> 2) >> cbsz) << cbsz) + (unsigned)abid) * 4u;
     emu_f32x4 d = c;
     for (int i = 0; i < 4; ++i) d[i] = fmaf(buf[0][blk + i], b, c[i]);
     return d;
