@@ -31,13 +31,23 @@ namespace enerf {
 //   slot 0/1: W[4*slot + i][4*cq + r][tap];  slot 2: the depth head W_d[4*cq + r][tap] repeated for every i (zeros when the
 //   layer has none) — repeated so that every lane loads it at the same lane-dependent offset as its weight row (a uniform
 //   address becomes 27*Cin scalar loads that hipcc hoists and spills).
-long long conv3d_b4_packed_floats(int cin) { return 27LL * (cin / 4) * 48; }
+// Round 5: behind it the BROADCAST-A image of the same layer (common.h mfma4_bc) for k_conv3d_s1_b4c:
+//   wcb[(cq*14 + r)*64 + l]: column c = 16r + (l >> 2) = (tap*4 + ch)*2 + half  ->  W[4*half + (l & 3)][4*cq + ch][tap]  (216 of 224)
+constexpr int kB4cRegs = 14;
+long long conv3d_b4_packed_floats(int cin) { return 27LL * (cin / 4) * 48 + (long long)(cin / 4) * kB4cRegs * 64; }
 
 __global__ __launch_bounds__(256) void k_conv3d_b4_pack(const float* __restrict__ w, const float* __restrict__ wd, int cin,
                                                         float* __restrict__ packed) {
     const long long total = 27LL * (cin / 4) * 48;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
+    if (idx >= total) {
+        const long long k = idx - total;
+        if (k >= (long long)(cin / 4) * kB4cRegs * 64) return;
+        const int l = (int)(k & 63), rr = (int)((k >> 6) % kB4cRegs), cq = (int)((k >> 6) / kB4cRegs), c = rr * 16 + (l >> 2);
+        const int half = c & 1, ch = (c >> 1) & 3, tap = c >> 3;
+        packed[idx] = tap < 27 ? w[((long long)(4 * half + (l & 3)) * cin + 4 * cq + ch) * 27 + tap] : 0.f;
+        return;
+    }
     const int e = (int)(idx % 48), r = e & 3, i = (e >> 2) & 3, slot = e >> 4;
     const long long q = idx / 48;
     const int nq = cin / 4, cq = (int)(q % nq), tap = (int)(q / nq);
@@ -366,12 +376,167 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_s1_b4g(const float* __restric
     }
 }
 
+// =====================================================================================================================
+// k_conv3d_s1_b4c (round 5) — k_conv3d_s1_b4g with the pass's weights in REGISTERS: 216 weight columns of a channel quad are 14
+// VGPRs (A-operand broadcast, common.h mfma4_bc), loaded with 14 coalesced 256-byte loads one pass ahead.  What leaves the
+// kernel: the weight half of every buffer (3.4-5 KB of LDS-DMA per pass and wave set), two of the four (heads: three of the
+// five) ds_read_b128 per tap.  The depth head's 27 x 4 weights (heads only) still travel as one DMA chunk and are read as a
+// uniform-address float4.  Same arithmetic and order as b4g: bit-identical outputs.
+// =====================================================================================================================
+template <int CIN, int BD, bool HEADS>
+__global__ __launch_bounds__(256, 3) void k_conv3d_s1_b4c(const float* __restrict__ wb4, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ in,
+                                                          float* __restrict__ out, float* __restrict__ out2, int relu, int B,
+                                                          int D, int H, int W, int nbd, int nbh, int nbw, int in_planar) {
+    constexpr int BH = 8, BW = 16, V = BD / 2;
+    constexpr int NQ = CIN / 4;
+    constexpr int HX = BW + 2, HY = BH + 2, HZ = BD + 2, NVOX = HZ * HY * HX;
+    constexpr int NCH = (NVOX + 63) / 64, PLANE = NCH * 64 * 4;   // plane chunks of 64 voxels (one glds instruction each)
+    constexpr int BUF = PLANE + (HEADS ? 256 : 0);                // + one chunk: the depth head's [tap][4] weights of the pass
+    constexpr int MYCH = (NCH + 3) / 4;
+    static_assert(NQ % 2 == 0, "passes are processed in pairs (two register sets)");
+    ENERF_DYN_SMEM(float, lds);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31;
+    const bool g1 = (m >= 4 && m < 12) || (m >= 16 && m < 20) || m >= 28;
+    const int xl = g1 ? (m < 12 ? m - 4 : m < 20 ? m - 8 : m - 16) : (m < 4 ? m : m < 16 ? m - 8 : m - 12);
+    const int yl = 4 * (wv & 1) + 2 * (lane >> 5) + (g1 ? 1 : 0), zl = wv >> 1;
+    int t = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+    const int bw = t % nbw; t /= nbw;
+    const int bh = t % nbh; t /= nbh;
+    const int bd = t % nbd;
+    const int b = t / nbd;
+    const int x0 = bw * BW, y0 = bh * BH, z0 = bd * BD;
+    const float* inb = in + (long long)b * D * H * W * CIN;
+    const long long vstride = in_planar ? 4 : CIN, qstride = in_planar ? (long long)D * H * W * 4 : 4;
+    const float* wcb = wb4 + 27 * NQ * 48;                        // the broadcast-A image follows the b4 image
+
+    long long src_off[MYCH];                                       // element offset of the voxel (channel 0), or -1: zeros
+#pragma unroll
+    for (int k = 0; k < MYCH; ++k) {
+        const int v = (wv + 4 * k) * 64 + lane;
+        const int dz = v / (HY * HX), r2 = v - dz * (HY * HX), dy = r2 / HX, dx = r2 - dy * HX;
+        const int gx = x0 + dx - 1, gy = y0 + dy - 1, gz = z0 + dz - 1;
+        const bool ok = v < NVOX && gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
+        src_off[k] = ok ? (((long long)gz * H + gy) * W + gx) * vstride : -1;
+    }
+    const int wd_off = ((lane < 27 ? lane : 26) * NQ * 3 + 2) * 16;   // b4 image: [tap][cq][slot 2][row 0][r]
+    auto issue = [&](int cq, float* buf) {
+#pragma unroll
+        for (int k = 0; k < MYCH; ++k)
+            if (wv + 4 * k < NCH)                                  // wave-uniform
+                glds16(src_off[k] >= 0 ? inb + src_off[k] + cq * qstride : g_b4_zeros, buf + (wv + 4 * k) * 256, lane);
+        if (HEADS && wv == (NCH & 3)) glds16(wb4 + wd_off + cq * 48, buf + PLANE, lane);
+    };
+    auto load_w = [&](int cq, float (&wr)[kB4cRegs]) {
+#pragma unroll
+        for (int r = 0; r < kB4cRegs; ++r) wr[r] = wcb[(cq * kB4cRegs + r) * 64 + lane];
+    };
+
+    f32x4 acc[V][2];
+    float dacc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { acc[v][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[v][1] = f32x4{0.f, 0.f, 0.f, 0.f}; dacc[v] = 0.f; }
+
+    // one pass (channel quad cq) from buffer cq & 1 with the weights in `wr`; the next pass's box + weights are requested first
+    auto pass = [&](int cq, const float (&wr)[kB4cRegs], float (&wnext)[kB4cRegs]) {
+        float* buf = lds + (cq & 1) * BUF;
+        glds_wait_all();                                           // this wave's copies of pass cq have landed
+        block_barrier_raw();                                       // everyone's have; everyone is done reading the other buffer
+        if (cq + 1 < NQ) {
+            issue(cq + 1, lds + ((cq + 1) & 1) * BUF);
+            load_w(cq + 1, wnext);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float* lbase = buf + ((zl * HY + yl) * HX + xl) * 4;
+        const float* wdl = buf + PLANE;
+        auto read_b = [&](int tap, float4 (&bv)[V], float4& wd) {
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+#pragma unroll
+            for (int v = 0; v < V; ++v) bv[v] = *reinterpret_cast<const float4*>(lbase + (((2 * v + kd) * HY + kh) * HX + kw) * 4);
+            if (HEADS) wd = *reinterpret_cast<const float4*>(wdl + tap * 4);
+        };
+        float4 bq[2][V], wq[2];
+        read_b(0, bq[0], wq[0]);
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            if (tap + 1 < 27) read_b(tap + 1, bq[(tap + 1) & 1], wq[(tap + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (HEADS) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float4 bb = bq[tap & 1][v], wd = wq[tap & 1];
+                    dacc[v] = __builtin_fmaf(wd.x, bb.x, dacc[v]);
+                    dacc[v] = __builtin_fmaf(wd.y, bb.y, dacc[v]);
+                    dacc[v] = __builtin_fmaf(wd.z, bb.z, dacc[v]);
+                    dacc[v] = __builtin_fmaf(wd.w, bb.w, dacc[v]);
+                    ENERF_PIN_VGPR(dacc[v]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float4 bb = bq[tap & 1][v];
+                    const float bx = r == 0 ? bb.x : r == 1 ? bb.y : r == 2 ? bb.z : bb.w;
+                    const int c = tap * 8 + r * 2;                 // column (tap*4 + ch)*2 + half
+                    acc[v][0] = mfma4_bc(wr[c >> 4], bx, acc[v][0], c & 15);
+                    acc[v][1] = mfma4_bc(wr[(c + 1) >> 4], bx, acc[v][1], (c + 1) & 15);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    float w0[kB4cRegs], w1[kB4cRegs];
+    issue(0, lds);
+    load_w(0, w0);
+#pragma unroll 1
+    for (int cq = 0; cq < NQ; cq += 2) {
+        pass(cq, w0, w1);
+        pass(cq + 1, w1, w0);
+    }
+
+    const int x = x0 + xl, y = y0 + yl;
+    if (x >= W || y >= H) return;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int z = z0 + zl + 2 * v;
+        if (z >= D) continue;
+        const long long o = (((long long)b * D + z) * H + y) * W + x;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float yv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                yv[r] = acc[v][half][r] * scale[4 * half + r] + shift[4 * half + r];
+                if (relu) yv[r] = fmaxf(yv[r], 0.f);
+            }
+            *reinterpret_cast<float4*>(out + o * 8 + 4 * half) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+        }
+        if (HEADS && out2 != nullptr) out2[o] = dacc[v] * scale[8] + shift[8];
+    }
+}
+
+// Measured (profiles/r05_ab_b4c_conv3d_upfront.txt): 34.8 KB of LDS per block lets FOUR blocks share a CU where b4g has three.  With >= 8 boxes
+// per CU that pays (zju level-0 conv0, 4096 boxes: 79.4 -> 65.3 us; zju level 1: 133.8 -> 131.0); at ~5 boxes per CU the
+// occupancy quantisation loses (dtu level-1 conv0, 1280 boxes = 4 + 1 instead of 3 + 2 per CU: 46.1 -> 51.4 us), and the
+// heads / dtu level 0 (1920 boxes) are unchanged: the tap loops were already at the instruction's rate.
+#ifndef ENERF_B4_CB
+#define ENERF_B4_CB 2048             // k_conv3d_s1_b4c (weights in registers) from this many boxes on; below: b4g.  0: never
+#endif
 template <int CIN, int BD, bool HEADS>
 static void launch_b4g(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W, hipStream_t st) {
     constexpr int NVOX = (BD + 2) * 10 * 18, NCH = (NVOX + 63) / 64, NS = HEADS ? 3 : 2, NWCH = (27 * NS * 4 + 63) / 64;
     const int nbd = cdiv(D, BD), nbh = cdiv(H, 8), nbw = cdiv(W, 16);
-    const size_t shmem = (size_t)2 * (NCH + NWCH) * 64 * 4 * sizeof(float);
     const unsigned grid = (unsigned)((long long)B * nbd * nbh * nbw);
+    if (ENERF_B4_CB > 0 && grid >= (unsigned)ENERF_B4_CB) {
+        const size_t shmem_c = (size_t)2 * (NCH + (HEADS ? 1 : 0)) * 64 * 4 * sizeof(float);
+        ENERF_LAUNCH((k_conv3d_s1_b4c<CIN, BD, HEADS>), grid, 256, shmem_c, st, L.w_b4, L.scale, L.shift, in, out, out2, L.relu, B,
+                     D, H, W, nbd, nbh, nbw, L.in_planar);
+        return;
+    }
+    const size_t shmem = (size_t)2 * (NCH + NWCH) * 64 * 4 * sizeof(float);
     ENERF_LAUNCH((k_conv3d_s1_b4g<CIN, BD, HEADS>), grid, 256, shmem, st, L.w_b4, L.scale, L.shift, in, out, out2, L.relu, B, D,
                  H, W, nbd, nbh, nbw, L.in_planar);
 }
