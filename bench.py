@@ -141,6 +141,160 @@ def live_pmc(workload, kernel_prefix="k_render_rays<3", child_flags=None):
     return out
 
 
+def kernel_time_table(run, frames=8):
+    """Per-kernel device time of `frames` calls of run(), measured in-process (torch.profiler = roctracer: every HIP kernel of
+    this process, the library's ctypes launches included).  Returns [(kernel name, launches, avg us, share of kernel time)],
+    largest total first.  Callers run it with enerf_options_t.single_stream = 1 so that every kernel is alone on the device."""
+    from torch.profiler import ProfilerActivity, profile
+    run(2)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        run(frames)
+        torch.cuda.synchronize()
+    rows = []
+    for e in prof.key_averages():
+        t = getattr(e, "device_time_total", None)
+        if t is None:
+            t = getattr(e, "cuda_time_total", 0.0)
+        if t and e.count:
+            rows.append((e.key.replace("void enerf::", "").replace("enerf::", ""), int(e.count), float(t)))
+    total = sum(r[2] for r in rows) or 1.0
+    rows.sort(key=lambda r: -r[2])
+    return [(k, c // 1, t / c, t / total) for k, c, t in rows]
+
+
+def kernel_work_model(name, cfg, S, H, W, n_rays_by_level):
+    """Algorithmic work of one launch of a library kernel at this workload's shapes: (bound, work, unit) or None.
+    FLOP counts are the dense counts of the layers a kernel evaluates (no halo recompute), the render kernel's the issued MFMA
+    tiles (its view-independent halves evaluated once per point)."""
+    import re
+    cas = cfg.cas
+    vox = [cas.volume_planes[i] * int(H * cas.volume_scale[i]) * int(W * cas.volume_scale[i]) for i in range(cas.num)]
+    m = re.match(r"k_render_rays<(\d+), (\d+)", name)
+    if m:
+        R, Sv = int(m.group(1)), int(m.group(2))
+        lvl = [i for i in range(cas.num) if cas.render_if[i] and (cas.nerf_model_feat_ch[i] + 3 + 3) // 4 == R]
+        if not lvl:
+            return None
+        n_samples = n_rays_by_level[lvl[0]] * cas.num_samples[lvl[0]]
+        return "mfma", render_mfma_tiles_per_16(Sv, R) * 2 * 16 * 16 * 4 / 16.0 * n_samples, "flop"
+    px = S * H * W
+    if name.startswith("k_smooth0"):
+        return "mfma", px * (2 * 9 * 32 * 8 + 2 * 8 * 32), "flop"                  # smooth0 3x3 32->8 + lat0 1x1 8->32
+    if name.startswith("k_conv0_fused"):
+        return "mfma", px * (2 * 9 * 3 * 8 + 2 * 9 * 8 * 8), "flop"
+    m = re.match(r"k_conv3d_s1_b4[gc]?<(\d+), \d+, (true|false)>", name)
+    if m:
+        cin, heads = int(m.group(1)), m.group(2) == "true"
+        if heads:                                                                   # the fused heads of every level share a name
+            return "mfma", sum(vox) / len(vox) * 2 * 27 * 8 * 9, "flop"
+        lv = [i for i in range(cas.num) if (32 >> i) == cin]
+        return ("mfma", vox[lv[0]] * 2 * 27 * cin * 8, "flop") if lv else None
+    m = re.match(r"k_conv2d<(\d+), (\d+), (\d+), (\d+)", name)
+    if m:                                                                           # FeatureNet layers (conv2d.hip launch table)
+        cinp, rt, k, st = (int(m.group(i)) for i in range(1, 5))
+        scale = {(8, 5, 2): 4, (16, 3, 1): 4, (16, 5, 2): 16, (32, 3, 1): 16 if rt == 2 else 4, (16, 1, 1): 4}.get((cinp, k, st))
+        if scale is None:
+            return None
+        cout = 16 * rt if not (cinp == 32 and rt == 1) else 16
+        fl = 2 * k * k * cinp * cout + (2 * 32 * 32 if (cinp == 32 and rt == 2) else 0)   # conv2.1 carries the toplayer
+        return "mfma", px / scale * fl, "flop"
+    return None
+
+
+def secondary_workload(name, dev, frames=100):
+    """BASELINE configs 3 / 4 inside the default run: the reference's per-frame-sync protocol on `frames` frames of
+    the workload (4 distinct resident batches, >= 100 untimed frames first), the per-stage times, and the kernel that holds the
+    largest share of the workload's kernel time (kernels alone: single_stream) with its roofline fraction."""
+    from __graft_entry__ import _seeded_network
+    from enerf_amd.lib import Options
+    cfg, batch_np, human, workload = make_workload(name, 0)
+    net = _seeded_network(cfg, dev, human=human)
+    S, H, W = batch_np["src_inps"].shape[1], batch_np["src_inps"].shape[3], batch_np["src_inps"].shape[4]
+    batches = [{k: torch.from_numpy(v).to(dev) for k, v in (batch_np if j == 0 else make_workload(name, 1000 * j)[1]).items()}
+               for j in range(4)]
+    no = [0]
+
+    def step():
+        no[0] += 1
+        return net(batches[no[0] % 4])
+    t_w, n_w = time.perf_counter(), 0
+    while n_w < 100 or time.perf_counter() - t_w < 0.3:
+        step()
+        torch.cuda.synchronize()
+        n_w += 1
+    lat = []
+    for _ in range(frames):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        out = step()
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t1)
+    ms = 1e3 * sum(lat) / len(lat)
+    res = {"workload": workload, "fps": round(1e3 / ms, 1), "ms": round(ms, 4), "frames": frames,
+           "protocol": "per-frame synchronize (run.py:62-76), default kernel options, 4 resident batches"}
+    cas = cfg.cas
+    n_rays = {i: int(out[f"depth_level{i}"].shape[1]) for i in range(cas.num) if cas.render_if[i]}
+    saved = net.options
+    net.options = Options(single_stream=1)
+    timer = StageTimer()
+    net._timer = timer
+    for _ in range(12):
+        step()
+    torch.cuda.synchronize()
+    net._timer = None
+    res["stages_ms"] = {k: round(v, 4) for k, v in timer.summary().items()}
+    try:
+        table = kernel_time_table(lambda n: [step() for _ in range(n)])
+    except Exception as e:                                  # profiler missing / refused: keep the line
+        table = []
+        res["kernel_table_error"] = str(e)[:160]
+    net.options = saved
+    if table:
+        res["top_kernels"] = [{"kernel": k[:80], "launches_per_frame": round(c / 8, 2), "avg_us": round(a, 1), "share": round(sh, 4)}
+                              for k, c, a, sh in table[:5]]
+        k, c, a, sh = table[0]
+        roof = {"kernel": k[:120], "share_of_kernel_time": round(sh, 4), "avg_launch_ms": round(a / 1e3, 4),
+                "avg_launch_ms_source": "torch.profiler (roctracer) device time over 8 frames with enerf_options_t.single_stream = 1 "
+                                        "(every kernel alone)"}
+        wm = kernel_work_model(k, cfg, S, H, W, n_rays)
+        if wm is not None:
+            ach = wm[1] / (a * 1e-6) / 1e12
+            roof.update({"bound": wm[0], "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "algorithmic_flops_per_launch": wm[1], "traffic": None})
+        else:
+            roof.update({"bound": None, "frac": None, "note": "no work model for this kernel (latency-bound gather / glue)"})
+        res["roofline"] = roof
+    t = res["stages_ms"].get("feature_net")
+    if t:
+        gf = 14.64 * (S * H * W) / (3 * 512 * 640)
+        res["feature_net_frac"] = round(gf / t / PEAK_F32_MFMA_TFLOPS, 4)
+    del net, batches
+    torch.cuda.empty_cache()
+    return res
+
+
+def train_child(timeout_s, live_pmc_ok=False):
+    """Config 5 inside the default run: `bench.py --train --no-perceptual --steps 20 --warmup 3` as a child process (its own
+    line: ms_per_step, roofline of k_mlp_bwd, cpu_baseline of the oracle's train_step)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--train", "--no-perceptual", "--steps", "20", "--warmup", "3"]
+    if not live_pmc_ok:                                   # (the rocprofv3 --pmc child passes of roofline.traffic cost ~25 s more)
+        cmd.append("--no-live-pmc")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd=ROOT)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {str(e)[:160]}"}
+    return {"ms_per_step": round(d["ms_per_step"], 3), "samples_per_s": round(d["value"], 2), "steps": d["steps"],
+            "roofline": d.get("roofline"), "cpu_baseline": d.get("cpu_baseline"), "step_launch": d["config"]["step_launch"],
+            "loss": "MSE at both levels (the VGG16 perceptual term off: no pretrained weights offline; `bench.py --train` times it with "
+                    "the term on)", "final_loss": d.get("final_loss"), "child_wall_s": round(time.perf_counter() - t0, 1),
+            "workload": d["config"]["workload"]}
+
+
 def make_workload(name, seed):
     from enerf_amd.config import EnerfConfig
     from enerf_amd.synth import make_batch, make_lego_batch, make_zju_batch
@@ -414,7 +568,7 @@ def train_bench(args, rank, world, dev, dist, emu_lib=None):
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not emu else "synthetic (CPU lane emulator, 32x64: launcher check, not a measurement)", "final_loss": float(loss.detach()),
             "collective_ranks_seen": args.binding["ranks_seen"], "collective_backend": args.binding["backend"],
-            "rank_devices": [{k: b[k] for k in ("rank", "device", "visible", "hw")} for b in args.binding["bindings"]],
+            "rank_devices": [{k: b.get(k) for k in ("rank", "device", "visible", "hw", "affinity")} for b in args.binding["bindings"]],
             "config": {"workload": "BASELINE config 5: DTU dtu_pretrain training, one sample per GPU per step, MSE loss "
                                    "(losses/enerf.py:21-24)" + (" + 0.01 x VGG16 perceptual L1 at both levels (losses/enerf.py:30-38; the "
                                    "architecture with seeded random-init weights: no pretrained weights offline)" if perceptual is not None
@@ -457,10 +611,15 @@ def main():
                          "the default line is measured with all-zero options")
     ap.add_argument("--batches", type=int, default=4,
                     help="distinct seeded input batches the timed frames rotate over (all uploaded before the timed region)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `workloads` extra (lego, zju, training step) of the default dtu run")
+    ap.add_argument("--time-budget", type=float, default=105.0,
+                    help="wall-clock budget (s) of the default run: extras that would start after it are skipped and say so")
     ap.add_argument("--emu", action="store_true",
                     help="launcher/CI check WITHOUT a GPU: run the same bench flow on the CPU lane emulator of the kernel "
                          "sources (tests/emu) over gloo with a 32x64 frame; the numbers mean nothing")
     args = ap.parse_args()
+    t_process = time.perf_counter()
 
     # ---- N > 1 without a launcher: become one.  `python bench.py --gpus 8` must not silently measure one GPU. ----
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -595,7 +754,7 @@ def main():
             "dtype": "f32", "data": "synthetic" if not args.emu else "synthetic (CPU lane emulator: launcher check, not a measurement)",
             "per_rank_fps": [round(v, 2) for v in per_rank], "internal_warmup_frames": internal_warmup,
             "collective_ranks_seen": args.binding["ranks_seen"], "collective_backend": args.binding["backend"],
-            "rank_devices": [{k: b[k] for k in ("rank", "device", "visible", "hw")} for b in args.binding["bindings"]],
+            "rank_devices": [{k: b.get(k) for k in ("rank", "device", "visible", "hw", "affinity")} for b in args.binding["bindings"]],
             "config": {"workload": workload, "distinct_batches": nb, "feature_net": args.feature_backend, "hip_graph": bool(args.graph),
                        "single_stream": bool(args.single_stream), "options": opt_fields,
                        "protocol": "per-frame synchronize (run.py:62-76), one frame at a time, default kernel options "
@@ -758,8 +917,13 @@ def main():
             if t:
                 Hs, Ws = H >> (2 - i), W >> (2 - i)
                 mb = (S * Hs * Ws * C + D * h * w * C + D * h * w) * 4 / 1e6       # features once + volume once + depth planes
-                sr[f"volume_{i}"] = {"bound": "hbm", "achieved": round(mb / t, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                     "frac": round(mb / t / PEAK_HBM_GBS, 4), "algorithmic_mbytes": round(mb, 2)}
+                # latency x occupancy bound (with no gathers and no stores the kernel keeps 70 % of its time), so no
+                # fraction of the HBM roof is quoted: voxels per ns, the kernel's static instructions per lane and its occupancy
+                sr[f"volume_{i}"] = {"bound": "latency", "frac": None, "voxels_per_us": round(D * h * w / (t * 1e3), 1),
+                                     "achieved_gbs_informational": round(mb / t, 1), "algorithmic_mbytes": round(mb, 2),
+                                     "instructions_per_lane": 300, "lanes_per_voxel": C // 4, "waves_per_simd": 5,
+                                     "note": "k_feature_volume_mp: ~300 instructions per lane, C/4 lanes per voxel pair, 92 VGPRs = 5 "
+                                             "waves per SIMD; bound by the dependent chain projection -> gathers at that occupancy"}
             t = stages.get(f"render_{i}")
             if t and cas.render_if[i]:
                 F = cas.nerf_model_feat_ch[i] + 3
@@ -820,6 +984,22 @@ def main():
                 "traffic_source": pmc_note, "library_source_digest": lib_digest, "pmc_source_digest": pmc_digest,
                 "pmc_stale": pmc_digest != lib_digest}
 
+    # ---- the other BASELINE configs in the SAME driver-visible line: lego, zju (100 frames each, the same
+    #      protocol) and the config-5 training step; `value` / `config` above are untouched ----
+    secondary = (rank == 0 and world == 1 and args.workload == "dtu" and not args.no_stages and not args.no_secondary
+                 and not args.graph and not args.emu and args.feature_backend == "hip" and not opt_fields)
+    if secondary:
+        wl = {}
+        for name in ("lego", "zju"):
+            if time.perf_counter() - t_process > args.time_budget - 45:
+                wl[name] = {"skipped": "time budget"}
+                continue
+            try:
+                wl[name] = secondary_workload(name, dev)
+            except Exception as e:
+                wl[name] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        result["workloads"] = wl
+
     # ---- CPU baseline: the oracle (torch CPU restatement of the reference) on this box's host cores + parity ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import enerf_oracle as O
@@ -858,6 +1038,12 @@ def main():
         err = float((o[key].cpu() - ref[key]).abs().max())
         result["parity_vs_oracle"] = {f"{key}_max_abs": err, "psnr_db": O.psnr(o[key].cpu(), ref[key])}
 
+    if secondary and not args.no_cpu_baseline:
+        left = args.time_budget - (time.perf_counter() - t_process)
+        # the training child needs ~35 s (graph capture + verification, 20 replays, one CPU step of the oracle)
+        result["workloads"]["train"] = train_child(left, live_pmc_ok=left > 75 and not args.no_live_pmc) if left > 40 else \
+            {"skipped": f"time budget ({left:.0f} s left)"}
+        result["workloads"]["wall_s"] = round(time.perf_counter() - t_process, 1)
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:

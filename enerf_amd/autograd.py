@@ -82,29 +82,14 @@ class CompositeFn(torch.autograd.Function):
         return None, g_raw.view(B, N, Ns, 4), None, None
 
 
-def gather_cameras(batch, render_scale: float, lib=None):
+def gather_cameras(batch, render_scale: float, lib):
     """The per-view constants of enerf_gather_*: cam (B,S,16) = K'E33 | K't | source centre | 0 and tcen (B,4), with
     K' = K scaled to the level (utils.py:697-704); products in fp64, stored fp32 (as the inference kernel's table).
-    With the library: ONE launch on the device (enerf_camera_tables; no host synchronisation, capturable)."""
-    if lib is not None:
-        return lib.camera_tables(_c(batch["src_ixts"]), _c(batch["src_exts"]), _c(batch["tar_ext"]), render_scale)
-    return gather_cameras_torch(batch, render_scale)
-
-
-def gather_cameras_torch(batch, render_scale: float):
-    """gather_cameras as torch ops (torch.inverse synchronises): the twin the kernel is tested against."""
-    E = batch["src_exts"].double()
-    K = batch["src_ixts"].double().clone()
-    K[:, :, :2] *= render_scale
-    B, S = E.shape[:2]
-    M = K @ E[:, :, :3, :3]
-    v = (K @ E[:, :, :3, 3:4])[..., 0]
-    cs = torch.inverse(E)[:, :, :3, 3]
-    z1 = torch.zeros(B, S, 1, dtype=torch.float64, device=E.device)
-    cam = torch.cat([M.reshape(B, S, 9), v, cs, z1], -1).float().contiguous()
-    ct = torch.inverse(batch["tar_ext"].double())[:, :3, 3]
-    tcen = torch.cat([ct, z1[:, 0]], -1).float().contiguous()
-    return cam, tcen
+    ONE launch on the device (enerf_camera_tables; no host synchronisation, capturable).  The torch-op twin the kernel is
+    tested against is tests/torch_twins.py::gather_cameras."""
+    if lib is None:
+        raise RuntimeError("gather_cameras: the HIP library is required")
+    return lib.camera_tables(_c(batch["src_ixts"]), _c(batch["src_exts"]), _c(batch["tar_ext"]), render_scale)
 
 
 class GatherFn(torch.autograd.Function):

@@ -141,6 +141,10 @@ int enerf_build_feature_volume(const float* feat, const float* proj, const float
             "build_feature_volume: source features too large for 32-bit gather offsets");
     REQUIRE((long long)B * D * h * w * (C / 4) < (1LL << 31) && (long long)h * w < (1LL << 23),
             "build_feature_volume: volume too large for 32-bit voxel indices");
+    // the launch carries (b, d) in gridDim.z and forms the voxel index with 24-bit multiplies (volume.hip, round 4)
+    REQUIRE((long long)B * D <= 65535 && (long long)B * D * h < (1LL << 23) && w < (1 << 23),
+            "build_feature_volume: B*D=%lld planes / B*D*h=%lld rows beyond the grid-carried voxel decomposition (65535 / 2^23)",
+            (long long)B * D, (long long)B * D * h);
     launch_feature_volume(feat, proj, depth_values, B, S, C, Hs, Ws, D, h, w, vol, (hipStream_t)stream);
     return check_launch("build_feature_volume");
 }

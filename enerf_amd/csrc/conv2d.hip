@@ -73,6 +73,9 @@ void launch_conv2d_pack(const float* w, const float* bias, const float* bn_w, co
 // epilogue.  This layer's D registers (rows 16rt+4g+r of pixel j) are exactly the B operands of the next layer's
 // k-steps in the standard packed-weight order (ci = 16cb + 4g + r), so the chained layer is 8*RT more MFMAs per
 // column tile on values that never leave the registers; this layer's own output is not stored.
+#ifndef ENERF_C2_PLANAR
+#define ENERF_C2_PLANAR 0            // 1: quad-plane LDS tile (bank-conflict free; measured: no change, profiles/r05_ab_conv2d_planar.txt); 0: pixel-major tile
+#endif
 template <int CINP, int RT, int K, int STR, int TH, bool NCHW3, bool CHAIN = false>
 __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, const float* __restrict__ scale,
                                                 const float* __restrict__ shift, const float* __restrict__ in,
@@ -93,6 +96,16 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
     // consecutive slots of one parity.
     constexpr int IWH = (IW + 1) / 2;
     auto slot = [](int ly, int lx) { return STR == 2 ? (ly * 2 + (lx & 1)) * IWH + (lx >> 1) : ly * IW + lx; };
+    // Round 5: the tile lives in LDS as channel-QUAD PLANES [quad][slot] float4 (pitch a multiple of 16 slots = 64 banks)
+    // instead of [slot][CB channels].  Pixel-major, a ds_read_b128 service group (lanes {0-3,12-15} of lane group g and {4-11}
+    // of g+1) lands on four bank quads twice (64-byte pixel pitch): PMC r04 counted bank-conflict cycles at 0.43 (smooth1) to
+    // 0.71 (conv1.0, 32-byte pitch, ds_read_b64) of the LDS-active cycles of these kernels.  With planes the 16 lanes of a
+    // group read 16 consecutive slots of two planes = 64 different banks.  The staging threads are permuted so that eight
+    // consecutive lanes store eight consecutive slots of ONE plane (a conflict-free ds_write_b128 group) while a wave's load
+    // instruction still covers whole 64-byte pixel records.
+    constexpr bool PLANAR = ENERF_C2_PLANAR && !NCHW3 && CB >= 8;
+    constexpr int NSLOT = STR == 2 ? IH * 2 * IWH : IH * IW;
+    constexpr int PITCH = (NSLOT + 15) / 16 * 16;
     ENERF_DYN_SMEM(float, lds);
 
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
@@ -159,25 +172,28 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
                         sk[it] ? make_float4(v0[it], v1[it], v2[it], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
-            constexpr int NIT = (NPX * QV + 255) / 256;
+            constexpr int NITEM = PLANAR ? (NPX + 7) / 8 * 8 * QV : NPX * QV;      // planar: groups of 8 pixels x QV quads
+            constexpr int NIT = (NITEM + 255) / 256;
             float4 sv[NIT];
             bool sk[NIT];
             int so[NIT];
             const float* base = in + (long long)n * Hi * Wi * CINP + cb * CB;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int i = threadIdx.x + it * 256, ic = i < NPX * QV ? i : NPX * QV - 1;
-                const int px = ic / QV, q = ic - px * QV;
+                const int i = threadIdx.x + it * 256, ic = i < NITEM ? i : NITEM - 1;
+                int px, q;
+                if (PLANAR) { px = (ic / (8 * QV)) * 8 + (ic & 7); q = (ic >> 3) % QV; if (px >= NPX) px = NPX - 1; }
+                else { px = ic / QV; q = ic - px * QV; }
                 const int ly = px / IW, lx = px - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
                 sk[it] = gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
-                so[it] = (slot(ly, lx) * QV + q) * 4;
+                so[it] = PLANAR ? (q * PITCH + slot(ly, lx)) * 4 : (slot(ly, lx) * QV + q) * 4;
                 const int off = sk[it] ? gy * Wi + gx : 0;
                 sv[it] = *reinterpret_cast<const float4*>(base + (long long)off * CINP + q * 4);
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int i = threadIdx.x + it * 256;
-                if (i < NPX * QV)
+                if (i < NITEM)        // (planar: the clamped tail items of the last 8-pixel group rewrite pixel NPX-1 with its own value)
                     *reinterpret_cast<float4*>(lds + so[it]) = sk[it] ? sv[it] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -188,7 +204,9 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
 #pragma unroll
             for (int c = 0; c < CTW; ++c) {
                 const int tile = wv * CTW + c, tr = tile / (TW / 16), tc = tile - tr * (TW / 16);
-                const float* p = lds + slot(tr * STR + kh, (tc * 16 + j) * STR + kw) * CB + g * CPL;
+                const int sl = slot(tr * STR + kh, (tc * 16 + j) * STR + kw);
+                const float* p = PLANAR ? (CPL == 4 ? lds + (g * PITCH + sl) * 4 : lds + ((g >> 1) * PITCH + sl) * 4 + (g & 1) * 2)
+                                        : lds + sl * CB + g * CPL;
                 if (CPL == 4) {
                     const float4 tq = *reinterpret_cast<const float4*>(p);
                     bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
@@ -324,7 +342,9 @@ static void launch_c2(const Conv2dDesc& L, const float* in, float* out, const fl
     const int Ho = (Hi + 2 * P - K) / STR + 1, Wo = (Wi + 2 * P - K) / STR + 1;
     const int tiles_y = cdiv(Ho, TH), tiles_x = cdiv(Wo, 32);
     constexpr int IH = (TH - 1) * STR + K, IW = 31 * STR + K;
-    const size_t shmem = (size_t)IH * (STR == 2 ? 2 * ((IW + 1) / 2) : IW) * CB * sizeof(float);   // stride 2: de-interleaved rows
+    const int nslot = IH * (STR == 2 ? 2 * ((IW + 1) / 2) : IW);                                    // stride 2: de-interleaved rows
+    const bool planar = ENERF_C2_PLANAR && !NCHW3 && CB >= 8;
+    const size_t shmem = (size_t)(planar ? (nslot + 15) / 16 * 16 : nslot) * CB * sizeof(float);
     const unsigned grid = (unsigned)((long long)N * tiles_y * tiles_x);
     ENERF_LAUNCH((k_conv2d<CINP, RT, K, STR, TH, NCHW3, CHAIN>), grid, 256, shmem, st, L.w, L.scale, L.shift, in, out, up,
                  rgb_src, out_stride, L.cout, L.relu, N, Hi, Wi, Ho, Wo, Hc, Wc, tiles_y, tiles_x, L.chain_w, L.chain_shift);

@@ -437,8 +437,9 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
             rc = enerf_build_feature_volume(f[i], proj, dv, a->B, a->S, L.C, L.Hs, L.Ws, L.D, L.h, L.w, vol, stream);
         else {      // same argument checks as the C entry (shapes come from the validated plan; the 32-bit limits are re-checked)
             REQUIRE((long long)a->B * a->S * L.Hs * L.Ws * L.C < (1LL << 32) && (long long)L.Hs * L.Ws < (1LL << 23) &&
-                    (long long)a->B * L.D * L.h * L.w * (L.C / 4) < (1LL << 31) && (long long)L.h * L.w < (1LL << 23),
-                    "forward: level %d volume too large for 32-bit indices", i);
+                    (long long)a->B * L.D * L.h * L.w * (L.C / 4) < (1LL << 31) && (long long)L.h * L.w < (1LL << 23) &&
+                    (long long)a->B * L.D <= 65535 && (long long)a->B * L.D * L.h < (1LL << 23) && L.w < (1 << 23),
+                    "forward: level %d volume too large for 32-bit indices / the grid-carried voxel decomposition", i);
             launch_feature_volume(f[i], proj, dv, a->B, a->S, L.C, L.Hs, L.Ws, L.D, L.h, L.w, vol, st, 1);
             rc = check_launch("build_feature_volume");
         }

@@ -646,9 +646,10 @@ int enerf_gather_fwd(const enerf_gather_args_t* u, enerf_stream_t stream) {
     REQUIRE(u->x && u->vox, "gather_fwd: null output");
     if (u->P == 0) return ENERF_OK;
     const long long waves = cdivl((long long)a.B * a.P, 64);
-    REQUIRE(a.Wr < 65535 && a.Hr < 65535 && a.w < 65535 && a.h < 65535 && a.D < 256, "gather_fwd: map sizes beyond the packed tap coordinates");
-    if (a.F <= 16) ENERF_LAUNCH(k_gather_fwd_w<1>, (unsigned)cdivl(waves, 4), 256, 0, (hipStream_t)stream, a);
-    else if (a.F <= 48) ENERF_LAUNCH(k_gather_fwd_w<3>, (unsigned)cdivl(waves, 4), 256, 0, (hipStream_t)stream, a);
+    // k_gather_fwd_w packs the tap coordinates (x, y in 16 bits, z in 8): larger maps take the thread-per-(point, view) kernel
+    const bool packable = a.Wr < 65535 && a.Hr < 65535 && a.w < 65535 && a.h < 65535 && a.D < 256;
+    if (packable && a.F <= 16) ENERF_LAUNCH(k_gather_fwd_w<1>, (unsigned)cdivl(waves, 4), 256, 0, (hipStream_t)stream, a);
+    else if (packable && a.F <= 48) ENERF_LAUNCH(k_gather_fwd_w<3>, (unsigned)cdivl(waves, 4), 256, 0, (hipStream_t)stream, a);
     else {
         const long long total = (long long)a.B * a.P * a.S;
         ENERF_LAUNCH_SIMPLE(k_gather_fwd, (unsigned)cdivl(total, 256), 256, 0, (hipStream_t)stream, a);
@@ -668,7 +669,9 @@ int enerf_gather_bwd(const enerf_gather_args_t* u, enerf_stream_t stream) {
     a.ray_w = u->ray_w; a.n_samples = u->n_samples;
     REQUIRE(a.ray_w >= 0 && a.n_samples >= 0, "gather_bwd: negative raster hint");
     const bool raster = a.ray_w > 0 && a.n_samples > 0 && a.n_samples <= 8 && a.P % ((long long)a.ray_w * a.n_samples) == 0 &&
-                        (long long)a.B * a.S * a.Hr * a.Wr * a.F < (1LL << 31) && a.F <= 48 && a.Wr < 65535 && a.Hr < 65535;
+                        (long long)a.B * a.S * a.Hr * a.Wr * a.F < (1LL << 31) && a.F <= 48 && a.Wr < 65535 && a.Hr < 65535 &&
+                        a.w < 65535 && a.h < 65535 && a.D < 256 &&      // the tiled kernel packs volume taps as (x, y: 16 bits, z: 8)
+                        a.Wr > 1 && a.Hr > 1;                           // its volume patch extent divides by (Wr - 1), (Hr - 1)
     if (raster) {
         GatherTile T;
         const bool wp = a.F <= 16;                            // wave-private patches (see the kernel)
@@ -685,7 +688,8 @@ int enerf_gather_bwd(const enerf_gather_args_t* u, enerf_stream_t stream) {
         T.tiles_x = cdiv(a.ray_w, T.tw); T.tiles_y = cdiv(rows, T.th);
         const size_t shmem = ((size_t)T.PH * T.PW * a.F + (size_t)T.VZ * T.VH * T.VW * 8) * sizeof(float) * (wp ? 4 : 1);
         const long long blocks = (long long)a.B * T.tiles_x * T.tiles_y * T.groups;
-        if (shmem <= 64 * 1024 && blocks < (1LL << 31)) {
+        // dynamic + the kernel's static __shared__ (geometry / point tables: <= 8 KB) inside the 64 KB every launch may use
+        if (shmem + 8 * 1024 <= 64 * 1024 && blocks < (1LL << 31)) {
             if (wp) ENERF_LAUNCH((k_gather_bwd_tiled<1, true>), (unsigned)blocks, 256, shmem, st, a, T);
             else ENERF_LAUNCH((k_gather_bwd_tiled<3, false>), (unsigned)blocks, 256, shmem, st, a, T);
             return check_launch("gather_bwd");

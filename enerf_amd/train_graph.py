@@ -7,8 +7,7 @@ captured once â€” forward, loss, backward, gradient clip and optimizer update â€
 into the captured input buffers.
 
 Nothing of the step stays outside the graph: the camera-only tables (train_path.camera_tables: 4x4 inverses) are device
-kernels since ABI v7 (enerf_get_proj_mats, enerf_camera_tables).  Only with the HIP stages switched off
-(``net.hip_backward = False``: torch.inverse synchronises) are they recomputed eagerly before every replay.
+kernels since ABI v7 (enerf_get_proj_mats, enerf_camera_tables) and are captured with it.
 
 DATA-PARALLEL (trainer.py:15-22; ``distributed=True``): the same ONE graph per rank, with the collectives inside it.
 DistributedDataParallel's reducer (autograd hooks, bucket views, a host-side bookkeeping pass per step) is an eager-step
@@ -31,12 +30,10 @@ semaphores with a memset) and gets wrong sums in about half of the replays.  Con
   * ``GraphedTrainStep(verify=True)`` (the default) replays a few steps against eager steps from the same state and
     compares every gradient before the graph is trusted; a mismatch raises ``GraphMismatch`` (bench.py then runs eager).
 """
-import time
 from typing import Callable, Dict, Iterable, Optional
 
 import torch
 
-from .train_path import camera_tables
 
 
 class GraphMismatch(RuntimeError):
@@ -134,11 +131,10 @@ class GraphedTrainStep:
             self.sync.broadcast()
         self.static = {k: v.clone() for k, v in example_batch.items() if torch.is_tensor(v)}
         self.extra = {k: v for k, v in example_batch.items() if not torch.is_tensor(v)}
-        # camera tables: with the HIP library the 4x4 inverses are device kernels inside the step (captured with it); without it
-        # (net.hip_backward = False) torch.inverse synchronises, so they are computed eagerly before each replay
+        # (the camera tables â€” 4x4 inverses â€” are device kernels of the library inside the step: captured with it)
         from .train_path import _hip_lib
-        self._tables_in_graph = _hip_lib(net, next(iter(self.static.values()))) is not None
-        self.tables = None if self._tables_in_graph else {k: v.clone() for k, v in camera_tables(net.cfg.cas, self.static).items()}
+        if _hip_lib(net, next(iter(self.static.values()))) is None:
+            raise RuntimeError("GraphedTrainStep: the HIP library is required (the training path has no eager fallback)")
         self._params = [p for p in net.parameters() if p.requires_grad]
         pristine_net = [(t, t.clone()) for t in net.state_dict().values()]
         pristine_opt = {id(t): t.clone() for st in optimizer.state.values() for t in st.values() if torch.is_tensor(t)}
@@ -180,14 +176,21 @@ class GraphedTrainStep:
             # The process group's watchdog thread polls the events of the collectives the warm-up enqueued until it has seen
             # them complete; an event query from another thread while THIS thread captures in the default ("global") mode is
             # an illegal call that takes the process down (seen once in ~10 runs on ROCm 7 / PyTorch 2.10: abort inside the
-            # capture).  Two guards: let the watchdog retire the finished work first (all ranks together; the device is idle
-            # after the synchronize, the sleep covers the watchdog's polling period â€” a heuristic), and capture in
-            # "thread_local" mode, which is the LOAD-BEARING one: only this thread's calls are policed, so a late watchdog
-            # query cannot abort the capture (kernels other threads â€” the autograd engine's â€” launch into the capturing
-            # stream are captured all the same; the price: an illegal call from those threads is not diagnosed).
+            # capture).  The guard is the capture MODE: in "thread_local" mode only this thread's calls are policed, so a
+            # watchdog query â€” whenever it comes â€” cannot abort the capture (kernels other threads, the autograd engine's,
+            # launch into the capturing stream are captured all the same; the price: an illegal call from those threads is
+            # not diagnosed).  In front of it the warm-up's collectives are drained DETERMINISTICALLY (round 4 slept 0.5 s
+            # here): a fence collective is enqueued behind them on the communicator â€” collectives of one communicator
+            # complete in order â€” and its Work handle is waited on and polled to completion on every rank, so every event
+            # the watchdog still holds has fired before the capture starts; then all ranks meet once more.
+            fence = self.sync.dist.all_reduce(torch.zeros(1, device=next(iter(self.static.values())).device),
+                                              group=self.sync.group, async_op=True)
+            fence.wait()
+            torch.cuda.synchronize()
+            while not fence.is_completed():
+                pass
             self.sync.dist.barrier(group=self.sync.group)
             torch.cuda.synchronize()
-            time.sleep(0.5)
             capture_kw["capture_error_mode"] = "thread_local"
         error = None
         try:
@@ -239,7 +242,7 @@ class GraphedTrainStep:
         self.net.invalidate_packed()
 
     def _eager_step(self, zero: bool = True):
-        batch = dict(self.static, **self.extra) if self.tables is None else dict(self.static, camera_tables=self.tables, **self.extra)
+        batch = dict(self.static, **self.extra)
         return train_step(self.net, self.opt, self.loss_fn, batch, self.clip, self.sync, zero, self._params)
 
     def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
@@ -247,9 +250,6 @@ class GraphedTrainStep:
             src = batch[k]
             if src.data_ptr() != dst.data_ptr():
                 dst.copy_(src, non_blocking=True)
-        if self.tables is not None:
-            for k, v in camera_tables(self.net.cfg.cas, self.static).items():
-                self.tables[k].copy_(v)
         self.graph.replay()
         self.net.invalidate_packed()                       # the inference weight images are stale after every update
         return self.loss

@@ -36,6 +36,10 @@ def test_plain_gpus2_invocation_self_spawns_two_ranks():
     # whole-job aggregate: 2 ranks x 3 frames over the slowest rank's time
     assert abs(d["value"] - 2 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-6
     assert d["config"]["distinct_batches"] == 4
+    # every rank is pinned to its own cores (frame_parallel.pin_rank_to_cores) and the line says which
+    aff = [r["affinity"] for r in d["rank_devices"]]
+    assert len(aff) == 2 and all(a and a["n"] >= 1 and a["cores"] for a in aff), aff
+    assert aff[0]["cores"] != aff[1]["cores"]
 
 
 def test_single_rank_emu_line_and_refusal_of_mismatched_world():

@@ -86,3 +86,13 @@ def test_io_entries_reject_bad_arguments(lib):
     with pytest.raises(EnerfError, match="contiguous float32"):
         lib.gather_fwd(torch.zeros(1, 4, 3, dtype=torch.float64), torch.zeros(1, 4), torch.zeros(1, 4, 2),
                        torch.zeros(1, 2, 4, 4, 11), torch.zeros(1, 2, 4, 4, 8), torch.zeros(1, 2, 16), torch.zeros(1, 4))
+
+
+def test_feature_volume_rejects_shapes_beyond_its_grid_decomposition(lib):
+    """the warp kernel carries (b, d) in gridDim.z and forms voxel indices with 24-bit multiplies; B*D > 65535 planes
+    (or B*D*h >= 2^23 rows) must be refused by the C entry, not launched."""
+    f = torch.zeros(1, 2, 4, 4, 8)
+    proj, dv, vol = torch.zeros(1, 2, 3, 4), torch.zeros(4), torch.zeros(4)
+    rc = lib.dll.enerf_build_feature_volume(f.data_ptr(), proj.data_ptr(), dv.data_ptr(), 1, 2, 8, 4, 4, 70000, 1, 1,
+                                            vol.data_ptr(), None)
+    assert rc != 0 and "grid-carried" in _msg(lib)

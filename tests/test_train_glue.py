@@ -1,12 +1,12 @@
 """ABI v7 (train_glue.hip): the parts of the training step that were eager PyTorch ops until round 3, each against its torch
-twin — the very expressions enerf_amd/train_path.py ran before (which restate utils.py:98-151, 390-441; feature_net.py:11,14).
+twin (tests/torch_twins.py) — the very expressions enerf_amd/train_path.py ran before round 4 (which restate utils.py:98-151, 390-441; feature_net.py:11,14).
 CPU: the kernel sources on the lane emulator.  GPU (-m gpu): the product library."""
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from enerf_amd import train_path as TP
+import torch_twins as TP
 from enerf_amd.config import EnerfConfig
 
 
@@ -110,7 +110,7 @@ def _check_ray_samples(lib, dev):
 
 
 def _check_camera_tables_and_layout(lib, dev):
-    from enerf_amd.autograd import gather_cameras_torch
+    from torch_twins import gather_cameras as gather_cameras_torch
     from enerf_amd.synth import make_batch
     cfg = EnerfConfig()
     b = {k: torch.from_numpy(v) for k, v in make_batch(32, 64, 3, cfg, seed=5, B=2).items()}
@@ -153,7 +153,7 @@ def _check_gather_bwd_tiled(lib, dev):
     tests/test_training.py): partial tiles in both directions, the one-patch-per-sample-index form of the coarse level, taps that
     do not fit a patch (random depths: the projections of a tile cover the whole source image), and a WRONG hint (permuted
     points) — all the same sums."""
-    from enerf_amd.autograd import gather_cameras_torch
+    from torch_twins import gather_cameras as gather_cameras_torch
     from enerf_amd.synth import make_batch
     g = torch.Generator().manual_seed(9)
     for Hr, Wr, Ns, Fc, wild, permute in ((20, 44, 2, 11, False, False), (12, 40, 4, 35, False, False), (9, 35, 2, 11, True, False),
@@ -195,7 +195,7 @@ def _check_round4_kernel_pairs(lib, dev):
     * enerf_channel_sums with scratch (partial rows + finish launch) and without (fp64 atomics): the same sums up to the fp64
       summation order, for every channel width, ragged position counts, all three input forms;
     * the wave-per-64-points gather forward on point counts that are not a multiple of 64 and straddle batch elements."""
-    from enerf_amd.autograd import gather_cameras_torch
+    from torch_twins import gather_cameras as gather_cameras_torch
     from enerf_amd.synth import make_batch
     g = torch.Generator().manual_seed(21)
     # ---- warp: D = 6 (two planes per wave) vs its first five planes as a D = 5 volume (one plane per wave) ----

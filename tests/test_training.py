@@ -103,10 +103,28 @@ def _loss(out, batch):                                # losses/enerf.py:21-24
     return sum(LOSS_W[i] * F.mse_loss(batch[f"rgb_{i}"], out[f"rgb_level{i}"]) for i in range(2))
 
 
-def _net(cfg):
+def _net(cfg, twins=False):
+    """twins=True: every stage of the training forward through its torch-op twin (tests/torch_twins.py) — the reference's own
+    ops on CPU tensors; the product path has no eager fallback and raises without the library."""
     net = Network(cfg)
     net.load_state_dict(load_weights(), strict=False)
+    if twins:
+        import torch_twins
+        torch_twins.install(net)
     return net.train()
+
+
+def test_training_forward_without_the_library_raises():
+    """no eager fallback in the product — CPU tensors and no injected emulator library = an error naming the
+    first stage, not a silent PyTorch forward; the torch twins are test infrastructure (tests/torch_twins.py)."""
+    cfg, batch = _train_batch()
+    net = _net(cfg)
+    with pytest.raises(RuntimeError, match="HIP library is required"):
+        net(batch)
+    import enerf_amd.train_path as TP
+    for name in ("depth_values", "proj_mats", "feature_volume", "depth_regression", "build_rays", "sample_along_depth", "img_feat",
+                 "raw2outputs", "agg_forward", "nerf_forward"):
+        assert not hasattr(TP, name), f"torch twin {name} is back in the product package"
 
 
 @pytest.mark.parametrize("case", list(TRAIN_CASES))
@@ -117,7 +135,7 @@ def test_training_step_matches_reference_gradients(case):
     for i in range(2):
         assert np.array_equal(batch[f"rgb_{i}"].numpy(), g[f"in/rgb_{i}"])
     torch.set_num_threads(1)
-    net = _net(cfg)
+    net = _net(cfg, twins=True)
     out = net(batch)
     loss = _loss(out, batch)
     assert float(loss) == pytest.approx(float(g["loss"]), rel=1e-5)
@@ -173,39 +191,30 @@ def test_mid_size_step_is_ill_conditioned_in_the_reference():
     reference's ops; bit-identical forward) are not reproducible beyond ~1e-3 at this size.  A 1e-6 relative perturbation of the
     cost volume — smaller than the difference between two fp32 summation orders of the warp — moves some parameter gradients
     by more than 1e-3 of their largest element."""
-    from enerf_amd import train_path as T
+    import torch_twins as T
     g = np.load(os.path.join(GOLDEN, "train_small.npz"))
     cfg, batch = _train_batch(**TRAIN_CASES["train_small"])
     gen = torch.Generator().manual_seed(0)
-    orig = T.feature_volume
-    T.feature_volume = lambda f, P, dv: (lambda v: v * (1 + 1e-6 * (torch.rand(v.shape, generator=gen) * 2 - 1)))(orig(f, P, dv))
-    try:
-        net = _net(cfg)
-        _loss(net(batch), batch).backward()
-    finally:
-        T.feature_volume = orig
+    net = _net(cfg, twins=True)
+    T.install(net, feature_volume=lambda f, P, dv: (lambda v: v * (1 + 1e-6 * (torch.rand(v.shape, generator=gen) * 2 - 1)))(T.feature_volume(f, P, dv)))
+    _loss(net(batch), batch).backward()
     errs = _grad_errors([(n, p.grad) for n, p in net.named_parameters() if p.grad is not None], g)
     assert max(errs.values()) > 1e-3, max(errs.values())          # (measured 7e-3; with 1 vs 8 CPU threads alone: 1.8e-3)
     assert max(errs.values()) < 1.5e-1                             # (the element-wise bound round 3 needed at this size)
     # the same with the FeatureNet's three output maps perturbed by 1e-5 relative (two fp32 summation orders of its convolutions
     # differ by that much): the reference's own gradients move by > 1e-2 somewhere (measured: worst 1.0e-1, median 4.4e-3)
-    orig_fn = T.feature_net_forward
     gen2 = torch.Generator().manual_seed(0)
-    T.feature_net_forward = lambda m, x, lib=None, hip=True: tuple(
-        v * (1 + 1e-5 * (torch.rand(v.shape, generator=gen2) * 2 - 1)) for v in orig_fn(m, x, lib, hip))
-    try:
-        net = _net(cfg)
-        _loss(net(batch), batch).backward()
-    finally:
-        T.feature_net_forward = orig_fn
+    net = _net(cfg, twins=True)
+    T.install(net, feature_net=lambda m, x: tuple(v * (1 + 1e-5 * (torch.rand(v.shape, generator=gen2) * 2 - 1)) for v in T.feature_net_forward(m, x)))
+    _loss(net(batch), batch).backward()
     errs = _grad_errors([(n, p.grad) for n, p in net.named_parameters() if p.grad is not None], g)
     assert max(errs.values()) > 1e-2, max(errs.values())
 
 
 def _check_hip_backward_stages(lib, dev):
     """Every autograd.Function of enerf_amd/autograd.py (HIP forward + HIP backward through the C ABI) against the same
-    stage in torch ops (enerf_amd/train_path.py), values and gradients."""
-    from enerf_amd import train_path as T
+    stage in torch ops (tests/torch_twins.py), values and gradients."""
+    import torch_twins as T
     from enerf_amd.autograd import CompositeFn, DepthRegressionFn, FeatureVolumeFn
     cfg, batch = _train_batch()
     batch = {k: v.to(dev) for k, v in batch.items()}
@@ -275,7 +284,8 @@ def _check_hip_backward_stages(lib, dev):
 
     # --- render-side fetches: get_img_feat + get_vox_feat (points in front of the cameras, some outside the images);
     #     two batch elements with different camera rigs ---
-    from enerf_amd.autograd import GatherFn, gather_cameras
+    from enerf_amd.autograd import GatherFn
+    gather_cameras = T.gather_cameras
     _, batch_b = _train_batch(seed=11)
     batch1 = batch
     batch = {k: torch.cat([v, batch_b[k].to(dev)], 0) for k, v in batch1.items()}
@@ -375,7 +385,7 @@ def _check_feature_net_train(lib, dev, H=32, W=64, n=3, tol=2e-4):
     result as the fp32 module path is (3x slack)."""
     from enerf_amd.autograd import feature_net_train
     from enerf_amd.network import FeatureNet
-    from enerf_amd.train_path import feature_net_forward
+    from torch_twins import feature_net_forward
     torch.manual_seed(5)
     # the upsampling adjoint on its own: enerf_up2_adjoint vs autograd through F.interpolate(2x, bilinear, align_corners)
     c = torch.randn(2, 16, H // 4, W // 4, device=dev, requires_grad=True)
@@ -399,7 +409,7 @@ def _check_feature_net_train(lib, dev, H=32, W=64, n=3, tol=2e-4):
     gen = torch.Generator().manual_seed(6)
     outs = []
     for i, net in enumerate(nets):                       # 0: HIP fp32, 1: modules fp32, 2: modules fp64
-        o = feature_net_train(lib, net, x) if i == 0 else feature_net_forward(net, x.double() if i == 2 else x, None)
+        o = feature_net_train(lib, net, x) if i == 0 else feature_net_forward(net, x.double() if i == 2 else x)
         if not outs:
             wts = [torch.randn(t.shape, generator=gen).to(dev) for t in o]
         sum((t * w_.to(t.dtype)).sum() for t, w_ in zip(o, wts)).backward()
@@ -518,7 +528,7 @@ def test_training_step_with_hip_stages_matches_reference_gradients():
     net.train()
     from enerf_amd import train_path as T
     from enerf_amd import autograd as AG
-    assert T._hip_lib(net, batch["src_inps"]) is not None
+    assert T._hip_lib(net, batch["src_inps"]) is not None and not getattr(net, "_stage_twins", None)
     calls = {"cost_reg": 0, "conv": 0, "feature_net": 0}
     orig_cr, orig_conv, orig_fn = AG.cost_reg_train, AG.conv_module, AG.feature_net_train
     AG.cost_reg_train = lambda *a: (calls.__setitem__("cost_reg", calls["cost_reg"] + 1), orig_cr(*a))[1]
@@ -586,7 +596,7 @@ def _ddp_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from torch.nn.parallel import DistributedDataParallel as DDP
     cfg, batch = _train_batch(seed=20 + rank)                          # DistributedSampler: a different sample per rank
-    net = DDP(_net(cfg), find_unused_parameters=True)                  # trainer.py:17-22
+    net = DDP(_net(cfg, twins=True), find_unused_parameters=True)      # trainer.py:17-22
     loss = _loss(net(batch), batch)
     loss.backward()                                                    # gradient all-reduce (RCCL on GPUs, gloo here)
     grads = {n: p.grad.clone() for n, p in net.module.named_parameters() if p.grad is not None}
@@ -650,7 +660,7 @@ def test_two_rank_syncbn_on_hip_training_path_equals_one_process_with_batch_two(
         assert not isinstance(r[1], str), r[1]
     torch.set_num_threads(1)
     cfg, full, _ = _batch2()
-    net = _net(cfg)                                                    # torch-op path, plain BatchNorm, B = 2
+    net = _net(cfg, twins=True)                                        # torch-op twins, plain BatchNorm, B = 2
     _loss(net(full), full).backward()
     ref = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
     checked = 0
@@ -681,7 +691,7 @@ def test_two_rank_ddp_gradients_equal_mean_of_single_process_gradients():
     single = []
     for rank in range(2):
         cfg, batch = _train_batch(seed=20 + rank)
-        net = _net(cfg)
+        net = _net(cfg, twins=True)
         loss = _loss(net(batch), batch)
         loss.backward()
         assert float(loss) == pytest.approx(res[rank][1], rel=1e-5)
@@ -700,7 +710,7 @@ def _flat_sync_worker(rank, world, port, q):
         from torch.nn.parallel import DistributedDataParallel as DDP
         from enerf_amd.train_graph import FlatGradSync, train_step
         cfg, batch = _train_batch(seed=40 + rank)                          # a different sample per rank
-        nets = [_net(cfg), _net(cfg)]
+        nets = [_net(cfg, twins=True), _net(cfg, twins=True)]
         with torch.no_grad():                                              # rank 1 starts from DIFFERENT weights: both schemes
             if rank == 1:                                                  # must begin by adopting rank 0's
                 for net in nets:
@@ -820,7 +830,8 @@ def test_cost_reg_training_stage_equals_its_float64_twin_on_the_steps_own_tensor
     stage (MFMA convolutions / dgrad / wgrad, BatchNorm-train kernels) must match it to 2e-5 of its largest element — measured
     6e-7 median / 2e-6 worst, the same as the stage's torch fp32 twin on the CPU (tools/diag_cost_reg_fp64.py)."""
     import copy
-    from enerf_amd import autograd as A, train_path as T
+    import torch_twins
+    from enerf_amd import autograd as A
     dev = torch.device("cuda:0")
     cfg, batch = _train_batch(**TRAIN_CASES["train_small"])
     batch = {k: v.to(dev) for k, v in batch.items()}
@@ -845,7 +856,7 @@ def test_cost_reg_training_stage_equals_its_float64_twin_on_the_steps_own_tensor
         m64 = copy.deepcopy(m).cpu().double().train()
         for p in m64.parameters():
             p.grad = None
-        feat, prob = T.cost_reg_forward(m64, cap[i]["vol"].cpu().double())
+        feat, prob = torch_twins.cost_reg_forward(m64, cap[i]["vol"].cpu().double())
         torch.autograd.backward([feat, prob], [cap[i]["g_feat"].cpu().double(), cap[i]["g_prob"].cpu().double()])
         worst = 0.0
         for (n, p), (_, p64) in zip(m.named_parameters(), m64.named_parameters()):
@@ -1046,7 +1057,7 @@ def test_graphed_data_parallel_step_captures_its_collectives():
 def _check_mlp_backward(lib, dev):
     """enerf_nerf_mlp_bwd + enerf_gemm_wgrad (NerfMlpFn) against torch autograd through the module's own layers, for both
     MLP widths (F = 11: level 1, F = 35: level 0) and S = 2, 3, 4 views; ragged point counts."""
-    from enerf_amd import train_path as T
+    import torch_twins as T
     from enerf_amd.autograd import nerf_mlp
     from enerf_amd.network import NerfParams
     g = torch.Generator().manual_seed(11)
@@ -1067,7 +1078,7 @@ def _check_mlp_backward(lib, dev):
         for p in m.parameters():
             p.grad = None
         vox.grad = x.grad = None
-        out = nerf_mlp(lib, m, T.nerf_forward, vox, x)
+        out = nerf_mlp(lib, m, None, vox, x)
         assert float((out - ref.detach()).abs().max()) <= 2e-5 * float(ref.abs().max())       # HIP forward (enerf_nerf_mlp_fwd)
         out.backward(gout)
         tol = lambda r: 5e-4 * float(r.abs().max()) + 1e-6

@@ -1,6 +1,7 @@
 import sys, os, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-from enerf_amd import train_path as T
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import torch_twins as T
 from enerf_amd.autograd import nerf_mlp
 from enerf_amd.network import NerfParams
 from enerf_amd.lib import get_lib

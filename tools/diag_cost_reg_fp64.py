@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from test_training import FULL_TRAIN_CASE, TRAIN_CASES, _loss, _net, _train_batch  # noqa: E402
-from enerf_amd import autograd as A, train_path as T  # noqa: E402
+from enerf_amd import autograd as A  # noqa: E402
+import torch_twins as T  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "small"
 kw = FULL_TRAIN_CASE if which == "full" else TRAIN_CASES["train_small"]

@@ -1,6 +1,6 @@
 """GPU diagnostic: which HIP training stage moves the gradients away from the float64 reference step?  For the 128x160 (and
 optionally the 512x640) fixture: the fp64 arbitration statistics (tests/test_training.py) with every HIP stage on, and with
-one stage at a time routed through its torch-op twin.   usage: python tools/diag_fp64_arbitration.py [small|full] ..."""
+one stage at a time routed through its torch-op twin (tests/torch_twins.py).   usage: python tools/diag_fp64_arbitration.py [small|full] ..."""
 import os
 import sys
 
@@ -12,8 +12,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from test_training import (FULL_TRAIN_CASE, GOLDEN, TRAIN_CASES, _distance_to_fp64, _loss, _net, _train_batch)  # noqa: E402
 
-TOGGLES = ["hip_geometry", "hip_gather", "hip_mlp_backward", "hip_cost_reg_train", "hip_feature_net_train", "hip_volume",
-           "hip_depth_regression", "hip_composite"]
+import torch_twins  # noqa: E402  (tests/torch_twins.py: the torch-op twins of the stages, test infrastructure)
+
+# a stage name routes that stage through its torch twin (torch_twins.install); "all" = every stage: PyTorch-ROCm end to end
+TOGGLES = ["depth_values", "rays", "gather", "mlp", "cost_reg", "feature_net", "feature_volume", "depth_regression", "composite"]
 
 
 def run(case, sparse, off):
@@ -24,8 +26,8 @@ def run(case, sparse, off):
     cfg, batch = _train_batch(**kw)
     batch = {k: v.to(dev) for k, v in batch.items()}
     net = _net(cfg).to(dev)
-    for t in off:
-        setattr(net, t, False)
+    if off:
+        torch_twins.install(net, *([] if "all" in off else off))
     _loss(net(batch), batch).backward()
     dist = _distance_to_fp64([(n, p.grad) for n, p in net.named_parameters() if p.grad is not None], g32, g64, sparse=sparse)
     ours = np.array([d[0] for d in dist.values()]); ref = np.array([d[1] for d in dist.values()])
@@ -52,4 +54,4 @@ if __name__ == "__main__":
         for t in TOGGLES:
             run("train_small", sparse, [t])
         run("train_small", sparse, TOGGLES)                 # every stage on torch ops (MIOpen etc.); conv weight gradients still HIP
-        run("train_small", sparse, ["hip_backward"])        # no library at all: PyTorch-ROCm end to end
+        run("train_small", sparse, ["all"])                 # every stage through its torch twin: PyTorch-ROCm end to end
