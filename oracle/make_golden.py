@@ -372,6 +372,108 @@ def run_train_case(case: str = "train_tiny") -> None:
           f"on {c.get('threads', 1)} thread(s), {'float64' if c.get('fp64') else 'float32'}")
 
 
+# Multi-step training trajectories: N optimizer steps of the reference's trainer loop on a fixed SEQUENCE of
+# batches (a different sample per step, like the data loader's), at two sizes.
+TRAJ_CASES = {"train_traj_tiny": dict(H=32, W=64, S=3, planes=(8, 8), render_if=(True, True), seed=50, steps=10, loss_weight=(0.1, 1.0)),
+              "train_traj_small": dict(H=64, W=96, S=3, planes=(16, 8), render_if=(True, True), seed=70, steps=10, loss_weight=(0.1, 1.0))}
+
+
+def traj_batch(c: dict, ecfg, step: int) -> dict:
+    """Batch `step` of a trajectory case (numpy): seed = case seed + step; target colours for both levels."""
+    from enerf_amd.synth import make_batch
+    b = make_batch(c["H"], c["W"], c["S"], ecfg, seed=c["seed"] + step, textured=True)
+    rng = np.random.default_rng(c["seed"] + step)
+    for i in range(2):
+        b[f"rgb_{i}"] = rng.uniform(0, 1, size=(1, b[f"rays_{i}"].shape[1], 3)).astype(np.float32)
+    return b
+
+
+def run_traj_case(case: str) -> None:
+    """`steps` iterations of the UNMODIFIED reference's training loop (lib/train/trainers/trainer.py:44-63: forward in .train(),
+    loss, optimizer.zero_grad(), backward, clip_grad_value_(40), optimizer.step()) with the optimizer the reference builds
+    (lib/train/optimizer.py make_optimizer: Adam, lr 5e-4, eps 1e-8, weight_decay 0 from dtu_pretrain.yaml) and the MSE part of
+    lib/train/losses/enerf.py:21-24.  Records the loss of every step, the final BatchNorm running statistics, the float64
+    norm of every final parameter, and the eval-mode frame of the FINAL network on a held-out batch."""
+    from oracle.ref_loader import load_reference
+    from enerf_amd.config import EnerfConfig
+
+    c = TRAJ_CASES[case]
+    opts = ["enerf.cas_config.volume_planes", ",".join(map(str, c["planes"])),
+            "enerf.cas_config.render_if", ",".join(map(str, c["render_if"]))]
+    cfg, ref_network = load_reference("configs/enerf/dtu_pretrain.yaml", opts)
+    # the reference's own optimizer factory, loaded from its FILE: `import lib.train` pulls the trainer, whose data utilities need
+    # imgaug / cv2 (absent here); optimizer.py itself only needs torch and the reference's RAdam
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_train_optimizer", "/root/reference/lib/train/optimizer.py")
+    ref_opt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_opt)
+    make_optimizer = ref_opt.make_optimizer
+    import time
+    torch.set_num_threads(1)
+    ecfg = EnerfConfig.from_yacs(cfg)
+
+    def trajectory(draw: int):
+        """draw 0: the trajectory itself; draw k > 0: the SAME loop with every batch's source images perturbed by one ulp
+        (x (1 +- 6e-8), seeded) — how far the REFERENCE's trajectory moves under a perturbation below its input precision."""
+        torch.manual_seed(0)
+        net = ref_network.Network()
+        net.load_state_dict(seeded_state_dict(net))
+        net.train()
+        optimizer = make_optimizer(cfg, net)
+        assert type(optimizer).__name__ == "Adam" and float(cfg.train.lr) == 5e-4
+        gen = torch.Generator().manual_seed(draw)
+        losses = []
+        for step in range(c["steps"]):
+            batch = {k: torch.from_numpy(v) for k, v in traj_batch(c, ecfg, step).items()}
+            if draw:
+                sign = torch.randint(0, 2, batch["src_inps"].shape, generator=gen).float() * 2 - 1
+                batch["src_inps"] = batch["src_inps"] * (1 + 6e-8 * sign)
+            out = net(batch)
+            loss = sum(c["loss_weight"][i] * torch.nn.functional.mse_loss(batch[f"rgb_{i}"], out[f"rgb_level{i}"]) for i in range(2))
+            optimizer.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_value_(net.parameters(), 40)
+            optimizer.step()
+            losses.append(float(loss.detach()))
+        pn = {name: float(p_.detach().double().norm()) for name, p_ in net.named_parameters()}
+        bufs = {name: buf.numpy().copy() for name, buf in net.named_buffers()
+                if name.endswith("running_mean") or name.endswith("running_var") or name.endswith("num_batches_tracked")}
+        net.eval()
+        with torch.no_grad():
+            held = {k: torch.from_numpy(v) for k, v in traj_batch(c, ecfg, 1000).items()}
+            ev = {k: v.float().numpy() for k, v in net(held).items()}
+        return losses, pn, bufs, ev, optimizer
+
+    t0 = time.perf_counter()
+    losses, pn, bufs, ev, optimizer = trajectory(0)
+    dt = time.perf_counter() - t0
+    save = {"loss": np.array(losses), "meta/steps": np.array(c["steps"]), "meta/reference_cpu_seconds": np.array(dt),
+            "meta/optimizer": np.array(f"{type(optimizer).__name__}(lr={cfg.train.lr}, eps={cfg.train.eps}, weight_decay={cfg.train.weight_decay})"),
+            "meta/torch_version": np.array(torch.__version__)}
+    save.update({f"pnorm/{k}": np.array(v) for k, v in pn.items()})
+    save.update({f"buf/{k}": v for k, v in bufs.items()})
+    save.update({f"eval/{k}": v for k, v in ev.items()})
+    # the reference against ITSELF: per-step loss deviation, final parameter-norm / BatchNorm-statistics / eval-frame deviation of
+    # NOISE_DRAWS one-ulp draws (the yardstick of tests/test_training.py's trajectory criterion)
+    NOISE_DRAWS = 6
+    nl, npn, nbuf, nev = [], [], [], []
+    for k in range(1, NOISE_DRAWS + 1):
+        l2, pn2, b2, ev2, _ = trajectory(k)
+        nl.append([abs(a - b) / b for a, b in zip(l2, losses)])
+        npn.append(max(abs(pn2[n] - pn[n]) / max(pn[n], 1e-6) for n in pn))
+        nbuf.append(max(float(np.abs(b2[n] - bufs[n]).max() / max(np.abs(bufs[n]).max(), 1e-12)) for n in bufs if bufs[n].dtype.kind == "f"))
+        nev.append({kk: float(np.abs(ev2[kk] - ev[kk]).max() / max(np.abs(ev[kk]).max(), 1e-12)) for kk in ev})
+    save["noise/loss_rel"] = np.array(nl)                                  # (draws, steps)
+    save["noise/pnorm_rel"] = np.array(npn)
+    save["noise/buf_rel"] = np.array(nbuf)
+    for kk in ev:
+        save[f"noise/eval/{kk}"] = np.array([d[kk] for d in nev])
+    print(f"[golden] {case}: reference vs itself under 1-ulp inputs: worst loss deviation per step {np.array(nl).max(0).round(6).tolist()}; "
+          f"pnorm {max(npn):.2e}; BN statistics {max(nbuf):.2e}; eval frame {({kk: round(max(d[kk] for d in nev), 5) for kk in ev})}")
+    np.savez_compressed(os.path.join(GOLDEN, f"{case}.npz"), **save)
+    print(f"[golden] {case}: {c['steps']} steps in {dt:.1f} s; loss {losses[0]:.6f} -> {losses[-1]:.6f}: {[round(l, 6) for l in losses]}")
+
+
 NOISE_CASES = {"train_small_noise": dict(base="train_small", draws=8, threads=1), "train_full_noise": dict(base="train_full", draws=6, threads=8)}
 
 
@@ -449,6 +551,9 @@ def main() -> None:
     if a.case in TRAIN_CASES:
         run_train_case(a.case)
         return
+    if a.case in TRAJ_CASES:
+        run_traj_case(a.case)
+        return
     if a.case in FULL_CASES:
         run_full_case(a.case)
         return
@@ -458,7 +563,7 @@ def main() -> None:
     wpath = os.path.join(GOLDEN, "weights_seed0.npz")
     if os.path.exists(wpath):
         os.remove(wpath)
-    for name in list(CASES) + list(TRAIN_CASES) + list(FULL_CASES) + list(NOISE_CASES):
+    for name in list(CASES) + list(TRAIN_CASES) + list(TRAJ_CASES) + list(FULL_CASES) + list(NOISE_CASES):
         subprocess.run([sys.executable, os.path.abspath(__file__), "--case", name], check=True, cwd=ROOT)
 
 
