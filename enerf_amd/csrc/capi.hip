@@ -423,8 +423,10 @@ int enerf_feature_net_stage(const float* packed, const float* src_inps, int n_im
         }
     }
     if (lvl1) {
-        rc |= launch_conv2d(d[7], c1, f1pre, feat_l0, n_img, H1, W1, H2, W2, st);      // up2(feat2) + lat1(conv1)
-        rc |= launch_conv2d(d[9], f1pre, feat_l1, nullptr, n_img, H1, W1, 0, 0, st);   // smooth1   -> level_1
+        if (opt.featnet_unfused || !launch_smooth1_fused(d[7], d[9], c1, feat_l0, f1pre, feat_l1, n_img, H1, W1, st)) {
+            rc |= launch_conv2d(d[7], c1, f1pre, feat_l0, n_img, H1, W1, H2, W2, st);      // up2(feat2) + lat1(conv1)
+            rc |= launch_conv2d(d[9], f1pre, feat_l1, nullptr, n_img, H1, W1, 0, 0, st);   // smooth1   -> level_1
+        }
     }
     if (lvl2) {
         d[10].out_stride = l2_stride;

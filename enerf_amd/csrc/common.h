@@ -68,6 +68,7 @@ __device__ __forceinline__ void glds16(const float* src, float* dst_wave_base, i
     for (int k = 0; k < 4; ++k) dst_wave_base[lane * 4 + k] = src[k];
 }
 __device__ __forceinline__ void glds_wait_all() {}
+template <int N> __device__ __forceinline__ void vmem_wait_pending() {}
 __device__ __forceinline__ void block_barrier_raw() { __syncthreads(); }
 #else
 __device__ __forceinline__ void glds16(const float* src, float* dst_wave_base, int lane) {
@@ -76,6 +77,9 @@ __device__ __forceinline__ void glds16(const float* src, float* dst_wave_base, i
                                      (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
 }
 __device__ __forceinline__ void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most N of this wave's vector-memory operations are outstanding: loads (LDS-DMA copies included) retire in issue
+// order, so with exactly N younger loads behind a copy this is "the copy has landed" without draining the younger loads
+template <int N> __device__ __forceinline__ void vmem_wait_pending() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void block_barrier_raw() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

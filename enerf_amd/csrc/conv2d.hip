@@ -1359,6 +1359,201 @@ __global__ __launch_bounds__(256, ENERF_S0_CB_BLOCKS) void k_smooth0_cb(
 }
 
 
+// =====================================================================================================================
+// smooth1( up2(f2) + lat1(c1) )  — feature_net.py:33-34 — in ONE kernel (round 5, VERDICT r04 #1a).
+// Unfused, the lateral kernel writes the 32-channel half-resolution FPN sum f1pre (31.5 MB at dtu, 134 MB at zju) and smooth1
+// reads it back with halos; on zju the top-down half IS the frame's critical path (FeatureNet 0.88 of 1.85 ms).  Here a block
+// rebuilds its haloed 10 x 34 tile of f1pre in LDS — lat1 (1x1, 16 -> 32) on the matrix cores from the c1 values the lanes hold
+// in registers, plus the align-corners x2 blend of the f2 patch that arrives by LDS-DMA — 16 channels per pass, runs the 3x3
+// 32 -> 16 convolution from there on 16x16x4 MFMAs, and stores the tile's INTERIOR of f1pre on the way (the fused smooth0
+// kernel consumes it).  One launch and the halo'd read-back of f1pre go away.  Structure = k_smooth0_cb's.
+// lat_w / sm_w: the layers' ordinary operand images (k_conv2d_pack): lat1 [ks 0..3][rt 0..1][64], smooth1 [tap][ks 0..7][64].
+// =====================================================================================================================
+#ifndef ENERF_S1F_BLOCKS
+#define ENERF_S1F_BLOCKS 4
+#endif
+__global__ __launch_bounds__(256, ENERF_S1F_BLOCKS) void k_smooth1_fused(const float* __restrict__ sm_w, const float* __restrict__ sm_scale,
+                                                          const float* __restrict__ sm_shift, const float* __restrict__ lat_w,
+                                                          const float* __restrict__ lat_shift, const float* __restrict__ c1,
+                                                          const float* __restrict__ f2, float* __restrict__ f1pre,
+                                                          float* __restrict__ out, int N, int H, int W, int tiles_y, int tiles_x) {
+    constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, NPX = IH * IW;             // 10 x 34 halo tile (half resolution)
+    constexpr int PH = 7, PW = 20, NPP = PH * PW;                                       // f2 patch (quarter resolution)
+    constexpr int NPCH = (NPP * 4 + 63) / 64;
+    constexpr int NT16 = (NPX + 15) / 16, NBI = (NT16 + 3) / 4;                         // build items (16 px x 16 ch): 22, <= 6 per wave
+    constexpr int CTW = 4;
+    ENERF_DYN_SMEM(float, lds);
+    float* pat = lds;                       // [NPCH * 64] float4: [patch pixel][16 channels of the pass], DMA destination
+    float* til = pat + NPCH * 256;          // [4 quads][NPX] float4 planes (16 channels of the current pass)
+    float* tabs = til + 4 * NPX * 4;        // bilinear tables of the x2 upsample (see k_smooth0_b4)
+
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+    const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int H2 = H / 2, W2 = W / 2;                                                   // (H, W: the half-resolution extent)
+    const float sy = ac_scale(H2, H), sx = ac_scale(W2, W);
+    const int py0 = (int)(sy * (float)max(iy0, 0)), px0 = (int)(sx * (float)max(ix0, 0));
+
+    // ---- requested before the first wait: pass 0's operands (lat1 + smooth1 weights), the lanes' c1 values, the f2 patch ----
+    // One register set for the per-pass operands (41 loads); pass 1's are requested behind pass 0's last MFMA and land during
+    // pass 1's build.  (A second set — and the ring / index registers given up below — cost the kernel its FOURTH wave per SIMD:
+    // dtu's 960 tiles are then co-resident in one round, 4 x 256 slots, instead of 768 + a quarter-filled second round.)
+    float a_lat[4];                                                   // lat1 A operands of the pass (row tile = pass): [k-step]
+    float4 bias4;
+    float aq[36];                                                     // smooth1 A operands of the pass: [tap][r]
+    auto load_pass_operands = [&](int cb) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) a_lat[ks] = lat_w[(ks * 2 + cb) * 64 + lane];
+        bias4 = *reinterpret_cast<const float4*>(lat_shift + cb * 16 + 4 * g);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) aq[t * 4 + r] = sm_w[(t * 8 + cb * 4 + r) * 64 + lane];
+    };
+    load_pass_operands(0);
+    f32x4 cvr[NBI];                                                   // c1 channels 4g..4g+3 of this lane's build pixels (both passes)
+#pragma unroll
+    for (int it = 0; it < NBI; ++it) {
+        const int t = wv + 4 * it;
+        cvr[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < NT16) {                                               // wave-uniform
+            const int px = t * 16 + j, pxc = px < NPX ? px : NPX - 1;
+            const int ly = (pxc * 241) >> 13, lx = pxc - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const long long off = ok ? ((long long)n * H + gy) * W + gx : 0;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(c1 + off * 16 + 4 * g);
+            if (ok) cvr[it] = v;
+        }
+    }
+    unsigned psrc[(NPCH + 3) / 4];
+#pragma unroll
+    for (int k = 0; k < (NPCH + 3) / 4; ++k) {
+        const int i = (wv + 4 * k) * 64 + lane, ic = i < NPP * 4 ? i : NPP * 4 - 1;
+        const int pp = ic >> 2, q = ic & 3, pr = pp / PW, pc = pp - pr * PW;
+        const int gy = min(py0 + pr, H2 - 1), gx = min(px0 + pc, W2 - 1);
+        psrc[k] = (unsigned)((((long long)n * H2 + gy) * W2 + gx) * 32 + q * 4);
+    }
+    auto issue_pat = [&](int cb) {
+#pragma unroll
+        for (int k = 0; k < (NPCH + 3) / 4; ++k)
+            if (wv + 4 * k < NPCH) glds16(f2 + psrc[k] + cb * 16, pat + (wv + 4 * k) * 256, lane);
+    };
+    issue_pat(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < IH + IW) {                                              // upsample tables, once per block (see k_smooth0_b4)
+        const bool isrow = tid < IH;
+        const int k = isrow ? tid : tid - IH, gq = (isrow ? iy0 : ix0) + k, lim = isrow ? H : W;
+        const Lerp1 v = ac_lerp(min(max(gq, 0), lim - 1), isrow ? sy : sx, isrow ? H2 : W2);
+        const int unit = isrow ? PW * 16 : 16, org = isrow ? py0 : px0;
+        const bool ok = gq >= 0 && gq < lim;
+        float4 e;
+        e.x = __int_as_float(ok ? (v.i0 - org) * unit : -1);
+        e.y = __int_as_float(ok ? (v.i1 - org) * unit : -1);
+        e.z = v.l0; e.w = v.l1;
+        *reinterpret_cast<float4*>(tabs + tid * 4) = e;
+    }
+    f32x4 acc[CTW];
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    glds_wait_all();
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        // ---- build f1pre's tile for this pass: lat1 on the matrix cores + bilinear x2 of the f2 patch; interior -> global ----
+#pragma unroll
+        for (int it = 0; it < NBI; ++it) {
+            const int t = wv + 4 * it;
+            if (t < NT16) {                                           // wave-uniform
+                const int px = t * 16 + j, pxc = px < NPX ? px : NPX - 1;
+                const int ly = (pxc * 241) >> 13, lx = pxc - ly * IW;
+                const float4 rt = *reinterpret_cast<const float4*>(tabs + ly * 4);
+                const float4 ct = *reinterpret_cast<const float4*>(tabs + (IH + lx) * 4);
+                const int ro0 = __float_as_int(rt.x), ro1 = __float_as_int(rt.y), co0 = __float_as_int(ct.x), co1 = __float_as_int(ct.y);
+                const bool inside = (ro0 | co0) >= 0;
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat[ks], cvr[it][ks], a, 0, 0, 0);
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (inside) {
+                    Lerp1 vy, vx;
+                    vy.l0 = rt.z; vy.l1 = rt.w; vx.l0 = ct.z; vx.l1 = ct.w; vy.i0 = vy.i1 = vx.i0 = vx.i1 = 0;
+                    const float* pb = pat + g * 4;
+                    const float4 u00 = *reinterpret_cast<const float4*>(pb + ro0 + co0), u01 = *reinterpret_cast<const float4*>(pb + ro0 + co1);
+                    const float4 u10 = *reinterpret_cast<const float4*>(pb + ro1 + co0), u11 = *reinterpret_cast<const float4*>(pb + ro1 + co1);
+                    // (the unfused kernel's order: lat1's epilogue computes y = acc * 1 + bias, then blend + y: conv2d.hip k_conv2d)
+                    o.x = ac_blend(vy, vx, u00.x, u01.x, u10.x, u11.x) + (a[0] * 1.f + bias4.x);
+                    o.y = ac_blend(vy, vx, u00.y, u01.y, u10.y, u11.y) + (a[1] * 1.f + bias4.y);
+                    o.z = ac_blend(vy, vx, u00.z, u01.z, u10.z, u11.z) + (a[2] * 1.f + bias4.z);
+                    o.w = ac_blend(vy, vx, u00.w, u01.w, u10.w, u11.w) + (a[3] * 1.f + bias4.w);
+                }
+                if (px < NPX) *reinterpret_cast<float4*>(til + (g * NPX + px) * 4) = o;
+                if (inside && px < NPX && ly >= 1 && ly <= TH && lx >= 1 && lx <= TW)      // the tile's interior -> f1pre (smooth0 reads it)
+                    *reinterpret_cast<float4*>(f1pre + (((long long)n * H + iy0 + ly) * W + ix0 + lx) * 32 + cb * 16 + 4 * g) = o;
+            }
+        }
+        __syncthreads();                                              // tile complete; nobody reads the patch any more
+        if (cb == 0) {                                                // pass 1's patch travels during pass 0's MFMAs
+            issue_pat(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- 3x3 conv over the pass's 16 channels on 16x16x4 MFMAs (no operand ring: four waves per SIMD cover the LDS latency) ----
+        auto read_b = [&](int tap, f32x4 (&bv)[CTW]) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+            for (int c = 0; c < CTW; ++c) {
+                const int ct = wv * CTW + c, tr = ct >> 1, tc = ct & 1;
+                bv[c] = *reinterpret_cast<const f32x4*>(til + (g * NPX + (tr + kh) * IW + tc * 16 + j + kw) * 4);
+            }
+        };
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            f32x4 bq[CTW];
+            read_b(tap, bq);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < CTW; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[tap * 4 + r], bq[c][r], acc[c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (cb == 0) {
+            // pass 1's operands into the SAME registers: requested behind pass 0's last MFMA, they land during pass 1's build phase
+            load_pass_operands(1);
+            __builtin_amdgcn_sched_barrier(0);
+            vmem_wait_pending<41>();                                  // the patch copy (issued before these 41 loads) has landed
+            block_barrier_raw();                                      // bare s_barrier: the 36 loads stay in flight across it
+        }
+    }
+    // ---- epilogue: bias (scale = 1), channels-last store: lane (g, j) owns channels 4g..4g+3 of its pixel ----
+    const float4 sc = *reinterpret_cast<const float4*>(sm_scale + 4 * g), sh = *reinterpret_cast<const float4*>(sm_shift + 4 * g);
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+        const int ct = wv * CTW + c, tr = ct >> 1, tc = ct & 1;
+        const int oy = oy0 + tr, ox = ox0 + tc * 16 + j;
+        if (oy >= H || ox >= W) continue;
+        const long long o = ((long long)n * H + oy) * W + ox;
+        *reinterpret_cast<float4*>(out + o * 16 + 4 * g) =
+            make_float4(acc[c][0] * sc.x + sh.x, acc[c][1] * sc.y + sh.y, acc[c][2] * sc.z + sh.z, acc[c][3] * sc.w + sh.w);
+    }
+}
+
+#ifndef ENERF_SMOOTH1_FUSED
+#define ENERF_SMOOTH1_FUSED 1        // 1: k_smooth1_fused (lat1 + up2 + smooth1 in one launch); 0: two k_conv2d launches
+#endif
+bool launch_smooth1_fused(const Conv2dDesc& Llat, const Conv2dDesc& Lsm, const float* c1, const float* f2, float* f1pre, float* out,
+                          int N, int H1, int W1, hipStream_t st) {
+    if (!ENERF_SMOOTH1_FUSED || Llat.cin != 16 || Llat.cout != 32 || Lsm.cin != 32 || Lsm.cout != 16 || (H1 & 1) || (W1 & 1)) return false;
+    const int tiles_y = cdiv(H1, 8), tiles_x = cdiv(W1, 32);
+    const size_t shmem = (size_t)(9 * 256 + 4 * 340 * 4 + 44 * 4) * sizeof(float);
+    ENERF_LAUNCH(k_smooth1_fused, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, Lsm.w, Lsm.scale, Lsm.shift, Llat.w, Llat.shift, c1,
+                 f2, f1pre, out, N, H1, W1, tiles_y, tiles_x);
+    return true;
+}
+
 #ifndef ENERF_SMOOTH0_B4
 #define ENERF_SMOOTH0_B4 1
 #endif

@@ -132,6 +132,9 @@ void launch_conv0_fused(const Conv2dDesc& L0, const Conv2dDesc& L1, const float*
                         float* out, int N, int H, int W, hipStream_t st);
 // smooth0(up2(f1pre) + lat0(c0)) fused (feature_net.py:32-35); L = smooth0's descriptor, lat_w/lat_b raw (32,8)/(32)
 // w_pq: the layer's P/Q tap-packed image (launch_conv2d_pq_pack) or nullptr for the plain 8x32 tiling
+// smooth1(up2(f2) + lat1(c1)) fused (feature_net.py:33-34, round 5): writes f1pre (N,H1,W1,32) and out (N,H1,W1,16); false: not applicable
+bool launch_smooth1_fused(const Conv2dDesc& Llat, const Conv2dDesc& Lsm, const float* c1, const float* f2, float* f1pre, float* out,
+                          int N, int H1, int W1, hipStream_t st);
 // w_cb: the layer's broadcast-A image (launch_conv2d_cb_pack; round 5 default kernel) or nullptr
 void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1pre, const float* lat_w, const float* lat_b,
                           const float* w_pq, const float* w_cb, float* out, int N, int H, int W, hipStream_t st);   // w_pq == nullptr: plain tiling

@@ -890,7 +890,9 @@ def test_full_size_training_step_is_as_close_to_fp64_as_the_reference():
     loss = _loss(out, batch)
     assert float(loss) == pytest.approx(float(g32["loss"]), rel=1e-4)
     assert float(g64["loss"]) == pytest.approx(float(g32["loss"]), rel=1e-4)
-    worst = check_sparse_golden("train_full", {k: v.detach() for k, v in out.items()}, 2e-4)
+    # 1e-4 like every eval-mode test (round 4 had widened it to 2e-4; measured 9.3e-5 on rgb_level1, 2.6e-5 and below elsewhere —
+    # train-mode BatchNorm divides by batch statistics over as few as 80 positions, which is where the forward's fp32 noise grows)
+    worst = check_sparse_golden("train_full", {k: v.detach() for k, v in out.items()}, 1e-4)
     loss.backward()
     named = [(n, p.grad) for n, p in net.named_parameters() if p.grad is not None]
     for n, gr in named:                                                # whole-tensor norms against the fp64 run
