@@ -1597,6 +1597,12 @@ int launch_conv2d(const Conv2dDesc& L, const float* in, float* out, const float*
     // 4-row tiles for the 3x3 layers whose 8-row tiling gives fewer than ~4 blocks per CU (quarter/half-resolution maps;
     // measured: smooth1 33.5 -> 30.0 us, conv2.1 18.0 -> 17.1, conv1.1 17.9 -> 17.2).
     const bool th4 = (long long)N * cdiv(Hi, 8) * cdiv(Wi, 32) < 1024;
+#ifndef ENERF_C2_TH2
+#define ENERF_C2_TH2 0               // 1: 2-row tiles for the quarter-resolution layers when 4-row tiles give < 2 blocks per CU (measured SLOWER: conv2.0 24.5 -> 29.1 us, conv2.1 16.7 -> 19.6, profiles/r05_ab_conv2d_planar.txt)
+#endif
+    // conv2.0 / conv2.1 at dtu: 61,440 output pixels = 480 four-row tiles for 256 CUs (< 2 waves per SIMD: a latency chain)
+    const bool th2_s2 = ENERF_C2_TH2 && (long long)N * cdiv((Hi + 1) / 2, 4) * cdiv((Wi + 1) / 2, 32) < 512;   // stride-2 layers: output extent
+    const bool th2 = ENERF_C2_TH2 && (long long)N * cdiv(Hi, 4) * cdiv(Wi, 32) < 512;
     switch (key) {
         case 3 * 10000 + 8 * 100 + 31: launch_c2<4, 1, 3, 1, 8, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;     // conv0.0
         case 8 * 10000 + 8 * 100 + 31: launch_c2<8, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;    // conv0.1
@@ -1605,9 +1611,13 @@ int launch_conv2d(const Conv2dDesc& L, const float* in, float* out, const float*
             if (th4) launch_c2<16, 1, 3, 1, 4, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             else launch_c2<16, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             return 0;
-        case 16 * 10000 + 32 * 100 + 52: launch_c2<16, 2, 5, 2, 4, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0; // conv2.0
+        case 16 * 10000 + 32 * 100 + 52:                                                                                   // conv2.0
+            if (th2_s2) launch_c2<16, 2, 5, 2, 2, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
+            else launch_c2<16, 2, 5, 2, 4, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
+            return 0;
         case 32 * 10000 + 32 * 100 + 31:                                                                                   // conv2.1 (+ toplayer)
-            if (L.chain_w != nullptr && th4) launch_c2<32, 2, 3, 1, 4, false, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
+            if (L.chain_w != nullptr && th2) launch_c2<32, 2, 3, 1, 2, false, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
+            else if (L.chain_w != nullptr && th4) launch_c2<32, 2, 3, 1, 4, false, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             else if (L.chain_w != nullptr) launch_c2<32, 2, 3, 1, 8, false, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             else launch_c2<32, 2, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             return 0;
