@@ -135,6 +135,84 @@ __global__ __launch_bounds__(256) void k_channel_affine(const float* __restrict_
 // (40 BatchNorm layers x 2 directions per training step).  fp64 like the torch expressions it replaces. ----
 // forward: sums = [sum z, sum z^2] -> mean, invstd (fp64), scale = gamma*invstd, shift = beta - mean*gamma*invstd (fp32),
 // running statistics updated in place (unbiased variance; momentum < 0: cumulative average 1/num_batches_tracked)
+// the forward coefficients of one channel from its two sums (shared by k_bn_train_coeffs and the fused k_bn_finish_coeffs)
+__device__ __forceinline__ void bn_fwd_channel(int c, int C, double s1, double s2, double n, long long tracked, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, double eps, double momentum, float* __restrict__ running_mean,
+                                               float* __restrict__ running_var, double* __restrict__ mean_invstd, float* __restrict__ scale_shift) {
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;                     // biased (normalisation)
+    var = var > 0.0 ? var : 0.0;
+    const double invstd = 1.0 / sqrt(var + eps);
+    mean_invstd[c] = mean;
+    mean_invstd[C + c] = invstd;
+    const double g = (double)gamma[c];
+    scale_shift[c] = (float)(g * invstd);
+    scale_shift[C + c] = (float)((double)beta[c] - mean * g * invstd);
+    if (running_mean != nullptr) {
+        const float mom = (float)(momentum >= 0.0 ? momentum : 1.0 / (double)tracked);
+        const double nm1 = n - 1.0 > 1.0 ? n - 1.0 : 1.0;
+        running_mean[c] = running_mean[c] * (1.f - mom) + (float)mean * mom;
+        running_var[c] = running_var[c] * (1.f - mom) + (float)(var * (n / nm1)) * mom;
+    }
+}
+__device__ __forceinline__ void bn_bwd_channel(int c, int C, double l1, double l2, double sg, double sgz, double n,
+                                               const double* __restrict__ mean_invstd, const float* __restrict__ scale,
+                                               float* __restrict__ dgamma_dbeta, float* __restrict__ k2k3) {
+    const double mean = mean_invstd[c], invstd = mean_invstd[C + c];
+    dgamma_dbeta[c] = (float)(invstd * (l2 - mean * l1));
+    dgamma_dbeta[C + c] = (float)l1;
+    const double sc = (double)scale[c];
+    const double k2 = -sc * invstd * (invstd * (sgz - mean * sg)) / n;
+    k2k3[c] = (float)k2;
+    k2k3[C + c] = (float)(-sc * sg / n - k2 * mean);
+}
+// the row reduction of k_channel_sums_finish as a device function: every thread of a 1024-thread block takes part; on return
+// tot[0 .. C2) (shared) holds the sums (same order of additions as k_channel_sums_finish: bit-identical)
+__device__ __forceinline__ void finish_rows(const double* __restrict__ partials, int nb, int C2, double* red, double* tot) {
+    const int c = threadIdx.x % C2, r0 = threadIdx.x / C2, nr = 1024 / C2;
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    int blk = r0;
+    for (; blk + 3 * nr < nb; blk += 4 * nr) {
+        const double v0 = partials[(long long)blk * C2 + c], v1 = partials[(long long)(blk + nr) * C2 + c];
+        const double v2 = partials[(long long)(blk + 2 * nr) * C2 + c], v3 = partials[(long long)(blk + 3 * nr) * C2 + c];
+        t0 += v0; t1 += v1; t2 += v2; t3 += v3;
+    }
+    for (; blk < nb; blk += nr) t0 += partials[(long long)blk * C2 + c];
+    red[threadIdx.x] = (t0 + t1) + (t2 + t3);
+    __syncthreads();
+    if (threadIdx.x < C2) {
+        double t = 0;
+        for (int q = 0; q < nr; ++q) t += red[q * C2 + c];
+        tot[c] = t;
+    }
+    __syncthreads();
+}
+// Round 5: the statistics' final reduction AND the C-sized coefficient arithmetic in ONE launch (without SyncBatchNorm nothing sits
+// between them): a training step had 46 BatchNorm directions x (partials, finish, coefficients) = 138 launches, 92 of them
+// single-block kernels at the ~4.6 us floor of a graph node.  Same additions and the same coefficient code: bit-identical.
+__global__ __launch_bounds__(1024) void k_bn_finish_coeffs(const double* __restrict__ partials, int nb, double n, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, double eps, double momentum,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           long long* __restrict__ nbt, int nbt_increment, int C,
+                                                           double* __restrict__ sums_out, double* __restrict__ mean_invstd,
+                                                           float* __restrict__ scale_shift) {
+    __shared__ double red[1024], tot[128];
+    const long long tracked = nbt != nullptr ? *nbt + nbt_increment : 1;
+    finish_rows(partials, nb, 2 * C, red, tot);                        // (its barriers order every thread's read of *nbt before the store)
+    const int c = threadIdx.x;
+    if (c == 0 && nbt != nullptr && nbt_increment) *nbt = tracked;
+    if (c < 2 * C && sums_out != nullptr) sums_out[c] = tot[c];
+    if (c < C) bn_fwd_channel(c, C, tot[c], tot[C + c], n, tracked, gamma, beta, eps, momentum, running_mean, running_var, mean_invstd, scale_shift);
+}
+__global__ __launch_bounds__(1024) void k_bn_finish_bwd_coeffs(const double* __restrict__ partials, int nb, double n,
+                                                               const double* __restrict__ mean_invstd, const float* __restrict__ scale, int C,
+                                                               float* __restrict__ dgamma_dbeta, float* __restrict__ k2k3) {
+    __shared__ double red[1024], tot[128];
+    finish_rows(partials, nb, 2 * C, red, tot);
+    const int c = threadIdx.x;
+    if (c < C) bn_bwd_channel(c, C, tot[c], tot[C + c], tot[c], tot[C + c], n, mean_invstd, scale, dgamma_dbeta, k2k3);
+}
+
 __global__ void k_bn_train_coeffs(const double* __restrict__ sums, const double* __restrict__ count_dev, double count_host,
                                   const float* __restrict__ gamma, const float* __restrict__ beta, double eps, double momentum,
                                   float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -344,6 +422,41 @@ int enerf_bn_train_bwd_coeffs(const double* sums_local, const double* sums_globa
     ENERF_LAUNCH_SIMPLE(k_bn_train_bwd_coeffs, 1, 256, 0, (hipStream_t)stream, sums_local, sums_global, count_dev, count_host,
                         mean_invstd, scale, C, dgamma_dbeta, k2k3);
     return check_launch("bn_train_bwd_coeffs");
+}
+int enerf_bn_train_stats(const float* z, long long n, int C, void* workspace, size_t workspace_bytes, const float* gamma,
+                         const float* beta, double eps, double momentum, float* running_mean, float* running_var,
+                         long long* num_batches_tracked, int increment_num_batches_tracked, double* sums_out, double* mean_invstd,
+                         float* scale_shift, enerf_stream_t stream) {
+    REQUIRE(z && gamma && beta && mean_invstd && scale_shift && workspace && n > 0 && C >= 4 && C <= 64 && C % 4 == 0 && (256 % (C / 4)) == 0,
+            "bn_train_stats: bad arguments (C in 4..64, power-of-two quads)");
+    REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_stats: running_mean and running_var come together");
+    const long long blocks = channel_sums_blocks(n, C);
+    REQUIRE(workspace_bytes >= (size_t)blocks * 2 * C * sizeof(double), "bn_train_stats: workspace of %zu bytes, need %zu", workspace_bytes,
+            (size_t)blocks * 2 * C * sizeof(double));
+    double* partials = (double*)workspace;
+    ENERF_LAUNCH((k_channel_sums<true, false>), (unsigned)blocks, 256, 0, (hipStream_t)stream, z, z, nullptr, nullptr, nullptr, n, C,
+                 (double*)nullptr, partials);
+    ENERF_LAUNCH(k_bn_finish_coeffs, 1, 1024, 0, (hipStream_t)stream, partials, (int)blocks, (double)n, gamma, beta, eps, momentum,
+                 running_mean, running_var, num_batches_tracked, increment_num_batches_tracked, C, sums_out, mean_invstd, scale_shift);
+    return check_launch("bn_train_stats");
+}
+int enerf_bn_train_bwd_stats(const float* g, const float* z, const float* z_mask, const float* mask_scale, const float* mask_shift,
+                             long long n, int C, void* workspace, size_t workspace_bytes, const double* mean_invstd,
+                             const float* scale, float* dgamma_dbeta, float* k2k3, enerf_stream_t stream) {
+    REQUIRE(g && z && mean_invstd && scale && dgamma_dbeta && k2k3 && workspace && n > 0 && C >= 4 && C <= 64 && C % 4 == 0 &&
+                (256 % (C / 4)) == 0, "bn_train_bwd_stats: bad arguments (C in 4..64, power-of-two quads)");
+    if (z_mask) REQUIRE(mask_scale && mask_shift, "bn_train_bwd_stats: mask needs its scale/shift");
+    const long long blocks = channel_sums_blocks(n, C);
+    REQUIRE(workspace_bytes >= (size_t)blocks * 2 * C * sizeof(double), "bn_train_bwd_stats: workspace of %zu bytes, need %zu",
+            workspace_bytes, (size_t)blocks * 2 * C * sizeof(double));
+    double* partials = (double*)workspace;
+    if (z_mask) ENERF_LAUNCH((k_channel_sums<false, true>), (unsigned)blocks, 256, 0, (hipStream_t)stream, g, z, z_mask, mask_scale, mask_shift,
+                             n, C, (double*)nullptr, partials);
+    else ENERF_LAUNCH((k_channel_sums<false, false>), (unsigned)blocks, 256, 0, (hipStream_t)stream, g, z, z_mask, mask_scale, mask_shift, n, C,
+                      (double*)nullptr, partials);
+    ENERF_LAUNCH(k_bn_finish_bwd_coeffs, 1, 1024, 0, (hipStream_t)stream, partials, (int)blocks, (double)n, mean_invstd, scale, C, dgamma_dbeta,
+                 k2k3);
+    return check_launch("bn_train_bwd_stats");
 }
 int enerf_channel_affine(const float* a, const float* b, const float* p, const float* q, const float* r, const float* z_mask,
                          const float* mask_scale, const float* mask_shift, const float* residual, int relu, long long n, int C,

@@ -29,7 +29,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // rounding needs) and the group then walks the views, each lane fetching the taps of the view in turn from
 // its owner with one lane broadcast per value.  Before, every lane projected every view — 4x (level 1) and
 // 8x (level 0) redundant VALU in a kernel that is VALU- not HBM-bound (48+37 us against a 16 us HBM floor).
-// The group's broadcasts: DPP register permutes (default) or, for A/B, the ds_bpermute round trips of rounds 1-3
+// The group's broadcasts: DPP register permutes (default) or, for A/B, the ds_bpermute round trips of rounds 1-3.
+// CONVERGENCE: group_bcast_i runs with bound_ctrl = true, i.e. an INACTIVE source lane yields 0 — all CQ lanes of a group must reach
+// every broadcast together.  They do: dead lanes (beyond the volume) shadow a live voxel instead of exiting (see `live` below), and
+// no broadcast sits under a lane-divergent branch.  (GPU check of the primitives: tools/micro/dpp_primitives.hip.)
 #ifndef ENERF_VOL_DPP
 #define ENERF_VOL_DPP 1
 #endif

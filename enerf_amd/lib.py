@@ -14,7 +14,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libenerf_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _f = C.c_void_p     # device float*
 _i = C.c_int
@@ -180,6 +180,9 @@ _SIGNATURES = {
     "enerf_bn_train_coeffs": (_i, [C.c_void_p, C.c_void_p, C.c_double, _f, _f, C.c_double, C.c_double, _f, _f, C.c_void_p, _i, _i,
                                    C.c_void_p, _f, _f]),
     "enerf_bn_train_bwd_coeffs": (_i, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, _f, _i, _f, _f, _f]),
+    "enerf_bn_train_stats": (_i, [_f, _ll, _i, C.c_void_p, C.c_size_t, _f, _f, C.c_double, C.c_double, _f, _f, C.c_void_p, _i, C.c_void_p,
+                                  C.c_void_p, _f, C.c_void_p]),
+    "enerf_bn_train_bwd_stats": (_i, [_f, _f, _f, _f, _f, _ll, _i, C.c_void_p, C.c_size_t, C.c_void_p, _f, _f, _f, C.c_void_p]),
     "enerf_channel_affine": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _ll, _i, _f, _f]),
     "enerf_conv2d_s2k5_dgrad_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "enerf_conv2d_s2k5_dgrad": (_i, [_f, _i, _i, _f, _f, _f, _i, _i, _i, C.c_void_p, C.c_size_t, _f]),
@@ -549,6 +552,41 @@ class EnerfLib:
                                                    bn.num_batches_tracked.data_ptr() if track else None, 1, Cc, mi.data_ptr(), _ptr(ss),
                                                    self.stream_of(sums)), "bn_train_coeffs")
         return mi, ss
+
+    def bn_stats_fit(self, z) -> bool:
+        """the channel widths enerf_channel_sums / enerf_bn_train_stats handle (C in 4..64, C/4 dividing 256)"""
+        Cc = z.shape[-1]
+        return 4 <= Cc <= 64 and Cc % 4 == 0 and 256 % (Cc // 4) == 0
+
+    def bn_train_stats(self, z, bn):
+        """ABI v8: batch statistics of z (..., C) AND the forward coefficients of the BatchNorm module in two launches (no
+        SyncBatchNorm): -> mean_invstd (2,C) fp64, scale_shift (2,C) fp32; updates the running statistics in place."""
+        Cc = z.shape[-1]
+        n = z.numel() // Cc
+        nb = self.dll.enerf_channel_sums_workspace_bytes(n, Cc)
+        ws = self._scratch(nb, z.device)
+        mi = torch.empty((2, Cc), dtype=torch.float64, device=z.device)
+        ss = torch.empty((2, Cc), dtype=torch.float32, device=z.device)
+        track = bn.track_running_stats and bn.running_mean is not None
+        self._check(self.dll.enerf_bn_train_stats(_ptr(z), n, Cc, ws.data_ptr(), nb, _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
+                                                  float(bn.eps), -1.0 if bn.momentum is None else float(bn.momentum),
+                                                  _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
+                                                  bn.num_batches_tracked.data_ptr() if track else None, 1, None, mi.data_ptr(), _ptr(ss),
+                                                  self.stream_of(z)), "bn_train_stats")
+        return mi, ss, n
+
+    def bn_train_bwd_stats(self, g, z, mean_invstd, scale, z_mask=None, mask_scale=None, mask_shift=None):
+        """ABI v8: sums of [g*m, g*m*z] AND the backward coefficients in two launches -> dgamma_dbeta (2,C), k2k3 (2,C)."""
+        Cc = z.shape[-1]
+        n = z.numel() // Cc
+        nb = self.dll.enerf_channel_sums_workspace_bytes(n, Cc)
+        ws = self._scratch(nb, z.device)
+        dgb = torch.empty((2, Cc), dtype=torch.float32, device=z.device)
+        k23 = torch.empty((2, Cc), dtype=torch.float32, device=z.device)
+        self._check(self.dll.enerf_bn_train_bwd_stats(_ptr(g), _ptr(z), _ptr(z_mask), _ptr(mask_scale), _ptr(mask_shift), n, Cc, ws.data_ptr(), nb,
+                                                      mean_invstd.data_ptr(), _ptr(scale), _ptr(dgb), _ptr(k23), self.stream_of(z)),
+                    "bn_train_bwd_stats")
+        return dgb, k23
 
     def bn_train_bwd_coeffs(self, local, glob, count, mean_invstd, scale):
         Cc = local.shape[1]

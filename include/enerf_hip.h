@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ENERF_ABI_VERSION 7
+#define ENERF_ABI_VERSION 8
 #define ENERF_OK 0
 #define ENERF_EINVAL (-1)   /* bad argument / unsupported shape */
 #define ENERF_ELAUNCH (-2)  /* HIP launch error */
@@ -384,6 +384,19 @@ int enerf_bn_train_coeffs(const double* sums, const double* count_dev, double co
 int enerf_bn_train_bwd_coeffs(const double* sums_local, const double* sums_global, const double* count_dev, double count_host,
                               const double* mean_invstd, const float* scale, int C, float* dgamma_dbeta, float* k2k3,
                               enerf_stream_t stream);
+/*   enerf_bn_train_stats / enerf_bn_train_bwd_stats  (ABI v8) the statistics AND the coefficients of one training-mode BatchNorm
+ *       direction in TWO launches (block partial sums; their reduction + the coefficient arithmetic) instead of three — the
+ *       path without SyncBatchNorm, where nothing sits between the sums and the coefficients.  Arguments as
+ *       enerf_channel_sums_ws (workspace: enerf_channel_sums_workspace_bytes) + enerf_bn_train_coeffs / _bwd_coeffs with the
+ *       position count n as a host number; forward: sums over z of [z, z^2] (sums_out optional, 2C fp64); backward: sums of
+ *       [g*m, g*m*z].  Bit-identical to the three-launch sequence.  (utils.py:10-33: BatchNorm2d/3d in .train()) */
+int enerf_bn_train_stats(const float* z, long long n, int C, void* workspace, size_t workspace_bytes, const float* gamma,
+                         const float* beta, double eps, double momentum, float* running_mean, float* running_var,
+                         long long* num_batches_tracked, int increment_num_batches_tracked, double* sums_out, double* mean_invstd,
+                         float* scale_shift, enerf_stream_t stream);
+int enerf_bn_train_bwd_stats(const float* g, const float* z, const float* z_mask, const float* mask_scale, const float* mask_shift,
+                             long long n, int C, void* workspace, size_t workspace_bytes, const double* mean_invstd,
+                             const float* scale, float* dgamma_dbeta, float* k2k3, enerf_stream_t stream);
 int enerf_channel_affine(const float* a, const float* b, const float* p, const float* q, const float* r, const float* z_mask,
                          const float* mask_scale, const float* mask_shift, const float* residual, int relu, long long n, int C,
                          float* out, enerf_stream_t stream);

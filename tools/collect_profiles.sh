@@ -6,7 +6,7 @@
 #   usage: bash tools/collect_profiles.sh TAG [WORKLOAD=dtu] [pmc=1|0]
 export TMPDIR=/tmp
 TAG=${1:-rXX}; WL=${2:-dtu}; PMC=${3:-1}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
-cd $R && python bench.py --workload $WL > $O/${TAG}_bench.json 2> $O/bench.err; tail -c 600 $O/${TAG}_bench.json; echo
+cd $R && python bench.py --workload $WL --no-secondary > $O/${TAG}_bench.json 2> $O/bench.err; tail -c 600 $O/${TAG}_bench.json; echo
 cd /tmp
 # frames enqueued back to back on one stream, nothing but the timed frames: clean per-kernel durations
 BENCH="python $R/bench.py --workload $WL --steps 20 --warmup 5 --no-cpu-baseline --no-stages --no-sync-per-frame"
