@@ -283,7 +283,34 @@ void k_render_rays(RenderArgs a) {
     const long long nbands = gridDim.x < 8 ? gridDim.x : 8;                      // (small launches: fewer blocks than XCDs)
     const long long xcd_ = blockIdx.x % nbands, nb8 = ((long long)gridDim.x + nbands - 1 - xcd_) / nbands, bi_ = blockIdx.x / nbands;
     const long long t_hi = ntiles * (xcd_ + 1) / nbands;
+#ifndef ENERF_RENDER_BALANCE
+#define ENERF_RENDER_BALANCE 1
+#endif
+// The level-0 kernel (R = 9; lego: 2500 tiles for 2048 waves) gains even more ALONE from the balanced deal (266 -> 201 us = 0.50 of
+// the fp32-MFMA peak: a SIMD carries 3 tiles instead of 4), but it runs FORKED beside level 1 as one persistent block per CU: unbalanced,
+// a third of the CUs are released at half time and level 1 starts there; balanced, every CU is held to the end — lego 543.9 -> 535.3
+// frames/s (profiles/r05_ab_render_balance.txt).  More, shorter blocks (ENERF_R9_GRID_MULT=2) do not fix that (539).  Default: off.
+#ifndef ENERF_RENDER_BALANCE_R9
+#define ENERF_RENDER_BALANCE_R9 0
+#endif
+#if ENERF_RENDER_BALANCE
+    // Round 5: the band's PARTIAL last round of tiles is dealt out evenly.  Round-robin, it went to the band's first blocks, 12
+    // tiles each: at dtu (2560 tiles per band = 6 full rounds of 32 x 12 + 256) 21 of a band's 32 CUs rendered 84 tiles and 10
+    // rendered 72 — the launch ends with the 84s, 5 % above the 80-tile average.  Now every block takes rem / nb8 of them
+    // (+- 1) on its FIRST waves: consecutive waves of a block sit on different SIMDs, so a SIMD's three waves end up with
+    // 7 + 7 + 6 tiles everywhere.  The full rounds keep the interleaved order (the band's blocks walk the same image rows).
+    const long long t_lo = ntiles * xcd_ / nbands, per_round = nb8 * WAVES, full = (t_hi - t_lo) / per_round;
+    const long long rem = (t_hi - t_lo) - full * per_round, rb = rem / nb8, rx = rem - rb * nb8;
+    const long long my_rem = rb + (bi_ < rx ? 1 : 0), my_rem_lo = bi_ * rb + (bi_ < rx ? bi_ : rx);
+    constexpr bool kBal = R == 3 || ENERF_RENDER_BALANCE_R9;
+    const long long n_it = kBal ? full + (wave_in_block < my_rem ? 1 : 0)
+                                : full + (full * per_round + bi_ * WAVES + wave_in_block < t_hi - t_lo ? 1 : 0);
+    for (long long it = 0; it < n_it; ++it) {
+        const long long tile = (it < full || !kBal) ? t_lo + it * per_round + bi_ * WAVES + wave_in_block
+                                                    : t_lo + full * per_round + my_rem_lo + wave_in_block;
+#else
     for (long long tile = ntiles * xcd_ / nbands + bi_ * WAVES + wave_in_block; tile < t_hi; tile += nb8 * WAVES) {
+#endif
 #else
     for (long long tile = (long long)blockIdx.x * WAVES + wave_in_block; tile < ntiles; tile += (long long)gridDim.x * WAVES) {
 #endif
@@ -840,7 +867,10 @@ int launch_render_rays(const RenderArgs& a, hipStream_t st) {
     if (R == 9) {                                                                   // C = 32: one 8-wave block per CU
         const size_t shmem = render_shmem<9, 8>(a);
         if (shmem > 160 * 1024) return -2;
-        const unsigned grid = grid_for(8, 1);
+#ifndef ENERF_R9_GRID_MULT
+#define ENERF_R9_GRID_MULT 1         // > 1: more blocks than CUs (each exits after fewer tiles: a forked level-0 render frees CUs sooner)
+#endif
+        const unsigned grid = grid_for(8, ENERF_R9_GRID_MULT);
         if (grid == 0) return 0;
         return dispatch_s<9, 8, 1, false, ENERF_R9_LEAN != 0>(a, grid, shmem, st);
     }
