@@ -870,7 +870,14 @@ int launch_render_rays(const RenderArgs& a, hipStream_t st) {
 #ifndef ENERF_R9_GRID_MULT
 #define ENERF_R9_GRID_MULT 1         // > 1: more blocks than CUs (each exits after fewer tiles: a forked level-0 render frees CUs sooner)
 #endif
-        const unsigned grid = grid_for(8, ENERF_R9_GRID_MULT);
+#ifndef ENERF_R9_TIGHT_GRID
+#define ENERF_R9_TIGHT_GRID 0        // 1 (with the balanced deal): only as many blocks as give every SIMD the same t = ceil(tiles / SIMDs) tiles
+#endif
+        unsigned grid = grid_for(8, ENERF_R9_GRID_MULT);
+        if (ENERF_R9_TIGHT_GRID && ENERF_RENDER_BALANCE_R9 && ntiles > 0) {
+            const long long t = cdivl(ntiles, 4LL * cus), tight = cdivl(ntiles, 4 * t);
+            if (tight < (long long)grid) grid = (unsigned)tight;
+        }
         if (grid == 0) return 0;
         return dispatch_s<9, 8, 1, false, ENERF_R9_LEAN != 0>(a, grid, shmem, st);
     }
