@@ -127,6 +127,13 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
         for (int rt = 0; rt < RT; ++rt) acc[c][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* wl = wpk + lane;
     constexpr int NAQ = K * CPL * RT;
+    // PRE: the whole pass's weights are requested before the tile is staged and stay in registers (k <= 3 always; round 5: also the
+    // 5x5 stride-2 layer with few channels, conv1.0: 50 registers — its per-row operand ring cost 11 of 79 us at zju sizes, timing
+    // ablation profiles/r05_conv2d_ablation.txt).  conv2.0 (200 registers) keeps the two-row ring.
+#ifndef ENERF_C2_PRE_REGS
+#define ENERF_C2_PRE_REGS 64
+#endif
+    constexpr bool PRE = K <= 3 || K * NAQ <= ENERF_C2_PRE_REGS;
 
 #pragma unroll 1
     for (int cb = 0; cb < NCB; ++cb) {
@@ -138,13 +145,17 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
                 for (int r = 0; r < CPL; ++r)
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
+#if defined(ENERF_ABL_C2) && (ENERF_ABL_C2 & 8)                          // timing ablation: no weight loads
+                        aq[(kw * CPL + r) * RT + rt] = 1e-3f * (float)((kw + r + rt + lane) & 7);
+#else
                         aq[(kw * CPL + r) * RT + rt] = wt[((long long)(kw * KS + r) * RT + rt) * 64];
+#endif
         };
         // k<=3: the whole pass's weights are requested BEFORE the tile is staged, so their L2 latency hides
         // behind the staging traffic; sched_barrier pins the loads here (hipcc otherwise sinks each load to
         // just before its MFMA and waits vmcnt(0) on it).
-        float aq_all[K <= 3 ? K : 1][NAQ];
-        if (K <= 3) {
+        float aq_all[PRE ? K : 1][NAQ];
+        if (PRE) {
 #pragma unroll
             for (int kh = 0; kh < K; ++kh) issue_a(kh, aq_all[kh]);
             __builtin_amdgcn_sched_barrier(0);
@@ -188,7 +199,11 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
                 sk[it] = gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
                 so[it] = PLANAR ? (q * PITCH + slot(ly, lx)) * 4 : (slot(ly, lx) * QV + q) * 4;
                 const int off = sk[it] ? gy * Wi + gx : 0;
+#if defined(ENERF_ABL_C2) && (ENERF_ABL_C2 & 1)                          // timing ablation (tools/build_variant.py): no staging loads
+                sv[it] = make_float4(1e-3f * (float)(off & 15), 0.01f, 0.f, 0.f);
+#else
                 sv[it] = *reinterpret_cast<const float4*>(base + (long long)off * CINP + q * 4);
+#endif
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -238,7 +253,13 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if (K <= 3) {
+#if defined(ENERF_ABL_C2) && (ENERF_ABL_C2 & 2)                                  // timing ablation: one tap row instead of K
+        if (PRE) compute(0, aq_all[0]);
+        else { float a0[NAQ]; issue_a(0, a0); compute(0, a0); }
+        if (false) {
+#else
+        if (PRE) {
+#endif
 #pragma unroll
             for (int kh = 0; kh < K; ++kh) compute(kh, aq_all[kh]);
         } else {
@@ -328,6 +349,9 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.f);
             }
+#if defined(ENERF_ABL_C2) && (ENERF_ABL_C2 & 4)                          // timing ablation: no output stores (a never-true guard keeps the math)
+            if (y[0] == 12345.678f)
+#endif
             *reinterpret_cast<float4*>(out + o * out_stride + c0) = make_float4(y[0], y[1], y[2], y[3]);
         }
     }
