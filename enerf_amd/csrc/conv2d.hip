@@ -1322,8 +1322,14 @@ __global__ __launch_bounds__(256, ENERF_S0_CB_BLOCKS) void k_smooth0_cb(
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat[cb].x, cvr[it].x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat[cb].y, cvr[it].y, acc, 0, 0, 0);
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#if defined(ENERF_ABL_S0) && (ENERF_ABL_S0 & 1)                          // timing ablation: no upsample blend (no patch reads)
+                if (inside) { o.x = acc[0] + bias4[cb].x; o.y = acc[1] + bias4[cb].y; o.z = acc[2] + bias4[cb].z; o.w = acc[3] + bias4[cb].w; }
+                if (false) {
+                    Lerp1 vy, vx;
+#else
                 if (inside) {
                     Lerp1 vy, vx;
+#endif
                     vy.l0 = rt.z; vy.l1 = rt.w; vx.l0 = ct.z; vx.l1 = ct.w; vy.i0 = vy.i1 = vx.i0 = vx.i1 = 0;
                     const float* pb = pat + g * 4;
                     const float4 u00 = *reinterpret_cast<const float4*>(pb + ro0 + co0), u01 = *reinterpret_cast<const float4*>(pb + ro0 + co1);
@@ -1347,7 +1353,11 @@ __global__ __launch_bounds__(256, ENERF_S0_CB_BLOCKS) void k_smooth0_cb(
         float4 bq[2];
         bq[0] = *reinterpret_cast<const float4*>(tb);
 #pragma unroll
+#if defined(ENERF_ABL_S0) && (ENERF_ABL_S0 & 2)                                  // timing ablation: one tap of nine
+        for (int tq = 0; tq < 4; ++tq) {
+#else
         for (int tq = 0; tq < 36; ++tq) {
+#endif
             if (tq + 1 < 36) {
                 const int t1 = (tq + 1) >> 2, q1 = (tq + 1) & 3;
                 bq[(tq + 1) & 1] = *reinterpret_cast<const float4*>(tb + q1 * NPX * 4 + ((t1 / 3) * IW + (t1 % 3)) * 4);
@@ -1370,6 +1380,9 @@ __global__ __launch_bounds__(256, ENERF_S0_CB_BLOCKS) void k_smooth0_cb(
     // ---- epilogue: bias, channels-last / texel store (cout = 8): a pixel's 8 features (+ rgb texel) from its own lane ----
     const int oy = oy0 + row, ox = ox0 + col;
     if (oy >= H || ox >= W) return;
+#if defined(ENERF_ABL_S0) && (ENERF_ABL_S0 & 4)                                  // timing ablation: no output stores
+    if (acc0[0] != 12345.678f) return;
+#endif
     const long long o = ((long long)n * H + oy) * W + ox;
     *reinterpret_cast<float4*>(out + o * out_stride) =
         make_float4(acc0[0] * scale[0] + shift[0], acc0[1] * scale[1] + shift[1], acc0[2] * scale[2] + shift[2], acc0[3] * scale[3] + shift[3]);
@@ -1393,6 +1406,218 @@ __global__ __launch_bounds__(256, ENERF_S0_CB_BLOCKS) void k_smooth0_cb(
 // kernel consumes it).  One launch and the halo'd read-back of f1pre go away.  Structure = k_smooth0_cb's.
 // lat_w / sm_w: the layers' ordinary operand images (k_conv2d_pack): lat1 [ks 0..3][rt 0..1][64], smooth1 [tap][ks 0..7][64].
 // =====================================================================================================================
+// ---- round 5, second step: k_smooth0_cb as a PERSISTENT, tile-pipelined kernel ------------------------------------------------
+// Timing ablations of k_smooth0_cb (profiles/r05_smooth0_ablation.txt; zju): conv MFMAs 116-131 us (at the instruction's rate),
+// stores 24, blend 18 — and a 98 us "skeleton" that is left with all three removed: the per-block prologue (36 weight registers
+// re-loaded by each of 16,384 blocks' four waves, the lanes' conv0 values, the patch copy) and five barriers per tile with nothing
+// in flight across them.  Here a block walks SEVERAL tiles (grid = co-resident blocks; tile t -> block t mod grid): the weights, the
+// lat0 operands and the epilogue constants are loaded ONCE, and the next tile's inputs — its conv0 values (registers), its pass-0
+// patch (LDS-DMA into the patch buffer, which is free after pass 1's build) and its upsample tables (second table buffer) — are
+// requested right after the current tile's last build phase, so they land during its pass-1 MFMAs and stores.
+// Same arithmetic and order as k_smooth0_cb: bit-identical outputs.
+#ifndef ENERF_S0_CBP_BLOCKS
+#define ENERF_S0_CBP_BLOCKS 4        // (at 5 blocks per CU = 96 registers the tile loop's double set of inputs spills)
+#endif
+__global__ __launch_bounds__(256, ENERF_S0_CBP_BLOCKS) void k_smooth0_cbp(
+    const float* __restrict__ wcb, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ c0,
+    const float* __restrict__ f1pre, const float* __restrict__ lat_w, const float* __restrict__ lat_b, float* __restrict__ out,
+    const float* __restrict__ rgb_src, int out_stride, int N, int H, int W, int tiles_y, int tiles_x) {
+    constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, NPX = IH * IW;
+    constexpr int PH = 7, PW = 20, NPP = PH * PW;
+    constexpr int NPCH = (NPP * 4 + 63) / 64, NPK = (NPCH + 3) / 4;
+    constexpr int NT16 = (NPX + 15) / 16, NBI = (NT16 + 3) / 4;
+    ENERF_DYN_SMEM(float, lds);
+    float* pat = lds;                       // [NPCH * 64] float4: patch of the current pass (DMA destination)
+    float* til = pat + NPCH * 256;          // [4 quads][NPX] float4 planes
+    float* tabs2 = til + 4 * NPX * 4;       // two upsample-table buffers (tile parity)
+
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H1 = H / 2, W1 = W / 2;
+    const float sy = ac_scale(H1, H), sx = ac_scale(W1, W);
+    const int ntiles = N * tiles_y * tiles_x;
+
+    // ---- once per block ----
+    float wr[2][18];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 18; ++r) wr[cb][r] = wcb[(cb * 18 + r) * 64 + lane];
+    float2 a_lat[2];
+    float4 bias4[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        a_lat[cb] = *reinterpret_cast<const float2*>(lat_w + (cb * 16 + j) * 8 + 2 * g);
+        bias4[cb] = *reinterpret_cast<const float4*>(lat_b + cb * 16 + 4 * g);
+    }
+    // stage-2 lane -> pixel map (as k_smooth0_cb)
+    const int m = lane & 31;
+    const bool g1 = (m >= 4 && m < 12) || (m >= 16 && m < 20) || m >= 28;
+    const int pos = g1 ? (m < 12 ? m - 4 : m < 20 ? m - 8 : m - 16) : (m < 4 ? m : m < 16 ? m - 8 : m - 12);
+    const int kgrp = 2 * (lane >> 5) + (g1 ? 1 : 0);
+    const int row = 2 * wv + (kgrp >> 1), col = (kgrp & 1) * 16 + pos;
+    const float* tb = til + (row * IW + col) * 4;
+
+    struct TilePos { int n, oy0, ox0; };
+    auto tile_pos = [&](int t) {
+        const int bid = (int)xcd_contiguous((unsigned)t, (unsigned)ntiles);     // the same tile order as the per-tile kernels
+        TilePos p;
+        const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y;
+        p.n = bid / (tiles_x * tiles_y);
+        p.oy0 = ty * TH; p.ox0 = tx * TW;
+        return p;
+    };
+    unsigned psrc[NPK];
+    // a tile's inputs: conv0 values -> registers, patch sources, pass-0 patch copy, upsample tables (buffer = tile parity)
+    auto request_tile = [&](const TilePos& pp_, float2 (&cv)[NBI], float* tabs) {
+        struct { int n, iy0, ix0, py0, px0; } p;
+        p.n = pp_.n; p.iy0 = pp_.oy0 - 1; p.ix0 = pp_.ox0 - 1;
+        p.py0 = (int)(sy * (float)max(p.iy0, 0)); p.px0 = (int)(sx * (float)max(p.ix0, 0));
+        int jq = j, gq_ = g, lq = lane;                              // opaque per call: see the tile loop
+        ENERF_OPAQUE_V(jq);
+        ENERF_OPAQUE_V(gq_);
+        ENERF_OPAQUE_V(lq);
+#pragma unroll
+        for (int it = 0; it < NBI; ++it) {
+            const int t = wv + 4 * it;
+            cv[it] = make_float2(0.f, 0.f);
+            if (t < NT16) {
+                const int px = t * 16 + jq, pxc = px < NPX ? px : NPX - 1;
+                const int ly = (pxc * 241) >> 13, lx = pxc - ly * IW, gy = p.iy0 + ly, gx = p.ix0 + lx;
+                const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const long long off = ok ? ((long long)p.n * H + gy) * W + gx : 0;
+                const float2 v = *reinterpret_cast<const float2*>(c0 + off * 8 + 2 * gq_);
+                cv[it] = ok ? v : make_float2(0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NPK; ++k) {
+            const int i = (wv + 4 * k) * 64 + lq, ic = i < NPP * 4 ? i : NPP * 4 - 1;
+            const int pp = ic >> 2, q = ic & 3, pr = pp / PW, pc = pp - pr * PW;
+            const int gy = min(p.py0 + pr, H1 - 1), gx = min(p.px0 + pc, W1 - 1);
+            psrc[k] = (unsigned)((((long long)p.n * H1 + gy) * W1 + gx) * 32 + q * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < NPK; ++k)
+            if (wv + 4 * k < NPCH) glds16(f1pre + psrc[k], pat + (wv + 4 * k) * 256, lane);
+        if (tid < IH + IW) {
+            const bool isrow = tid < IH;
+            const int k = isrow ? tid : tid - IH, gq = (isrow ? p.iy0 : p.ix0) + k, lim = isrow ? H : W;
+            const Lerp1 v = ac_lerp(min(max(gq, 0), lim - 1), isrow ? sy : sx, isrow ? H1 : W1);
+            const int unit = isrow ? PW * 16 : 16, org = isrow ? p.py0 : p.px0;
+            const bool ok = gq >= 0 && gq < lim;
+            float4 e;
+            e.x = __int_as_float(ok ? (v.i0 - org) * unit : -1);
+            e.y = __int_as_float(ok ? (v.i1 - org) * unit : -1);
+            e.z = v.l0; e.w = v.l1;
+            *reinterpret_cast<float4*>(tabs + tid * 4) = e;
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    TilePos P = tile_pos(t);
+    float2 cvr[NBI], cvn[NBI];
+    request_tile(P, cvr, tabs2);
+    int par = 0;
+#pragma unroll 1
+    for (; t < ntiles; t += gridDim.x) {
+        const float* tabs = tabs2 + par * (IH + IW) * 4;
+        const int tn = t + (int)gridDim.x;
+        TilePos Pn = P;
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (the build items' pixel geometry does not depend on the tile: hipcc hoists all of it out of this loop — ~40 registers that
+        //  live across the whole kernel: 166 VGPRs — unless the lane coordinates are opaque per iteration)
+        int jv = j, gv = g;
+        ENERF_OPAQUE_V(jv);
+        ENERF_OPAQUE_V(gv);
+        glds_wait_all();                                              // this tile's pass-0 patch (and conv0 values) have landed
+        __syncthreads();                                              // ... everyone's; the tables are visible; the previous tile's conv is over
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+            for (int it = 0; it < NBI; ++it) {
+                const int tt = wv + 4 * it;
+                if (tt < NT16) {
+                    const int px = tt * 16 + jv, pxc = px < NPX ? px : NPX - 1;
+                    const int ly = (pxc * 241) >> 13, lx = pxc - ly * IW;
+                    const float4 rt = *reinterpret_cast<const float4*>(tabs + ly * 4);
+                    const float4 ct = *reinterpret_cast<const float4*>(tabs + (IH + lx) * 4);
+                    const int ro0 = __float_as_int(rt.x), ro1 = __float_as_int(rt.y), co0 = __float_as_int(ct.x), co1 = __float_as_int(ct.y);
+                    const bool inside = (ro0 | co0) >= 0;
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat[cb].x, cvr[it].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat[cb].y, cvr[it].y, acc, 0, 0, 0);
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (inside) {
+                        Lerp1 vy, vx;
+                        vy.l0 = rt.z; vy.l1 = rt.w; vx.l0 = ct.z; vx.l1 = ct.w; vy.i0 = vy.i1 = vx.i0 = vx.i1 = 0;
+                        const float* pb = pat + gv * 4;
+                        const float4 u00 = *reinterpret_cast<const float4*>(pb + ro0 + co0), u01 = *reinterpret_cast<const float4*>(pb + ro0 + co1);
+                        const float4 u10 = *reinterpret_cast<const float4*>(pb + ro1 + co0), u11 = *reinterpret_cast<const float4*>(pb + ro1 + co1);
+                        o.x = ac_blend(vy, vx, u00.x, u01.x, u10.x, u11.x) + (acc[0] + bias4[cb].x);
+                        o.y = ac_blend(vy, vx, u00.y, u01.y, u10.y, u11.y) + (acc[1] + bias4[cb].y);
+                        o.z = ac_blend(vy, vx, u00.z, u01.z, u10.z, u11.z) + (acc[2] + bias4[cb].z);
+                        o.w = ac_blend(vy, vx, u00.w, u01.w, u10.w, u11.w) + (acc[3] + bias4[cb].w);
+                    }
+                    if (px < NPX) *reinterpret_cast<float4*>(til + (gv * NPX + px) * 4) = o;
+                }
+            }
+            __syncthreads();                                          // tile complete; nobody reads the patch any more
+            if (cb == 0) {                                            // pass 1's patch travels during pass 0's MFMAs
+#pragma unroll
+                for (int k = 0; k < NPK; ++k)
+                    if (wv + 4 * k < NPCH) glds16(f1pre + psrc[k] + 16, pat + (wv + 4 * k) * 256, lane);
+            } else if (tn < ntiles) {                                 // the NEXT tile's inputs travel during pass 1's MFMAs + the stores
+                Pn = tile_pos(tn);
+                request_tile(Pn, cvn, tabs2 + (par ^ 1) * (IH + IW) * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float4 bq[2];
+            bq[0] = *reinterpret_cast<const float4*>(tb);
+#pragma unroll
+            for (int tq = 0; tq < 36; ++tq) {
+                if (tq + 1 < 36) {
+                    const int t1 = (tq + 1) >> 2, q1 = (tq + 1) & 3;
+                    bq[(tq + 1) & 1] = *reinterpret_cast<const float4*>(tb + q1 * NPX * 4 + ((t1 / 3) * IW + (t1 % 3)) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 bb = bq[tq & 1];
+                const float a = wr[cb][tq >> 1];
+                const int kb = (tq & 1) * 8;
+                acc0 = mfma4_bc(a, bb.x, acc0, kb + 0); acc1 = mfma4_bc(a, bb.x, acc1, kb + 1);
+                acc0 = mfma4_bc(a, bb.y, acc0, kb + 2); acc1 = mfma4_bc(a, bb.y, acc1, kb + 3);
+                acc0 = mfma4_bc(a, bb.z, acc0, kb + 4); acc1 = mfma4_bc(a, bb.z, acc1, kb + 5);
+                acc0 = mfma4_bc(a, bb.w, acc0, kb + 6); acc1 = mfma4_bc(a, bb.w, acc1, kb + 7);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (cb == 0) {
+                glds_wait_all();
+                __syncthreads();
+            }
+        }
+        // ---- epilogue of this tile ----
+        const int oy = P.oy0 + row, ox = P.ox0 + col;
+        if (oy < H && ox < W) {
+            const long long o = ((long long)P.n * H + oy) * W + ox;
+            *reinterpret_cast<float4*>(out + o * out_stride) =
+                make_float4(acc0[0] * scale[0] + shift[0], acc0[1] * scale[1] + shift[1], acc0[2] * scale[2] + shift[2], acc0[3] * scale[3] + shift[3]);
+            *reinterpret_cast<float4*>(out + o * out_stride + 4) =
+                make_float4(acc1[0] * scale[4] + shift[4], acc1[1] * scale[5] + shift[5], acc1[2] * scale[6] + shift[6], acc1[3] * scale[7] + shift[7]);
+            if (rgb_src != nullptr) {
+                const float* sp = rgb_src + (long long)P.n * 3 * H * W + (long long)oy * W + ox;
+                *reinterpret_cast<float4*>(out + o * out_stride + 8) =
+                    make_float4(sp[0] * 0.5f + 0.5f, sp[(long long)H * W] * 0.5f + 0.5f, sp[2LL * H * W] * 0.5f + 0.5f, 0.f);
+            }
+        }
+        // next tile: its conv0 values were loaded into cvn, its patch / tables are in flight or landed
+#pragma unroll
+        for (int it = 0; it < NBI; ++it) cvr[it] = cvn[it];
+        P = Pn;
+        par ^= 1;
+    }
+}
+
 #ifndef ENERF_S1F_BLOCKS
 #define ENERF_S1F_BLOCKS 4
 #endif
@@ -1587,7 +1812,18 @@ bool launch_smooth1_fused(const Conv2dDesc& Llat, const Conv2dDesc& Lsm, const f
 void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1pre, const float* lat_w, const float* lat_b,
                           const float* w_pq, const float* w_cb, float* out, int N, int H, int W, hipStream_t st) {
     const int out_stride = L.out_stride > 0 ? L.out_stride : 8;
-    if (ENERF_SMOOTH0_CB && ENERF_SMOOTH0_B4 && w_pq != nullptr && w_cb != nullptr) {   // default (round 5): weights in registers
+#ifndef ENERF_S0_PERSIST
+#define ENERF_S0_PERSIST 0           // 1: k_smooth0_cbp (persistent blocks, the next tile's inputs in flight: measured NOT faster, profiles/r05_smooth0_ablation.txt); 0: one tile per block
+#endif
+    if (ENERF_S0_PERSIST && ENERF_SMOOTH0_CB && ENERF_SMOOTH0_B4 && w_pq != nullptr && w_cb != nullptr) {
+        const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
+        const long long ntiles = (long long)N * tiles_y * tiles_x, resident = (long long)device_cu_count() * ENERF_S0_CBP_BLOCKS;
+        const size_t shmem = (size_t)(9 * 256 + 4 * 340 * 4 + 2 * 44 * 4) * sizeof(float);
+        ENERF_LAUNCH(k_smooth0_cbp, (unsigned)(ntiles < resident ? ntiles : resident), 256, shmem, st, w_cb, L.scale, L.shift, c0, f1pre,
+                     lat_w, lat_b, out, L.rgb_src, out_stride, N, H, W, tiles_y, tiles_x);
+        return;
+    }
+    if (ENERF_SMOOTH0_CB && ENERF_SMOOTH0_B4 && w_pq != nullptr && w_cb != nullptr) {   // round 5, first step: weights in registers
         const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
         const size_t shmem = (size_t)(9 * 256 + 4 * 340 * 4 + 44 * 4) * sizeof(float);
         ENERF_LAUNCH(k_smooth0_cb, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, w_cb, L.scale, L.shift, c0, f1pre, lat_w,
