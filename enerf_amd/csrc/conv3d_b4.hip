@@ -522,15 +522,21 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_s1_b4c(const float* __restric
 // per CU that pays (zju level-0 conv0, 4096 boxes: 79.4 -> 65.3 us; zju level 1: 133.8 -> 131.0); at ~5 boxes per CU the
 // occupancy quantisation loses (dtu level-1 conv0, 1280 boxes = 4 + 1 instead of 3 + 2 per CU: 46.1 -> 51.4 us), and the
 // heads / dtu level 0 (1920 boxes) are unchanged: the tap loops were already at the instruction's rate.
+// Routing (round 5, second pass): what decides is the occupancy QUANTISATION, not the box count — with k co-resident blocks per CU a
+// layer of n boxes needs ceil(n / (CUs k)) rounds of k slots: zju level 0 (1024 boxes = exactly one round of four: 79.4 -> 65.3 us) and
+// zju level 1 (4096 = four rounds of four instead of 5.33 of three) want b4c, dtu level 1 (1280 = 3 + 2 instead of 4 + 1) wants b4g.
+// b4c is taken when its slot-rounds ceil(n / (4 CUs)) * 4 do not exceed b4g's ceil(n / (3 CUs)) * 3.
 #ifndef ENERF_B4_CB
-#define ENERF_B4_CB 2048             // k_conv3d_s1_b4c (weights in registers) from this many boxes on; below: b4g.  0: never
+#define ENERF_B4_CB 1                // 1: route by slot-rounds (above); 2: b4c always; 0: never
 #endif
 template <int CIN, int BD, bool HEADS>
 static void launch_b4g(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W, hipStream_t st) {
     constexpr int NVOX = (BD + 2) * 10 * 18, NCH = (NVOX + 63) / 64, NS = HEADS ? 3 : 2, NWCH = (27 * NS * 4 + 63) / 64;
     const int nbd = cdiv(D, BD), nbh = cdiv(H, 8), nbw = cdiv(W, 16);
     const unsigned grid = (unsigned)((long long)B * nbd * nbh * nbw);
-    if (ENERF_B4_CB > 0 && grid >= (unsigned)ENERF_B4_CB) {
+    const long long cus_ = device_cu_count();
+    const long long sr4 = cdivl(grid, 4 * cus_) * 4, sr3 = cdivl(grid, 3 * cus_) * 3;
+    if (ENERF_B4_CB == 2 || (ENERF_B4_CB == 1 && sr4 <= sr3)) {
         const size_t shmem_c = (size_t)2 * (NCH + (HEADS ? 1 : 0)) * 64 * 4 * sizeof(float);
         ENERF_LAUNCH((k_conv3d_s1_b4c<CIN, BD, HEADS>), grid, 256, shmem_c, st, L.w_b4, L.scale, L.shift, in, out, out2, L.relu, B,
                      D, H, W, nbd, nbh, nbw, L.in_planar);
