@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import torch
 
+from . import pack_plan
 from .lib import EnerfLib
 
 
@@ -322,11 +323,13 @@ class _BatchNormTrain:
 
 
 class _Block:
-    """One Conv3d/ConvTranspose3d + BatchNorm3d (+ ReLU) (+ skip add) in training mode."""
+    """One Conv3d/ConvTranspose3d + BatchNorm3d (+ ReLU) (+ skip add) in training mode.  ``images``: the packed weight images
+    of the forward layer and of its input-gradient layer (pack_plan.cost_reg_plan: one gather launch per network and step)."""
 
-    def __init__(self, lib, w, bn, kind, relu):
+    def __init__(self, lib, w, bn, kind, relu, images):
         self.lib, self.w, self.kind = lib, w, kind
         self.norm = _BatchNormTrain(lib, bn, relu)
+        self.pk_fwd, self.pk_bwd = images
         if kind == _T2:
             self.cin, self.cout = w.shape[0], w.shape[1]
         else:
@@ -335,8 +338,7 @@ class _Block:
     def forward(self, x, residual=None):
         lib = self.lib
         self.x = x
-        packed = lib.conv3d_layer_pack(self.w.detach().contiguous(), self.cin, self.cout, self.kind)
-        z = lib.conv3d_layer(packed, self.cin, self.cout, self.kind, x)
+        z = lib.conv3d_layer(self.pk_fwd, self.cin, self.cout, self.kind, x)
         return self.norm.forward(z, residual)
 
     def backward(self, g):
@@ -344,19 +346,14 @@ class _Block:
         (grad_input, grad_weight, grad_bn_weight, grad_bn_bias)."""
         lib = self.lib
         dz, dgamma, dbeta = self.norm.backward(g)
-        w = self.w.detach()
-        if self.kind == _S1:                                                         # dgrad: flipped, channel-transposed
-            wd = lib.weights_flip_transpose(w.contiguous())
-            pk = lib.conv3d_layer_pack(wd, self.cout, self.cin, _S1)
-            gx = lib.conv3d_layer(pk, self.cout, self.cin, _S1, dz)
+        if self.kind == _S1:                                                         # dgrad: flipped, channel-transposed weights
+            gx = lib.conv3d_layer(self.pk_bwd, self.cout, self.cin, _S1, dz)
             gw = lib.conv_wgrad_cl(dz, self.x, 1)
         elif self.kind == _S2:                                                       # dgrad of a stride-2 conv = transposed conv on w
-            pk = lib.conv3d_layer_pack(w.contiguous(), self.cout, self.cin, _T2)
-            gx = lib.conv3d_layer(pk, self.cout, self.cin, _T2, dz)
+            gx = lib.conv3d_layer(self.pk_bwd, self.cout, self.cin, _T2, dz)
             gw = lib.conv_wgrad_cl(dz, self.x, 2)
         else:                                                                        # dgrad of a transposed conv = stride-2 conv on w
-            pk = lib.conv3d_layer_pack(w.contiguous(), self.cout, self.cin, _S2)
-            gx = lib.conv3d_layer(pk, self.cout, self.cin, _S2, dz)
+            gx = lib.conv3d_layer(self.pk_bwd, self.cout, self.cin, _S2, dz)
             gw = lib.conv_wgrad_cl(self.x, dz, 2)
         return gx, gw, dgamma, dbeta
 
@@ -368,15 +365,16 @@ class CostRegTrainFn(torch.autograd.Function):
     def forward(ctx, lib: EnerfLib, m, vol, *params):
         x = vol.permute(0, 2, 3, 4, 1).contiguous()                                   # channels-last (a view of FeatureVolumeFn's output)
         blk = {}
+        img = pack_plan.plan_of(lib, m, pack_plan.cost_reg_plan, x.device).run()     # every weight image of the step: one launch
 
         def cbr(i, kind):
             mod = getattr(m, f"conv{i}")
-            blk[i] = _Block(lib, mod.conv.weight, mod.bn, kind, True)
+            blk[i] = _Block(lib, mod.conv.weight, mod.bn, kind, True, (img[i, "fwd"], img[i, "bwd"]))
             return blk[i]
 
         def up(i):
             mod = getattr(m, f"conv{i}")
-            blk[i] = _Block(lib, mod[0].weight, mod[1], _T2, False)
+            blk[i] = _Block(lib, mod[0].weight, mod[1], _T2, False, (img[i, "fwd"], img[i, "bwd"]))
             return blk[i]
         c0 = cbr(0, _S1).forward(x)
         c2 = cbr(2, _S1).forward(cbr(1, _S2).forward(c0))
@@ -388,10 +386,8 @@ class CostRegTrainFn(torch.autograd.Function):
         y = up(9).forward(y, residual=c2)
         y = up(11).forward(y, residual=c0)
         # heads: feat_conv (8 -> 8) ++ depth_conv (8 -> 1) as one 8 -> 16 layer (rows 9..15 zero)
-        wf, wd = m.feat_conv[0].weight.detach(), m.depth_conv[0].weight.detach()
-        w16 = lib.concat2_pad(_c(wf), _c(wd), 16 * 8 * 27).view(16, 8, 3, 3, 3)
-        heads = lib.conv3d_layer(lib.conv3d_layer_pack(w16, 8, 16, _S1), 8, 16, _S1, y)
-        ctx.lib, ctx.m, ctx.blk, ctx.y, ctx.w16 = lib, m, blk, y, w16
+        heads = lib.conv3d_layer(img["heads", "fwd"], 8, 16, _S1, y)
+        ctx.lib, ctx.m, ctx.blk, ctx.y, ctx.heads_bwd = lib, m, blk, y, img["heads", "bwd"]
         feat = lib.slice_channels(heads, 0, 8).permute(0, 4, 1, 2, 3)      # contiguous channels-last (what the render-side fetch reads)
         prob = lib.slice_channels(heads, 8, 1)[..., 0]                     # contiguous (B,D,h,w)
         return feat, prob
@@ -401,8 +397,7 @@ class CostRegTrainFn(torch.autograd.Function):
         lib, m, blk, y = ctx.lib, ctx.m, ctx.blk, ctx.y
         B, D, h, w, _ = y.shape
         g16 = lib.concat_channels(_c(g_feat.permute(0, 2, 3, 4, 1)), _c(g_prob).unsqueeze(-1), 16)
-        wd = lib.weights_flip_transpose(ctx.w16)
-        g = lib.conv3d_layer(lib.conv3d_layer_pack(wd, 16, 8, _S1), 16, 8, _S1, g16)     # d y11
+        g = lib.conv3d_layer(ctx.heads_bwd, 16, 8, _S1, g16)                         # d y11
         gw16 = lib.conv_wgrad_cl(g16, y, 1)
         grads = {"feat": gw16[:8], "depth": gw16[8:9]}
 
@@ -468,23 +463,21 @@ def cost_reg_train(lib, m, vol):
 # transposed 5x5 convolution: no kernel of ours).
 # ---------------------------------------------------------------------------------------------------------------------
 class _Conv2d:
-    """One convolution of the FeatureNet on channels-last tensors (cin = 3: the NCHW image batch)."""
+    """One convolution of the FeatureNet on channels-last tensors (cin = 3: the NCHW image batch).  ``img``: the step's packed
+    weight images (pack_plan.feature_net_plan), ``name`` this layer's key in it."""
 
-    def __init__(self, lib, conv):
-        self.lib, self.conv = lib, conv
+    def __init__(self, lib, conv, img, name):
+        self.lib, self.conv, self.img, self.name = lib, conv, img, name
         self.cout, self.cin, self.k, _ = conv.weight.shape
         self.stride = int(conv.stride[0])
 
     def forward(self, x, up=None):
-        lib, w = self.lib, self.conv.weight.detach()
         self.x = x
-        bias = None if self.conv.bias is None else self.conv.bias.detach()
-        return lib.conv2d_layer(lib.conv2d_layer_pack(w.contiguous(), bias, self.cin, self.cout, self.k), self.cin, self.cout, self.k,
-                                self.stride, x, up)
+        return self.lib.conv2d_layer(self.img[self.name, "fwd"], self.cin, self.cout, self.k, self.stride, x, up)
 
     def backward(self, dz, need_input=True, add=None):
         """dz = gradient w.r.t. the convolution's output (channels-last) -> (grad_input (+ add) or None, grad_weight, grad_bias or None)."""
-        lib, w = self.lib, self.conv.weight.detach()
+        lib = self.lib
         if self.cin == 3:                                       # the NCHW image batch -> channels-last (the library's adapter kernel)
             N, _, H, W = self.x.shape
             x_cl = lib.channels_last(self.x.reshape(N, 3, H * W), N, 3, H * W).view(N, H, W, 3)
@@ -494,13 +487,12 @@ class _Conv2d:
         gb = None if self.conv.bias is None else lib.cast_f32(lib.channel_sums(dz, dz)[0])
         gx = None
         if need_input and self.stride == 1:                    # the stride-1 kernel on the flipped, channel-transposed weights
-            wd = lib.weights_flip_transpose(w.contiguous())
-            gx = lib.conv2d_layer(lib.conv2d_layer_pack(wd, None, self.cout, self.cin, self.k), self.cout, self.cin, self.k, 1, dz)
+            gx = lib.conv2d_layer(self.img[self.name, "bwd"], self.cout, self.cin, self.k, 1, dz)
             if add is not None:
                 gx = lib.add(gx, add)
         elif need_input:                                        # transposed 5x5 stride-2 convolution (feature_net.py:11,14): four
-            gx = lib.conv2d_s2k5_dgrad(w.contiguous(), dz, add=add)   # parity classes on the stride-1 MFMA kernel + depth-to-space
-        return gx, gw, gb
+            gx = lib.conv2d_s2k5_dgrad_packed(self.img[self.name, "s2k5"], self.cin, self.cout, dz, add=add)   # parity classes on the
+        return gx, gw, gb                                       # stride-1 MFMA kernel + depth-to-space
 
 
 _FEAT_ORDER = ("conv0.0", "conv0.1", "conv1.0", "conv1.1", "conv2.0", "conv2.1", "toplayer", "lat1", "lat0", "smooth1", "smooth0")
@@ -514,15 +506,16 @@ class FeatureNetTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lib: EnerfLib, m, x, *params):
         conv, norm = {}, {}
+        img = pack_plan.plan_of(lib, m, pack_plan.feature_net_plan, x.device).run()  # every weight image of the step: one launch
 
         def cbr(name, t):
             blk = getattr(m, name[:5])[int(name[6])]
-            conv[name] = _Conv2d(lib, blk.conv)
+            conv[name] = _Conv2d(lib, blk.conv, img, name)
             norm[name] = _BatchNormTrain(lib, blk.bn, True)
             return norm[name].forward(conv[name].forward(t))
 
         def plain(name, t, up=None):
-            conv[name] = _Conv2d(lib, getattr(m, name))
+            conv[name] = _Conv2d(lib, getattr(m, name), img, name)
             return conv[name].forward(t, up)
         c0 = cbr("conv0.1", cbr("conv0.0", x.contiguous()))
         c1 = cbr("conv1.1", cbr("conv1.0", c0))

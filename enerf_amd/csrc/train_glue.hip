@@ -321,14 +321,16 @@ __global__ __launch_bounds__(256) void k_concat_channels(const float* __restrict
     const int c = (int)(i - p * C);
     out[i] = c < Ca ? a[p * Ca + c] : (c < Ca + Cb ? b[p * Cb + (c - Ca)] : 0.f);
 }
-// out[i] = idx[i] >= 0 ? srcs[which[i]][idx[i]] : 0     (<= 8 source tensors: the MLP backward's transposed-weight images)
-struct GatherSrcs { const float* p[8]; };
+// out[i] = idx[i] >= 0 ? srcs[which[i]][idx[i]] : 0     (<= 64 source tensors: the MLP backward's transposed-weight images, and
+// every packed convolution-weight image of a network's training step in one launch — enerf_amd/pack_plan.py)
+constexpr int kGatherSrcs = 64;
+struct GatherSrcs { const float* p[kGatherSrcs]; };
 __global__ __launch_bounds__(256) void k_gather_images(GatherSrcs s, const int* __restrict__ which, const int* __restrict__ idx,
                                                        long long n, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int j = idx[i];
-    out[i] = j >= 0 ? s.p[which[i] & 7][j] : 0.f;
+    out[i] = j >= 0 ? s.p[which[i] & (kGatherSrcs - 1)][j] : 0.f;
 }
 // sum_i w_i * mean((a_i - b_i)^2) is the trainer's; this is its plain building block: out = a (+ b), any length
 __global__ __launch_bounds__(256) void k_add2(const float* __restrict__ a, const float* __restrict__ b, long long n, float* __restrict__ out) {
@@ -366,28 +368,54 @@ static S2k5Plan s2k5_plan(int cin, int cout, int N, int Ho, int Wo) {
 size_t enerf_conv2d_s2k5_dgrad_workspace_bytes(int cin, int cout, int N, int Ho, int Wo) {
     return (size_t)s2k5_plan(cin, cout, N, Ho, Wo).total * sizeof(float);
 }
+// the packed 3x3 sub-kernel images alone (parts x enerf_conv2d_layer_packed_floats(cout, cout3, 3), 64-float aligned pieces):
+// what a caller that prepares all of a step's weight images in one launch (enerf_amd/pack_plan.py) traces and then hands to
+// enerf_conv2d_s2k5_dgrad_packed.  `w3_scratch`: 4*cin*cout*9 floats.
+long long enerf_conv2d_s2k5_dgrad_packed_floats(int cin, int cout) {
+    const S2k5Plan pl = s2k5_plan(cin, cout, 1, 1, 1);
+    return pl.parts * pl.pk;
+}
+int enerf_conv2d_s2k5_dgrad_pack(const float* w, int cin, int cout, float* w3_scratch, float* packed, enerf_stream_t stream) {
+    REQUIRE(w && w3_scratch && packed, "conv2d_s2k5_dgrad_pack: null pointer");
+    REQUIRE((cin == 8 && cout == 16) || (cin == 16 && cout == 32), "conv2d_s2k5_dgrad_pack: the FeatureNet's layers are 8 -> 16 and 16 -> 32 (got %d -> %d)", cin, cout);
+    const S2k5Plan pl = s2k5_plan(cin, cout, 1, 1, 1);
+    const long long w3n = (long long)4 * cin * cout * 9;
+    ENERF_LAUNCH_SIMPLE(k_t5_subkernels, (unsigned)cdivl(w3n, 256), 256, 0, (hipStream_t)stream, w, cout, cin, w3_scratch);
+    for (int q = 0; q < pl.parts; ++q) {
+        int rc = enerf_conv2d_layer_pack(w3_scratch + (long long)q * pl.cout3 * cout * 9, nullptr, cout, pl.cout3, 3, packed + q * pl.pk, stream);
+        if (rc != ENERF_OK) return rc;
+    }
+    return check_launch("conv2d_s2k5_dgrad_pack");
+}
+// workspace: the class outputs only (enerf_conv2d_s2k5_dgrad_workspace_bytes covers it)
+int enerf_conv2d_s2k5_dgrad_packed(const float* packed, int cin, int cout, const float* dz, const float* add, float* gx, int N, int Ho,
+                                   int Wo, void* workspace, size_t workspace_bytes, enerf_stream_t stream) {
+    REQUIRE(packed && dz && gx && workspace && N > 0 && Ho > 0 && Wo > 0, "conv2d_s2k5_dgrad_packed: bad arguments");
+    REQUIRE((cin == 8 && cout == 16) || (cin == 16 && cout == 32), "conv2d_s2k5_dgrad_packed: the FeatureNet's layers are 8 -> 16 and 16 -> 32 (got %d -> %d)", cin, cout);
+    const S2k5Plan pl = s2k5_plan(cin, cout, N, Ho, Wo);
+    REQUIRE(workspace_bytes >= (size_t)pl.parts * pl.cls * sizeof(float), "conv2d_s2k5_dgrad_packed: workspace too small");
+    float* cls = (float*)workspace;
+    for (int q = 0; q < pl.parts; ++q) {
+        int rc = enerf_conv2d_layer(packed + q * pl.pk, cout, pl.cout3, 3, 1, dz, nullptr, cls + q * pl.cls, N, Ho, Wo, stream);
+        if (rc != ENERF_OK) return rc;
+    }
+    const long long total = (long long)N * 2 * Ho * 2 * Wo * (cin / 4);
+    ENERF_LAUNCH_SIMPLE(k_depth_to_space2, (unsigned)cdivl(total, 256), 256, 0, (hipStream_t)stream, cls, pl.parts == 2 ? cls + pl.cls : nullptr,
+                        4 / pl.parts, add, N, Ho, Wo, cin / 4, gx);
+    return check_launch("conv2d_s2k5_dgrad_packed");
+}
 int enerf_conv2d_s2k5_dgrad(const float* w, int cin, int cout, const float* dz, const float* add, float* gx, int N, int Ho, int Wo,
                             void* workspace, size_t workspace_bytes, enerf_stream_t stream) {
     REQUIRE(w && dz && gx && workspace && N > 0 && Ho > 0 && Wo > 0, "conv2d_s2k5_dgrad: bad arguments");
     REQUIRE((cin == 8 && cout == 16) || (cin == 16 && cout == 32), "conv2d_s2k5_dgrad: the FeatureNet's layers are 8 -> 16 and 16 -> 32 (got %d -> %d)", cin, cout);
     const S2k5Plan pl = s2k5_plan(cin, cout, N, Ho, Wo);
     REQUIRE(workspace_bytes >= (size_t)pl.total * sizeof(float), "conv2d_s2k5_dgrad: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
     float* w3 = (float*)workspace;
     float* packed = w3 + pl.w3;
-    float* cls = packed + pl.parts * pl.pk;
-    const long long w3n = (long long)4 * cin * cout * 9;
-    ENERF_LAUNCH_SIMPLE(k_t5_subkernels, (unsigned)cdivl(w3n, 256), 256, 0, st, w, cout, cin, w3);
-    for (int q = 0; q < pl.parts; ++q) {
-        int rc = enerf_conv2d_layer_pack(w3 + (long long)q * pl.cout3 * cout * 9, nullptr, cout, pl.cout3, 3, packed + q * pl.pk, stream);
-        if (rc != ENERF_OK) return rc;
-        rc = enerf_conv2d_layer(packed + q * pl.pk, cout, pl.cout3, 3, 1, dz, nullptr, cls + q * pl.cls, N, Ho, Wo, stream);
-        if (rc != ENERF_OK) return rc;
-    }
-    const long long total = (long long)N * 2 * Ho * 2 * Wo * (cin / 4);
-    ENERF_LAUNCH_SIMPLE(k_depth_to_space2, (unsigned)cdivl(total, 256), 256, 0, st, cls, pl.parts == 2 ? cls + pl.cls : nullptr,
-                        4 / pl.parts, add, N, Ho, Wo, cin / 4, gx);
-    return check_launch("conv2d_s2k5_dgrad");
+    int rc = enerf_conv2d_s2k5_dgrad_pack(w, cin, cout, w3, packed, stream);
+    if (rc != ENERF_OK) return rc;
+    return enerf_conv2d_s2k5_dgrad_packed(packed, cin, cout, dz, add, gx, N, Ho, Wo, packed + pl.parts * pl.pk,
+                                          (size_t)pl.parts * pl.cls * sizeof(float), stream);
 }
 
 int enerf_resize_ac_adjoint(const float* grad_fine, const float* add, int n_maps, int Hf, int Wf, int Hc, int Wc, float* grad_coarse,
@@ -474,9 +502,9 @@ int enerf_concat_channels(const float* a, int Ca, const float* b, int Cb, long l
 }
 int enerf_gather_images(const float* const* srcs, int n_srcs, const int* which, const int* idx, long long n, float* out,
                         enerf_stream_t stream) {
-    REQUIRE(srcs && which && idx && out && n > 0 && n_srcs >= 1 && n_srcs <= 8, "gather_images: bad arguments");
+    REQUIRE(srcs && which && idx && out && n > 0 && n_srcs >= 1 && n_srcs <= kGatherSrcs, "gather_images: bad arguments");
     GatherSrcs s;
-    for (int k = 0; k < 8; ++k) s.p[k] = k < n_srcs ? srcs[k] : srcs[0];
+    for (int k = 0; k < kGatherSrcs; ++k) s.p[k] = k < n_srcs ? srcs[k] : srcs[0];
     ENERF_LAUNCH_SIMPLE(k_gather_images, (unsigned)cdivl(n, 256), 256, 0, (hipStream_t)stream, s, which, idx, n, out);
     return check_launch("gather_images");
 }

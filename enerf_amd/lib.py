@@ -186,6 +186,9 @@ _SIGNATURES = {
     "enerf_channel_affine": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _ll, _i, _f, _f]),
     "enerf_conv2d_s2k5_dgrad_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "enerf_conv2d_s2k5_dgrad": (_i, [_f, _i, _i, _f, _f, _f, _i, _i, _i, C.c_void_p, C.c_size_t, _f]),
+    "enerf_conv2d_s2k5_dgrad_packed_floats": (_ll, [_i, _i]),
+    "enerf_conv2d_s2k5_dgrad_pack": (_i, [_f, _i, _i, _f, _f, _f]),
+    "enerf_conv2d_s2k5_dgrad_packed": (_i, [_f, _i, _i, _f, _f, _f, _i, _i, _i, C.c_void_p, C.c_size_t, _f]),
     "enerf_resize_ac_adjoint": (_i, [_f, _f, _i, _i, _i, _i, _i, _f, _f]),
     "enerf_get_depth_values_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f]),
     "enerf_ray_samples_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
@@ -730,6 +733,28 @@ class EnerfLib:
                                                      ws.numel(), self.stream_of(dz)), "conv2d_s2k5_dgrad")
         return gx
 
+    def conv2d_s2k5_dgrad_pack(self, w):
+        """The packed sub-kernel images of conv2d_s2k5_dgrad alone -> (packed (zero slack), parts, floats per part incl. slack,
+        floats per part, output channels per part)."""
+        cout, cin = w.shape[0], w.shape[1]
+        total = self.dll.enerf_conv2d_s2k5_dgrad_packed_floats(cin, cout)
+        cout3 = 2 * cin if 4 * cin > 32 else 4 * cin
+        parts = 4 * cin // cout3
+        packed = torch.zeros((total,), dtype=torch.float32, device=w.device)
+        w3 = torch.empty((4 * cin * cout * 9,), dtype=torch.float32, device=w.device)
+        self._check(self.dll.enerf_conv2d_s2k5_dgrad_pack(_ptr(w.contiguous()), cin, cout, _ptr(w3), _ptr(packed), self.stream_of(w)),
+                    "conv2d_s2k5_dgrad_pack")
+        return packed, parts, total // parts, self.dll.enerf_conv2d_layer_packed_floats(cout, cout3, 3), cout3
+
+    def conv2d_s2k5_dgrad_packed(self, packed, cin, cout, dz, add=None):
+        """conv2d_s2k5_dgrad on images prepared by conv2d_s2k5_dgrad_pack (or a PackPlan's gather)."""
+        N, Ho, Wo, _ = dz.shape
+        gx = torch.empty((N, 2 * Ho, 2 * Wo, cin), dtype=torch.float32, device=dz.device)
+        ws = self._scratch(self.dll.enerf_conv2d_s2k5_dgrad_workspace_bytes(cin, cout, N, Ho, Wo), dz.device)
+        self._check(self.dll.enerf_conv2d_s2k5_dgrad_packed(_ptr(packed), cin, cout, _ptr(dz), _ptr(add), _ptr(gx), N, Ho, Wo, ws.data_ptr(),
+                                                            ws.numel(), self.stream_of(dz)), "conv2d_s2k5_dgrad_packed")
+        return gx
+
     def resize_ac_adjoint(self, g_fine, Hc, Wc, add=None):
         """(..., Hf, Wf) planar gradient maps -> (..., Hc, Wc): adjoint of the align-corners bilinear resize."""
         lead, (Hf, Wf) = g_fine.shape[:-2], g_fine.shape[-2:]
@@ -816,7 +841,7 @@ class EnerfLib:
         return out
 
     def gather_images(self, srcs, which, idx):
-        """out[i] = idx[i] >= 0 ? srcs[which[i]].flatten()[idx[i]] : 0; srcs: <= 8 contiguous float tensors; which/idx int32."""
+        """out[i] = idx[i] >= 0 ? srcs[which[i]].flatten()[idx[i]] : 0; srcs: <= 64 contiguous float tensors; which/idx int32."""
         arr = (C.c_void_p * len(srcs))(*[_ptr(t) for t in srcs])
         out = torch.empty((idx.numel(),), dtype=torch.float32, device=idx.device)
         self._check(self.dll.enerf_gather_images(C.cast(arr, C.c_void_p), len(srcs), which.data_ptr(), idx.data_ptr(), idx.numel(), _ptr(out),

@@ -479,13 +479,19 @@ int enerf_composite_bwd(const float* raw, const float* z, const float* grad_rgb,
  *   enerf_pack_texels_train    tex (n,Hr,Wr,C+3) = [feat_cl (n,Hr,Wr,C) | bilinear_ac(src*0.5+0.5) (3)] (network.py:28-33).
  *   enerf_slice_channels       dst (n,C) = src (n,F)[:, c0:c0+C].
  *   enerf_concat_channels      out (n,C) = [a (n,Ca) | b (n,Cb) | 0]  (the fused heads' gradient from d feat and d prob).
- *   enerf_gather_images        out[i] = idx[i] >= 0 ? srcs[which[i]][idx[i]] : 0 over <= 8 source tensors (the transposed-
- *       weight images of enerf_nerf_mlp_bwd in one launch).
+ *   enerf_gather_images        out[i] = idx[i] >= 0 ? srcs[which[i]][idx[i]] : 0 over <= 64 source tensors (the transposed-
+ *       weight images of enerf_nerf_mlp_bwd, and every packed convolution-weight image of a network's training step, in one launch each).
  *   enerf_add                  out = a + b.
  *   enerf_cast_f64_f32         out (n) fp32 = in (n) fp64 (bias gradients come out of enerf_channel_sums in fp64).
  *   enerf_reciprocal           out = 1 / x  (depth_mvs of a disparity-space level, network.py:105-108).
  *   enerf_composite_bwd        (changed) grad_rgb / grad_depth / grad_weights may be NULL = zeros (outputs the loss ignores). */
 size_t enerf_conv2d_s2k5_dgrad_workspace_bytes(int cin, int cout, int N, int Ho, int Wo);
+/* (ABI v9) the same in two halves, for a caller that prepares the step's weight images itself: _pack writes the parts' packed
+ * sub-kernel images (enerf_conv2d_s2k5_dgrad_packed_floats floats; w3_scratch: 4*cin*cout*9 floats), _packed runs on them. */
+long long enerf_conv2d_s2k5_dgrad_packed_floats(int cin, int cout);
+int enerf_conv2d_s2k5_dgrad_pack(const float* w, int cin, int cout, float* w3_scratch, float* packed, enerf_stream_t stream);
+int enerf_conv2d_s2k5_dgrad_packed(const float* packed, int cin, int cout, const float* dz, const float* add, float* gx, int N, int Ho,
+                                   int Wo, void* workspace, size_t workspace_bytes, enerf_stream_t stream);
 int enerf_conv2d_s2k5_dgrad(const float* w, int cin, int cout, const float* dz, const float* add, float* gx, int N, int Ho, int Wo,
                             void* workspace, size_t workspace_bytes, enerf_stream_t stream);
 int enerf_resize_ac_adjoint(const float* grad_fine, const float* add, int n_maps, int Hf, int Wf, int Hc, int Wc, float* grad_coarse,

@@ -508,6 +508,70 @@ def test_graphed_step_shape_key_and_flat_sync_guards():
         FlatGradSync(torch.nn.Linear(2, 2))
 
 
+def _check_pack_plan_images(lib, dev):
+    """enerf_amd/pack_plan.py: the one-launch gather of a network's packed weight images is, element for element, what the
+    per-layer pack entries (enerf_conv3d_layer_pack / enerf_conv2d_layer_pack / enerf_weights_flip_transpose /
+    enerf_conv2d_s2k5_dgrad_pack) produce from the same parameters — after a parameter update too (the plan holds getters)."""
+    from enerf_amd import pack_plan as PP
+    from enerf_amd.network import CostRegParams, FeatureNet
+    torch.manual_seed(11)
+    S1, S2, T2 = 0, 1, 2
+    for full in (True, False):
+        m = CostRegParams(32 if full else 8, full).to(dev)
+        plan = PP.plan_of(lib, m, PP.cost_reg_plan, dev)
+        assert PP.plan_of(lib, m, PP.cost_reg_plan, dev) is plan                  # cached on the module
+        for rnd in range(2):
+            if rnd == 1:
+                with torch.no_grad():
+                    for p_ in m.parameters():
+                        p_.add_(torch.randn_like(p_) * 0.1)
+            img = plan.run()
+            kinds = {0: S1, 1: S2, 2: S1, 3: S2, 4: S1, 5: S2, 6: S1, 7: T2, 9: T2, 11: T2}
+            for i in [0, 1, 2, 3, 4] + ([5, 6, 7] if full else []) + [9, 11]:
+                mod = getattr(m, f"conv{i}")
+                w = (mod[0] if i in (7, 9, 11) else mod.conv).weight.detach().contiguous()
+                k = kinds[i]
+                cin, cout = (w.shape[0], w.shape[1]) if k == T2 else (w.shape[1], w.shape[0])
+                assert torch.equal(img[i, "fwd"], lib.conv3d_layer_pack(w, cin, cout, k)), (i, "fwd")
+                if k == S1:
+                    ref = lib.conv3d_layer_pack(lib.weights_flip_transpose(w), cout, cin, S1)
+                else:
+                    ref = lib.conv3d_layer_pack(w, cout, cin, T2 if k == S2 else S2)
+                assert torch.equal(img[i, "bwd"], ref), (i, "bwd")
+            wf, wd = m.feat_conv[0].weight.detach().contiguous(), m.depth_conv[0].weight.detach().contiguous()
+            w16 = lib.concat2_pad(wf, wd, 16 * 8 * 27).view(16, 8, 3, 3, 3)
+            assert torch.equal(img["heads", "fwd"], lib.conv3d_layer_pack(w16, 8, 16, S1))
+            assert torch.equal(img["heads", "bwd"], lib.conv3d_layer_pack(lib.weights_flip_transpose(w16), 16, 8, S1))
+    f = FeatureNet().to(dev)
+    with torch.no_grad():
+        for p_ in f.parameters():
+            p_.add_(torch.randn_like(p_) * 0.1)
+    img = PP.plan_of(lib, f, PP.feature_net_plan, dev).run()
+    for name in PP.FEAT_LAYERS:
+        conv = getattr(f, name[:5])[int(name[6])].conv if name.startswith("conv") else getattr(f, name)
+        w = conv.weight.detach().contiguous()
+        b = None if conv.bias is None else conv.bias.detach()
+        cout, cin, k, _ = w.shape
+        assert torch.equal(img[name, "fwd"], lib.conv2d_layer_pack(w, b, cin, cout, k)), name
+        if name == "conv0.0":
+            continue
+        if int(conv.stride[0]) == 1:
+            assert torch.equal(img[name, "bwd"], lib.conv2d_layer_pack(lib.weights_flip_transpose(w), None, cout, cin, k)), name
+        else:
+            assert torch.equal(img[name, "s2k5"], lib.conv2d_s2k5_dgrad_pack(w)[0]), name
+
+
+def test_pack_plan_images_emulated():
+    from emu_lib import emu_lib
+    _check_pack_plan_images(emu_lib(), torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_pack_plan_images_on_gpu():
+    from enerf_amd.lib import get_lib
+    _check_pack_plan_images(get_lib(), torch.device("cuda:0"))
+
+
 def test_feature_net_train_emulated():
     from emu_lib import emu_lib
     _check_feature_net_train(emu_lib(), torch.device("cpu"))
