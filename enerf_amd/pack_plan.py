@@ -14,6 +14,8 @@ them).  Reference for what is being packed: cost_reg_net.py:7-86 (layers), featu
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 _S1, _S2, _T2 = 0, 1, 2
@@ -160,9 +162,13 @@ def feature_net_plan(lib, m, device):
     return plan.finish()
 
 
+_PLANS = weakref.WeakKeyDictionary()          # module -> {(builder, device, library): plan}; NOT an attribute of the module: a plan
+                                              # holds the ctypes library, and modules must stay deep-copyable / picklable
+
+
 def plan_of(lib, m, build, device):
     """The module's cached plan (built on first use — the eager warm-up steps of GraphedTrainStep — per device)."""
-    cache = m.__dict__.setdefault("_enerf_pack_plans", {})
+    cache = _PLANS.setdefault(m, {})
     key = (build.__name__, str(device), id(lib))
     if key not in cache:
         cache[key] = build(lib, m, device)

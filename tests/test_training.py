@@ -519,7 +519,9 @@ def _check_pack_plan_images(lib, dev):
     for full in (True, False):
         m = CostRegParams(32 if full else 8, full).to(dev)
         plan = PP.plan_of(lib, m, PP.cost_reg_plan, dev)
-        assert PP.plan_of(lib, m, PP.cost_reg_plan, dev) is plan                  # cached on the module
+        assert PP.plan_of(lib, m, PP.cost_reg_plan, dev) is plan                  # cached per module
+        import copy
+        copy.deepcopy(m)                                                          # (the cache must not ride on the module)
         for rnd in range(2):
             if rnd == 1:
                 with torch.no_grad():
