@@ -234,9 +234,214 @@ static int wgrad_chunks(long long npos, int pairs, int taps, bool two_stage) {
     const long long maxc = cdivl(groups, wgrad_pl(taps, npos) * 8);
     return (int)(want < maxc ? want : (maxc < 1 ? 1 : maxc));
 }
+#ifndef ENERF_WGRAD2D_BPC
+#define ENERF_WGRAD2D_BPC 4                      /* persistent blocks per CU (112 VGPRs: four waves per SIMD; 21 KB of LDS each) */
+#endif
+#ifndef ENERF_WGRAD2D_TILE
+#define ENERF_WGRAD2D_TILE 1                     /* 0: these layers stay on k_conv_wgrad (A/B builds) */
+#endif
 size_t conv_wgrad_workspace_bytes(long long npos, int Ca, int Cb, int taps, int bias) {
     const int pairs = cdiv(Ca, 16) * cdiv(Cb + bias, 16);
-    return (size_t)pairs * wgrad_chunks(npos, pairs, taps, true) * taps * 256 * sizeof(float);
+    const size_t two_stage = (size_t)pairs * wgrad_chunks(npos, pairs, taps, true) * taps * 256 * sizeof(float);
+    // k_wgrad2d_3x3_c8 (below): one compact row of Ca*Cb*9 sums per persistent block (the query does not know the grid: the bound)
+    const size_t tiled = (ENERF_WGRAD2D_TILE && taps == 9 && Ca <= 8 && Cb <= 32 && !bias)
+                             ? (size_t)device_cu_count() * ENERF_WGRAD2D_BPC * Ca * Cb * 9 * sizeof(float) : 0;
+    return two_stage > tiled ? two_stage : tiled;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the 3x3 stride-1 2-D layers with <= 8 gradient channels (FeatureNet conv0.0 3 -> 8, conv0.1 8 -> 8, smooth0 32 -> 8:
+// full resolution, 983k positions each at dtu_pretrain) from LDS tiles, three kernel rows per MFMA.
+//
+// k_conv_wgrad spends one buffer load (offset add + select) per MFMA and three integer divisions per group of nine: these
+// layers ran at 0.12 - 0.15 of the matrix pipe (200 - 260 us each against a 29 us issue floor), and a 16 x 16 tile with 8 x 8
+// live channels wastes three quarters of every MFMA on top.  Here a block stages a (TH + 1) x TW tile of A and the haloed
+// (TH + 2) x (TW + 2) tile of B in LDS once (zeros outside the image) and a tap's operand is one ds_read_b32 at an immediate
+// offset: no address arithmetic per tap, no masks.  And the idle halves of the tile carry SHIFTED copies:
+//     A operand row (a, s):  A[a][(y + s, x)]                 s = 0, 1   (the next image row)
+//     B operand col (b, u):  B[b][(y + 2u - 1, x + kw - 1)]   u = 0, 1   (two image rows down)
+//     D[(a, s)][(b, u)] = sum_p A[a][p + s W] B[b][p + (2u - 1) W + kw - 1] = dW[a][b][kh = 2u - s][kw]
+// so ONE MFMA per kw yields kh = 0, 1, 2 (and one discarded quadrant, kh = -1): 3 MFMAs and 4 LDS reads per group of four
+// positions instead of 9 and 10.  Every output position o must be counted once per s: the tiles start one row ABOVE the image
+// (y0 = -1 + ty TH), where A is zero, so s = 1 reaches row 0 and s = 0 loses nothing.  Row pitches are chosen so that the 64
+// lanes of either operand read hit 64 different banks (A: pitch = 32 mod 64 floats; B: 2 x pitch = 32 mod 64).
+// Blocks are persistent over tiles and end with one compact row of Ca*Cb*9 partial sums (dW's own order); k_colsum adds the
+// rows in a fixed order: deterministic, no atomics.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kW2TH = 8, kW2TW = 32;
+constexpr int kW2APitch = kW2TW * 8 + 32, kW2BCols = kW2TW + 2, kW2BPitch = kW2BCols * 8;
+static_assert(kW2APitch % 64 == 32 && (2 * kW2BPitch) % 64 == 32, "bank-conflict-free operand reads");
+
+// one tile of `src` (n, H, W, ld floats per position; C <= 8 NCB channels used) into LDS: rows y0 .., cols x0 .., zeros outside
+// the image; one plane of PLANE floats per block of 8 channels, pixel pitch 8 floats inside a plane (so that the 64 lanes of an
+// operand read hit 64 banks whatever C is).  V4: 16-byte loads (C a power of two >= 4, ld % 4 == 0, 16-byte aligned base).
+template <int ROWS, int COLS, int PITCH, int PLANE, int NCB, bool V4>
+__device__ __forceinline__ void w2_stage(const float* __restrict__ src, int img, int H, int W, int C, int ld, int y0, int x0,
+                                         float* __restrict__ dst) {
+    if (V4) {
+        const int nq = C >> 2, sh = nq >= 8 ? 3 : nq >= 4 ? 2 : nq >= 2 ? 1 : 0;       // quads per pixel (1, 2, 4, 8)
+        constexpr int NIT = (ROWS * COLS * 2 * NCB + 255) / 256;
+        float4 v[NIT];
+        int o[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = (int)threadIdx.x + it * 256;
+            const int pos = i >> sh, qd = i & (nq - 1);
+            const int r = pos / COLS, c = pos - r * COLS;
+            const int y = y0 + r, x = x0 + c;
+            const bool live = pos < ROWS * COLS;
+            const bool in = live && y >= 0 && y < H && x >= 0 && x < W;
+            o[it] = live ? (qd >> 1) * PLANE + r * PITCH + c * 8 + (qd & 1) * 4 : -1;
+            v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in) v[it] = *reinterpret_cast<const float4*>(src + (((long long)img * H + y) * W + x) * ld + qd * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (o[it] >= 0) *reinterpret_cast<float4*>(dst + o[it]) = v[it];
+    } else {
+        for (int i = (int)threadIdx.x; i < ROWS * COLS * C; i += 256) {
+            const int pos = i / C, ch = i - pos * C;
+            const int r = pos / COLS, c = pos - r * COLS;
+            const int y = y0 + r, x = x0 + c;
+            float v = 0.f;
+            if (y >= 0 && y < H && x >= 0 && x < W) v = src[(((long long)img * H + y) * W + x) * ld + ch];
+            dst[(ch >> 3) * PLANE + r * PITCH + c * 8 + (ch & 7)] = v;
+        }
+    }
+}
+
+// NCB: blocks of 8 B channels (Cb <= 8 NCB): one accumulator per (channel block, kw); Ca <= 8.
+template <bool A4, bool B4, int NCB>
+__global__ __launch_bounds__(256) void k_wgrad2d_3x3_c8(const float* __restrict__ A, const float* __restrict__ Bt, int n, int H, int W,
+                                                        int Ca, int Cb, int lda, int ldb, int tiles_y, int tiles_x,
+                                                        float* __restrict__ scratch) {
+    constexpr int TH = kW2TH, TW = kW2TW, AP = kW2APitch, BP = kW2BPitch, BPL = (TH + 2) * BP;
+    constexpr int GC = NCB == 1 ? TW / 4 : 4;              // groups whose operands are in registers at once (GC x (1 + 3 NCB) values)
+    __shared__ float la[(TH + 1) * AP];
+    __shared__ float lb[NCB * BPL];
+    static_assert(BPL >= 3 * 3 * 256, "the cross-wave reduction reuses the B tile");
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
+    const int lo = j & 7, hi = j >> 3;                     // A operand: (a, s) = (lo, hi); B operand: (b, u) = (lo, hi)
+    f32x4 acc[NCB][3];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[cb][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntiles = n * tiles_y * tiles_x;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+        const int x0 = tx * TW, y0 = ty * TH - 1;
+        w2_stage<TH + 1, TW, AP, 0, 1, A4>(A, img, H, W, Ca, lda, y0, x0, la);
+        w2_stage<TH + 2, kW2BCols, BP, BPL, NCB, B4>(Bt, img, H, W, Cb, ldb, y0 - 1, x0 - 1, lb);
+        __syncthreads();
+        // a chunk's operands are all requested before its first MFMA (left to itself hipcc waited for each ds_read2 pair in
+        // front of the two MFMAs that use it)
+#pragma unroll
+        for (int rr = 0; rr < TH / 4; ++rr) {
+            const int tr = wv + 4 * rr;
+            const float* pa = la + (tr + hi) * AP + g * 8 + lo;
+            const float* pb = lb + (tr + 2 * hi) * BP + g * 8 + lo;
+#pragma unroll
+            for (int c0 = 0; c0 < TW / 4; c0 += GC) {
+                float av[GC], bv[GC][NCB][3];
+#pragma unroll
+                for (int cg = 0; cg < GC; ++cg) {
+                    av[cg] = pa[(c0 + cg) * 32];
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) bv[cg][cb][k] = pb[cb * BPL + (c0 + cg) * 32 + k * 8];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int cg = 0; cg < GC; ++cg)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) acc[cb][k] = ENERF_MFMA_W(av[cg], bv[cg][cb][k], acc[cb][k]);
+                if (NCB > 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+    // waves 1..3 hand their tiles to wave 0 through LDS (the B tile's storage: the loop ended with a barrier)
+    float* red = lb;
+    if (wv != 0) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[cb * BPL + ((wv - 1) * 3 + k) * 256 + r * 64 + lane] = acc[cb][k][r];
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    float* out = scratch + (long long)blockIdx.x * (Ca * Cb * 9);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[cb][k][r];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) v += red[cb * BPL + (w * 3 + k) * 256 + r * 64 + lane];
+                // D rows 4g + r = (a, s), columns j = (b, u): kh = 2u - s, kw = k
+                const int row = 4 * g + r, a = row & 7, s = row >> 3, b = cb * 8 + lo, u = hi, kh = 2 * u - s;
+                if (kh >= 0 && a < Ca && b < Cb) out[(a * Cb + b) * 9 + kh * 3 + k] = v;
+            }
+}
+// out[i] = sum over the rows c < chunks of part[c * n_out + i], fixed order: 16 waves take rows c = w, w + 16, ... (four loads in
+// flight), then wave 0 adds the 16 partial sums.
+__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ part, int chunks, int n_out, float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    const bool live = i < n_out;
+    const float* sp = part + (live ? i : 0);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = w;
+    for (; c + 48 < chunks; c += 64) {
+        s0 += sp[(long long)c * n_out]; s1 += sp[(long long)(c + 16) * n_out];
+        s2 += sp[(long long)(c + 32) * n_out]; s3 += sp[(long long)(c + 48) * n_out];
+    }
+    for (; c < chunks; c += 16) s0 += sp[(long long)c * n_out];
+    red[w][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w != 0 || !live) return;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[k][lane];
+    out[i] = v;
+}
+static int wgrad2d_bpc(int Cb) { return Cb <= 8 ? ENERF_WGRAD2D_BPC : Cb <= 16 ? 3 : 2; }      // by LDS: 21 / 32 / 54 KB per block
+static int wgrad2d_blocks(int n, int H, int W, int Cb) {
+    const long long ntiles = (long long)n * cdiv(H + 1, kW2TH) * cdiv(W, kW2TW);
+    const long long cap = (long long)device_cu_count() * wgrad2d_bpc(Cb);
+    return (int)(ntiles < cap ? ntiles : cap);
+}
+static bool wgrad2d_fits(int n, int Da, int Ha, int Wa, int Ca, int Db, int Hb, int Wb, int Cb, int kd, int kh, int kw, int stride,
+                         int pad_d, int pad_h, int pad_w, bool bias) {
+    return ENERF_WGRAD2D_TILE && kd == 1 && kh == 3 && kw == 3 && stride == 1 && pad_d == 0 && pad_h == 1 && pad_w == 1 && Da == 1 &&
+           Db == 1 && Ha == Hb && Wa == Wb && Ca <= 8 && (Cb <= 8 || Cb == 16 || Cb == 32) && !bias && (long long)n * Ha * Wa >= 2048;
+}
+static size_t wgrad2d_workspace_bytes(int n, int H, int W, int Ca, int Cb) {
+    return (size_t)wgrad2d_blocks(n, H, W, Cb) * Ca * Cb * 9 * sizeof(float);
+}
+static bool launch_wgrad2d(const float* A, const float* Bt, int n, int H, int W, int Ca, int Cb, int lda, int ldb, float* dW,
+                           float* scratch, hipStream_t st) {
+    const int blocks = wgrad2d_blocks(n, H, W, Cb), tiles_y = cdiv(H + 1, kW2TH), tiles_x = cdiv(W, kW2TW);
+    const bool a4 = (Ca == 4 || Ca == 8) && lda % 4 == 0 && ((uintptr_t)A & 15) == 0;
+    const bool b4 = (Cb == 4 || Cb == 8 || Cb == 16 || Cb == 32) && ldb % 4 == 0 && ((uintptr_t)Bt & 15) == 0;
+    if (Cb > 8 && !b4) return false;
+#define ENERF_W2(A4, B4, NCB) ENERF_LAUNCH((k_wgrad2d_3x3_c8<A4, B4, NCB>), (unsigned)blocks, 256, 0, st, A, Bt, n, H, W, Ca, Cb, lda, ldb, tiles_y, tiles_x, scratch)
+    if (Cb == 32) { if (a4) ENERF_W2(true, true, 4); else ENERF_W2(false, true, 4); }
+    else if (Cb == 16) { if (a4) ENERF_W2(true, true, 2); else ENERF_W2(false, true, 2); }
+    else if (a4) { if (b4) ENERF_W2(true, true, 1); else ENERF_W2(true, false, 1); }
+    else { if (b4) ENERF_W2(false, true, 1); else ENERF_W2(false, false, 1); }
+#undef ENERF_W2
+    ENERF_LAUNCH(k_colsum, (unsigned)cdiv(Ca * Cb * 9, 64), 1024, 0, st, scratch, blocks, Ca * Cb * 9, dW);
+    return true;
 }
 
 bool launch_conv_wgrad(const float* A, const float* Bt, int n, int Da, int Ha, int Wa, int Ca, int Db, int Hb, int Wb, int Cb,
@@ -251,6 +456,10 @@ bool launch_conv_wgrad(const float* A, const float* Bt, int n, int Da, int Ha, i
     q.npos = (long long)n * Da * Ha * Wa;
     q.abytes = (unsigned)(q.npos * q.lda * 4);                       // (< 2^32: checked by the C entries)
     q.bbytes = (unsigned)((long long)n * Db * Hb * Wb * q.ldb * 4);
+    if (wgrad2d_fits(n, Da, Ha, Wa, Ca, Db, Hb, Wb, Cb, kd, kh, kw, stride, pad_d, pad_h, pad_w, dbias != nullptr) && workspace != nullptr &&
+        workspace_bytes >= wgrad2d_workspace_bytes(n, Ha, Wa, Ca, Cb) &&
+        launch_wgrad2d(A, Bt, n, Ha, Wa, Ca, Cb, q.lda, q.ldb, dW, (float*)workspace, st))
+        return true;
     const int taps = kd * kh * kw, pairs = q.tiles_a * q.tiles_b;
     float* scratch = (workspace != nullptr && workspace_bytes >= conv_wgrad_workspace_bytes(q.npos, Ca, Cb, taps, q.bias)) ? (float*)workspace : nullptr;
     q.chunks = wgrad_chunks(q.npos, pairs, taps, scratch != nullptr);

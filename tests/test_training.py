@@ -347,6 +347,20 @@ def _check_conv_wgrad(lib, dev):
         got = lib.conv_wgrad(gy, x, (k, k), st, (pad, pad))
         assert got.shape == ref.shape
         assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (cin, cout, k, st)
+    # the LDS-tiled 3x3 kernel of the <= 8-channel layers (k_wgrad2d_3x3_c8: >= 2048 positions): image edges inside a tile, a
+    # partial last tile row / column, the row above the image, 16-byte and scalar staging (channel counts 8, 4, 5, 3), two and
+    # four blocks of 8 input channels (smooth0: 32 -> 8)
+    for cin, cout, H, W in [(8, 8, 40, 70), (3, 8, 33, 64), (8, 4, 47, 45), (5, 8, 9, 250), (8, 8, 64, 32), (32, 8, 40, 70), (16, 8, 17, 66),
+                            (32, 5, 33, 40)]:
+        x = rnd(2, cin, H, W)
+        w = rnd(cout, cin, 3, 3).requires_grad_(True)
+        y = F.conv2d(x, w, None, 1, 1)
+        gy = rnd(*y.shape)
+        (ref,) = torch.autograd.grad(y, w, gy)
+        got = lib.conv_wgrad(gy, x, (3, 3), 1, (1, 1))
+        assert got.shape == ref.shape
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (cin, cout, H, W, float((got - ref).abs().max() / ref.abs().max()))
+        assert torch.equal(got, lib.conv_wgrad(gy, x, (3, 3), 1, (1, 1)))                       # deterministic
     for cin, cout, st in [(32, 8, 1), (8, 16, 2), (16, 32, 2), (64, 64, 1), (8, 1, 1), (8, 8, 1)]:
         x = rnd(1, cin, 4, 6, 10)
         w = rnd(cout, cin, 3, 3, 3).requires_grad_(True)
