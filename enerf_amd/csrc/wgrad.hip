@@ -19,6 +19,10 @@
 // the block adds its partial tile set to dW with fp32 atomics.  Out-of-range taps (padding) and channels >= C load zeros.
 #include "kernels.h"
 
+#ifndef ENERF_WGRAD_REDUCE_8
+#define ENERF_WGRAD_REDUCE_8 1            /* k_wgrad_reduce: eight (1) or four (0) loads in flight per thread */
+#endif
+
 namespace enerf {
 
 #define ENERF_MFMA_W(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -187,13 +191,19 @@ __global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__
     const int pair = gemm ? 0 : item / nt, t = gemm ? item : item - pair * nt;
     const float* sp = scratch + (((long long)pair * chunks) * nt + t) * 256 + r * 64 + lane;
     const long long cstride = (long long)nt * 256;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
     int c = w;
-    for (; c + 48 < chunks; c += 64) {                      // four independent loads in flight per thread
+#if ENERF_WGRAD_REDUCE_8
+    for (; c + 112 < chunks; c += 128) {                    // eight independent loads in flight per thread (the kernel is a chain of
+        s0 += sp[c * cstride]; s1 += sp[(c + 16) * cstride]; s2 += sp[(c + 32) * cstride]; s3 += sp[(c + 48) * cstride];   // L2 round trips)
+        s4 += sp[(c + 64) * cstride]; s5 += sp[(c + 80) * cstride]; s6 += sp[(c + 96) * cstride]; s7 += sp[(c + 112) * cstride];
+    }
+#endif
+    for (; c + 48 < chunks; c += 64) {                      // four
         s0 += sp[c * cstride]; s1 += sp[(c + 16) * cstride]; s2 += sp[(c + 32) * cstride]; s3 += sp[(c + 48) * cstride];
     }
     for (; c < chunks; c += 16) s0 += sp[c * cstride];
-    red[w][lane] = (s0 + s1) + (s2 + s3);
+    red[w][lane] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
     __syncthreads();
     if (w != 0) return;
     float v = 0.f;
@@ -240,13 +250,20 @@ static int wgrad_chunks(long long npos, int pairs, int taps, bool two_stage) {
 #ifndef ENERF_WGRAD2D_TILE
 #define ENERF_WGRAD2D_TILE 1                     /* 0: these layers stay on k_conv_wgrad (A/B builds) */
 #endif
+#ifndef ENERF_WGRAD3D_TILE
+#define ENERF_WGRAD3D_TILE 1
+#endif
 size_t conv_wgrad_workspace_bytes(long long npos, int Ca, int Cb, int taps, int bias) {
     const int pairs = cdiv(Ca, 16) * cdiv(Cb + bias, 16);
     const size_t two_stage = (size_t)pairs * wgrad_chunks(npos, pairs, taps, true) * taps * 256 * sizeof(float);
     // k_wgrad2d_3x3_c8 (below): one compact row of Ca*Cb*9 sums per persistent block (the query does not know the grid: the bound)
     const size_t tiled = (ENERF_WGRAD2D_TILE && taps == 9 && Ca <= 8 && Cb <= 32 && !bias)
                              ? (size_t)device_cu_count() * ENERF_WGRAD2D_BPC * Ca * Cb * 9 * sizeof(float) : 0;
-    return two_stage > tiled ? two_stage : tiled;
+    // k_wgrad3d_c8: at most 2 blocks per CU in all, one row of the whole dW each
+    const size_t tiled3 = (ENERF_WGRAD3D_TILE && taps == 27 && !bias && ((Ca <= 8 && Cb <= 32) || (Ca == 16 && Cb <= 8)))
+                              ? (size_t)device_cu_count() * 2 * Ca * Cb * 27 * sizeof(float) : 0;
+    const size_t t = two_stage > tiled ? two_stage : tiled;
+    return t > tiled3 ? t : tiled3;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -391,14 +408,16 @@ __global__ __launch_bounds__(256) void k_wgrad2d_3x3_c8(const float* __restrict_
                 if (kh >= 0 && a < Ca && b < Cb) out[(a * Cb + b) * 9 + kh * 3 + k] = v;
             }
 }
-// out[i] = sum over the rows c < chunks of part[c * n_out + i], fixed order: 16 waves take rows c = w, w + 16, ... (four loads in
-// flight), then wave 0 adds the 16 partial sums.
-__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ part, int chunks, int n_out, float* __restrict__ out) {
+// out[.] = sum over the rows c < chunks of part[c * n_out + i], fixed order: 16 waves take rows c = w, w + 16, ... (four loads in
+// flight), then wave 0 adds the 16 partial sums.  blockIdx.y = segment: its rows start at part + y * chunks * n_out and element i
+// goes to out[(i / inner) * ostride + y * inner + i % inner] (channel halves of a wider layer; one segment, inner = n_out: out[i]).
+__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ part, int chunks, int n_out, int inner, int ostride,
+                                                 float* __restrict__ out) {
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     const bool live = i < n_out;
-    const float* sp = part + (live ? i : 0);
+    const float* sp = part + (long long)blockIdx.y * chunks * n_out + (live ? i : 0);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int c = w;
     for (; c + 48 < chunks; c += 64) {
@@ -412,7 +431,111 @@ __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ part,
     float v = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) v += red[k][lane];
-    out[i] = v;
+    const int o = i / inner;
+    out[(long long)o * ostride + (int)blockIdx.y * inner + (i - o * inner)] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same for the 3x3x3 stride-1 layers of the cost-regularisation networks with <= 8 channels on one side: conv0 (32 / 16 -> 8:
+// A = d y has 8 channels) and the fused heads (8 -> 16: B = y has 8 channels — run with the roles SWAPPED, A' = y, B' = d heads:
+// dW[b'][a'][t] = dW'[a'][b'][26 - t]).  A volume is n D images: a tile of plane d stages A's plane d and B's planes d-1, d, d+1
+// (zeros outside the volume) and runs the 2-D scheme once per kd: 9 MFMAs per group of four positions and block of 8 B channels
+// instead of 27 per 16, operands from LDS at immediate offsets.  Two blocks of 8 B channels per launch column; a 32-channel B is
+// two columns (blockIdx.y) on the two 16-channel halves of its rows.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool A4, int NCB>
+__global__ __launch_bounds__(256) void k_wgrad3d_c8(const float* __restrict__ A, const float* __restrict__ Bt, int n, int D, int H, int W,
+                                                    int Ca, int Cb, int lda, int ldb, int tiles_y, int tiles_x, int swapped,
+                                                    float* __restrict__ scratch) {
+    constexpr int TH = kW2TH, TW = kW2TW, AP = kW2APitch, BP = kW2BPitch, BPL = (TH + 2) * BP;
+    constexpr int GC = NCB == 1 ? 4 : 2;                   // groups whose operands are in registers at once (GC x (1 + 9 NCB) values)
+    __shared__ float la[(TH + 1) * AP];
+    __shared__ float lb[3 * NCB * BPL];                    // [kd][channel block][rows][cols][8]
+    static_assert(3 * BPL >= 3 * 9 * 256, "the cross-wave reduction reuses the B planes, one channel block at a time");
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
+    const int lo = j & 7, hi = j >> 3;
+    Bt += (int)blockIdx.y * 16;                            // this column's 16-channel half of B's rows
+    f32x4 acc[3][NCB][3];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[kd][cb][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntiles = n * D * tiles_y * tiles_x;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y), d = img % D;   // img = (b, d)
+        const int x0 = tx * TW, y0 = ty * TH - 1;
+        w2_stage<TH + 1, TW, AP, 0, 1, A4>(A, img, H, W, Ca, lda, y0, x0, la);
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const bool in = (unsigned)(d + kd - 1) < (unsigned)D;                  // (uniform) a plane outside the volume: H = 0 -> zeros
+            w2_stage<TH + 2, kW2BCols, BP, BPL, NCB, true>(Bt, img + kd - 1, in ? H : 0, W, 8 * NCB, ldb, y0 - 1, x0 - 1, lb + kd * NCB * BPL);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < TH / 4; ++rr) {
+            const int tr = wv + 4 * rr;
+            const float* pa = la + (tr + hi) * AP + g * 8 + lo;
+            const float* pb = lb + (tr + 2 * hi) * BP + g * 8 + lo;
+#pragma unroll
+            for (int c0 = 0; c0 < TW / 4; c0 += GC) {
+                float av[GC], bv[GC][3][NCB][3];
+#pragma unroll
+                for (int cg = 0; cg < GC; ++cg) {
+                    av[cg] = pa[(c0 + cg) * 32];
+#pragma unroll
+                    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) bv[cg][kd][cb][k] = pb[(kd * NCB + cb) * BPL + (c0 + cg) * 32 + k * 8];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int cg = 0; cg < GC; ++cg)
+#pragma unroll
+                    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) acc[kd][cb][k] = ENERF_MFMA_W(av[cg], bv[cg][kd][cb][k], acc[kd][cb][k]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+    // waves 1..3 hand their tiles to wave 0 through LDS (the B planes' storage), one channel block at a time
+    const int n_row = Ca * Cb * 27;
+    float* out = scratch + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * n_row;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        if (wv != 0) {
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lb[((wv - 1) * 9 + kd * 3 + k) * 256 + r * 64 + lane] = acc[kd][cb][k][r];
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[kd][cb][k][r];
+#pragma unroll
+                        for (int w = 0; w < 3; ++w) v += lb[(w * 9 + kd * 3 + k) * 256 + r * 64 + lane];
+                        const int row = 4 * g + r, a = row & 7, s = row >> 3, b = cb * 8 + lo, u = hi, kh = 2 * u - s;
+                        const int tap = kd * 9 + kh * 3 + k;
+                        if (kh >= 0 && a < Ca && b < Cb) out[swapped ? (b * Ca + a) * 27 + (26 - tap) : (a * Cb + b) * 27 + tap] = v;
+                    }
+        }
+        __syncthreads();
+    }
 }
 static int wgrad2d_bpc(int Cb) { return Cb <= 8 ? ENERF_WGRAD2D_BPC : Cb <= 16 ? 3 : 2; }      // by LDS: 21 / 32 / 54 KB per block
 static int wgrad2d_blocks(int n, int H, int W, int Cb) {
@@ -440,7 +563,46 @@ static bool launch_wgrad2d(const float* A, const float* Bt, int n, int H, int W,
     else if (a4) { if (b4) ENERF_W2(true, true, 1); else ENERF_W2(true, false, 1); }
     else { if (b4) ENERF_W2(false, true, 1); else ENERF_W2(false, false, 1); }
 #undef ENERF_W2
-    ENERF_LAUNCH(k_colsum, (unsigned)cdiv(Ca * Cb * 9, 64), 1024, 0, st, scratch, blocks, Ca * Cb * 9, dW);
+    ENERF_LAUNCH(k_colsum, (unsigned)cdiv(Ca * Cb * 9, 64), 1024, 0, st, scratch, blocks, Ca * Cb * 9, Ca * Cb * 9, 0, dW);
+    return true;
+}
+#ifndef ENERF_WGRAD3D_TILE
+#define ENERF_WGRAD3D_TILE 1                     /* 0: these layers stay on k_conv_wgrad (A/B builds) */
+#endif
+// normal: Ca <= 8 gradient channels, Cb = 8 / 16 / 32 input channels; swapped: Ca = 16, Cb <= 8 (the fused heads)
+static bool wgrad3d_fits(int n, int Da, int Ha, int Wa, int Ca, int Db, int Hb, int Wb, int Cb, int kd, int kh, int kw, int stride,
+                         int pad_d, int pad_h, int pad_w, bool bias) {
+    const bool shape = (Ca <= 8 && (Cb == 8 || Cb == 16 || Cb == 32)) || (Ca == 16 && Cb <= 8);
+    return ENERF_WGRAD3D_TILE && kd == 3 && kh == 3 && kw == 3 && stride == 1 && pad_d == 1 && pad_h == 1 && pad_w == 1 && Da == Db &&
+           Ha == Hb && Wa == Wb && shape && !bias && (long long)n * Da * Ha * Wa >= 32768;
+}
+static int wgrad3d_blocks(int n, int D, int H, int W, int cols) {
+    const long long ntiles = (long long)n * D * cdiv(H + 1, kW2TH) * cdiv(W, kW2TW);
+    const long long cap = (long long)device_cu_count() * 2 / cols;                   // 76 KB of LDS per block: two per CU
+    return (int)(ntiles < cap ? ntiles : (cap < 1 ? 1 : cap));
+}
+static size_t wgrad3d_workspace_bytes(int n, int D, int H, int W, int Ca, int Cb) {
+    const int cols = (Ca <= 8 && Cb == 32) ? 2 : 1;
+    return (size_t)cols * wgrad3d_blocks(n, D, H, W, cols) * Ca * (Cb / cols) * 27 * sizeof(float);
+}
+static bool launch_wgrad3d(const float* A, const float* Bt, int n, int D, int H, int W, int Ca, int Cb, int lda, int ldb, float* dW,
+                           float* scratch, hipStream_t st) {
+    const bool swapped = Ca > 8;
+    const float* Ak = swapped ? Bt : A;                    // the kernel's A' (<= 8 channels) and B' (8 or 16 per column)
+    const float* Bk = swapped ? A : Bt;
+    const int Cak = swapped ? Cb : Ca, ldak = swapped ? ldb : lda, ldbk = swapped ? lda : ldb;
+    const int Cbt = swapped ? Ca : Cb, cols = Cbt == 32 ? 2 : 1, Cbk = Cbt / cols;
+    if (ldbk % 4 != 0 || ((uintptr_t)Bk & 15) != 0) return false;
+    const bool a4 = (Cak == 4 || Cak == 8) && ldak % 4 == 0 && ((uintptr_t)Ak & 15) == 0;
+    const int blocks = wgrad3d_blocks(n, D, H, W, cols), tiles_y = cdiv(H + 1, kW2TH), tiles_x = cdiv(W, kW2TW);
+    const dim3 grid((unsigned)blocks, (unsigned)cols);
+#define ENERF_W3(A4, NCB) ENERF_LAUNCH((k_wgrad3d_c8<A4, NCB>), grid, 256, 0, st, Ak, Bk, n, D, H, W, Cak, Cbk, ldak, ldbk, tiles_y, tiles_x, swapped ? 1 : 0, scratch)
+    if (Cbk == 16) { if (a4) ENERF_W3(true, 2); else ENERF_W3(false, 2); }
+    else { if (a4) ENERF_W3(true, 1); else ENERF_W3(false, 1); }
+#undef ENERF_W3
+    const int n_row = Cak * Cbk * 27;
+    ENERF_LAUNCH(k_colsum, dim3((unsigned)cdiv(n_row, 64), (unsigned)cols), 1024, 0, st, scratch, blocks, n_row, swapped ? n_row : Cbk * 27,
+                 Cbt * 27, dW);
     return true;
 }
 
@@ -459,6 +621,10 @@ bool launch_conv_wgrad(const float* A, const float* Bt, int n, int Da, int Ha, i
     if (wgrad2d_fits(n, Da, Ha, Wa, Ca, Db, Hb, Wb, Cb, kd, kh, kw, stride, pad_d, pad_h, pad_w, dbias != nullptr) && workspace != nullptr &&
         workspace_bytes >= wgrad2d_workspace_bytes(n, Ha, Wa, Ca, Cb) &&
         launch_wgrad2d(A, Bt, n, Ha, Wa, Ca, Cb, q.lda, q.ldb, dW, (float*)workspace, st))
+        return true;
+    if (wgrad3d_fits(n, Da, Ha, Wa, Ca, Db, Hb, Wb, Cb, kd, kh, kw, stride, pad_d, pad_h, pad_w, dbias != nullptr) && workspace != nullptr &&
+        workspace_bytes >= wgrad3d_workspace_bytes(n, Da, Ha, Wa, Ca, Cb) &&
+        launch_wgrad3d(A, Bt, n, Da, Ha, Wa, Ca, Cb, q.lda, q.ldb, dW, (float*)workspace, st))
         return true;
     const int taps = kd * kh * kw, pairs = q.tiles_a * q.tiles_b;
     float* scratch = (workspace != nullptr && workspace_bytes >= conv_wgrad_workspace_bytes(q.npos, Ca, Cb, taps, q.bias)) ? (float*)workspace : nullptr;

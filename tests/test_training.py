@@ -361,6 +361,18 @@ def _check_conv_wgrad(lib, dev):
         assert got.shape == ref.shape
         assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (cin, cout, H, W, float((got - ref).abs().max() / ref.abs().max()))
         assert torch.equal(got, lib.conv_wgrad(gy, x, (3, 3), 1, (1, 1)))                       # deterministic
+    # ... and its 3-D form (k_wgrad3d_c8: >= 32768 positions): conv0 (32 / 16 -> 8, two columns of 16 channels for 32), 8 -> 8, and the
+    # fused heads 8 -> 16 (roles swapped, taps mirrored); volume borders in d, h and w inside tiles
+    for cin, cout, D, H, W in [(16, 8, 5, 81, 83), (32, 8, 3, 100, 112), (8, 16, 6, 70, 80), (8, 8, 4, 96, 96), (32, 5, 5, 81, 83)]:
+        x = rnd(1, cin, D, H, W)
+        w = rnd(cout, cin, 3, 3, 3).requires_grad_(True)
+        y = F.conv3d(x, w, None, 1, 1)
+        gy = rnd(*y.shape)
+        (ref,) = torch.autograd.grad(y, w, gy)
+        got = lib.conv_wgrad(gy, x, (3, 3, 3), 1, (1, 1, 1))
+        assert got.shape == ref.shape
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (cin, cout, D, H, W, float((got - ref).abs().max() / ref.abs().max()))
+        assert torch.equal(got, lib.conv_wgrad(gy, x, (3, 3, 3), 1, (1, 1, 1)))
     for cin, cout, st in [(32, 8, 1), (8, 16, 2), (16, 32, 2), (64, 64, 1), (8, 1, 1), (8, 8, 1)]:
         x = rnd(1, cin, 4, 6, 10)
         w = rnd(cout, cin, 3, 3, 3).requires_grad_(True)
