@@ -19,6 +19,12 @@
 // the block adds its partial tile set to dW with fp32 atomics.  Out-of-range taps (padding) and channels >= C load zeros.
 #include "kernels.h"
 
+#ifndef ENERF_WGRAD_PREFETCH
+#define ENERF_WGRAD_PREFETCH 1            /* tiled 2-D kernel: the next tile's global loads are issued before this tile's MFMAs */
+#endif
+#ifndef ENERF_WGRAD3D_PREFETCH
+#define ENERF_WGRAD3D_PREFETCH 1          /* the same in the 3-D kernel */
+#endif
 #ifndef ENERF_WGRAD_REDUCE_8
 #define ENERF_WGRAD_REDUCE_8 1            /* k_wgrad_reduce: eight (1) or four (0) loads in flight per thread */
 #endif
@@ -291,41 +297,58 @@ static_assert(kW2APitch % 64 == 32 && (2 * kW2BPitch) % 64 == 32, "bank-conflict
 
 // one tile of `src` (n, H, W, ld floats per position; C <= 8 NCB channels used) into LDS: rows y0 .., cols x0 .., zeros outside
 // the image; one plane of PLANE floats per block of 8 channels, pixel pitch 8 floats inside a plane (so that the 64 lanes of an
-// operand read hit 64 banks whatever C is).  V4: 16-byte loads (C a power of two >= 4, ld % 4 == 0, 16-byte aligned base).
+// operand read hit 64 banks whatever C is).  Two halves, so that the loads of the NEXT tile are in flight while this tile's MFMAs
+// run (a block spent ~5 us per tile waiting for them in front of 0.6 - 2.6 us of MFMAs): fetch() = the global loads into registers,
+// commit() = the LDS stores.  V4: 16-byte loads (C a power of two >= 4, ld % 4 == 0, 16-byte aligned base); otherwise (the
+// 3-channel image of conv0.0) a scalar loop at commit time, not pipelined.
 template <int ROWS, int COLS, int PITCH, int PLANE, int NCB, bool V4>
-__device__ __forceinline__ void w2_stage(const float* __restrict__ src, int img, int H, int W, int C, int ld, int y0, int x0,
-                                         float* __restrict__ dst) {
-    if (V4) {
+struct W2Stage {
+    static constexpr int NIT = V4 ? (ROWS * COLS * 2 * NCB + 255) / 256 : 1;
+    float4 v[NIT];
+    int key[NIT];                                          // tile-invariant slot of this thread: (r << 20) | (c << 8) | quad, -1 = none
+    const float* src; int img, H, W, C, ld, y0, x0;        // (scalar path)
+    __device__ __forceinline__ void init(int C_) {
+        C = C_;
+        if (!V4) return;
         const int nq = C >> 2, sh = nq >= 8 ? 3 : nq >= 4 ? 2 : nq >= 2 ? 1 : 0;       // quads per pixel (1, 2, 4, 8)
-        constexpr int NIT = (ROWS * COLS * 2 * NCB + 255) / 256;
-        float4 v[NIT];
-        int o[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = (int)threadIdx.x + it * 256;
             const int pos = i >> sh, qd = i & (nq - 1);
             const int r = pos / COLS, c = pos - r * COLS;
-            const int y = y0 + r, x = x0 + c;
-            const bool live = pos < ROWS * COLS;
-            const bool in = live && y >= 0 && y < H && x >= 0 && x < W;
-            o[it] = live ? (qd >> 1) * PLANE + r * PITCH + c * 8 + (qd & 1) * 4 : -1;
+            key[it] = pos < ROWS * COLS ? (r << 20) | (c << 8) | qd : -1;
+        }
+    }
+    __device__ __forceinline__ void fetch(const float* __restrict__ src_, int img_, int H_, int W_, int ld_, int y0_, int x0_) {
+        src = src_; img = img_; H = H_; W = W_; ld = ld_; y0 = y0_; x0 = x0_;
+        if (!V4) return;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int y = y0 + (key[it] >> 20), x = x0 + ((key[it] >> 8) & 0xfff), qd = key[it] & 0xff;
+            const bool in = key[it] >= 0 && y >= 0 && y < H && x >= 0 && x < W;
             v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (in) v[it] = *reinterpret_cast<const float4*>(src + (((long long)img * H + y) * W + x) * ld + qd * 4);
         }
+    }
+    __device__ __forceinline__ void commit(float* __restrict__ dst) const {
+        if (V4) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it)
-            if (o[it] >= 0) *reinterpret_cast<float4*>(dst + o[it]) = v[it];
-    } else {
-        for (int i = (int)threadIdx.x; i < ROWS * COLS * C; i += 256) {
-            const int pos = i / C, ch = i - pos * C;
-            const int r = pos / COLS, c = pos - r * COLS;
-            const int y = y0 + r, x = x0 + c;
-            float v = 0.f;
-            if (y >= 0 && y < H && x >= 0 && x < W) v = src[(((long long)img * H + y) * W + x) * ld + ch];
-            dst[(ch >> 3) * PLANE + r * PITCH + c * 8 + (ch & 7)] = v;
+            for (int it = 0; it < NIT; ++it) {
+                const int r = key[it] >> 20, c = (key[it] >> 8) & 0xfff, qd = key[it] & 0xff;
+                if (key[it] >= 0) *reinterpret_cast<float4*>(dst + (qd >> 1) * PLANE + r * PITCH + c * 8 + (qd & 1) * 4) = v[it];
+            }
+        } else {
+            for (int i = (int)threadIdx.x; i < ROWS * COLS * C; i += 256) {
+                const int pos = i / C, ch = i - pos * C;
+                const int r = pos / COLS, c = pos - r * COLS;
+                const int y = y0 + r, x = x0 + c;
+                float val = 0.f;
+                if (y >= 0 && y < H && x >= 0 && x < W) val = src[(((long long)img * H + y) * W + x) * ld + ch];
+                dst[(ch >> 3) * PLANE + r * PITCH + c * 8 + (ch & 7)] = val;
+            }
         }
     }
-}
+};
 
 // NCB: blocks of 8 B channels (Cb <= 8 NCB): one accumulator per (channel block, kw); Ca <= 8.
 template <bool A4, bool B4, int NCB>
@@ -345,12 +368,22 @@ __global__ __launch_bounds__(256) void k_wgrad2d_3x3_c8(const float* __restrict_
 #pragma unroll
         for (int k = 0; k < 3; ++k) acc[cb][k] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ntiles = n * tiles_y * tiles_x;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    W2Stage<TH + 1, TW, AP, 0, 1, A4> sa;
+    W2Stage<TH + 2, kW2BCols, BP, BPL, NCB, B4> sb;
+    sa.init(Ca);
+    sb.init(Cb);
+    auto fetch = [&](int t) {
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
         const int x0 = tx * TW, y0 = ty * TH - 1;
-        w2_stage<TH + 1, TW, AP, 0, 1, A4>(A, img, H, W, Ca, lda, y0, x0, la);
-        w2_stage<TH + 2, kW2BCols, BP, BPL, NCB, B4>(Bt, img, H, W, Cb, ldb, y0 - 1, x0 - 1, lb);
+        sa.fetch(A, img, H, W, lda, y0, x0);
+        sb.fetch(Bt, img, H, W, ldb, y0 - 1, x0 - 1);
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        sa.commit(la);
+        sb.commit(lb);
         __syncthreads();
+        if (ENERF_WGRAD_PREFETCH && t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);       // in flight behind this tile's MFMAs
         // a chunk's operands are all requested before its first MFMA (left to itself hipcc waited for each ds_read2 pair in
         // front of the two MFMAs that use it)
 #pragma unroll
@@ -380,6 +413,7 @@ __global__ __launch_bounds__(256) void k_wgrad2d_3x3_c8(const float* __restrict_
             }
         }
         __syncthreads();
+        if (!ENERF_WGRAD_PREFETCH && t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
     }
     // waves 1..3 hand their tiles to wave 0 through LDS (the B tile's storage: the loop ended with a barrier)
     float* red = lb;
@@ -463,16 +497,28 @@ __global__ __launch_bounds__(256) void k_wgrad3d_c8(const float* __restrict__ A,
 #pragma unroll
             for (int k = 0; k < 3; ++k) acc[kd][cb][k] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ntiles = n * D * tiles_y * tiles_x;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    W2Stage<TH + 1, TW, AP, 0, 1, A4> sa;
+    W2Stage<TH + 2, kW2BCols, BP, BPL, NCB, true> sb[3];
+    sa.init(Ca);
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) sb[kd].init(8 * NCB);
+    auto fetch = [&](int t) {
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y), d = img % D;   // img = (b, d)
         const int x0 = tx * TW, y0 = ty * TH - 1;
-        w2_stage<TH + 1, TW, AP, 0, 1, A4>(A, img, H, W, Ca, lda, y0, x0, la);
+        sa.fetch(A, img, H, W, lda, y0, x0);
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd) {
             const bool in = (unsigned)(d + kd - 1) < (unsigned)D;                  // (uniform) a plane outside the volume: H = 0 -> zeros
-            w2_stage<TH + 2, kW2BCols, BP, BPL, NCB, true>(Bt, img + kd - 1, in ? H : 0, W, 8 * NCB, ldb, y0 - 1, x0 - 1, lb + kd * NCB * BPL);
+            sb[kd].fetch(Bt, img + kd - 1, in ? H : 0, W, ldb, y0 - 1, x0 - 1);
         }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        sa.commit(la);
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) sb[kd].commit(lb + kd * NCB * BPL);
         __syncthreads();
+        if (ENERF_WGRAD3D_PREFETCH && t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
 #pragma unroll
         for (int rr = 0; rr < TH / 4; ++rr) {
             const int tr = wv + 4 * rr;
@@ -504,6 +550,7 @@ __global__ __launch_bounds__(256) void k_wgrad3d_c8(const float* __restrict__ A,
             }
         }
         __syncthreads();
+        if (!ENERF_WGRAD3D_PREFETCH && t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
     }
     // waves 1..3 hand their tiles to wave 0 through LDS (the B planes' storage), one channel block at a time
     const int n_row = Ca * Cb * 27;
