@@ -96,6 +96,9 @@ __device__ __forceinline__ BufRsrc buf_rsrc(const void* p, unsigned bytes) { ret
 __device__ __forceinline__ float buf_load_f32(const BufRsrc& r, unsigned byte_off) {
     return byte_off < r.bytes ? *reinterpret_cast<const float*>(r.base + byte_off) : 0.f;
 }
+__device__ __forceinline__ float4 buf_load_f32x4(const BufRsrc& r, unsigned byte_off) {
+    return byte_off < r.bytes && r.bytes - byte_off >= 16u ? *reinterpret_cast<const float4*>(r.base + byte_off) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
 #else
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 __device__ __forceinline__ BufRsrc buf_rsrc(const void* p, unsigned bytes) {
@@ -103,6 +106,10 @@ __device__ __forceinline__ BufRsrc buf_rsrc(const void* p, unsigned bytes) {
 }
 __device__ __forceinline__ float buf_load_f32(const BufRsrc& r, unsigned byte_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+// 16 bytes per lane; an offset at or past the resource's size reads zeros (no branch, no 64-bit address)
+__device__ __forceinline__ float4 buf_load_f32x4(const BufRsrc& r, unsigned byte_off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
 #endif
 

@@ -306,8 +306,9 @@ struct W2Stage {
     static constexpr int NIT = V4 ? (ROWS * COLS * 2 * NCB + 255) / 256 : 1;
     float4 v[NIT];
     int key[NIT];                                          // tile-invariant slot of this thread: (r << 20) | (c << 8) | quad, -1 = none
+    unsigned koff[NIT];                                    // ... and its byte offset from the tile's first element: ((r W + c) ld + 4 quad) 4
     const float* src; int img, H, W, C, ld, y0, x0;        // (scalar path)
-    __device__ __forceinline__ void init(int C_) {
+    __device__ __forceinline__ void init(int C_, int W_, int ld_) {
         C = C_;
         if (!V4) return;
         const int nq = C >> 2, sh = nq >= 8 ? 3 : nq >= 4 ? 2 : nq >= 2 ? 1 : 0;       // quads per pixel (1, 2, 4, 8)
@@ -317,17 +318,21 @@ struct W2Stage {
             const int pos = i >> sh, qd = i & (nq - 1);
             const int r = pos / COLS, c = pos - r * COLS;
             key[it] = pos < ROWS * COLS ? (r << 20) | (c << 8) | qd : -1;
+            koff[it] = (unsigned)(((r * W_ + c) * ld_ + qd * 4) * 4);
         }
     }
-    __device__ __forceinline__ void fetch(const float* __restrict__ src_, int img_, int H_, int W_, int ld_, int y0_, int x0_) {
+    // V4: raw buffer loads — a uniform tile offset + the slot's offset, out-of-image slots get an out-of-range offset (zeros): ~6
+    // VALU per 16 bytes.  (First version: 64-bit addresses and a branch per load, ~60 VALU each: 845 VALU per tile next to 192
+    // MFMAs in the 32-channel kernel, and VALU and MFMA share the issue port: the tiles ran at 0.47 of the matrix rate.)
+    __device__ __forceinline__ void fetch(const float* __restrict__ src_, const BufRsrc& rs, int img_, int H_, int W_, int ld_, int y0_, int x0_) {
         src = src_; img = img_; H = H_; W = W_; ld = ld_; y0 = y0_; x0 = x0_;
         if (!V4) return;
+        const unsigned tile_off = (unsigned)((((img * H + y0) * W + x0) * ld) * 4);   // (may wrap below zero at the borders: mod 2^32)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int y = y0 + (key[it] >> 20), x = x0 + ((key[it] >> 8) & 0xfff), qd = key[it] & 0xff;
-            const bool in = key[it] >= 0 && y >= 0 && y < H && x >= 0 && x < W;
-            v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (in) v[it] = *reinterpret_cast<const float4*>(src + (((long long)img * H + y) * W + x) * ld + qd * 4);
+            const int y = y0 + (key[it] >> 20), x = x0 + ((key[it] >> 8) & 0xfff);
+            const bool in = key[it] >= 0 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            v[it] = buf_load_f32x4(rs, in ? tile_off + koff[it] : 0xffffffffu);
         }
     }
     __device__ __forceinline__ void commit(float* __restrict__ dst) const {
@@ -354,7 +359,7 @@ struct W2Stage {
 template <bool A4, bool B4, int NCB>
 __global__ __launch_bounds__(256) void k_wgrad2d_3x3_c8(const float* __restrict__ A, const float* __restrict__ Bt, int n, int H, int W,
                                                         int Ca, int Cb, int lda, int ldb, int tiles_y, int tiles_x,
-                                                        float* __restrict__ scratch) {
+                                                        unsigned abytes, unsigned bbytes, float* __restrict__ scratch) {
     constexpr int TH = kW2TH, TW = kW2TW, AP = kW2APitch, BP = kW2BPitch, BPL = (TH + 2) * BP;
     constexpr int GC = NCB == 1 ? TW / 4 : 4;              // groups whose operands are in registers at once (GC x (1 + 3 NCB) values)
     __shared__ float la[(TH + 1) * AP];
@@ -370,13 +375,14 @@ __global__ __launch_bounds__(256) void k_wgrad2d_3x3_c8(const float* __restrict_
     const int ntiles = n * tiles_y * tiles_x;
     W2Stage<TH + 1, TW, AP, 0, 1, A4> sa;
     W2Stage<TH + 2, kW2BCols, BP, BPL, NCB, B4> sb;
-    sa.init(Ca);
-    sb.init(Cb);
+    sa.init(Ca, W, lda);
+    sb.init(Cb, W, ldb);
+    const BufRsrc ra = buf_rsrc(A, abytes), rb = buf_rsrc(Bt, bbytes);
     auto fetch = [&](int t) {
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
         const int x0 = tx * TW, y0 = ty * TH - 1;
-        sa.fetch(A, img, H, W, lda, y0, x0);
-        sb.fetch(Bt, img, H, W, ldb, y0 - 1, x0 - 1);
+        sa.fetch(A, ra, img, H, W, lda, y0, x0);
+        sb.fetch(Bt, rb, img, H, W, ldb, y0 - 1, x0 - 1);
     };
     if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ part,
 template <bool A4, int NCB>
 __global__ __launch_bounds__(256) void k_wgrad3d_c8(const float* __restrict__ A, const float* __restrict__ Bt, int n, int D, int H, int W,
                                                     int Ca, int Cb, int lda, int ldb, int tiles_y, int tiles_x, int swapped,
-                                                    float* __restrict__ scratch) {
+                                                    unsigned abytes, unsigned bbytes, float* __restrict__ scratch) {
     constexpr int TH = kW2TH, TW = kW2TW, AP = kW2APitch, BP = kW2BPitch, BPL = (TH + 2) * BP;
     constexpr int GC = NCB == 1 ? 4 : 2;                   // groups whose operands are in registers at once (GC x (1 + 9 NCB) values)
     __shared__ float la[(TH + 1) * AP];
@@ -499,17 +505,19 @@ __global__ __launch_bounds__(256) void k_wgrad3d_c8(const float* __restrict__ A,
     const int ntiles = n * D * tiles_y * tiles_x;
     W2Stage<TH + 1, TW, AP, 0, 1, A4> sa;
     W2Stage<TH + 2, kW2BCols, BP, BPL, NCB, true> sb[3];
-    sa.init(Ca);
+    sa.init(Ca, W, lda);
 #pragma unroll
-    for (int kd = 0; kd < 3; ++kd) sb[kd].init(8 * NCB);
+    for (int kd = 0; kd < 3; ++kd) sb[kd].init(8 * NCB, W, ldb);
+    const BufRsrc ra = buf_rsrc(A, abytes), rb = buf_rsrc(Bt, bbytes - (unsigned)blockIdx.y * 64u);
     auto fetch = [&](int t) {
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y), d = img % D;   // img = (b, d)
         const int x0 = tx * TW, y0 = ty * TH - 1;
-        sa.fetch(A, img, H, W, lda, y0, x0);
+        sa.fetch(A, ra, img, H, W, lda, y0, x0);
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd) {
-            const bool in = (unsigned)(d + kd - 1) < (unsigned)D;                  // (uniform) a plane outside the volume: H = 0 -> zeros
-            sb[kd].fetch(Bt, img + kd - 1, in ? H : 0, W, ldb, y0 - 1, x0 - 1);
+            // (uniform) a plane outside the volume: every slot out of range -> zeros.  The tile offset is taken with the real H.
+            const bool in = (unsigned)(d + kd - 1) < (unsigned)D;
+            sb[kd].fetch(Bt, rb, img + kd - 1, H, in ? W : 0, ldb, y0 - 1, x0 - 1);
         }
     };
     if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
@@ -601,10 +609,11 @@ static size_t wgrad2d_workspace_bytes(int n, int H, int W, int Ca, int Cb) {
 static bool launch_wgrad2d(const float* A, const float* Bt, int n, int H, int W, int Ca, int Cb, int lda, int ldb, float* dW,
                            float* scratch, hipStream_t st) {
     const int blocks = wgrad2d_blocks(n, H, W, Cb), tiles_y = cdiv(H + 1, kW2TH), tiles_x = cdiv(W, kW2TW);
+    const unsigned abytes = (unsigned)((long long)n * H * W * lda * 4), bbytes = (unsigned)((long long)n * H * W * ldb * 4);   // (< 2^32: checked by the C entries)
     const bool a4 = (Ca == 4 || Ca == 8) && lda % 4 == 0 && ((uintptr_t)A & 15) == 0;
     const bool b4 = (Cb == 4 || Cb == 8 || Cb == 16 || Cb == 32) && ldb % 4 == 0 && ((uintptr_t)Bt & 15) == 0;
     if (Cb > 8 && !b4) return false;
-#define ENERF_W2(A4, B4, NCB) ENERF_LAUNCH((k_wgrad2d_3x3_c8<A4, B4, NCB>), (unsigned)blocks, 256, 0, st, A, Bt, n, H, W, Ca, Cb, lda, ldb, tiles_y, tiles_x, scratch)
+#define ENERF_W2(A4, B4, NCB) ENERF_LAUNCH((k_wgrad2d_3x3_c8<A4, B4, NCB>), (unsigned)blocks, 256, 0, st, A, Bt, n, H, W, Ca, Cb, lda, ldb, tiles_y, tiles_x, abytes, bbytes, scratch)
     if (Cb == 32) { if (a4) ENERF_W2(true, true, 4); else ENERF_W2(false, true, 4); }
     else if (Cb == 16) { if (a4) ENERF_W2(true, true, 2); else ENERF_W2(false, true, 2); }
     else if (a4) { if (b4) ENERF_W2(true, true, 1); else ENERF_W2(true, false, 1); }
@@ -642,8 +651,9 @@ static bool launch_wgrad3d(const float* A, const float* Bt, int n, int D, int H,
     if (ldbk % 4 != 0 || ((uintptr_t)Bk & 15) != 0) return false;
     const bool a4 = (Cak == 4 || Cak == 8) && ldak % 4 == 0 && ((uintptr_t)Ak & 15) == 0;
     const int blocks = wgrad3d_blocks(n, D, H, W, cols), tiles_y = cdiv(H + 1, kW2TH), tiles_x = cdiv(W, kW2TW);
+    const unsigned abytes = (unsigned)((long long)n * D * H * W * ldak * 4), bbytes = (unsigned)((long long)n * D * H * W * ldbk * 4);
     const dim3 grid((unsigned)blocks, (unsigned)cols);
-#define ENERF_W3(A4, NCB) ENERF_LAUNCH((k_wgrad3d_c8<A4, NCB>), grid, 256, 0, st, Ak, Bk, n, D, H, W, Cak, Cbk, ldak, ldbk, tiles_y, tiles_x, swapped ? 1 : 0, scratch)
+#define ENERF_W3(A4, NCB) ENERF_LAUNCH((k_wgrad3d_c8<A4, NCB>), grid, 256, 0, st, Ak, Bk, n, D, H, W, Cak, Cbk, ldak, ldbk, tiles_y, tiles_x, swapped ? 1 : 0, abytes, bbytes, scratch)
     if (Cbk == 16) { if (a4) ENERF_W3(true, 2); else ENERF_W3(false, 2); }
     else { if (a4) ENERF_W3(true, 1); else ENERF_W3(false, 1); }
 #undef ENERF_W3
