@@ -259,6 +259,12 @@ static int wgrad_chunks(long long npos, int pairs, int taps, bool two_stage) {
 #ifndef ENERF_WGRAD3D_TILE
 #define ENERF_WGRAD3D_TILE 1
 #endif
+#ifndef ENERF_WGRAD_1X1_GEMM
+#define ENERF_WGRAD_1X1_GEMM 1                   /* 0: 1x1 layers stay on k_conv_wgrad<1,1,1> (A/B builds) */
+#endif
+size_t gemm_wgrad_workspace_bytes(long long P, int Ca, int Cb, int bias);
+bool launch_gemm_wgrad(const float* A, int lda, int Ca, const float* Bt, int ldb, int Cb, long long P, float* dW, float* dbias,
+                       hipStream_t st, void* workspace, size_t workspace_bytes);
 size_t conv_wgrad_workspace_bytes(long long npos, int Ca, int Cb, int taps, int bias) {
     const int pairs = cdiv(Ca, 16) * cdiv(Cb + bias, 16);
     const size_t two_stage = (size_t)pairs * wgrad_chunks(npos, pairs, taps, true) * taps * 256 * sizeof(float);
@@ -268,8 +274,14 @@ size_t conv_wgrad_workspace_bytes(long long npos, int Ca, int Cb, int taps, int 
     // k_wgrad3d_c8: at most 2 blocks per CU in all, one row of the whole dW each
     const size_t tiled3 = (ENERF_WGRAD3D_TILE && taps == 27 && !bias && ((Ca <= 8 && Cb <= 32) || (Ca == 16 && Cb <= 8)))
                               ? (size_t)device_cu_count() * 2 * Ca * Cb * 27 * sizeof(float) : 0;
-    const size_t t = two_stage > tiled ? two_stage : tiled;
-    return t > tiled3 ? t : tiled3;
+    size_t t = two_stage > tiled ? two_stage : tiled;
+    t = t > tiled3 ? t : tiled3;
+    // a 1x1 stride-1 layer is a plain position-reduction GEMM (k_gemm_wgrad: all tile pairs in one wave, rows read once)
+    if (ENERF_WGRAD_1X1_GEMM && taps == 1 && cdiv(Ca, 16) <= 4 && cdiv(Cb + bias, 16) <= 6) {
+        const size_t gm = gemm_wgrad_workspace_bytes(npos, Ca, Cb, bias);
+        t = t > gm ? t : gm;
+    }
+    return t;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -675,6 +687,14 @@ bool launch_conv_wgrad(const float* A, const float* Bt, int n, int Da, int Ha, i
     q.npos = (long long)n * Da * Ha * Wa;
     q.abytes = (unsigned)(q.npos * q.lda * 4);                       // (< 2^32: checked by the C entries)
     q.bbytes = (unsigned)((long long)n * Db * Hb * Wb * q.ldb * 4);
+    // 1x1(x1) stride-1 layers (FeatureNet toplayer / lat1 / lat0): k_conv_wgrad<1,1,1> decodes every position (three divisions per
+    // MFMA) and re-reads the rows once per tile pair (lat0 at full resolution: 108 us); as a GEMM over the positions the rows are
+    // read once and there is nothing to decode.  (enerf_gemm_wgrad falls back to this function for > 4 x 6 tiles: no recursion,
+    // that case fails the tile test here too.)
+    if (ENERF_WGRAD_1X1_GEMM && kd == 1 && kh == 1 && kw == 1 && stride == 1 && pad_d == 0 && pad_h == 0 && pad_w == 0 && Da == Db && Ha == Hb &&
+        Wa == Wb && cdiv(Ca, 16) <= 4 && cdiv(Cb + q.bias, 16) <= 6 && q.npos * (long long)(q.lda > q.ldb ? q.lda : q.ldb) < (1LL << 30) &&
+        launch_gemm_wgrad(A, q.lda, Ca, Bt, q.ldb, Cb, q.npos, dW, dbias, st, workspace, workspace_bytes))
+        return true;
     if (wgrad2d_fits(n, Da, Ha, Wa, Ca, Db, Hb, Wb, Cb, kd, kh, kw, stride, pad_d, pad_h, pad_w, dbias != nullptr) && workspace != nullptr &&
         workspace_bytes >= wgrad2d_workspace_bytes(n, Ha, Wa, Ca, Cb) &&
         launch_wgrad2d(A, Bt, n, Ha, Wa, Ca, Cb, q.lda, q.ldb, dW, (float*)workspace, st))
@@ -803,7 +823,7 @@ size_t gemm_wgrad_workspace_bytes(long long P, int Ca, int Cb, int bias) {
 }
 // all tile pairs in one wave when they fit (<= 4 x 6 tiles); false -> the caller falls back to k_conv_wgrad<1,1,1>
 bool launch_gemm_wgrad(const float* A, int lda, int Ca, const float* Bt, int ldb, int Cb, long long P, float* dW, float* dbias,
-                       hipStream_t st, void* workspace = nullptr, size_t workspace_bytes = 0) {
+                       hipStream_t st, void* workspace, size_t workspace_bytes) {
     const int bias = dbias != nullptr;
     const int ta = cdiv(Ca, 16), tb = cdiv(Cb + bias, 16);
     if (ta > 4 || tb > 6) return false;
