@@ -483,8 +483,14 @@ class _Conv2d:
             x_cl = lib.channels_last(self.x.reshape(N, 3, H * W), N, 3, H * W).view(N, H, W, 3)
         else:
             x_cl = self.x
-        gw = lib.conv_wgrad_cl2d(dz, x_cl, self.k, self.stride)
-        gb = None if self.conv.bias is None else lib.cast_f32(lib.channel_sums(dz, dz)[0])
+        if self.k == 1 and self.stride == 1 and self.conv.bias is not None:
+            # toplayer / lat1 / lat0: a 1x1 layer is a GEMM over the positions, and its bias gradient is one more column of the same
+            # pass (enerf_gemm_wgrad's virtual all-ones column) instead of three launches (channel sums, their finish, the fp32 cast)
+            gw, gb = lib.gemm_wgrad(dz.reshape(-1, self.cout), x_cl.reshape(-1, self.cin), bias=True)
+            gw = gw.view(self.cout, self.cin, 1, 1)
+        else:
+            gw = lib.conv_wgrad_cl2d(dz, x_cl, self.k, self.stride)
+            gb = None if self.conv.bias is None else lib.cast_f32(lib.channel_sums(dz, dz)[0])
         gx = None
         if need_input and self.stride == 1:                    # the stride-1 kernel on the flipped, channel-transposed weights
             gx = lib.conv2d_layer(self.img[self.name, "bwd"], self.cout, self.cin, self.k, 1, dz)

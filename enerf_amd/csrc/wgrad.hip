@@ -339,7 +339,8 @@ struct W2Stage {
     __device__ __forceinline__ void fetch(const float* __restrict__ src_, const BufRsrc& rs, int img_, int H_, int W_, int ld_, int y0_, int x0_) {
         src = src_; img = img_; H = H_; W = W_; ld = ld_; y0 = y0_; x0 = x0_;
         if (!V4) return;
-        const unsigned tile_off = (unsigned)((((img * H + y0) * W + x0) * ld) * 4);   // (may wrap below zero at the borders: mod 2^32)
+        // (the position index may be below zero at the borders, and the byte offset may pass 2^31: unsigned arithmetic, mod 2^32)
+        const unsigned tile_off = (unsigned)((img * H + y0) * W + x0) * (unsigned)(ld * 4);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int y = y0 + (key[it] >> 20), x = x0 + ((key[it] >> 8) & 0xfff);

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ENERF_ABI_VERSION 8
+#define ENERF_ABI_VERSION 9
 #define ENERF_OK 0
 #define ENERF_EINVAL (-1)   /* bad argument / unsupported shape */
 #define ENERF_ELAUNCH (-2)  /* HIP launch error */
