@@ -547,15 +547,15 @@ def train_bench(args, rank, world, dev, dist, emu_lib=None):
                 from enerf_amd.train_graph import FlatGradSync, train_step
                 sync = FlatGradSync(net)
                 step = lambda: train_step(net, opt, loss_fn, batch, 40.0, sync)
+    import gc
+    gc.collect()                                                         # before the warm-up: no idle gap in front of the timed region,
+    gc.disable()                                                         # no collector pause inside it (see the rendering region in main())
     for _ in range(args.warmup):
         step()
     device_sync()
     if dist is not None:
         dist.barrier()
     device_sync()
-    import gc
-    gc.collect()
-    gc.disable()                                                         # (no collector pause inside the timed region: see the rendering region in main())
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
