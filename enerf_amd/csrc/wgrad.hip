@@ -304,8 +304,19 @@ size_t conv_wgrad_workspace_bytes(long long npos, int Ca, int Cb, int taps, int 
 // rows in a fixed order: deterministic, no atomics.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kW2TH = 8, kW2TW = 32;
-constexpr int kW2APitch = kW2TW * 8 + 32, kW2BCols = kW2TW + 2, kW2BPitch = kW2BCols * 8;
-static_assert(kW2APitch % 64 == 32 && (2 * kW2BPitch) % 64 == 32, "bank-conflict-free operand reads");
+// LDS pitches (floats).  ds_read_b32 / ds_read2_b32 are serviced in the two 32-lane halves of a wave with bank = (a / 4) mod 32
+// (MI355X_MICROARCH.md, LDS): the lanes of a half are (g in {0,1} or {2,3}, lo 0..7, hi 0..1) at g * 8 + lo + hi * (shift), so the
+// shifted copy must sit 16 banks away: A rows ≡ 16 (mod 32), TWO B rows ≡ 16 (mod 32).  (First version: 32 mod 64 — right for a
+// 64-bank model, a 2-way conflict on every operand read with 32: PMC counted SQ_LDS_BANK_CONFLICT at 0.42 - 0.55 of the LDS-active
+// cycles, profiles/r05_micro_wgrad_pmc.txt.)  The 8-lane groups of the ds_write_b128 staging stores cover one pixel's quads in
+// four channel planes: the plane stride ≡ 8 (mod 32) keeps those apart too.
+#ifndef ENERF_WGRAD_PITCH32
+#define ENERF_WGRAD_PITCH32 1                    /* 0: the first version's pitches (A/B builds) */
+#endif
+constexpr int kW2BCols = kW2TW + 2;
+constexpr int kW2APitch = kW2TW * 8 + (ENERF_WGRAD_PITCH32 ? 16 : 32), kW2BPitch = kW2BCols * 8 + (ENERF_WGRAD_PITCH32 ? 8 : 0);
+constexpr int kW2BPlane = (kW2TH + 2) * kW2BPitch + (ENERF_WGRAD_PITCH32 ? 8 : 0);
+static_assert(!ENERF_WGRAD_PITCH32 || (kW2APitch % 32 == 16 && (2 * kW2BPitch) % 32 == 16 && kW2BPlane % 32 == 24), "bank-conflict-free operand reads / staging stores");
 
 // one tile of `src` (n, H, W, ld floats per position; C <= 8 NCB channels used) into LDS: rows y0 .., cols x0 .., zeros outside
 // the image; one plane of PLANE floats per block of 8 channels, pixel pitch 8 floats inside a plane (so that the 64 lanes of an
@@ -373,7 +384,7 @@ template <bool A4, bool B4, int NCB>
 __global__ __launch_bounds__(256) void k_wgrad2d_3x3_c8(const float* __restrict__ A, const float* __restrict__ Bt, int n, int H, int W,
                                                         int Ca, int Cb, int lda, int ldb, int tiles_y, int tiles_x,
                                                         unsigned abytes, unsigned bbytes, float* __restrict__ scratch) {
-    constexpr int TH = kW2TH, TW = kW2TW, AP = kW2APitch, BP = kW2BPitch, BPL = (TH + 2) * BP;
+    constexpr int TH = kW2TH, TW = kW2TW, AP = kW2APitch, BP = kW2BPitch, BPL = kW2BPlane;
     constexpr int GC = NCB == 1 ? TW / 4 : 4;              // groups whose operands are in registers at once (GC x (1 + 3 NCB) values)
     __shared__ float la[(TH + 1) * AP];
     __shared__ float lb[NCB * BPL];
@@ -500,7 +511,7 @@ template <bool A4, int NCB>
 __global__ __launch_bounds__(256) void k_wgrad3d_c8(const float* __restrict__ A, const float* __restrict__ Bt, int n, int D, int H, int W,
                                                     int Ca, int Cb, int lda, int ldb, int tiles_y, int tiles_x, int swapped,
                                                     unsigned abytes, unsigned bbytes, float* __restrict__ scratch) {
-    constexpr int TH = kW2TH, TW = kW2TW, AP = kW2APitch, BP = kW2BPitch, BPL = (TH + 2) * BP;
+    constexpr int TH = kW2TH, TW = kW2TW, AP = kW2APitch, BP = kW2BPitch, BPL = kW2BPlane;
     constexpr int GC = NCB == 1 ? 4 : 2;                   // groups whose operands are in registers at once (GC x (1 + 9 NCB) values)
     __shared__ float la[(TH + 1) * AP];
     __shared__ float lb[3 * NCB * BPL];                    // [kd][channel block][rows][cols][8]
