@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_wgrad2d_3x3_c8(const float* __restrict_
                                                         int Ca, int Cb, int lda, int ldb, int tiles_y, int tiles_x,
                                                         unsigned abytes, unsigned bbytes, float* __restrict__ scratch) {
     constexpr int TH = kW2TH, TW = kW2TW, AP = kW2APitch, BP = kW2BPitch, BPL = kW2BPlane;
-    constexpr int GC = NCB == 1 ? TW / 4 : 4;              // groups whose operands are in registers at once (GC x (1 + 3 NCB) values)
+    constexpr int GC = NCB == 1 ? 4 : 2;                   // groups per operand chunk (two chunks in registers: 2 GC (1 + 3 NCB) values)
     __shared__ float la[(TH + 1) * AP];
     __shared__ float lb[NCB * BPL];
     static_assert(BPL >= 3 * 3 * 256, "the cross-wave reduction reuses the B tile");
@@ -414,33 +414,36 @@ __global__ __launch_bounds__(256) void k_wgrad2d_3x3_c8(const float* __restrict_
         sb.commit(lb);
         __syncthreads();
         if (ENERF_WGRAD_PREFETCH && t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);       // in flight behind this tile's MFMAs
-        // a chunk's operands are all requested before its first MFMA (left to itself hipcc waited for each ds_read2 pair in
-        // front of the two MFMAs that use it)
-#pragma unroll
-        for (int rr = 0; rr < TH / 4; ++rr) {
-            const int tr = wv + 4 * rr;
+        // Operand pipeline: chunk c + 1's LDS reads are issued before chunk c's MFMAs (two register sets), so a wave's MFMAs run back
+        // to back.  (Left to itself hipcc waited for each ds_read2 pair in front of the two MFMAs that use it; with one set per
+        // chunk a wave idled a read round trip per chunk: PMC 0.47 matrix-pipe busy at 0.59 SQ_WAIT_INST_ANY.)
+        constexpr int NCH = (TH / 4) * (TW / 4) / GC;          // chunks of GC groups per wave and tile, row-major
+        float av[2][GC], bv[2][GC][NCB][3];
+        auto load = [&](int c, float (&a_)[GC], float (&b_)[GC][NCB][3]) {
+            const int rr = (c * GC) / (TW / 4), c0 = (c * GC) % (TW / 4), tr = wv + 4 * rr;
             const float* pa = la + (tr + hi) * AP + g * 8 + lo;
             const float* pb = lb + (tr + 2 * hi) * BP + g * 8 + lo;
 #pragma unroll
-            for (int c0 = 0; c0 < TW / 4; c0 += GC) {
-                float av[GC], bv[GC][NCB][3];
+            for (int cg = 0; cg < GC; ++cg) {
+                a_[cg] = pa[(c0 + cg) * 32];
 #pragma unroll
-                for (int cg = 0; cg < GC; ++cg) {
-                    av[cg] = pa[(c0 + cg) * 32];
+                for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-                    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) bv[cg][cb][k] = pb[cb * BPL + (c0 + cg) * 32 + k * 8];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int cg = 0; cg < GC; ++cg)
-#pragma unroll
-                    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) acc[cb][k] = ENERF_MFMA_W(av[cg], bv[cg][cb][k], acc[cb][k]);
-                if (NCB > 1) __builtin_amdgcn_sched_barrier(0);
+                    for (int k = 0; k < 3; ++k) b_[cg][cb][k] = pb[cb * BPL + (c0 + cg) * 32 + k * 8];
             }
+        };
+        load(0, av[0], bv[0]);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c + 1 < NCH) load(c + 1, av[(c + 1) & 1], bv[(c + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cg = 0; cg < GC; ++cg)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc[cb][k] = ENERF_MFMA_W(av[c & 1][cg], bv[c & 1][cg][cb][k], acc[cb][k]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         if (!ENERF_WGRAD_PREFETCH && t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(256) void k_wgrad3d_c8(const float* __restrict__ A,
                                                     int Ca, int Cb, int lda, int ldb, int tiles_y, int tiles_x, int swapped,
                                                     unsigned abytes, unsigned bbytes, float* __restrict__ scratch) {
     constexpr int TH = kW2TH, TW = kW2TW, AP = kW2APitch, BP = kW2BPitch, BPL = kW2BPlane;
-    constexpr int GC = NCB == 1 ? 4 : 2;                   // groups whose operands are in registers at once (GC x (1 + 9 NCB) values)
+    constexpr int GC = NCB == 1 ? 2 : 1;                   // groups per operand chunk (two chunks in registers: 2 GC (1 + 9 NCB) values)
     __shared__ float la[(TH + 1) * AP];
     __shared__ float lb[3 * NCB * BPL];                    // [kd][channel block][rows][cols][8]
     static_assert(3 * BPL >= 3 * 9 * 256, "the cross-wave reduction reuses the B planes, one channel block at a time");
@@ -551,35 +554,37 @@ __global__ __launch_bounds__(256) void k_wgrad3d_c8(const float* __restrict__ A,
         for (int kd = 0; kd < 3; ++kd) sb[kd].commit(lb + kd * NCB * BPL);
         __syncthreads();
         if (ENERF_WGRAD3D_PREFETCH && t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
-#pragma unroll
-        for (int rr = 0; rr < TH / 4; ++rr) {
-            const int tr = wv + 4 * rr;
+        constexpr int NCH = (TH / 4) * (TW / 4) / GC;          // the 2-D kernel's operand pipeline, 9 NCB B values per group
+        float av[2][GC], bv[2][GC][3][NCB][3];
+        auto load = [&](int c, float (&a_)[GC], float (&b_)[GC][3][NCB][3]) {
+            const int rr = (c * GC) / (TW / 4), c0 = (c * GC) % (TW / 4), tr = wv + 4 * rr;
             const float* pa = la + (tr + hi) * AP + g * 8 + lo;
             const float* pb = lb + (tr + 2 * hi) * BP + g * 8 + lo;
 #pragma unroll
-            for (int c0 = 0; c0 < TW / 4; c0 += GC) {
-                float av[GC], bv[GC][3][NCB][3];
+            for (int cg = 0; cg < GC; ++cg) {
+                a_[cg] = pa[(c0 + cg) * 32];
 #pragma unroll
-                for (int cg = 0; cg < GC; ++cg) {
-                    av[cg] = pa[(c0 + cg) * 32];
+                for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
-                    for (int kd = 0; kd < 3; ++kd)
+                    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-                        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) bv[cg][kd][cb][k] = pb[(kd * NCB + cb) * BPL + (c0 + cg) * 32 + k * 8];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int cg = 0; cg < GC; ++cg)
-#pragma unroll
-                    for (int kd = 0; kd < 3; ++kd)
-#pragma unroll
-                        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) acc[kd][cb][k] = ENERF_MFMA_W(av[cg], bv[cg][kd][cb][k], acc[kd][cb][k]);
-                __builtin_amdgcn_sched_barrier(0);
+                        for (int k = 0; k < 3; ++k) b_[cg][kd][cb][k] = pb[(kd * NCB + cb) * BPL + (c0 + cg) * 32 + k * 8];
             }
+        };
+        load(0, av[0], bv[0]);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c + 1 < NCH) load(c + 1, av[(c + 1) & 1], bv[(c + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cg = 0; cg < GC; ++cg)
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) acc[kd][cb][k] = ENERF_MFMA_W(av[c & 1][cg], bv[c & 1][cg][kd][cb][k], acc[kd][cb][k]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         if (!ENERF_WGRAD3D_PREFETCH && t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
