@@ -770,6 +770,14 @@ def main():
             if abs(a - b) <= 0.015 * a or now - t_w > 2.0:
                 break
     device_sync()
+    if dist is not None:
+        # N > 1: the ranks leave their warm-ups at different moments, and the first to reach the timed region's barrier would idle
+        # there (the same gap, seen from its device).  Meet once HERE, run a few more untimed frames from a common start, and the
+        # barrier in front of the window finds every rank within a frame or two of the others.
+        dist.barrier()
+        for _ in range(2 if args.emu else 40):
+            step()
+            device_sync()
     # frame f -> rank f mod world: every rank renders `steps` frames; barrier + sync both sides, MAX over ranks
     t_rank = time.perf_counter()
     _, fps, elapsed = render_sharded(timed_frame, args.steps * world, rank, world, sync=device_sync)
