@@ -65,6 +65,23 @@ def test_training_entries_reject_bad_arguments(lib):
         s = torch.zeros(2, 6, dtype=torch.float64)
         t = torch.zeros(5, 6)
         lib._check(lib.dll.enerf_channel_sums(t.data_ptr(), t.data_ptr(), None, None, None, 5, 6, s.data_ptr(), None), "channel_sums")
+    # ABI v9: the two halves of the 5x5 stride-2 input gradient, and the 64-source image gather
+    w, pk, dz = torch.zeros(16, 8, 5, 5), torch.zeros(lib.dll.enerf_conv2d_s2k5_dgrad_packed_floats(8, 16)), torch.zeros(1, 4, 4, 16)
+    w3 = torch.zeros(4 * 8 * 16 * 9)
+    with pytest.raises(EnerfError, match="null pointer"):
+        lib._check(lib.dll.enerf_conv2d_s2k5_dgrad_pack(w.data_ptr(), 8, 16, None, pk.data_ptr(), None), "s2k5_pack")
+    with pytest.raises(EnerfError, match="8 -> 16 and 16 -> 32"):
+        lib._check(lib.dll.enerf_conv2d_s2k5_dgrad_pack(w.data_ptr(), 8, 8, w3.data_ptr(), pk.data_ptr(), None), "s2k5_pack")
+    with pytest.raises(EnerfError, match="workspace too small"):
+        gx = torch.zeros(1, 8, 8, 8)
+        ws = torch.zeros(4)
+        lib._check(lib.dll.enerf_conv2d_s2k5_dgrad_packed(pk.data_ptr(), 8, 16, dz.data_ptr(), None, gx.data_ptr(), 1, 4, 4, ws.data_ptr(), 16, None),
+                   "s2k5_packed")
+    with pytest.raises(EnerfError, match="bad arguments"):              # 65 sources
+        srcs = (C.c_void_p * 65)(*([w.data_ptr()] * 65))
+        idx = torch.zeros(4, dtype=torch.int32)
+        out = torch.zeros(4)
+        lib._check(lib.dll.enerf_gather_images(C.cast(srcs, C.c_void_p), 65, idx.data_ptr(), idx.data_ptr(), 4, out.data_ptr(), None), "gather_images")
     g = GatherArgs()
     assert lib.dll.enerf_gather_fwd(None, None) != 0 and "null args" in _msg(lib)
     assert lib.dll.enerf_gather_fwd(C.byref(g), None) != 0 and "null input" in _msg(lib)
