@@ -351,7 +351,7 @@ def _check_conv_wgrad(lib, dev):
     # partial last tile row / column, the row above the image, 16-byte and scalar staging (channel counts 8, 4, 5, 3), two and
     # four blocks of 8 input channels (smooth0: 32 -> 8)
     for cin, cout, H, W in [(8, 8, 40, 70), (3, 8, 33, 64), (8, 4, 47, 45), (5, 8, 9, 250), (8, 8, 64, 32), (32, 8, 40, 70), (16, 8, 17, 66),
-                            (32, 5, 33, 40)]:
+                            (32, 5, 33, 40), (8, 8, 300, 7)]:                          # (the last: an image narrower than a tile)
         x = rnd(2, cin, H, W)
         w = rnd(cout, cin, 3, 3).requires_grad_(True)
         y = F.conv2d(x, w, None, 1, 1)
@@ -363,8 +363,9 @@ def _check_conv_wgrad(lib, dev):
         assert torch.equal(got, lib.conv_wgrad(gy, x, (3, 3), 1, (1, 1)))                       # deterministic
     # ... and its 3-D form (k_wgrad3d_c8: >= 32768 positions): conv0 (32 / 16 -> 8, two columns of 16 channels for 32), 8 -> 8, and the
     # fused heads 8 -> 16 (roles swapped, taps mirrored); volume borders in d, h and w inside tiles
-    for cin, cout, D, H, W in [(16, 8, 5, 81, 83), (32, 8, 3, 100, 112), (8, 16, 6, 70, 80), (8, 8, 4, 96, 96), (32, 5, 5, 81, 83)]:
-        x = rnd(1, cin, D, H, W)
+    for cin, cout, D, H, W, nb in [(16, 8, 5, 81, 83, 1), (32, 8, 3, 100, 112, 1), (8, 16, 6, 70, 80, 1), (8, 8, 4, 96, 96, 1), (32, 5, 5, 81, 83, 1),
+                                   (16, 8, 3, 80, 72, 2)]:                              # (the last: two volumes — planes of different volumes never mix)
+        x = rnd(nb, cin, D, H, W)
         w = rnd(cout, cin, 3, 3, 3).requires_grad_(True)
         y = F.conv3d(x, w, None, 1, 1)
         gy = rnd(*y.shape)
