@@ -269,8 +269,8 @@ size_t conv_wgrad_workspace_bytes(long long npos, int Ca, int Cb, int taps, int 
     const int pairs = cdiv(Ca, 16) * cdiv(Cb + bias, 16);
     const size_t two_stage = (size_t)pairs * wgrad_chunks(npos, pairs, taps, true) * taps * 256 * sizeof(float);
     // k_wgrad2d_3x3_c8 (below): one compact row of Ca*Cb*9 sums per persistent block (the query does not know the grid: the bound)
-    const size_t tiled = (ENERF_WGRAD2D_TILE && taps == 9 && Ca <= 8 && Cb <= 32 && !bias)
-                             ? (size_t)device_cu_count() * ENERF_WGRAD2D_BPC * Ca * Cb * 9 * sizeof(float) : 0;
+    const size_t tiled = (ENERF_WGRAD2D_TILE && taps == 9 && Ca <= 32 && Cb <= 32 && !bias)
+                             ? (size_t)device_cu_count() * (Ca <= 8 ? ENERF_WGRAD2D_BPC : 3) * Ca * Cb * 9 * sizeof(float) : 0;
     // k_wgrad3d_c8: at most 2 blocks per CU in all, one row of the whole dW each
     const size_t tiled3 = (ENERF_WGRAD3D_TILE && taps == 27 && !bias && ((Ca <= 8 && Cb <= 32) || (Ca == 16 && Cb <= 8)))
                               ? (size_t)device_cu_count() * 2 * Ca * Cb * 27 * sizeof(float) : 0;
@@ -324,9 +324,10 @@ static_assert(!ENERF_WGRAD_PITCH32 || (kW2APitch % 32 == 16 && (2 * kW2BPitch) %
 // run (a block spent ~5 us per tile waiting for them in front of 0.6 - 2.6 us of MFMAs): fetch() = the global loads into registers,
 // commit() = the LDS stores.  V4: 16-byte loads (C a power of two >= 4, ld % 4 == 0, 16-byte aligned base); otherwise (the
 // 3-channel image of conv0.0) a scalar loop at commit time, not pipelined.
-template <int ROWS, int COLS, int PITCH, int PLANE, int NCB, bool V4>
+template <int ROWS, int COLS, int PITCH, int PLANE, int NCB, bool V4, int CPP = 8>      // CPP: channels per plane and pixel (8 or 16)
 struct W2Stage {
-    static constexpr int NIT = V4 ? (ROWS * COLS * 2 * NCB + 255) / 256 : 1;
+    static constexpr int QPP = CPP / 4;
+    static constexpr int NIT = V4 ? (ROWS * COLS * QPP * NCB + 255) / 256 : 1;
     float4 v[NIT];
     int key[NIT];                                          // tile-invariant slot of this thread: (r << 20) | (c << 8) | quad, -1 = none
     unsigned koff[NIT];                                    // ... and its byte offset from the tile's first element: ((r W + c) ld + 4 quad) 4
@@ -364,7 +365,7 @@ struct W2Stage {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int r = key[it] >> 20, c = (key[it] >> 8) & 0xfff, qd = key[it] & 0xff;
-                if (key[it] >= 0) *reinterpret_cast<float4*>(dst + (qd >> 1) * PLANE + r * PITCH + c * 8 + (qd & 1) * 4) = v[it];
+                if (key[it] >= 0) *reinterpret_cast<float4*>(dst + (qd / QPP) * PLANE + r * PITCH + c * CPP + (qd % QPP) * 4) = v[it];
             }
         } else {
             for (int i = (int)threadIdx.x; i < ROWS * COLS * C; i += 256) {
@@ -373,7 +374,7 @@ struct W2Stage {
                 const int y = y0 + r, x = x0 + c;
                 float val = 0.f;
                 if (y >= 0 && y < H && x >= 0 && x < W) val = src[(((long long)img * H + y) * W + x) * ld + ch];
-                dst[(ch >> 3) * PLANE + r * PITCH + c * 8 + (ch & 7)] = val;
+                dst[(ch / CPP) * PLANE + r * PITCH + c * CPP + (ch % CPP)] = val;
             }
         }
     }
@@ -474,6 +475,101 @@ __global__ __launch_bounds__(256) void k_wgrad2d_3x3_c8(const float* __restrict_
                 const int row = 4 * g + r, a = row & 7, s = row >> 3, b = cb * 8 + lo, u = hi, kh = 2 * u - s;
                 if (kh >= 0 && a < Ca && b < Cb) out[(a * Cb + b) * 9 + kh * 3 + k] = v;
             }
+}
+// The 3x3 stride-1 2-D layers with 16 NA x 16 NB channels (conv1.1 16 <- 16, smooth1 16 <- 32, conv2.1 32 <- 32): the same LDS tiles
+// without shifted copies (there is no idle half): nine MFMAs per group and tile pair, operands at immediate LDS offsets; pixel pitch
+// 16 floats, so lane (g, j) reads bank (16 g + j) mod 32 — conflict-free per 32-lane half.
+template <int NA, int NB>
+__global__ __launch_bounds__(256) void k_wgrad2d_3x3_p16(const float* __restrict__ A, const float* __restrict__ Bt, int n, int H, int W,
+                                                         int lda, int ldb, int tiles_y, int tiles_x, unsigned abytes, unsigned bbytes,
+                                                         float* __restrict__ scratch) {
+    constexpr int TH = kW2TH, TW = kW2TW, AP = TW * 16, APL = TH * AP + 16, BC = TW + 2, BP = BC * 16, BPL = (TH + 2) * BP + 16;
+    static_assert(APL % 32 == 16 && BPL % 32 == 16, "the two planes of a 32-channel pixel 16 banks apart (ds_write_b128 groups)");
+    constexpr int Ca = 16 * NA, Cb = 16 * NB;
+    __shared__ float lds[NA * APL + NB * BPL];
+    static_assert(NA * APL + NB * BPL >= 3 * 9 * 256, "the cross-wave reduction reuses the tiles");
+    float* la = lds;
+    float* lb = lds + NA * APL;
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
+    f32x4 acc[NA][NB][9];
+#pragma unroll
+    for (int na = 0; na < NA; ++na)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[na][nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntiles = n * tiles_y * tiles_x;
+    W2Stage<TH, TW, AP, APL, NA, true, 16> sa;
+    W2Stage<TH + 2, BC, BP, BPL, NB, true, 16> sb;
+    sa.init(Ca, W, lda);
+    sb.init(Cb, W, ldb);
+    const BufRsrc ra = buf_rsrc(A, abytes), rb = buf_rsrc(Bt, bbytes);
+    auto fetch = [&](int t) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+        sa.fetch(A, ra, img, H, W, lda, ty * TH, tx * TW);
+        sb.fetch(Bt, rb, img, H, W, ldb, ty * TH - 1, tx * TW - 1);
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        sa.commit(la);
+        sb.commit(lb);
+        __syncthreads();
+        if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+        constexpr int NCH = (TH / 4) * (TW / 4);               // one group per chunk, two register sets (the c8 kernels' pipeline)
+        float av[2][NA], bv[2][NB][9];
+        auto load = [&](int c, float (&a_)[NA], float (&b_)[NB][9]) {
+            const int rr = c / (TW / 4), cg = c % (TW / 4), tr = wv + 4 * rr;
+            const float* pa = la + tr * AP + (4 * cg + g) * 16 + j;
+            const float* pb = lb + tr * BP + (4 * cg + g) * 16 + j;
+#pragma unroll
+            for (int na = 0; na < NA; ++na) a_[na] = pa[na * APL];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) b_[nb][kh * 3 + kw] = pb[nb * BPL + kh * BP + kw * 16];
+        };
+        load(0, av[0], bv[0]);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c + 1 < NCH) load(c + 1, av[(c + 1) & 1], bv[(c + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int na = 0; na < NA; ++na)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int t9 = 0; t9 < 9; ++t9) acc[na][nb][t9] = ENERF_MFMA_W(av[c & 1][na], bv[c & 1][nb][t9], acc[na][nb][t9]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    float* out = scratch + (long long)blockIdx.x * (Ca * Cb * 9);
+#pragma unroll
+    for (int na = 0; na < NA; ++na)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (wv != 0) {
+#pragma unroll
+                for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lds[((wv - 1) * 9 + t9) * 256 + r * 64 + lane] = acc[na][nb][t9][r];
+            }
+            __syncthreads();
+            if (wv == 0) {
+#pragma unroll
+                for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[na][nb][t9][r];
+#pragma unroll
+                        for (int w = 0; w < 3; ++w) v += lds[(w * 9 + t9) * 256 + r * 64 + lane];
+                        out[((na * 16 + 4 * g + r) * Cb + nb * 16 + j) * 9 + t9] = v;      // D rows 4g + r, column j
+                    }
+            }
+            __syncthreads();
+        }
 }
 // out[.] = sum over the rows c < chunks of part[c * n_out + i], fixed order: 16 waves take rows c = w, w + 16, ... (four loads in
 // flight), then wave 0 adds the 16 partial sums.  blockIdx.y = segment: its rows start at part + y * chunks * n_out and element i
@@ -621,24 +717,41 @@ __global__ __launch_bounds__(256) void k_wgrad3d_c8(const float* __restrict__ A,
         __syncthreads();
     }
 }
-static int wgrad2d_bpc(int Cb) { return Cb <= 8 ? ENERF_WGRAD2D_BPC : Cb <= 16 ? 3 : 2; }      // by LDS: 21 / 32 / 54 KB per block
-static int wgrad2d_blocks(int n, int H, int W, int Cb) {
-    const long long ntiles = (long long)n * cdiv(H + 1, kW2TH) * cdiv(W, kW2TW);
-    const long long cap = (long long)device_cu_count() * wgrad2d_bpc(Cb);
+static int wgrad2d_bpc(int Ca, int Cb) {               // by LDS (21 / 32 / 54 KB per block; p16: 38 / 60 / 77 KB) and registers
+    if (Ca > 8) return Cb == 32 ? 1 : 3;                // (272 / 356 registers with a 32-channel B: one wave per SIMD)
+    return Cb <= 8 ? ENERF_WGRAD2D_BPC : Cb <= 16 ? 3 : 2;
+}
+static int wgrad2d_blocks(int n, int H, int W, int Ca, int Cb) {
+    const long long ntiles = (long long)n * cdiv(Ca > 8 ? H : H + 1, kW2TH) * cdiv(W, kW2TW);
+    const long long cap = (long long)device_cu_count() * wgrad2d_bpc(Ca, Cb);
     return (int)(ntiles < cap ? ntiles : cap);
 }
+#ifndef ENERF_WGRAD2D_P16
+#define ENERF_WGRAD2D_P16 1                      /* 0: the 16 / 32-channel 3x3 layers stay on k_conv_wgrad (A/B builds) */
+#endif
+static bool wgrad2d_p16(int Ca, int Cb) { return ENERF_WGRAD2D_P16 && ((Ca == 16 && (Cb == 16 || Cb == 32)) || (Ca == 32 && Cb == 32)); }
 static bool wgrad2d_fits(int n, int Da, int Ha, int Wa, int Ca, int Db, int Hb, int Wb, int Cb, int kd, int kh, int kw, int stride,
                          int pad_d, int pad_h, int pad_w, bool bias) {
+    const bool shape = (Ca <= 8 && (Cb <= 8 || Cb == 16 || Cb == 32)) || wgrad2d_p16(Ca, Cb);
     return ENERF_WGRAD2D_TILE && kd == 1 && kh == 3 && kw == 3 && stride == 1 && pad_d == 0 && pad_h == 1 && pad_w == 1 && Da == 1 &&
-           Db == 1 && Ha == Hb && Wa == Wb && Ca <= 8 && (Cb <= 8 || Cb == 16 || Cb == 32) && !bias && (long long)n * Ha * Wa >= 2048;
+           Db == 1 && Ha == Hb && Wa == Wb && shape && !bias && (long long)n * Ha * Wa >= 2048;
 }
 static size_t wgrad2d_workspace_bytes(int n, int H, int W, int Ca, int Cb) {
-    return (size_t)wgrad2d_blocks(n, H, W, Cb) * Ca * Cb * 9 * sizeof(float);
+    return (size_t)wgrad2d_blocks(n, H, W, Ca, Cb) * Ca * Cb * 9 * sizeof(float);
 }
 static bool launch_wgrad2d(const float* A, const float* Bt, int n, int H, int W, int Ca, int Cb, int lda, int ldb, float* dW,
                            float* scratch, hipStream_t st) {
-    const int blocks = wgrad2d_blocks(n, H, W, Cb), tiles_y = cdiv(H + 1, kW2TH), tiles_x = cdiv(W, kW2TW);
+    const int blocks = wgrad2d_blocks(n, H, W, Ca, Cb), tiles_y = cdiv(H + 1, kW2TH), tiles_x = cdiv(W, kW2TW);
     const unsigned abytes = (unsigned)((long long)n * H * W * lda * 4), bbytes = (unsigned)((long long)n * H * W * ldb * 4);   // (< 2^32: checked by the C entries)
+    if (Ca > 8) {                                          // 16 / 32 gradient channels: the plain tiles
+        if (lda % 4 != 0 || ldb % 4 != 0 || (((uintptr_t)A | (uintptr_t)Bt) & 15) != 0) return false;
+        const int ty16 = cdiv(H, kW2TH);
+#define ENERF_W2P(NA, NB) ENERF_LAUNCH((k_wgrad2d_3x3_p16<NA, NB>), (unsigned)blocks, 256, 0, st, A, Bt, n, H, W, lda, ldb, ty16, tiles_x, abytes, bbytes, scratch)
+        if (Ca == 32) ENERF_W2P(2, 2); else if (Cb == 32) ENERF_W2P(1, 2); else ENERF_W2P(1, 1);
+#undef ENERF_W2P
+        ENERF_LAUNCH(k_colsum, (unsigned)cdiv(Ca * Cb * 9, 64), 1024, 0, st, scratch, blocks, Ca * Cb * 9, Ca * Cb * 9, 0, dW);
+        return true;
+    }
     const bool a4 = (Ca == 4 || Ca == 8) && lda % 4 == 0 && ((uintptr_t)A & 15) == 0;
     const bool b4 = (Cb == 4 || Cb == 8 || Cb == 16 || Cb == 32) && ldb % 4 == 0 && ((uintptr_t)Bt & 15) == 0;
     if (Cb > 8 && !b4) return false;

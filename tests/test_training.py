@@ -351,7 +351,8 @@ def _check_conv_wgrad(lib, dev):
     # partial last tile row / column, the row above the image, 16-byte and scalar staging (channel counts 8, 4, 5, 3), two and
     # four blocks of 8 input channels (smooth0: 32 -> 8)
     for cin, cout, H, W in [(8, 8, 40, 70), (3, 8, 33, 64), (8, 4, 47, 45), (5, 8, 9, 250), (8, 8, 64, 32), (32, 8, 40, 70), (16, 8, 17, 66),
-                            (32, 5, 33, 40), (8, 8, 300, 7)]:                          # (the last: an image narrower than a tile)
+                            (32, 5, 33, 40), (8, 8, 300, 7),                           # (an image narrower than a tile)
+                            (16, 16, 40, 70), (32, 16, 33, 45), (32, 32, 17, 66)]:      # (the plain 16 / 32-channel tiles: conv1.1, smooth1, conv2.1)
         x = rnd(2, cin, H, W)
         w = rnd(cout, cin, 3, 3).requires_grad_(True)
         y = F.conv2d(x, w, None, 1, 1)
