@@ -219,16 +219,28 @@ def secondary_workload(name, dev, frames=100):
         no[0] += 1
         return net(batches[no[0] % 4])
     import gc
-    t_w, n_w = time.perf_counter(), 0
-    while n_w < 150 or time.perf_counter() - t_w < 0.5:
-        step()
-        torch.cuda.synchronize()
-        n_w += 1
     # the default run has built and dropped two networks by now: collect that garbage BEFORE the timed frames and keep the survivors
     # out of later collections (a generation-2 pass over them in the middle of 100 frames cost up to 30 ms in one run: 545 -> 468
-    # frames/s on zju); the distribution is reported so that such an outlier is visible
+    # frames/s on zju); the distribution is reported so that such an outlier is visible.  The collection itself comes BEFORE the
+    # warm-up: an idle gap in front of the timed frames takes the device out of its steady clocks (see main()).
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
     gc.collect()
     gc.freeze()
+    t_w, n_w, recent = time.perf_counter(), 0, []
+    while True:
+        t_f = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        recent.append(now - t_f)
+        n_w += 1
+        if n_w < 150 or now - t_w < 0.5:
+            continue
+        a, b = sum(recent[-20:-10]), sum(recent[-10:])
+        if abs(a - b) <= 0.015 * a or now - t_w > 2.0:                  # settled (or give up after 2 s)
+            break
     lat = []
     for _ in range(frames):
         torch.cuda.synchronize()
