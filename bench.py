@@ -63,6 +63,12 @@ class StageTimer:
 
 
 # ---- algorithmic work --------------------------------------------------------------------------------
+# reference-over-port time ratios of the CPU baseline (`kind: "port"`): the unmodified reference modules against oracle/enerf_oracle.py
+# on the same inputs and threads in the build container (profiles/r03_cpu_ref_vs_port.txt, r05_cpu_ref_vs_port_train.txt; outputs /
+# gradients bit-identical).  reference seconds = port seconds x this; the reference cannot travel to the GPU box.
+REF_OVER_PORT = {"render_ft": round(1 / 0.820, 3), "render_tt": round(1 / 1.007, 3), "train": round(1 / 0.935, 3)}
+
+
 def render_mfma_tiles_per_16(S, R):
     """16x16x4 fp32 MFMA tiles k_render_rays issues per 16 samples (render.hip): view_fc, global_fc (shared + per view),
     fc, lr0, color.0 (shared + per view)."""
@@ -95,11 +101,42 @@ def cost_reg_gflop(C, full, D, h, w):
     return f / 1e9
 
 
-def live_pmc(workload, kernel_prefix="k_render_rays<3", child_flags=None):
-    """HBM traffic + matrix-pipe busy fraction of the dominant kernel, measured NOW: three short rocprofv3 --pmc passes
-    (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE; separate passes, --kernel-trace only — the
-    MI355X_MICROARCH.md recipe, as tools/collect_profiles.sh) over a child run of this script (3 frames, kernels alone on one
-    stream).  Returns None when rocprofv3 is missing or a pass fails: the caller then replays the committed figures."""
+PMC_SENTINEL = "k_pack_rgb8"          # a library kernel no frame launches: brackets the measured frames of a workload in the PMC child
+
+
+def pmc_sequence_child(names, dev):
+    """`bench.py --pmc-sequence dtu,lego,zju` (the child of live_pmc): per workload, build the network, run two untimed frames,
+    then a sentinel launch, three frames with every kernel alone on one stream, and a sentinel again.  The parent cuts the
+    dispatch-ordered counter rows at the sentinels, so ONE child per counter pass covers every workload of the line."""
+    from __graft_entry__ import _seeded_network
+    from enerf_amd.lib import Options, get_lib
+    lib = get_lib()
+    dummy = torch.zeros((64, 3), device=dev)
+    for name in names:
+        cfg, batch_np, human, _ = make_workload(name, 0)
+        net = _seeded_network(cfg, dev, human=human)
+        net.options = Options(single_stream=1)
+        batch = {k: torch.from_numpy(v).to(dev) for k, v in batch_np.items()}
+        with torch.no_grad():
+            for _ in range(2):
+                net(batch)
+            torch.cuda.synchronize()
+            lib.pack_rgb8(dummy, 8, 8)
+            for _ in range(3):
+                net(batch)
+            lib.pack_rgb8(dummy, 8, 8)
+            torch.cuda.synchronize()
+        del net, batch
+        torch.cuda.empty_cache()
+
+
+def live_pmc(workloads, child_flags=None, kernel_prefix=None):
+    """HBM traffic + matrix-pipe busy fraction per kernel, measured NOW: three short rocprofv3 --pmc passes (FETCH_SIZE /
+    WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE; separate passes, --kernel-trace only — the MI355X_MICROARCH.md
+    recipe, as tools/collect_profiles.sh) over a child run of this script (`--pmc-sequence`: three frames per workload, kernels
+    alone on one stream).  Returns {workload: {kernel name: {hbm_bytes_per_launch, fetch_size_kb, write_size_kb, mfma_busy_frac}}}
+    — with ``child_flags`` (the training line: eager steps of the same loss) {"": {...}} over the whole child — or None when
+    rocprofv3 is missing or a pass fails: the caller then replays the committed figures."""
     import csv
     import glob
     import shutil
@@ -108,37 +145,62 @@ def live_pmc(workload, kernel_prefix="k_render_rays<3", child_flags=None):
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None
-    child = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
-             "--no-stages", "--no-sync-per-frame", "--single-stream", "--no-live-pmc"]
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-sequence", ",".join(workloads)]
     if child_flags is not None:                           # (the training line: eager steps of the same loss, kernels alone)
         child = [sys.executable, os.path.abspath(__file__), *child_flags, "--no-cpu-baseline", "--no-live-pmc"]
     env = dict(os.environ, TMPDIR="/tmp")
     env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    means = {}
+    acc = {}                                              # (workload, kernel) -> counter -> [values]
     for counters in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"):
         d = tempfile.mkdtemp(prefix="enerf_pmc_", dir="/tmp")
         try:
             subprocess.run([rocprof, "--pmc", *counters.split(), "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", *child],
                            cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            acc = {}
-            for r in csv.DictReader(open(files[0])):
+            rows = sorted(csv.DictReader(open(files[0])), key=lambda r: int(r["Dispatch_Id"]))
+            seg, inside, last_dispatch = -1, False, None
+            for r in rows:
                 k = r["Kernel_Name"].replace("void enerf::", "").replace("enerf::", "")
-                if k.startswith(kernel_prefix):
-                    acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-            for c, v in acc.items():
-                means[c] = sum(v) / len(v)
+                if child_flags is None:
+                    if k.startswith(PMC_SENTINEL):
+                        if r["Dispatch_Id"] != last_dispatch:     # (one row per counter and dispatch)
+                            inside = not inside
+                            seg += 1 if inside else 0
+                            last_dispatch = r["Dispatch_Id"]
+                        continue
+                    if not inside or seg >= len(workloads):
+                        continue
+                    key = (workloads[seg], k)
+                else:
+                    if kernel_prefix is not None and not k.startswith(kernel_prefix):
+                        continue
+                    key = ("", k)
+                acc.setdefault(key, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         except Exception:
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    if not all(c in means for c in ("FETCH_SIZE", "WRITE_SIZE")):
+    out = {}
+    for (w, k), c in acc.items():
+        m = {n: sum(v) / len(v) for n, v in c.items()}
+        if not all(n in m for n in ("FETCH_SIZE", "WRITE_SIZE")):
+            continue
+        e = {"hbm_bytes_per_launch": (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0,      # gfx950: FETCH_SIZE doubled
+             "fetch_size_kb": m["FETCH_SIZE"], "write_size_kb": m["WRITE_SIZE"], "launches_measured": len(c["FETCH_SIZE"])}
+        if m.get("GRBM_GUI_ACTIVE"):
+            e["mfma_busy_frac"] = round(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * m["GRBM_GUI_ACTIVE"] / 8.0), 4)
+        out.setdefault(w, {})[k] = e
+    return out or None
+
+
+def pmc_lookup(pmc, workload, kernel_prefix):
+    """The entry of the first kernel of `workload` whose name starts with `kernel_prefix` (live_pmc's result), or None."""
+    if not pmc or workload not in pmc:
         return None
-    out = {"hbm_bytes_per_launch": (2.0 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024.0,      # gfx950: FETCH_SIZE doubled
-           "fetch_size_kb": means["FETCH_SIZE"], "write_size_kb": means["WRITE_SIZE"]}
-    if means.get("GRBM_GUI_ACTIVE"):
-        out["mfma_busy_frac"] = round(means.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * means["GRBM_GUI_ACTIVE"] / 8.0), 4)
-    return out
+    for k, e in pmc[workload].items():
+        if k.startswith(kernel_prefix):
+            return e
+    return None
 
 
 def kernel_time_table(run, frames=8):
@@ -202,7 +264,7 @@ def kernel_work_model(name, cfg, S, H, W, n_rays_by_level):
     return None
 
 
-def secondary_workload(name, dev, frames=100):
+def secondary_workload(name, dev, frames=100, pmc=None):
     """BASELINE configs 3 / 4 inside the default run: the reference's per-frame-sync protocol on `frames` frames of
     the workload (4 distinct resident batches, >= 100 untimed frames first), the per-stage times, and the kernel that holds the
     largest share of the workload's kernel time (kernels alone: single_stream) with its roofline fraction."""
@@ -228,27 +290,29 @@ def secondary_workload(name, dev, frames=100):
     torch.cuda.synchronize()
     gc.collect()
     gc.freeze()
-    t_w, n_w, recent = time.perf_counter(), 0, []
-    while True:
-        t_f = time.perf_counter()
-        step()
-        torch.cuda.synchronize()
-        now = time.perf_counter()
-        recent.append(now - t_f)
-        n_w += 1
-        if n_w < 150 or now - t_w < 0.5:
-            continue
-        a, b = sum(recent[-20:-10]), sum(recent[-10:])
-        if abs(a - b) <= 0.015 * a or now - t_w > 2.0:                  # settled (or give up after 2 s)
-            break
-    lat = []
-    for _ in range(frames):
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        out = step()
-        torch.cuda.synchronize()
-        lat.append(time.perf_counter() - t1)
-    gc.unfreeze()
+    try:                                                  # (an exception in the timed frames must not leave the collector frozen)
+        t_w, n_w, recent = time.perf_counter(), 0, []
+        while True:
+            t_f = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            recent.append(now - t_f)
+            n_w += 1
+            if n_w < 150 or now - t_w < 0.5:
+                continue
+            a, b = sum(recent[-20:-10]), sum(recent[-10:])
+            if abs(a - b) <= 0.015 * a or now - t_w > 2.0:                  # settled (or give up after 2 s)
+                break
+        lat = []
+        for _ in range(frames):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            out = step()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+    finally:
+        gc.unfreeze()
     ms = 1e3 * sum(lat) / len(lat)
     ls = sorted(lat)
     res = {"workload": workload, "fps": round(1e3 / ms, 1), "ms": round(ms, 4), "frames": frames,
@@ -285,6 +349,11 @@ def secondary_workload(name, dev, frames=100):
                          "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "algorithmic_flops_per_launch": wm[1], "traffic": None})
         else:
             roof.update({"bound": None, "frac": None, "note": "no work model for this kernel (latency-bound gather / glue)"})
+        e = pmc_lookup(pmc, name, k.split("(")[0])
+        if e is not None:                                   # HBM bytes of one launch from the line's live PMC child (live_pmc)
+            roof.update({"traffic": e["hbm_bytes_per_launch"], "traffic_measured_live": True, "mfma_pipe_busy_frac_pmc": e.get("mfma_busy_frac"),
+                         "traffic_source": "this run's rocprofv3 --pmc child (bench.py --pmc-sequence: FETCH_SIZE, WRITE_SIZE, "
+                                           "SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE in separate passes); bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB"})
         res["roofline"] = roof
     t = res["stages_ms"].get("feature_net")
     if t:
@@ -295,12 +364,17 @@ def secondary_workload(name, dev, frames=100):
     return res
 
 
-def train_child(timeout_s, live_pmc_ok=False):
+def train_child(timeout_s, live_pmc_ok=False, perceptual=False):
     """Config 5 inside the default run: `bench.py --train --no-perceptual --steps 20 --warmup 3` as a child process (its own
-    line: ms_per_step, roofline of k_mlp_bwd, cpu_baseline of the oracle's train_step)."""
+    line: ms_per_step, roofline of k_mlp_bwd, cpu_baseline of the oracle's train_step).  perceptual=True: the same step with the
+    reference's full loss (the VGG16 term on, `bench.py --train`), 20 replays, ms_per_step only."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--train", "--no-perceptual", "--steps", "20", "--warmup", "3"]
-    if not live_pmc_ok:                                   # (the rocprofv3 --pmc child passes of roofline.traffic cost ~25 s more)
+    cmd = [sys.executable, os.path.abspath(__file__), "--train", "--steps", "20", "--warmup", "3"]
+    if perceptual:
+        cmd += ["--no-stages", "--no-cpu-baseline", "--no-live-pmc"]
+    else:
+        cmd.append("--no-perceptual")
+    if not live_pmc_ok and not perceptual:                # (the rocprofv3 --pmc child passes of roofline.traffic cost ~25 s more)
         cmd.append("--no-live-pmc")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     t0 = time.perf_counter()
@@ -311,8 +385,10 @@ def train_child(timeout_s, live_pmc_ok=False):
         return {"error": f"{type(e).__name__}: {str(e)[:160]}"}
     return {"ms_per_step": round(d["ms_per_step"], 3), "samples_per_s": round(d["value"], 2), "steps": d["steps"],
             "roofline": d.get("roofline"), "cpu_baseline": d.get("cpu_baseline"), "step_launch": d["config"]["step_launch"],
-            "loss": "MSE at both levels (the VGG16 perceptual term off: no pretrained weights offline; `bench.py --train` times it with "
-                    "the term on)", "final_loss": d.get("final_loss"), "child_wall_s": round(time.perf_counter() - t0, 1),
+            "loss": ("MSE + 0.01 x VGG16 perceptual L1 at both levels (losses/enerf.py:16-38; the VGG16 architecture with seeded random-init "
+                     "weights: no pretrained weights offline)") if perceptual else
+                    ("MSE at both levels (the VGG16 perceptual term off; `workloads.train_perceptual` is the step with the term on)"),
+            "final_loss": d.get("final_loss"), "child_wall_s": round(time.perf_counter() - t0, 1),
             "workload": d["config"]["workload"]}
 
 
@@ -448,7 +524,8 @@ def train_extras(args, net, batch, loss_fn, cfg, dev, ms_per_step):
             # HBM bytes of one launch, measured now: rocprofv3 --pmc passes over two EAGER steps of a child run (the same kernels
             # as the captured step; counters serialise the kernels either way)
             flags = ["--train", "--train-eager", "--steps", "2", "--warmup", "1"] + (["--no-perceptual"] if args.no_perceptual else [])
-            live = live_pmc(args.workload, kernel_prefix=f"k_mlp_bwd<{R}, {S}>", child_flags=flags)
+            live = live_pmc([], kernel_prefix=f"k_mlp_bwd<{R}, {S}>", child_flags=flags)
+            live = next(iter(live[""].values())) if live and live.get("") else None
             if live is not None:
                 out["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = ("live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over a child run of "
@@ -466,9 +543,30 @@ def train_extras(args, net, batch, loss_fn, cfg, dev, ms_per_step):
         O.train_step(cfg, sd, cb)
         cpu_s = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "samples/s", "cores": ncores, "kind": "port",
+                               "ref_over_port": REF_OVER_PORT["train"],
                                "sample": f"1 training step (forward + MSE loss + backward, no optimizer update) of this batch through "
                                          f"oracle/enerf_oracle.py::train_step (torch CPU, {ncores} of {os.cpu_count()} host threads)"}
     return out
+
+
+def collective_stack_note():
+    """RCCL version and the peer-access matrix of the visible devices (hipDeviceCanAccessPeer: xGMI / PCIe P2P), for stderr."""
+    import torch
+    try:
+        ver = ".".join(map(str, torch.cuda.nccl.version()))
+    except Exception as e:                                               # noqa: BLE001 — a note, never a failure
+        ver = f"unknown ({e})"
+    n = torch.cuda.device_count()
+    rows = []
+    for i in range(n):
+        row = ""
+        for j in range(n):
+            try:
+                row += "-" if i == j else ("1" if torch.cuda.can_device_access_peer(i, j) else "0")
+            except Exception:                                            # noqa: BLE001
+                row += "?"
+        rows.append(row)
+    return f"RCCL {ver}; {n} visible device(s); peer access (hipDeviceCanAccessPeer) rows = from, columns = to: {' '.join(rows)}"
 
 
 def train_bench(args, rank, world, dev, dist, emu_lib=None):
@@ -545,38 +643,33 @@ def train_bench(args, rank, world, dev, dist, emu_lib=None):
         step = lambda: train_step(net, opt, loss_fn, batch, 40.0, sync)
         launch_note = "DRY RUN on the CPU lane emulator over gloo: train_graph.train_step with the flat gradient all-reduce, not captured"
     if graphed:
-        try:
-            gstep = GraphedTrainStep(net, opt, loss_fn, batch, clip_value=40.0, distributed=dp)   # verifies replays against eager steps
-            step = lambda: gstep(batch)                                  # copies the batch in, camera tables, one replay
-            launch_note = "one hipGraph replay per step (enerf_amd/train_graph.py; replays verified against eager steps)" + \
-                (": the flat gradient all-reduce and the SyncBatchNorm statistics exchanges are graph nodes" if dp else "")
-        except (GraphMismatch, RuntimeError) as e:                       # the verdict is collective: every rank lands here together
-            # (RuntimeError: a capture the stack refuses, e.g. a collective that cannot be captured — the same on every rank)
-            kind = "graph replay failed verification" if isinstance(e, GraphMismatch) else "capture failed"
-            launch_note = f"eager ({kind}: {str(e)[:200]})"
-            opt.zero_grad(set_to_none=True)
-            if dp:
-                from enerf_amd.train_graph import FlatGradSync, train_step
-                sync = FlatGradSync(net)
-                step = lambda: train_step(net, opt, loss_fn, batch, 40.0, sync)
+        # fallback="eager": a capture the stack refuses (first contact with N > 1: >= 35 RCCL nodes per step) or a replay that fails
+        # the verification on ANY rank costs the graph, not the job — the verdict is one MAX all-reduce, so every rank keeps
+        # training with the same eager train_step (flat gradient all-reduce + per-layer SyncBatchNorm exchanges) and says so
+        gstep = GraphedTrainStep(net, opt, loss_fn, batch, clip_value=40.0, distributed=dp, fallback="eager")
+        step = lambda: gstep(batch)                                      # copies the batch in, camera tables, one replay
+        launch_note = gstep.step_launch + (" (enerf_amd/train_graph.py)" if gstep.graph is not None else "") + \
+            (": the flat gradient all-reduce and the SyncBatchNorm statistics exchanges are graph nodes" if dp and gstep.graph is not None else "")
     import gc
     gc.collect()                                                         # before the warm-up: no idle gap in front of the timed region,
     gc.disable()                                                         # no collector pause inside it (see the rendering region in main())
-    for _ in range(args.warmup):
-        step()
-    device_sync()
-    if dist is not None:
-        dist.barrier()
-    device_sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    device_sync()
-    if dist is not None:
-        dist.barrier()
-    device_sync()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
+    try:
+        for _ in range(args.warmup):
+            step()
+        device_sync()
+        if dist is not None:
+            dist.barrier()
+        device_sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        device_sync()
+        if dist is not None:
+            dist.barrier()
+        device_sync()
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.enable()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -634,6 +727,8 @@ def main():
     ap.add_argument("--options", default="",
                     help="A/B and profiling runs: enerf_options_t fields as 'field:value,field:value' (recorded in config.options); "
                          "the default line is measured with all-zero options")
+    ap.add_argument("--pmc-sequence", default="",
+                    help="internal (live_pmc's child): render three frames of each listed workload, kernels alone, bracketed by sentinel launches")
     ap.add_argument("--batches", type=int, default=4,
                     help="distinct seeded input batches the timed frames rotate over (all uploaded before the timed region)")
     ap.add_argument("--no-secondary", action="store_true",
@@ -699,11 +794,15 @@ def main():
     except RuntimeError as e:
         raise SystemExit(f"rank {rank}: {e}: refusing to print an n_gpus={world} line")
     print(f"[bench] rank {rank}/{world} local_rank {local} -> {args.binding['bindings'][rank if world > 1 else 0]}", file=sys.stderr, flush=True)
+    if world > 1 and rank == 0 and dev.type == "cuda":                   # first contact with a multi-GPU node: what the job runs on
+        print(f"[bench] {collective_stack_note()}", file=sys.stderr, flush=True)
     if args.binding["ranks_seen"] != world:
         raise SystemExit(f"communicator holds {args.binding['ranks_seen']} ranks, --gpus says {world}")
 
     if args.train:
         return train_bench(args, rank, world, dev, dist, emu_lib)
+    if args.pmc_sequence:
+        return pmc_sequence_child([w for w in args.pmc_sequence.split(",") if w], dev)
     nb = max(1, args.batches)
     cfg, batch_np, human, workload = make_workload(args.workload, rank)
     cas = cfg.cas
@@ -764,37 +863,39 @@ def main():
     import torch.distributed as _td  # noqa: F401  (render_sharded imports it: not inside the gap)
     gc.collect()
     gc.disable()
-    internal_warmup = 0
-    if not args.emu:
+    try:                                                  # (whatever happens in the timed region: the collector comes back)
+        internal_warmup = 0
+        if not args.emu:
+            device_sync()
+            t_w = time.perf_counter()
+            recent = []
+            while True:
+                t_f = time.perf_counter()
+                step()
+                device_sync()
+                now = time.perf_counter()
+                recent.append(now - t_f)
+                internal_warmup += 1
+                if internal_warmup + args.warmup < 100 or now - t_w < 0.3:
+                    continue
+                a, b = sum(recent[-20:-10]), sum(recent[-10:])
+                if abs(a - b) <= 0.015 * a or now - t_w > 2.0:
+                    break
         device_sync()
-        t_w = time.perf_counter()
-        recent = []
-        while True:
-            t_f = time.perf_counter()
-            step()
-            device_sync()
-            now = time.perf_counter()
-            recent.append(now - t_f)
-            internal_warmup += 1
-            if internal_warmup + args.warmup < 100 or now - t_w < 0.3:
-                continue
-            a, b = sum(recent[-20:-10]), sum(recent[-10:])
-            if abs(a - b) <= 0.015 * a or now - t_w > 2.0:
-                break
-    device_sync()
-    if dist is not None:
-        # N > 1: the ranks leave their warm-ups at different moments, and the first to reach the timed region's barrier would idle
-        # there (the same gap, seen from its device).  Meet once HERE, run a few more untimed frames from a common start, and the
-        # barrier in front of the window finds every rank within a frame or two of the others.
-        dist.barrier()
-        for _ in range(2 if args.emu else 40):
-            step()
-            device_sync()
-    # frame f -> rank f mod world: every rank renders `steps` frames; barrier + sync both sides, MAX over ranks
-    t_rank = time.perf_counter()
-    _, fps, elapsed = render_sharded(timed_frame, args.steps * world, rank, world, sync=device_sync)
-    t_rank = time.perf_counter() - t_rank
-    gc.enable()
+        if dist is not None:
+            # N > 1: the ranks leave their warm-ups at different moments, and the first to reach the timed region's barrier would idle
+            # there (the same gap, seen from its device).  Meet once HERE, run a few more untimed frames from a common start, and the
+            # barrier in front of the window finds every rank within a frame or two of the others.
+            dist.barrier()
+            for _ in range(2 if args.emu else 40):
+                step()
+                device_sync()
+        # frame f -> rank f mod world: every rank renders `steps` frames; barrier + sync both sides, MAX over ranks
+        t_rank = time.perf_counter()
+        _, fps, elapsed = render_sharded(timed_frame, args.steps * world, rank, world, sync=device_sync)
+        t_rank = time.perf_counter() - t_rank
+    finally:
+        gc.enable()
     assert bool(torch.isfinite(out[f"rgb_level{last}"]).all()), "non-finite render"
     per_rank = [args.steps / t_rank]
     if dist is not None:                                # every rank's own rate next to the aggregate (reporting only)
@@ -817,7 +918,10 @@ def main():
             "config": {"workload": workload, "distinct_batches": nb, "feature_net": args.feature_backend, "hip_graph": bool(args.graph),
                        "single_stream": bool(args.single_stream), "options": opt_fields,
                        "protocol": "per-frame synchronize (run.py:62-76), one frame at a time, default kernel options "
-                                   "(inside the frame the FeatureNet's top-down half runs on the library's side stream)"
+                                   "(inside the frame the FeatureNet's top-down half runs on the library's side stream); untimed "
+                                   "warm-up = --warmup frames + frames until the last 10 frame times are within 1.5 % of the 10 before "
+                                   "them (>= 100 frames and 0.3 s, at most 2 s; N > 1: 40 more from a common barrier) — "
+                                   "`internal_warmup_frames`"
                                    if not args.no_sync_per_frame else "frames enqueued back to back on one stream",
                        "frames_per_step_per_gpu": 1, "parallelism": f"frame-parallel x{world} (no collectives)"},
         }
@@ -825,6 +929,9 @@ def main():
             result["vs_baseline_note"] = ("value / 21.78 FPS (README.md:121, one RTX 3090, the same per-frame-sync protocol); "
                                           "for N > 1 the numerator is the whole-job aggregate")
 
+    secondary = (rank == 0 and world == 1 and args.workload == "dtu" and not args.no_stages and not args.no_secondary
+                 and not args.graph and not args.emu and args.feature_backend == "hip" and not opt_fields)
+    pmc_all = None
     # ---- extras on rank 0 (not in the timed region) ----
     if rank == 0 and not args.no_stages and not args.graph:
         t0 = time.perf_counter()                      # host-side enqueue cost (no device sync inside)
@@ -1017,11 +1124,15 @@ def main():
             live = None
             if world == 1 and not args.no_live_pmc and dom == f"render_{last}" and cas.num_samples[last] <= 2:
                 torch.cuda.synchronize()
-                live = live_pmc(args.workload)
+                # ONE child per counter pass renders this workload and (default dtu run) the secondary ones: their rooflines read
+                # `pmc_all` further down
+                pmc_all = live_pmc([args.workload] + (["lego", "zju"] if secondary else []))
+                live = pmc_lookup(pmc_all, args.workload, f"k_render_rays<{(cas.nerf_model_feat_ch[last] + 3 + 3) // 4}, {S}")
             if live is not None:
                 traffic, busy, pmc_digest = live["hbm_bytes_per_launch"], live.get("mfma_busy_frac"), lib_digest
                 pmc_note = ("measured by this run: rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE) "
-                            "over a 3-frame child run of bench.py --single-stream; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB")
+                            "over a child run of bench.py --pmc-sequence (3 frames per workload, every kernel alone on one stream); "
+                            "bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB")
             for cand in (() if live is not None else (f"pmc_render_{args.workload}.json", f"r02_pmc_render_{args.workload}.json")):
                 pmc_path = os.path.join(ROOT, "profiles", cand)
                 if os.path.exists(pmc_path):
@@ -1045,8 +1156,6 @@ def main():
 
     # ---- the other BASELINE configs in the SAME driver-visible line: lego, zju (100 frames each, the same
     #      protocol) and the config-5 training step; `value` / `config` above are untouched ----
-    secondary = (rank == 0 and world == 1 and args.workload == "dtu" and not args.no_stages and not args.no_secondary
-                 and not args.graph and not args.emu and args.feature_backend == "hip" and not opt_fields)
     if secondary:
         wl = {}
         for name in ("lego", "zju"):
@@ -1054,7 +1163,7 @@ def main():
                 wl[name] = {"skipped": "time budget"}
                 continue
             try:
-                wl[name] = secondary_workload(name, dev)
+                wl[name] = secondary_workload(name, dev, pmc=pmc_all)
             except Exception as e:
                 wl[name] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
         result["workloads"] = wl
@@ -1078,6 +1187,7 @@ def main():
                 n_frames += 1
             cpu_s = (time.perf_counter() - t0) / n_frames
         result["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": ncores, "kind": "port",
+                                  "ref_over_port": REF_OVER_PORT["render_ft" if not cas.render_if[0] else "render_tt"],
                                   "sample": f"{n_frames} full {H}x{W} {S}-view frame(s) of this workload through "
                                             f"oracle/enerf_oracle.py (torch CPU, {ncores} of {os.cpu_count()} host threads), "
                                             "first small frame untimed"}
@@ -1090,6 +1200,7 @@ def main():
                 O.forward(cfg1, sd, cb)
                 c1 = time.perf_counter() - t0
             result["cpu_baseline_config1"] = {"value": 1.0 / c1, "unit": "frames/s", "cores": ncores, "kind": "port",
+                                              "ref_over_port": REF_OVER_PORT["render_tt"],
                                               "sample": "1 frame, render_if True,True, volume_planes 48,8 (BASELINE configs[0])"}
         net.static_shapes = False
         o = net(batch)
@@ -1100,7 +1211,12 @@ def main():
     if secondary and not args.no_cpu_baseline:
         left = args.time_budget - (time.perf_counter() - t_process)
         # the training child needs ~35 s (graph capture + verification, 20 replays, one CPU step of the oracle)
-        result["workloads"]["train"] = train_child(left, live_pmc_ok=left > 58 and not args.no_live_pmc) if left > 40 else \
+        result["workloads"]["train"] = train_child(left, live_pmc_ok=left > 75 and not args.no_live_pmc) if left > 40 else \
+            {"skipped": f"time budget ({left:.0f} s left)"}
+        # the reference's REAL loss (losses/enerf.py:30-38: + 0.01 x VGG16 perceptual at both levels, dtu_pretrain.yaml:41
+        # train_img True,True) beside the MSE-only step: 20 replays, no extras
+        left = args.time_budget - (time.perf_counter() - t_process)
+        result["workloads"]["train_perceptual"] = train_child(left, perceptual=True) if left > 25 else \
             {"skipped": f"time budget ({left:.0f} s left)"}
         result["workloads"]["wall_s"] = round(time.perf_counter() - t_process, 1)
     if dist is not None:

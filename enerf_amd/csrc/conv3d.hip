@@ -428,7 +428,7 @@ static bool dispatch_rt(const Conv3dDesc& L, const float* in, const float* resid
     const long long tiles = cdivl(n, 16);
     const int ct_default = rt_total == 1 ? 4 : (rt_total == 2 ? 2 : 1);
     const bool small = cdivl(tiles, ct_default) < 1024;      // fewer waves than SIMDs: split finer
-    if (small && KIND != kConvT2 && CIN >= 16 && small_variant >= 2) {
+    if (small && KIND != kConvT2 && CIN >= 16 && (small_variant == 2 || small_variant == 3)) {
         // A/B (enerf_options_t.conv3d_small_variant): operand reuse instead of wave count for the deep layers
         if (small_variant == 2 && rt_total >= 2) { launch_one<CIN, 2, KIND, 2>(L, in, residual, out, out2, B, Di, Hi, Wi, st); return true; }
         launch_one<CIN, 1, KIND, 4>(L, in, residual, out, out2, B, Di, Hi, Wi, st);
@@ -694,6 +694,16 @@ bool launch_conv3d(const Conv3dDesc& L, const float* in, const float* residual, 
             default: break;
         }
         if (ok) return true;
+    }
+    // small deep stride-1 / stride-2 layers whose input is one or two planes thick (level 1's conv4 .. conv6 at 8 depth planes): whole kd
+    // taps are padding there, and conv3d_wl.hip skips them per block — copy, loads and MFMAs (conv6 12.0 -> 7.5 us, conv5 8.3 -> 7.3,
+    // conv4 15.1 -> 14.3; on thicker volumes the tap-split kernel below is as fast or faster: profiles/r06_ab_conv3d_wl.txt).
+    // conv3d_small_variant: 0 = this routing, 4 = conv3d_wl for every small layer (A/B), 1 .. 3 = the round-2 .. 5 forms only
+    if ((L.kind == kConvS1 || L.kind == kConvS2) && residual == nullptr && out2 == nullptr && lds_ok && L.cin >= 16 &&
+        L.cout % 16 == 0 && (o.conv3d_small_variant == 4 || (o.conv3d_small_variant == 0 && Di <= 2))) {
+        const int rt_total = cdiv(L.cout, 16), ct_default = rt_total == 1 ? 4 : (rt_total == 2 ? 2 : 1);
+        const long long n = L.kind == kConvS1 ? vox_in : (long long)B * ((Di - 1) / 2 + 1) * ((Hi - 1) / 2 + 1) * ((Wi - 1) / 2 + 1);
+        if (cdivl(cdivl(n, 16), ct_default) < 1024 && launch_conv3d_wl(L, in, out, B, Di, Hi, Wi, st)) return true;
     }
     switch (L.kind) {
         case kConvS1: return dispatch_cin<kConvS1>(L, in, residual, out, out2, B, Di, Hi, Wi, o.conv3d_small_variant, st);

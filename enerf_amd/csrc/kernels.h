@@ -91,6 +91,8 @@ bool launch_conv3d_t2_lds(const Conv3dDesc& L, const float* in, const float* res
                           int Wi, hipStream_t st);   // LDS-staged transposed variant, 16 -> 8 (conv3d_t2.hip)
 bool launch_conv3d_t2_all(const Conv3dDesc& L, const float* in, const float* residual, float* out, int B, int Di, int Hi,
                           int Wi, hipStream_t st);   // every-class transposed kernel: 16 -> 8 (class-paired), 32 -> 16 (conv3d_t2.hip)
+// small deep stride-1 / stride-2 layers (Cin 16 / 32 / 64, Cout % 16 == 0): block-shared weight tile in LDS, operands up front (conv3d_wl.hip)
+bool launch_conv3d_wl(const Conv3dDesc& L, const float* in, float* out, int B, int Di, int Hi, int Wi, hipStream_t st);
 bool launch_conv3d_pk8(const Conv3dDesc& L, const float* in, float* out, float* out2, int B, int D, int H, int W,
                        bool all_layers, hipStream_t st);
 // number of floats of the packed weight image for a layer

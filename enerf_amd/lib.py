@@ -14,7 +14,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libenerf_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _f = C.c_void_p     # device float*
 _i = C.c_int

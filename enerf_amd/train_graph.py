@@ -118,23 +118,34 @@ class GraphedTrainStep:
     optimizer that already carried state before construction gets that state back instead."""
 
     def __init__(self, net, optimizer, loss_fn: Callable, example_batch: Dict[str, torch.Tensor], clip_value: float = 40.0,
-                 warmup: int = 3, verify: bool = True, verify_steps: int = 4, distributed: bool = False, group=None):
+                 warmup: int = 3, verify: bool = True, verify_steps: int = 4, distributed: bool = False, group=None,
+                 fallback: str = "raise"):
         """``distributed=True``: data-parallel step (see DATA-PARALLEL above) — ``net`` is the plain network (SyncBatchNorm
-        converted, NOT wrapped in DistributedDataParallel); parameters and buffers are broadcast from rank 0 first."""
+        converted, NOT wrapped in DistributedDataParallel); parameters and buffers are broadcast from rank 0 first.
+
+        ``fallback``: what happens when the stack refuses the capture or a replay fails the verification — on ANY rank; the
+        verdict is one MAX all-reduce over the group, so all ranks take the same branch at the same point and nobody is left
+        alone inside a collective.  ``"raise"`` (default): ``RuntimeError`` / ``GraphMismatch`` on every rank.  ``"eager"``:
+        every rank keeps training with eager steps — the same ``train_step`` the graph would have captured, ``FlatGradSync``'s
+        one flat all-reduce and the per-layer SyncBatchNorm exchanges enqueued per step — and ``step_launch`` says so.  (First
+        contact with a multi-GPU node is a capture of >= 35 RCCL nodes that no 1-GPU lease can rehearse: a refused capture
+        there must cost the graph, not the job.)"""
         if not net.training:
             raise ValueError("GraphedTrainStep captures a training step: call net.train() first")
         if warmup < 1:
             raise ValueError("at least one eager warm-up step: optimizer state must exist before the capture")
-        self.net, self.opt, self.loss_fn, self.clip = net, optimizer, loss_fn, clip_value
+        if fallback not in ("raise", "eager"):
+            raise ValueError("fallback: 'raise' or 'eager'")
+        self.net, self.opt, self.loss_fn, self.clip, self.fallback = net, optimizer, loss_fn, clip_value, fallback
+        self.graph, self.loss = None, None
+        self.step_launch = "not constructed"
         self.sync = FlatGradSync(net, group) if distributed else None
         if self.sync is not None:
             self.sync.broadcast()
         self.static = {k: v.clone() for k, v in example_batch.items() if torch.is_tensor(v)}
         self.extra = {k: v for k, v in example_batch.items() if not torch.is_tensor(v)}
         # (the camera tables — 4x4 inverses — are device kernels of the library inside the step: captured with it)
-        from .train_path import _hip_lib
-        if _hip_lib(net, next(iter(self.static.values()))) is None:
-            raise RuntimeError("GraphedTrainStep: the HIP library is required (the training path has no eager fallback)")
+        self._require_library()
         self._params = [p for p in net.parameters() if p.requires_grad]
         pristine_net = [(t, t.clone()) for t in net.state_dict().values()]
         pristine_opt = {id(t): t.clone() for st in optimizer.state.values() for t in st.values() if torch.is_tensor(t)}
@@ -144,7 +155,7 @@ class GraphedTrainStep:
             # undo the training the construction did (warm-up + capture + verification steps on example_batch) — on the
             # failure paths too (GraphMismatch, a refused capture): a caller that falls back to eager steps (bench.py)
             # must start from the weights, BatchNorm buffers and optimizer state it handed in
-            torch.cuda.synchronize()
+            self._device_sync()
             with torch.no_grad():
                 self._restore(pristine_net)
                 for st in optimizer.state.values():
@@ -153,15 +164,18 @@ class GraphedTrainStep:
                             t.copy_(pristine_opt[id(t)]) if id(t) in pristine_opt else t.zero_()
             net.invalidate_packed()
 
-    def _agree(self, failed: bool) -> bool:
-        """One verdict for all ranks (MAX over the group): nobody is left alone inside a collective."""
-        if self.sync is None:
-            return failed
-        flag = torch.tensor([1.0 if failed else 0.0], device=next(iter(self.static.values())).device)
-        self.sync.dist.all_reduce(flag, op=self.sync.dist.ReduceOp.MAX, group=self.sync.group)
-        return bool(flag.item())
+    # ---- device hooks: everything that needs a GPU, so that the collective protocol around them (capture -> one verdict for
+    # all ranks -> verification -> one verdict -> graph or eager steps) runs unchanged on gloo in tests/test_world8_gloo.py ----
+    def _require_library(self):
+        from .train_path import _hip_lib
+        if _hip_lib(self.net, next(iter(self.static.values()))) is None:
+            raise RuntimeError("GraphedTrainStep: the HIP library is required (the training path has no eager fallback)")
 
-    def _construct(self, warmup: int, verify: bool, verify_steps: int):
+    @staticmethod
+    def _device_sync():
+        torch.cuda.synchronize()
+
+    def _warm_up(self, warmup: int):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up on a side stream: lazy initialisation, caches, allocator
@@ -169,8 +183,10 @@ class GraphedTrainStep:
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.opt.zero_grad(set_to_none=True)               # gradients are (re)allocated inside the graph's memory pool
-        self.graph = torch.cuda.CUDAGraph()
+
+    def _capture(self):
+        """Capture one step; returns the graph (``.replay()``).  Raises RuntimeError when the stack refuses the capture."""
+        graph = torch.cuda.CUDAGraph()
         capture_kw = {}
         if self.sync is not None:
             # The process group's watchdog thread polls the events of the collectives the warm-up enqueued until it has seen
@@ -192,17 +208,49 @@ class GraphedTrainStep:
             self.sync.dist.barrier(group=self.sync.group)
             torch.cuda.synchronize()
             capture_kw["capture_error_mode"] = "thread_local"
+        with torch.cuda.graph(graph, **capture_kw):
+            self.loss = self._eager_step(zero=False)
+        return graph
+
+    def _agree(self, failed: bool) -> bool:
+        """One verdict for all ranks (MAX over the group): nobody is left alone inside a collective."""
+        if self.sync is None:
+            return failed
+        flag = torch.tensor([1.0 if failed else 0.0], device=next(iter(self.static.values())).device)
+        self.sync.dist.all_reduce(flag, op=self.sync.dist.ReduceOp.MAX, group=self.sync.group)
+        return bool(flag.item())
+
+    def _construct(self, warmup: int, verify: bool, verify_steps: int):
+        self._warm_up(warmup)
+        self.opt.zero_grad(set_to_none=True)               # gradients are (re)allocated inside the graph's memory pool
         error = None
         try:
-            with torch.cuda.graph(self.graph, **capture_kw):
-                self.loss = self._eager_step(zero=False)
+            self.graph = self._capture()
         except RuntimeError as e:                          # a refused capture executes nothing: every rank can still talk
             error = e
         if self._agree(error is not None):
-            raise error if error is not None else RuntimeError("GraphedTrainStep: the capture failed on another rank")
+            self.graph, self.loss = None, None
+            why = f"capture failed: {str(error)[:200]}" if error is not None else "the capture failed on another rank"
+            if self.fallback != "eager":
+                raise error if error is not None else RuntimeError("GraphedTrainStep: " + why)
+            self._fall_back(why)
+            return
         self.net.invalidate_packed()
+        self.step_launch = "one hipGraph replay per step" + ("" if verify else " (replays NOT verified against eager steps)")
         if verify:
-            self._verify(verify_steps)
+            try:
+                self._verify(verify_steps)                 # raises on EVERY rank or on none (the verdict inside is collective)
+                self.step_launch += " (replays verified against eager steps)"
+            except GraphMismatch as e:
+                self.graph, self.loss = None, None
+                if self.fallback != "eager":
+                    raise
+                self._fall_back(f"graph replay failed verification: {str(e)[:200]}")
+
+    def _fall_back(self, why: str):
+        self.opt.zero_grad(set_to_none=True)               # drop the graph pool's gradient buffers
+        self.step_launch = f"eager steps on every rank ({why})" + \
+            ("; gradient mean = one flat all-reduce per step, SyncBatchNorm exchanges per layer" if self.sync is not None else "")
 
     # ---- replay-vs-eager check (see MEMSET NODES above) ----
     def _snapshot(self):
@@ -238,7 +286,8 @@ class GraphedTrainStep:
             failed = bool(bad) or not abs(loss_graph - loss_eager) <= 1e-3 * abs(loss_eager) + 1e-7
             if self._agree(failed):
                 raise GraphMismatch(f"replay {k}: loss {loss_graph} vs eager {loss_eager}; gradient mismatches "
-                                    f"(name, max err, max |g|): {bad[:6]}")
+                                    f"(name, max err, max |g|): {bad[:6]}" if failed else
+                                    f"replay {k}: this rank's replay matched its eager step, another rank's did not")
         self.net.invalidate_packed()
 
     def _eager_step(self, zero: bool = True):
@@ -250,6 +299,8 @@ class GraphedTrainStep:
             src = batch[k]
             if src.data_ptr() != dst.data_ptr():
                 dst.copy_(src, non_blocking=True)
+        if self.graph is None:                             # fallback="eager" after a refused capture / failed verification
+            return self._eager_step()
         self.graph.replay()
         self.net.invalidate_packed()                       # the inference weight images are stale after every update
         return self.loss

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ENERF_ABI_VERSION 9
+#define ENERF_ABI_VERSION 10
 #define ENERF_OK 0
 #define ENERF_EINVAL (-1)   /* bad argument / unsupported shape */
 #define ENERF_ELAUNCH (-2)  /* HIP launch error */
@@ -67,10 +67,13 @@ typedef struct {
     int conv3d_t2_variant;           /* transposed 3-D layers (conv9 32->16, conv11 16->8), ABI >= 5: 0 = the every-class LDS kernel
                                         with x-parity-paired MFMA rows where it measured faster (default); 1 = the round-2
                                         kernels only (A/B); 2 = the every-class kernel for every layer it handles */
-    int conv3d_small_variant;        /* deep (< 1024 wave-tile) stride-1/2 layers, ABI >= 5: 0 = default choice per layer;
+    int conv3d_small_variant;        /* deep (< 1024 wave-tile) stride-1/2 layers, ABI >= 5: 0 = default choice per layer (ABI >= 10: layers whose
+                                        input is 1 - 2 planes thick on the block-shared-weight kernel that skips padding kd taps,
+                                        conv3d_wl.hip; the others as 1);
                                         1 = taps split over 3 waves + LDS reduce, one tile per wave (the round-2 default);
                                         2 = no tap split, 2 row tiles x 2 column tiles per wave (operand reuse over wave count);
-                                        3 = no tap split, 1 row tile x 4 column tiles */
+                                        3 = no tap split, 1 row tile x 4 column tiles;
+                                        4 = every small layer on the block-shared-weight kernel (A/B) */
     int render_precision;            /* enerf_render_rays / enerf_forward, ABI >= 7, the cascade's last level (F = 11, <= 2 samples per
                                         ray): how the dense layers of the Agg/NeRF MLP are multiplied.
                                         0 / 1 (default) = exact fp32 16x16x4 MFMAs;

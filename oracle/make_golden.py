@@ -43,6 +43,10 @@ CASES = {
     # 4 source views and the projected-bbox mask_at_box (enerf_amd.synth.make_zju_batch)
     "zju_small": dict(H=64, W=64, S=4, planes=(32, 8), render_if=(False, True), seed=6, human=True, inter="maps",
                       rig="zju", cfg_file="configs/enerf/zjumocap_eval.yaml"),
+    # the reference's fourth eval config on this path (configs/enerf/llff_eval.yaml: planes 32,8, render_if False,True, 640x960)
+    # at 1/5 of its size (the reference's U-Nets need H, W divisible by 32): the 2:3 aspect, level-0 volume 32 x 16 x 24
+    "llff_small": dict(H=128, W=192, S=3, planes=(32, 8), render_if=(False, True), seed=7, textured=True, human=False,
+                       inter="maps", cfg_file="configs/enerf/llff_eval.yaml"),
 }
 
 
@@ -194,6 +198,9 @@ FULL_CASES = {
                       cfg_file="configs/enerf/nerf/lego.yaml"),
     "zju_full": dict(H=1024, W=1024, S=4, planes=(32, 8), render_if=(False, True), seed=6, human=True, rig="zju",
                      cfg_file="configs/enerf/zjumocap_eval.yaml"),
+    # configs/enerf/llff_eval.yaml at its own size (input_h_w 640, 960; the reference's fourth eval config; not a BASELINE config)
+    "llff_full": dict(H=640, W=960, S=3, planes=(32, 8), render_if=(False, True), seed=7, textured=True, human=False,
+                      cfg_file="configs/enerf/llff_eval.yaml"),
 }
 
 

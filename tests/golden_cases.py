@@ -19,6 +19,8 @@ CASES = {
     "small_s3_eval": dict(H=64, W=96, S=3, planes=(16, 8), render_if=(False, True), seed=4, textured=True, human=False),
     "lego_small": dict(H=64, W=64, S=4, planes=(64, 8), render_if=(True, True), seed=5, human=False, rig="lego"),
     "zju_small": dict(H=64, W=64, S=4, planes=(32, 8), render_if=(False, True), seed=6, human=True, rig="zju"),
+    # configs/enerf/llff_eval.yaml (planes 32,8; 640x960) at 1/5 size (2:3 aspect, level-0 volume 32 x 16 x 24)
+    "llff_small": dict(H=128, W=192, S=3, planes=(32, 8), render_if=(False, True), seed=7, textured=True, human=False),
 }
 
 
@@ -56,6 +58,8 @@ FULL_CASES = {
     "dtu_full_tt": dict(H=512, W=640, S=3, planes=(48, 8), render_if=(True, True), seed=0, textured=True, human=False),
     "lego_full": dict(H=800, W=800, S=4, planes=(64, 8), render_if=(True, True), seed=5, human=False, rig="lego"),
     "zju_full": dict(H=1024, W=1024, S=4, planes=(32, 8), render_if=(False, True), seed=6, human=True, rig="zju"),
+    # configs/enerf/llff_eval.yaml at its own size (the reference's fourth eval config; not a BASELINE config)
+    "llff_full": dict(H=640, W=960, S=3, planes=(32, 8), render_if=(False, True), seed=7, textured=True, human=False),
 }
 
 

@@ -5,6 +5,9 @@
   * SyncBatchNorm on the HIP training kernels (autograd._BatchNormTrain on the lane emulator): statistics over 8 ranks with
     DIFFERENT position counts per rank == one process normalising the concatenation, also on a 4-rank SUBGROUP
     (``process_group``: ADVICE r03) while the other four ranks form their own;
+  * ``GraphedTrainStep(distributed=True, fallback=...)``: the agreement protocol with a capture refused on ONE rank and with a
+    replay that fails the verification on ONE rank — every rank lands in the same branch (eager steps, or the same exception),
+    the model is handed back untouched, and the eager steps that follow keep the ranks' parameters identical;
   * ``rank_bindings``: every rank listed once, communicator size counted by a collective, duplicates refused on all ranks;
   * ``bench.py --gpus 8`` and ``bench.py --train --gpus 8`` self-spawn eight ranks (CPU lane emulator, tiny frame).
 """
@@ -33,6 +36,76 @@ def _bn_data(relu):
     zs = [torch.randn(n, 8, generator=g) * 2 + 1 for n in _counts()]
     gs = [torch.randn(n, 8, generator=g) for n in _counts()]
     return zs, gs
+
+
+class _ToyNet(torch.nn.Module):
+    """Stands in for the network in the protocol test: batch dict in, output dict out, `invalidate_packed` like Network."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.body = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+
+    def forward(self, batch):
+        return {"y": self.body(batch["x"])}
+
+    def invalidate_packed(self):
+        pass
+
+
+def _cpu_step_class(rank, inject):
+    """GraphedTrainStep with its GPU hooks replaced (no library, no stream, a 'graph' whose replay runs the step eagerly): the
+    collective protocol around the hooks is the product's own code.  inject = (kind, rank) makes ONE rank fail."""
+    from enerf_amd.train_graph import GraphedTrainStep
+
+    class CpuStep(GraphedTrainStep):
+        def _require_library(self):
+            pass
+
+        @staticmethod
+        def _device_sync():
+            pass
+
+        def _warm_up(self, warmup):
+            for _ in range(warmup):
+                self._eager_step()
+
+        def _capture(self):
+            if inject == ("capture", rank):
+                raise RuntimeError("injected: operation not permitted when stream is capturing")
+            step = self
+
+            class Graph:
+                def replay(self):
+                    step.loss = step._eager_step()
+                    if inject == ("verify", rank):       # a replay that computes something else on this rank only
+                        with torch.no_grad():
+                            next(p for p in step.net.parameters() if p.grad is not None).grad.mul_(3.0)
+            return Graph()                               # like a real capture: nothing executes (no collective runs) here
+    return CpuStep
+
+
+def _fallback_scenarios(rank):
+    from enerf_amd.train_graph import GraphMismatch
+    out = {}
+    for name, inject, fallback in (("clean", None, "eager"), ("capture_r5", ("capture", 5), "eager"), ("verify_r2", ("verify", 2), "eager"),
+                                   ("capture_r5_raise", ("capture", 5), "raise"), ("verify_r2_raise", ("verify", 2), "raise")):
+        net = _ToyNet().train()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+        g = torch.Generator().manual_seed(200 + rank)
+        batch = {"x": torch.randn(6, 5, generator=g), "t": torch.randn(6, 3, generator=g)}
+        loss_fn = lambda o, b: (o["y"] - b["t"]).square().mean()
+        before = [p.detach().clone() for p in net.parameters()]
+        try:
+            step = _cpu_step_class(rank, inject)(net, opt, loss_fn, batch, distributed=True, fallback=fallback, warmup=1, verify_steps=2)
+        except (GraphMismatch, RuntimeError) as e:
+            out[name] = ("raised", type(e).__name__, all(torch.equal(a, p) for a, p in zip(before, net.parameters())))
+            continue
+        untouched = all(torch.equal(a, p) for a, p in zip(before, net.parameters()))
+        for _ in range(3):
+            loss = step(batch)
+        out[name] = (step.step_launch, step.graph is None, untouched, [p.detach().numpy().copy() for p in net.parameters()], float(loss.detach()))
+    return out
 
 
 def _worker(rank, world, port, q):
@@ -81,6 +154,7 @@ def _worker(rank, world, port, q):
             out = blk.forward(zs[rank].clone())
             dz, dgamma, dbeta = blk.backward(gs[rank].clone())
             res[tag] = tuple(t.detach().numpy().copy() for t in (out, dz, dgamma, dbeta, bn.running_mean, bn.running_var))
+        res["fallback"] = _fallback_scenarios(rank)
         q.put((rank, res))
         dist.barrier()
         dist.destroy_process_group()
@@ -130,6 +204,29 @@ def test_flat_gradient_sync_is_the_mean_over_eight_ranks(world8):
             assert np.abs(v - mean[n]).max() <= 1e-6 * max(np.abs(mean[n]).max(), 1e-12) + 1e-9, n
         for n, v in params.items():                      # rank 3's edited weights were replaced by rank 0's
             assert np.array_equal(v, world8[0]["flat"][3][n]), n
+
+
+def test_graphed_step_falls_back_on_every_rank_together(world8):
+    """One rank refuses the capture (or fails the replay verification): with fallback="eager" EVERY rank ends up stepping
+    eagerly from the untouched model and the ranks stay in lock step; with fallback="raise" every rank raises."""
+    for r in world8:
+        f = r["fallback"]
+        launch, eager, untouched, _, _ = f["clean"]
+        assert launch.startswith("one hipGraph replay per step") and "verified" in launch and not eager and untouched
+        for name, why in (("capture_r5", "capture failed"), ("verify_r2", "graph replay failed verification")):
+            launch, eager, untouched, _, _ = f[name]
+            assert eager and untouched and launch.startswith("eager steps on every rank") and "one flat all-reduce" in launch, (name, launch)
+        # the rank that failed names its error, the others say another rank failed — same branch either way
+        assert f["capture_r5_raise"][0] == "raised" and f["capture_r5_raise"][1] == "RuntimeError" and f["capture_r5_raise"][2]
+        assert f["verify_r2_raise"][:2] == ("raised", "GraphMismatch") and f["verify_r2_raise"][2]
+    assert "injected" in world8[5]["fallback"]["capture_r5"][0] and "another rank" in world8[0]["fallback"]["capture_r5"][0]
+    for name in ("clean", "capture_r5", "verify_r2"):      # three steps later: identical parameters on all ranks, and the three
+        ref = world8[0]["fallback"][name][3]               # ways of stepping (graph double / eager fallback) agree
+        for r in world8:
+            for a, b in zip(r["fallback"][name][3], ref):
+                assert np.array_equal(a, b), name
+        for a, b in zip(ref, world8[0]["fallback"]["clean"][3]):
+            assert np.abs(a - b).max() < 1e-6, name
 
 
 def _bn_reference(ranks):

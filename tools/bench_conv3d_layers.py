@@ -20,8 +20,10 @@ LAYERS = [  # name, kind, cin, cout, input (D,h,w), residual
     ("L0.conv3", S2, 16, 32, (24, 32, 40), False), ("L0.conv4", S1, 32, 32, (12, 16, 20), False),
     ("L0.conv9", T2, 32, 16, (12, 16, 20), True), ("L0.conv11", T2, 16, 8, (24, 32, 40), True),
 ]
-VARIANTS = {"default": Options(), "t2=1": Options(conv3d_t2_variant=1), "t2=2": Options(conv3d_t2_variant=2),
-            "global": Options(conv3d_global_only=1), "default2": Options()}
+VARIANTS = {"default": Options(), "small=1": Options(conv3d_small_variant=1), "t2=1": Options(conv3d_t2_variant=1),
+            "t2=2": Options(conv3d_t2_variant=2), "global": Options(conv3d_global_only=1), "default2": Options()}
+if os.environ.get("ENERF_LAYER_VARIANTS"):                # e.g. "default,small=1"
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["ENERF_LAYER_VARIANTS"].split(",")}
 g = torch.Generator().manual_seed(0)
 _w = torch.randn(4096, 4096, device=dev)
 for _ in range(40):                                     # clocks up before the first timed kernel
@@ -36,7 +38,7 @@ for name, kind, cin, cout, (D, h, w), res in LAYERS:
     ref = None
     row = []
     for vn, opt in VARIANTS.items():
-        applies = (vn.startswith("t2") and kind == T2) or vn in ("default", "global", "default2")
+        applies = (vn.startswith("t2") and kind == T2) or (vn.startswith("small") and kind != T2 and cin >= 16) or vn in ("default", "global", "default2")
         if not applies:
             row.append("        -")
             continue
