@@ -1211,7 +1211,7 @@ def main():
     if secondary and not args.no_cpu_baseline:
         left = args.time_budget - (time.perf_counter() - t_process)
         # the training child needs ~35 s (graph capture + verification, 20 replays, one CPU step of the oracle)
-        result["workloads"]["train"] = train_child(left, live_pmc_ok=left > 75 and not args.no_live_pmc) if left > 40 else \
+        result["workloads"]["train"] = train_child(left, live_pmc_ok=left > 58 and not args.no_live_pmc) if left > 40 else \
             {"skipped": f"time budget ({left:.0f} s left)"}
         # the reference's REAL loss (losses/enerf.py:30-38: + 0.01 x VGG16 perceptual at both levels, dtu_pretrain.yaml:41
         # train_img True,True) beside the MSE-only step: 20 replays, no extras

@@ -375,6 +375,15 @@ int enerf_feature_net(const float* packed, const float* src_inps, int n_img, int
 int enerf_feature_net_stage(const float* packed, const float* src_inps, int n_img, int H, int W, float* feat_l0,
                             float* feat_l1, float* feat_l2, int l2_stride, void* workspace, size_t workspace_bytes,
                             int stage, const enerf_options_t* options, enerf_stream_t stream) {
+    return enerf::feature_net_stage_job(packed, src_inps, n_img, H, W, feat_l0, feat_l1, feat_l2, l2_stride, workspace, workspace_bytes,
+                                        stage, options, (hipStream_t)stream, nullptr, nullptr);
+}
+}  // extern "C"
+namespace enerf {
+int feature_net_stage_job(const float* packed, const float* src_inps, int n_img, int H, int W, float* feat_l0, float* feat_l1,
+                          float* feat_l2, int l2_stride, void* workspace, size_t workspace_bytes, int stage,
+                          const enerf_options_t* options, hipStream_t stream, const PrepJob* job, int* job_done) {
+    if (job_done != nullptr) *job_done = 0;
     const Options opt = resolve_options(options);
     REQUIRE(stage >= ENERF_FEAT_ALL && stage <= ENERF_FEAT_LEVEL2, "feature_net: unknown stage %d", stage);
     const bool trunk = stage == ENERF_FEAT_ALL || stage == ENERF_FEAT_TRUNK;
@@ -405,7 +414,8 @@ int enerf_feature_net_stage(const float* packed, const float* src_inps, int n_im
     int rc = 0;
     if (trunk) {
         if (!opt.featnet_unfused) {
-            launch_conv0_fused(d[0], d[1], p + 320 + 3072 + 2304, p + 320 + 3072 + 2304 + 256, src_inps, c0, n_img, H, W, st);   // conv0.1(conv0.0(image))
+            const bool took = launch_conv0_fused(d[0], d[1], p + 320 + 3072 + 2304, p + 320 + 3072 + 2304 + 256, src_inps, c0, n_img, H, W, st, job);   // conv0.1(conv0.0(image))
+            if (took && job_done != nullptr) *job_done = 1;
         } else {
             rc |= launch_conv2d(d[0], src_inps, c0a, nullptr, n_img, H, W, 0, 0, st);  // conv0.0 (NCHW image in)
             rc |= launch_conv2d(d[1], c0a, c0, nullptr, n_img, H, W, 0, 0, st);        // conv0.1
@@ -443,6 +453,8 @@ int enerf_feature_net_stage(const float* packed, const float* src_inps, int n_im
     if (rc != 0) return fail(ENERF_EINVAL, "feature_net: unsupported layer shape");
     return check_launch("feature_net");
 }
+}  // namespace enerf
+extern "C" {
 int enerf_pack_texels_cl(const float* feat_cl, int C, const float* src_inps, int H, int W, int Hr, int Wr, int tex,
                          int n_img, float* out, enerf_stream_t stream) {
     REQUIRE(feat_cl && src_inps && out, "pack_texels_cl: null pointer");

@@ -14,6 +14,8 @@
 // tap is one k-step with lane group g supplying channel g.
 
 #include "kernels.h"
+#include "prep_job.h"
+#include <cstring>
 
 namespace enerf {
 
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(256) void k_conv0_fused_cb(const float* __restrict_
                                                         const float* __restrict__ shift0, const float* __restrict__ wc1,
                                                         const float* __restrict__ scale1, const float* __restrict__ shift1,
                                                         const float* __restrict__ img, float* __restrict__ out, int N, int H,
-                                                        int W, int tiles_y, int tiles_x) {
+                                                        int W, int tiles_y, int tiles_x, PrepJob job) {
     constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, NPX = IH * IW;      // conv0.1 input tile (10 x 34)
     constexpr int PH = IH + 2, PW = IW + 2, NPP = PH * PW;                        // image patch (12 x 36)
     ENERF_DYN_SMEM(float, lds);
@@ -659,8 +661,14 @@ __global__ __launch_bounds__(256) void k_conv0_fused_cb(const float* __restrict_
     float* til = pat + NPP * 4;         // [2 quads][NPX] float4: conv0.0 output planes
 
     const int tid = threadIdx.x, lane = tid & 63;
+    const int nconv = N * tiles_y * tiles_x;
+    // the blocks beside the convolution's own carry the frame's camera-only preparation (prep_job.h): first kernel of the frame,
+    // so level 0's depth planes and every level's projection matrices are ready long before the warp asks for them
+    // (in FRONT of them in dispatch order: the one block with the fp64 inverse chain starts at once and ends under conv0's blocks;
+    // behind them it was the kernel's tail — 25.4 -> 32.2 us, the whole launch it was meant to save)
+    if ((int)blockIdx.x < job.nblocks) { prep_job_block(job, (int)blockIdx.x, tid, 256); return; }
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+    const int bid = (int)xcd_contiguous(blockIdx.x - (unsigned)job.nblocks, (unsigned)nconv);
     const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
     const int oy0 = ty * TH, ox0 = tx * TW;
 
@@ -769,24 +777,28 @@ __global__ __launch_bounds__(256) void k_conv0_fused_cb(const float* __restrict_
 #ifndef ENERF_CONV0_CB
 #define ENERF_CONV0_CB 1            // 1: k_conv0_fused_cb (weights in registers); 0: k_conv0_fused_b4
 #endif
-void launch_conv0_fused(const Conv2dDesc& L0, const Conv2dDesc& L1, const float* w_cb0, const float* w_cb1, const float* img,
-                        float* out, int N, int H, int W, hipStream_t st) {
+bool launch_conv0_fused(const Conv2dDesc& L0, const Conv2dDesc& L1, const float* w_cb0, const float* w_cb1, const float* img,
+                        float* out, int N, int H, int W, hipStream_t st, const PrepJob* job) {
     const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
     if (ENERF_CONV0_CB && ENERF_CONV0_B4 && w_cb0 != nullptr && w_cb1 != nullptr) {
         const size_t shmem = (size_t)(12 * 36 * 4 + 2 * 10 * 34 * 4) * sizeof(float);
-        ENERF_LAUNCH(k_conv0_fused_cb, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, w_cb0, L0.scale, L0.shift, w_cb1,
-                     L1.scale, L1.shift, img, out, N, H, W, tiles_y, tiles_x);
-        return;
+        PrepJob none;
+        memset(&none, 0, sizeof(none));
+        const PrepJob& J = job != nullptr ? *job : none;
+        ENERF_LAUNCH(k_conv0_fused_cb, (unsigned)(N * tiles_y * tiles_x + J.nblocks), 256, shmem, st, w_cb0, L0.scale, L0.shift, w_cb1,
+                     L1.scale, L1.shift, img, out, N, H, W, tiles_y, tiles_x, J);
+        return job != nullptr;
     }
     if (ENERF_CONV0_B4) {
         const size_t shmem = (size_t)(12 * 36 * 4 + 2 * 10 * 34 * 4 + 9 * 32 + 9 * 64) * sizeof(float);
         ENERF_LAUNCH(k_conv0_fused_b4, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, L0.w, L0.scale, L0.shift, L1.w,
                      L1.scale, L1.shift, img, out, N, H, W, tiles_y, tiles_x);
-        return;
+        return false;
     }
     const size_t shmem = (size_t)(12 * 36 * 4 + 10 * 34 * 8) * sizeof(float);
     ENERF_LAUNCH(k_conv0_fused, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, L0.w, L0.scale, L0.shift, L1.w, L1.scale,
                  L1.shift, img, out, N, H, W, tiles_y, tiles_x);
+    return false;
 }
 
 // =====================================================================================================

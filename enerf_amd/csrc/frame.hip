@@ -7,6 +7,7 @@
 #include <mutex>
 
 #include "kernels.h"
+#include "prep_job.h"
 
 using namespace enerf;
 
@@ -335,11 +336,31 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
         need_level(1); need_level(2);
         return code;
     };
+    // The camera-only preparation — level 0's depth planes and EVERY level's projection matrices (utils.py:35-55, 98-111) — rides
+    // in the frame's first launch (prep_job.h): its blocks run beside conv0's instead of as a launch of their own between the trunk
+    // and the warp.  prep_carried: a kernel took the job (the fused conv0 pair; otherwise the level loop launches the prep kernels).
+    int prep_carried = 0;
+    PrepJob job;
+    memset(&job, 0, sizeof(job));
+#ifndef ENERF_PREP_JOB
+#define ENERF_PREP_JOB 1             // 0 (A/B): the preparation as launches of its own inside the level loop (rounds 1 - 5)
+#endif
+    if (P.hip_feats && ENERF_PREP_JOB) {
+        const LevelPlan& L0 = P.L[0];
+        job.near_far = a->near_far; job.dv = ws + L0.dv; job.nf = ws + L0.nf;
+        job.B = a->B; job.D = L0.D; job.h = L0.h; job.w = L0.w; job.depth_inv = c.depth_inv[0];
+        for (int i = 0; i < c.num && i < 3; ++i)
+            job.pj[i] = ProjJob{a->src_ixts, a->src_exts, a->tar_ixt, a->tar_ext, ws + P.L[i].proj, a->S, (float)c.im_feat_scale[i],
+                                (float)c.volume_scale[i]};
+        job.nblocks = prep_job_blocks(a->B, L0.D, L0.h, L0.w, 256);
+    }
     if (P.hip_feats) {
         const int l2s = P.tex2 ? 12 : 8;
         auto fstage = [&](int stage, enerf_stream_t s) {
-            return enerf_feature_net_stage(a->feature_net_packed, a->src_inps, n_img, a->H, a->W, f[0], f[1], f[2], l2s,
-                                           ws + P.featnet_ws, P.featnet_ws_bytes, stage, a->options, s);
+            const bool first = stage == ENERF_FEAT_ALL || stage == ENERF_FEAT_TRUNK;
+            return feature_net_stage_job(a->feature_net_packed, a->src_inps, n_img, a->H, a->W, f[0], f[1], f[2], l2s,
+                                         ws + P.featnet_ws, P.featnet_ws_bytes, stage, a->options, (hipStream_t)s,
+                                         first && job.nblocks > 0 ? &job : nullptr, first ? &prep_carried : nullptr);
         };
 #ifndef ENERF_EMU
         if (!(a->options && a->options->single_stream)) lane = side_lane(st);
@@ -413,8 +434,9 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
         // std are then only this level's inputs): one launch instead of two on the critical chain between the levels
         bool prep_done = false;
         if (pending_prob != nullptr) {
+            // (the level's projection matrices are already there when the frame's first launch carried the preparation job)
             prep_done = launch_regress_and_values(a->src_ixts, a->src_exts, a->tar_ixt, a->tar_ext, a->S, (float)c.im_feat_scale[i],
-                                                  (float)c.volume_scale[i], proj, pending_prob, pending_dv, pnf, pending_D, hp, wp,
+                                                  (float)c.volume_scale[i], prep_carried && i < 3 ? nullptr : proj, pending_prob, pending_dv, pnf, pending_D, hp, wp,
                                                   pending_inv, const_cast<float*>(pdepth), const_cast<float*>(pstd), a->B, L.D,
                                                   L.h, L.w, c.depth_inv[i], dv, nf, st);
             if (!prep_done)         // shape outside the fused kernel's limits: the two separate launches
@@ -422,6 +444,7 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
                                         const_cast<float*>(pdepth), const_cast<float*>(pstd), nullptr, st);
             pending_prob = nullptr;
         }
+        if (i == 0 && prep_carried) prep_done = true;                  // level 0: planes + matrices came with the first launch
         if (!prep_done)
             rc = enerf_level_prep(a->src_ixts, a->src_exts, a->tar_ixt, a->tar_ext, a->B, a->S, (float)c.im_feat_scale[i],
                                   (float)c.volume_scale[i], proj, a->near_far, pdepth, pstd, pnf, L.D, L.h, L.w, hp, wp,
@@ -514,6 +537,14 @@ int enerf_forward(const enerf_frame_args_t* a, enerf_stream_t stream) {
         ra.render_scale = (float)c.render_scale[i];
         ra.rays8 = rays8; ra.depth_map = depth; ra.std_map = std; ra.nf_map = nf; ra.map_h = L.h; ra.map_w = L.w;
         ra.options = a->options;
+        // A forked render is a leaf that shares the device with the next level.  As one persistent block per compute unit (130 KB of
+        // LDS each at C = 32) it kept the next level's LDS-staged kernels off every CU until its blocks exited; on HALF of the CUs,
+        // with the balanced tile deal, the next level starts at once and the leaf ends under its small layers: lego 543 -> 558
+        // frames/s (64 blocks 509, 96: 556, 128: 558, 160: 546, all 256: 535; profiles/r06_ab_bg_render_blocks.txt)
+#ifndef ENERF_BG_RENDER_DIV
+#define ENERF_BG_RENDER_DIV 2        // a forked render's persistent blocks = compute units / this; 0 = one per compute unit
+#endif
+        if (render_forked && ENERF_BG_RENDER_DIV > 0) ra.max_blocks = device_cu_count() / ENERF_BG_RENDER_DIV;
         if (L.masked) {
             ra.ray_index = ray_index; ra.ray_count = ray_count; ra.scatter_rgb = 1;
             zero_async(a->rgb[i], (size_t)L.n_rays * 3 * sizeof(float), (hipStream_t)rs);      // torch.zeros_like(...), network_human.py:103

@@ -1,6 +1,7 @@
 // geometry.hip — layout packers and the small per-pixel / per-ray stages of the ENeRF hot path.
 // HBM-bound elementwise kernels: one thread per output element, coalesced along the fastest axis.
 #include "kernels.h"
+#include "prep_job.h"
 
 namespace enerf {
 
@@ -153,37 +154,7 @@ void launch_pack_texels_cl(const float* feat_cl, int C, const float* src_inps, i
 // K' = K with rows 0,1 scaled.  One thread per (b,s); fp64 internally (a 4x4 inverse per frame),
 // rounded to fp32 on store.
 // -------------------------------------------------------------------------------------------------
-// proj3x4 = K'(3x3, rows 0,1 scaled) * E[:3] (3x4)
-__device__ __forceinline__ void k_times_e(const float* K, const float* E, float scale, double* out34) {
-    for (int r = 0; r < 3; ++r) {
-        double sc = r < 2 ? (double)scale : 1.0;
-        for (int c = 0; c < 4; ++c) {
-            double a = 0;
-            for (int k = 0; k < 3; ++k) a += ((double)K[r * 3 + k] * sc) * (double)E[k * 4 + c];
-            out34[r * 4 + c] = a;
-        }
-    }
-}
-// one (b, s) projection matrix (get_proj_mats utils.py:35-55), fp64 like torch.inverse's LU on these sizes
-__device__ __forceinline__ void proj_one(int i, const float* __restrict__ src_ixts, const float* __restrict__ src_exts,
-                                         const float* __restrict__ tar_ixt, const float* __restrict__ tar_ext, int S,
-                                         float src_scale, float tar_scale, float* __restrict__ proj) {
-    const int b = i / S;
-    double t44[16], tinv[16], s34[12];
-    k_times_e(tar_ixt + b * 9, tar_ext + b * 16, tar_scale, t44);
-    t44[12] = t44[13] = t44[14] = 0.0;
-    t44[15] = 1.0;
-    if (!inv4x4(t44, tinv)) {
-        for (int k = 0; k < 16; ++k) tinv[k] = NAN;
-    }
-    k_times_e(src_ixts + i * 9, src_exts + i * 16, src_scale, s34);
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 4; ++c) {
-            double a = 0;
-            for (int k = 0; k < 4; ++k) a += s34[r * 4 + k] * tinv[k * 4 + c];
-            proj[i * 12 + r * 4 + c] = (float)a;
-        }
-}
+// (k_times_e / proj_one: prep_job.h)
 __global__ void k_proj_mats(const float* __restrict__ src_ixts, const float* __restrict__ src_exts,
                             const float* __restrict__ tar_ixt, const float* __restrict__ tar_ext, int B, int S,
                             float src_scale, float tar_scale, float* __restrict__ proj) {
@@ -205,14 +176,7 @@ void launch_proj_mats(const float* src_ixts, const float* src_exts, const float*
 // [1/min(d+s, nf0), 1/max(d-s, nf1)] and D planes in between.
 // torch.linspace(0,1,D): step=1/(D-1); t_k = k<D/2 ? step*k : 1 - step*(D-1-k).
 // -------------------------------------------------------------------------------------------------
-// Optional piggy-backed get_proj_mats of the same level (enerf_level_prep): the B*S fp64 inverses are a 4.7 us
-// latency chain in a launch of their own; here the last block's first threads run them next to the plane writes.
-struct ProjJob {
-    const float *src_ixts, *src_exts, *tar_ixt, *tar_ext;
-    float* proj;          // nullptr: no projection matrices in this launch
-    int S;
-    float src_scale, tar_scale;
-};
+// (ProjJob: prep_job.h)
 __global__ __launch_bounds__(256) void k_depth_values(const float* __restrict__ near_far,
                                                       const float* __restrict__ pdepth, const float* __restrict__ pstd,
                                                       const float* __restrict__ pnf, int B, int D, int h, int w, int hp,
@@ -250,15 +214,7 @@ __global__ __launch_bounds__(256) void k_depth_values(const float* __restrict__ 
         nn = 1.f / lo;            // utils.py:128
         ff = 1.f / hi;
     }
-    const float inn = 1.f / nn, iff = 1.f / ff;
-    const float t = linspace01(k, D);
-    const float v = depth_inv ? 1.f / (inn + t * (iff - inn)) : nn + t * (ff - nn);
-    dv[i] = v;                                   // (B,D,h,w): the thread index is the element index
-    if (k == 0 || k == D - 1) {                  // utils.py:149-150 (k == 0 == D-1 writes both)
-        const float e = depth_inv ? 1.f / clamp_min(v, 1e-6f) : v;
-        if (k == 0) nf_out[((long long)b * 2 + 0) * hw + p] = e;
-        if (k == D - 1) nf_out[((long long)b * 2 + 1) * hw + p] = e;
-    }
+    depth_plane_value(nn, ff, b, k, p, D, hw, depth_inv, dv + i, nf_out);      // (B,D,h,w): the thread index is the element index
 }
 void launch_depth_values(const float* near_far, const float* pdepth, const float* pstd, const float* pnf, int B, int D,
                          int h, int w, int hp, int wp, int depth_inv, float* dv, float* nf_out, hipStream_t st) {

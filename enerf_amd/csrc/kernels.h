@@ -130,8 +130,14 @@ void launch_conv2d_pack(const float* w, const float* bias, const float* bn_w, co
 int launch_conv2d(const Conv2dDesc& L, const float* in, float* out, const float* up, int N, int Hi, int Wi, int Hc,
                   int Wc, hipStream_t st);
 // conv0.1(conv0.0(image)) fused (feature_net.py:7-9): L0/L1 = the two layers' descriptors, img (N,3,H,W) -> out (N,H,W,8)
-void launch_conv0_fused(const Conv2dDesc& L0, const Conv2dDesc& L1, const float* w_cb0, const float* w_cb1, const float* img,
-                        float* out, int N, int H, int W, hipStream_t st);
+// job (prep_job.h, optional): the frame's camera-only preparation carried by extra blocks of this launch; returns whether it was
+struct PrepJob;
+bool launch_conv0_fused(const Conv2dDesc& L0, const Conv2dDesc& L1, const float* w_cb0, const float* w_cb1, const float* img,
+                        float* out, int N, int H, int W, hipStream_t st, const PrepJob* job = nullptr);
+// enerf_feature_net_stage with a preparation job for the trunk's first launch; *job_done = 1 when a kernel carried it
+int feature_net_stage_job(const float* packed, const float* src_inps, int n_img, int H, int W, float* feat_l0, float* feat_l1,
+                          float* feat_l2, int l2_stride, void* workspace, size_t workspace_bytes, int stage,
+                          const enerf_options_t* options, hipStream_t stream, const PrepJob* job, int* job_done);
 // smooth0(up2(f1pre) + lat0(c0)) fused (feature_net.py:32-35); L = smooth0's descriptor, lat_w/lat_b raw (32,8)/(32)
 // w_pq: the layer's P/Q tap-packed image (launch_conv2d_pq_pack) or nullptr for the plain 8x32 tiling
 // smooth1(up2(f2) + lat1(c1)) fused (feature_net.py:33-34, round 5): writes f1pre (N,H1,W1,32) and out (N,H1,W1,16); false: not applicable

@@ -287,11 +287,12 @@ void k_render_rays(RenderArgs a) {
 #define ENERF_RENDER_BALANCE 1
 #endif
 // The level-0 kernel (R = 9; lego: 2500 tiles for 2048 waves) gains even more ALONE from the balanced deal (266 -> 201 us = 0.50 of
-// the fp32-MFMA peak: a SIMD carries 3 tiles instead of 4), but it runs FORKED beside level 1 as one persistent block per CU: unbalanced,
-// a third of the CUs are released at half time and level 1 starts there; balanced, every CU is held to the end — lego 543.9 -> 535.3
-// frames/s (profiles/r05_ab_render_balance.txt).  More, shorter blocks (ENERF_R9_GRID_MULT=2) do not fix that (539).  Default: off.
+// the fp32-MFMA peak: a SIMD carries 3 tiles instead of 4).  In the frame it runs FORKED beside level 1; as one persistent block per CU
+// the balanced form held every CU to the end and delayed level 1 (lego 543.9 -> 535.3 frames/s, profiles/r05_ab_render_balance.txt).
+// Round 6: the forked launch is capped at half of the CUs (enerf_render_args_t.max_blocks, frame.hip), which turns the balanced deal
+// into the better one there too (lego 543 -> 558 frames/s; unbalanced on half of the CUs 553): default on.
 #ifndef ENERF_RENDER_BALANCE_R9
-#define ENERF_RENDER_BALANCE_R9 0
+#define ENERF_RENDER_BALANCE_R9 1
 #endif
 #if ENERF_RENDER_BALANCE
     // Round 5: the band's PARTIAL last round of tiles is dealt out evenly.  Round-robin, it went to the band's first blocks, 12
@@ -821,7 +822,9 @@ int launch_render_rays(const RenderArgs& a, hipStream_t st) {
     // (3 per SIMD, 168 VGPRs + spills) 215 us; 16-wave blocks (4 per SIMD) 247 us; 1 wave per SIMD 350 us.
     const int cus = device_cu_count();
     auto grid_for = [&](int waves, int occ) {
-        const long long blocks = cdivl(ntiles, waves), resident = (long long)cus * occ;
+        const long long blocks = cdivl(ntiles, waves);
+        long long resident = (long long)cus * occ;
+        if (a.max_blocks > 0 && a.max_blocks < resident) resident = a.max_blocks;       // a render that shares the device (frame.hip)
         return (unsigned)(blocks < resident ? blocks : resident);
     };
 #ifndef ENERF_R9_LEAN

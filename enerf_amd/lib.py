@@ -83,7 +83,7 @@ class RenderArgs(C.Structure):
                 + [("render_scale", _fl)]
                 + [(n, _f) for n in ("rays8", "depth_map", "std_map", "nf_map")] + [("map_h", _i), ("map_w", _i)]
                 + [("options", C.POINTER(Options)), ("ray_index", C.c_void_p), ("ray_count", C.c_void_p),
-                   ("scatter_rgb", _i)])
+                   ("scatter_rgb", _i), ("max_blocks", _i)])
 
 
 MAX_LEVELS = 3

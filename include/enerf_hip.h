@@ -235,6 +235,9 @@ typedef struct {
     const int* ray_index;
     const int* ray_count;
     int scatter_rgb;
+    int max_blocks;        /* ABI >= 10: > 0 caps the launch at this many persistent blocks (a render that overlaps other work of the
+                              frame — enerf_forward's forked non-final level — leaves the remaining compute units to that work);
+                              0 = as many blocks as the device holds */
 } enerf_render_args_t;
 int enerf_render_rays(const enerf_render_args_t* args, enerf_stream_t stream);
 
