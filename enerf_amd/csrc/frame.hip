@@ -243,6 +243,8 @@ SideLane* side_lane(hipStream_t main) {
     // on the lane stretched a small level-0 layer on the caller's stream 10x at 1024x1024: zju 430 -> 437 frames/s)
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    // (a CU-masked lane stream — hipExtStreamCreateWithCUMask keeping 4 / 6 / 7 of every 8 CUs, so that the chain's small layers always
+    // find free CUs — measured round 6: dtu 1320 -> 962 frames/s, zju 555 -> 479 whatever the mask: profiles/r06_ab_lane_cu_mask.txt)
     bool ok = hipStreamCreateWithPriority(&L->stream, hipStreamNonBlocking, least) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&L->trunk, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&L->l1, hipEventDisableTiming) == hipSuccess;
