@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BASELINE_FPS_RTX3090 = 21.778975517304048      # BASELINE.md §1 / README.md:121 (DTU eval config only)
+PEAK_L1_GATHER_TBS = 24.1          # measured: tools/micro/gather_rate.hip (L1-resident float4 gathers, requested bytes)
 PEAK_F32_MFMA_TFLOPS = 157.3                   # MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32, 2.4 GHz)
 PEAK_HBM_GBS = 8000.0
 
@@ -790,7 +791,7 @@ def main():
     # one process per GPU, checked: every rank's device binding is exchanged, duplicates are refused on all ranks, and the
     # size of the communicator is counted on the devices (`collective_ranks_seen`, next to n_gpus in the line)
     try:
-        args.binding = rank_bindings(rank, world, local, dev)
+        args.binding = rank_bindings(rank, world, local, dev, pin=world > 1)     # N > 1: one core set per rank (inherited by children)
     except RuntimeError as e:
         raise SystemExit(f"rank {rank}: {e}: refusing to print an n_gpus={world} line")
     print(f"[bench] rank {rank}/{world} local_rank {local} -> {args.binding['bindings'][rank if world > 1 else 0]}", file=sys.stderr, flush=True)
@@ -1083,13 +1084,16 @@ def main():
             if t:
                 Hs, Ws = H >> (2 - i), W >> (2 - i)
                 mb = (S * Hs * Ws * C + D * h * w * C + D * h * w) * 4 / 1e6       # features once + volume once + depth planes
-                # latency x occupancy bound (with no gathers and no stores the kernel keeps 70 % of its time), so no
-                # fraction of the HBM roof is quoted: voxels per ns, the kernel's static instructions per lane and its occupancy
-                sr[f"volume_{i}"] = {"bound": "latency", "frac": None, "voxels_per_us": round(D * h * w / (t * 1e3), 1),
-                                     "achieved_gbs_informational": round(mb / t, 1), "algorithmic_mbytes": round(mb, 2),
-                                     "instructions_per_lane": 300, "lanes_per_voxel": C // 4, "waves_per_simd": 5,
-                                     "note": "k_feature_volume_mp: ~300 instructions per lane, C/4 lanes per voxel pair, 92 VGPRs = 5 "
-                                             "waves per SIMD; bound by the dependent chain projection -> gathers at that occupancy"}
+                # The stage's roof is the vector-memory REQUEST rate (tools/micro/gather_rate.hip, profiles/r06_gather_rate_micro.txt): 4 bilinear
+                # taps of C channels per voxel and view, 24.1 TB/s of requested bytes when the texels sit in L1 (8.5 TB/s from L2; loads in
+                # flight per wave do not change it).  achieved = S * 4 * C * 4 bytes * voxels / time.
+                req_gb = D * h * w * S * 4 * C * 4 / 1e9
+                sr[f"volume_{i}"] = {"bound": "l1-gather", "achieved": round(req_gb / t, 2), "peak": PEAK_L1_GATHER_TBS, "unit": "TB/s requested",
+                                     "frac": round(req_gb / t / PEAK_L1_GATHER_TBS, 4), "voxels_per_us": round(D * h * w / (t * 1e3), 1),
+                                     "requested_gather_gbytes": round(req_gb, 4), "algorithmic_hbm_mbytes": round(mb, 2),
+                                     "note": "k_feature_volume_mp: requested gather bytes against the measured L1-hit request rate of this access "
+                                             "shape (64/CQ texels x CQ lanes x 16 B per wave instruction); the L2-hit rate is 8.5 TB/s, so the "
+                                             "kernel runs on L1 line sharing between neighbouring voxels"}
             t = stages.get(f"render_{i}")
             if t and cas.render_if[i]:
                 F = cas.nerf_model_feat_ch[i] + 3

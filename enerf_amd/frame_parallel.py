@@ -105,7 +105,7 @@ def pin_rank_to_cores(local_rank: int, local_world: int, device: torch.device) -
             "n": len(mine), "numa_node": node, "how": how}
 
 
-def rank_bindings(rank: int, world: int, local_rank: int, device: torch.device, group=None) -> dict:
+def rank_bindings(rank: int, world: int, local_rank: int, device: torch.device, group=None, pin: bool = False) -> dict:
     """Which device every rank of the job is bound to, and how many ranks the communicator really holds.
 
     Returns ``{"bindings": [{rank, local_rank, device, visible, id}, ...], "ranks_seen": n, "backend": name}`` on every rank.
@@ -129,7 +129,21 @@ def rank_bindings(rank: int, world: int, local_rank: int, device: torch.device, 
                 "id": f"visible[{visible}]#{device.index}", "hw": hw, "name": p.name}
     else:                                               # CPU lane-emulator ranks (launcher tests): one "device" per process
         mine = {"rank": rank, "local_rank": local_rank, "device": "cpu", "visible": visible, "id": f"cpu-rank{rank}", "hw": None, "name": "cpu"}
-    mine["affinity"] = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), device)
+    # Reporting by default.  ``pin=True`` (bench.py's N > 1 runs ask for it explicitly) ALSO narrows this process's affinity mask and
+    # torch's thread count — a side effect every thread and child created later inherits (DataLoader workers, subprocesses) — so it
+    # is the caller's decision, and the split is over the ranks of THIS node: LOCAL_WORLD_SIZE when the launcher sets it (torchrun
+    # does), else the number of visible devices, never the global world size of a multi-node job.
+    if pin:
+        local_world = os.environ.get("LOCAL_WORLD_SIZE")
+        if local_world is None:
+            local_world = torch.cuda.device_count() if device.type == "cuda" and torch.cuda.device_count() > 0 else world
+        mine["affinity"] = pin_rank_to_cores(local_rank, max(1, min(int(local_world), world)), device)
+    else:
+        try:
+            n_allowed = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            n_allowed = 0
+        mine["affinity"] = {"cores": None, "n": n_allowed, "numa_node": None, "how": "not pinned (rank_bindings(pin=False))"}
     use_dist = world > 1 and dist.is_available() and dist.is_initialized()
     if not use_dist:
         return {"bindings": [mine], "ranks_seen": 1, "backend": None}

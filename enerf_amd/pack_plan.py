@@ -124,8 +124,10 @@ def cost_reg_plan(lib, m, device):
             bwd, bk = lib.conv3d_layer_pack(wi, cout, cin, _S2), _S2
         plan.add((i, "bwd"), bwd, _conv3d_regions(lib, cout, cin, bk))
     # heads: feat_conv (8 -> 8) ++ depth_conv (8 -> 1) as one 8 -> 16 layer (rows 9..15 zero)
-    sf = plan.source("feat_conv", lambda: m.feat_conv[0].weight)
-    sd = plan.source("depth_conv", lambda: m.depth_conv[0].weight)
+    # (the getters capture the SUBMODULES, never `m` itself: `m` is the weak key of _PLANS, and a value that holds its key
+    # strongly would keep module, index tensors and library alive for ever)
+    sf = plan.source("feat_conv", lambda c=m.feat_conv[0]: c.weight)
+    sd = plan.source("depth_conv", lambda c=m.depth_conv[0]: c.weight)
     w16 = lib.concat2_pad(plan.index_tensor(sf).reshape(-1), plan.index_tensor(sd).reshape(-1), 16 * 8 * 27).view(16, 8, 3, 3, 3)
     plan.add(("heads", "fwd"), lib.conv3d_layer_pack(w16, 8, 16, _S1), _conv3d_regions(lib, 8, 16, _S1))
     plan.add(("heads", "bwd"), lib.conv3d_layer_pack(lib.weights_flip_transpose(w16), 16, 8, _S1), _conv3d_regions(lib, 16, 8, _S1))
@@ -166,10 +168,21 @@ _PLANS = weakref.WeakKeyDictionary()          # module -> {(builder, device, lib
                                               # holds the ctypes library, and modules must stay deep-copyable / picklable
 
 
+def _lib_key(lib):
+    """What identifies a loaded library: its path (two EnerfLib objects of one .so serve the same plan; `id()` of a freed object
+    can be handed to the next one)."""
+    return getattr(lib, "path", None) or getattr(getattr(lib, "dll", None), "_name", None) or repr(lib)
+
+
 def plan_of(lib, m, build, device):
-    """The module's cached plan (built on first use — the eager warm-up steps of GraphedTrainStep — per device)."""
+    """The module's cached plan (built on first use — the eager warm-up steps of GraphedTrainStep — per device).  Building
+    launches pack kernels, host-to-device copies and index arithmetic, none of which may be captured: a plan that is missing
+    while the stream is capturing is an error, not a silent build."""
     cache = _PLANS.setdefault(m, {})
-    key = (build.__name__, str(device), id(lib))
+    key = (build.__name__, str(device), _lib_key(lib))
     if key not in cache:
+        if torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(f"pack_plan.{build.__name__}: no plan for this module / device / library yet and the stream is capturing "
+                               "— run one eager training step first (GraphedTrainStep's warm-up does)")
         cache[key] = build(lib, m, device)
     return cache[key]
