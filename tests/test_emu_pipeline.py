@@ -190,6 +190,34 @@ def test_frame_sizes_the_reference_cannot_run_fail_loudly():
                 _net(cfg)(batch)
 
 
+def test_source_view_counts_outside_2_to_4_are_refused_and_the_reference_never_ships_them():
+    """The render kernel maps source views onto its four lane groups, so ``enerf_forward`` takes S in 2..4 (frame.hip make_plan)
+    while the reference's code is generic in S (nerf.py:74-89, network.py:58-67).  Pinned here (VERDICT r05 #6b): (i) every view
+    count a shipped reference config asks for — test_input_views, train_input_views, the samplers' input_views_num — is 2, 3 or 4
+    (tests/golden/ref_view_counts.json, regenerated from /root/reference when it is present); (ii) S = 1 is not a frame the
+    reference can render either: Agg's unbiased variance over one view is NaN (nerf.py:81, restated by the oracle); (iii) S = 1
+    and S = 5 are refused loudly by the C entry, never rendered from a partial lane mapping."""
+    import json
+    import os
+    from enerf_amd.config import EnerfConfig
+    from enerf_amd.synth import make_batch
+    from golden_cases import GOLDEN
+    from oracle import enerf_oracle as O
+    counts = json.load(open(os.path.join(GOLDEN, "ref_view_counts.json")))
+    assert len(counts) >= 10 and {v for c in counts.values() for v in c} <= {2, 3, 4}
+    if os.path.isdir("/root/reference/configs/enerf"):
+        from oracle.scan_ref_view_counts import scan
+        assert scan() == counts, "tests/golden/ref_view_counts.json is stale: python oracle/scan_ref_view_counts.py"
+    cfg = EnerfConfig().with_cas(volume_planes=(8, 8), render_if=(False, True))
+    with torch.no_grad():
+        one = {k: torch.from_numpy(v) for k, v in make_batch(32, 64, 1, cfg, seed=1, textured=True).items()}
+        assert torch.isnan(O.forward(cfg, load_weights(), one)["rgb_level1"]).all()          # the reference's own arithmetic: var of ONE view
+        for S in (1, 5):
+            batch = {k: torch.from_numpy(v) for k, v in make_batch(32, 64, S, cfg, seed=1, textured=True).items()}
+            with pytest.raises(EnerfError, match="S in 2..4"):
+                _net(cfg)(batch)
+
+
 def test_empty_ray_list():
     name = "tiny_s3"
     cfg, batch, g = case_config(name), case_batch(name), load_golden(name)

@@ -269,6 +269,15 @@ def test_full_size_lego_800x800_4views_both_levels_vs_oracle():
     assert d.min() >= 2.5 - 1e-4 and d.max() <= 5.5 + 1e-4
 
 
+def test_full_size_llff_640x960_vs_oracle():
+    """The reference's fourth eval config on this path (configs/enerf/llff_eval.yaml:9-16,26-28: planes 32,8, render_if False,True,
+    input_h_w 640 x 960; not a BASELINE config) at its real shape: a 2:3 aspect, level-0 volume 32 x 80 x 120, 614,400 rays, pinned
+    to the unmodified reference's digest (llff_full) and to the oracle (VERDICT r05 #6a)."""
+    cfg = EnerfConfig().with_cas(volume_planes=(32, 8), render_if=(False, True))
+    out, ref = _full_size_check(cfg, make_batch(640, 960, 3, cfg, seed=7, textured=True), False, ("rgb_level1",), "llff_full")
+    assert out["rgb_level1"].shape == (1, 640 * 960, 3) and out["depth_mvs_level1"].shape == (1, 320, 480)
+
+
 def test_full_size_zju_1024_4views_masked_vs_oracle():
     """BASELINE config 4 at its real shape (configs/enerf/zjumocap_eval.yaml:14,20,39 with input_ratio 1.0 and 4 input
     views; lib/networks/enerf/network_human.py:90-107): 1024x1024, S=4, planes 32,8, render_if False,True, rays compacted
