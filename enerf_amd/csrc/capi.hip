@@ -354,7 +354,7 @@ int enerf_feature_net_pack(const enerf_featnet_raw_t* raw, float* packed, enerf_
     }
     hipMemcpyAsync(p, raw->lat0_w, 256 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
     hipMemcpyAsync(p + 256, raw->lat0_b, 32 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
-    launch_conv2d_pq_pack(raw->smooth0_w, 32, p + 320, (hipStream_t)stream);             // tap-packed smooth0 (conv2d.hip PK)
+    zero_async(p + 320, 3072 * sizeof(float), (hipStream_t)stream);                      // reserved (rounds 2-5: smooth0's tap-packed P/Q image)
     launch_conv2d_cb_pack(raw->smooth0_w, 32, 0, 16, p + 320 + 3072, (hipStream_t)stream);          // broadcast-A images (conv2d.hip
     launch_conv2d_cb_pack(raw->smooth0_w, 32, 16, 16, p + 320 + 3072 + 1152, (hipStream_t)stream);  //  k_smooth0_cb, k_conv0_fused_cb)
     launch_conv2d_cb_pack(raw->conv[0].w, 3, 0, 3, p + 320 + 3072 + 2304, (hipStream_t)stream);
@@ -441,11 +441,10 @@ int feature_net_stage_job(const float* packed, const float* src_inps, int n_img,
     if (lvl2) {
         d[10].out_stride = l2_stride;
         d[10].rgb_src = (l2_stride == 12) ? src_inps : nullptr;
-        if (!opt.featnet_unfused) {
+        if (!opt.featnet_unfused && !opt.featnet_smooth0_plain) {
             // smooth0(up2(feat1) + lat0(conv0)) in one kernel: the 32-channel full-res sum never touches HBM
-            launch_smooth0_fused(d[10], c0, f1pre, p, p + 256, opt.featnet_smooth0_plain ? nullptr : p + 320, p + 320 + 3072, feat_l2,
-                                 n_img, H, W, st);
-        } else {
+            launch_smooth0_fused(d[10], c0, f1pre, p, p + 256, p + 320 + 3072, feat_l2, n_img, H, W, st);
+        } else {                                                                       // the two plain 16x16x4-MFMA launches
             rc |= launch_conv2d(d[8], c0, f0pre, f1pre, n_img, H, W, H1, W1, st);      // up2(feat1) + lat0(conv0)
             rc |= launch_conv2d(d[10], f0pre, feat_l2, nullptr, n_img, H, W, 0, 0, st);  // smooth0 -> level_2 / texels
         }

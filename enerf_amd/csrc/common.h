@@ -49,7 +49,7 @@ __device__ __forceinline__ void wave_sync() {
 // intrinsic rather than inline asm, keeps the MFMA->VALU hazard wait states hipcc inserts (an inline-asm
 // v_max_f32 on MFMA results read stale registers in the C=32 render variant: caught by the GPU parity tests).
 __device__ __forceinline__ float relu1(float x) {
-#if defined(ENERF_EMU) || defined(ENERF_NO_RELU_MED3)
+#ifdef ENERF_EMU
     return fmaxf(x, 0.f);
 #else
     return __builtin_amdgcn_fmed3f(x, 0.f, 3.402823466e+38f);
@@ -315,7 +315,7 @@ struct Taps2 {
 // 24-bit integer multiply (full-rate v_mul_u32_u24; v_mul_lo_u32 is quarter rate).  Only for operands that are
 // image/volume coordinates and extents (< 2^24, launchers check) with a product < 2^32.
 __device__ __forceinline__ int mul24(int a, int b) {
-#if defined(ENERF_EMU) || defined(ENERF_NO_MUL24)
+#ifdef ENERF_EMU
     return a * b;
 #else
     return __mul24(a, b);
@@ -364,8 +364,6 @@ __device__ __forceinline__ float clamp_min(float v, float lo) { return v < lo ? 
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
 #ifdef ENERF_EMU
     atomicAdd(p, v);
-#elif defined(ENERF_ABL_NOATOMIC)
-    *p = v;                         // timing ablation only (tools/build_variant.py): what the scatter kernels cost without the L2 atomics
 #else
     unsafeAtomicAdd(p, v);          // global_atomic_add_f32 (hipMalloc memory is coarse-grained)
 #endif

@@ -75,9 +75,6 @@ void launch_conv2d_pack(const float* w, const float* bias, const float* bn_w, co
 // epilogue.  This layer's D registers (rows 16rt+4g+r of pixel j) are exactly the B operands of the next layer's
 // k-steps in the standard packed-weight order (ci = 16cb + 4g + r), so the chained layer is 8*RT more MFMAs per
 // column tile on values that never leave the registers; this layer's own output is not stored.
-#ifndef ENERF_C2_PLANAR
-#define ENERF_C2_PLANAR 0            // 1: quad-plane LDS tile (bank-conflict free; measured: no change, profiles/r05_ab_conv2d_planar.txt); 0: pixel-major tile
-#endif
 template <int CINP, int RT, int K, int STR, int TH, bool NCHW3, bool CHAIN = false>
 __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, const float* __restrict__ scale,
                                                 const float* __restrict__ shift, const float* __restrict__ in,
@@ -98,16 +95,8 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
     // consecutive slots of one parity.
     constexpr int IWH = (IW + 1) / 2;
     auto slot = [](int ly, int lx) { return STR == 2 ? (ly * 2 + (lx & 1)) * IWH + (lx >> 1) : ly * IW + lx; };
-    // Round 5: the tile lives in LDS as channel-QUAD PLANES [quad][slot] float4 (pitch a multiple of 16 slots = 64 banks)
-    // instead of [slot][CB channels].  Pixel-major, a ds_read_b128 service group (lanes {0-3,12-15} of lane group g and {4-11}
-    // of g+1) lands on four bank quads twice (64-byte pixel pitch): PMC r04 counted bank-conflict cycles at 0.43 (smooth1) to
-    // 0.71 (conv1.0, 32-byte pitch, ds_read_b64) of the LDS-active cycles of these kernels.  With planes the 16 lanes of a
-    // group read 16 consecutive slots of two planes = 64 different banks.  The staging threads are permuted so that eight
-    // consecutive lanes store eight consecutive slots of ONE plane (a conflict-free ds_write_b128 group) while a wave's load
-    // instruction still covers whole 64-byte pixel records.
-    constexpr bool PLANAR = ENERF_C2_PLANAR && !NCHW3 && CB >= 8;
-    constexpr int NSLOT = STR == 2 ? IH * 2 * IWH : IH * IW;
-    constexpr int PITCH = (NSLOT + 15) / 16 * 16;
+    // (round 5 measured the tile as channel-quad PLANES — conflict-free ds_read_b128 / ds_write_b128 groups — with no change on any
+    // layer: the bank conflicts PMC counts do not bound these kernels; profiles/r05_ab_conv2d_planar.txt, tools/patches/)
     ENERF_DYN_SMEM(float, lds);
 
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
@@ -147,11 +136,7 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
                 for (int r = 0; r < CPL; ++r)
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
-#if defined(ENERF_ABL_C2) && (ENERF_ABL_C2 & 8)                          // timing ablation: no weight loads
-                        aq[(kw * CPL + r) * RT + rt] = 1e-3f * (float)((kw + r + rt + lane) & 7);
-#else
                         aq[(kw * CPL + r) * RT + rt] = wt[((long long)(kw * KS + r) * RT + rt) * 64];
-#endif
         };
         // k<=3: the whole pass's weights are requested BEFORE the tile is staged, so their L2 latency hides
         // behind the staging traffic; sched_barrier pins the loads here (hipcc otherwise sinks each load to
@@ -185,7 +170,7 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
                         sk[it] ? make_float4(v0[it], v1[it], v2[it], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
-            constexpr int NITEM = PLANAR ? (NPX + 7) / 8 * 8 * QV : NPX * QV;      // planar: groups of 8 pixels x QV quads
+            constexpr int NITEM = NPX * QV;
             constexpr int NIT = (NITEM + 255) / 256;
             float4 sv[NIT];
             bool sk[NIT];
@@ -194,23 +179,17 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int i = threadIdx.x + it * 256, ic = i < NITEM ? i : NITEM - 1;
-                int px, q;
-                if (PLANAR) { px = (ic / (8 * QV)) * 8 + (ic & 7); q = (ic >> 3) % QV; if (px >= NPX) px = NPX - 1; }
-                else { px = ic / QV; q = ic - px * QV; }
+                const int px = ic / QV, q = ic - px * QV;
                 const int ly = px / IW, lx = px - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
                 sk[it] = gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
-                so[it] = PLANAR ? (q * PITCH + slot(ly, lx)) * 4 : (slot(ly, lx) * QV + q) * 4;
+                so[it] = (slot(ly, lx) * QV + q) * 4;
                 const int off = sk[it] ? gy * Wi + gx : 0;
-#if defined(ENERF_ABL_C2) && (ENERF_ABL_C2 & 1)                          // timing ablation (tools/build_variant.py): no staging loads
-                sv[it] = make_float4(1e-3f * (float)(off & 15), 0.01f, 0.f, 0.f);
-#else
                 sv[it] = *reinterpret_cast<const float4*>(base + (long long)off * CINP + q * 4);
-#endif
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int i = threadIdx.x + it * 256;
-                if (i < NITEM)        // (planar: the clamped tail items of the last 8-pixel group rewrite pixel NPX-1 with its own value)
+                if (i < NITEM)
                     *reinterpret_cast<float4*>(lds + so[it]) = sk[it] ? sv[it] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -222,8 +201,7 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
             for (int c = 0; c < CTW; ++c) {
                 const int tile = wv * CTW + c, tr = tile / (TW / 16), tc = tile - tr * (TW / 16);
                 const int sl = slot(tr * STR + kh, (tc * 16 + j) * STR + kw);
-                const float* p = PLANAR ? (CPL == 4 ? lds + (g * PITCH + sl) * 4 : lds + ((g >> 1) * PITCH + sl) * 4 + (g & 1) * 2)
-                                        : lds + sl * CB + g * CPL;
+                const float* p = lds + sl * CB + g * CPL;
                 if (CPL == 4) {
                     const float4 tq = *reinterpret_cast<const float4*>(p);
                     bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
@@ -255,13 +233,7 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-#if defined(ENERF_ABL_C2) && (ENERF_ABL_C2 & 2)                                  // timing ablation: one tap row instead of K
-        if (PRE) compute(0, aq_all[0]);
-        else { float a0[NAQ]; issue_a(0, a0); compute(0, a0); }
-        if (false) {
-#else
         if (PRE) {
-#endif
 #pragma unroll
             for (int kh = 0; kh < K; ++kh) compute(kh, aq_all[kh]);
         } else {
@@ -351,9 +323,6 @@ __global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, c
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.f);
             }
-#if defined(ENERF_ABL_C2) && (ENERF_ABL_C2 & 4)                          // timing ablation: no output stores (a never-true guard keeps the math)
-            if (y[0] == 12345.678f)
-#endif
             *reinterpret_cast<float4*>(out + o * out_stride + c0) = make_float4(y[0], y[1], y[2], y[3]);
         }
     }
@@ -369,8 +338,7 @@ static void launch_c2(const Conv2dDesc& L, const float* in, float* out, const fl
     const int tiles_y = cdiv(Ho, TH), tiles_x = cdiv(Wo, 32);
     constexpr int IH = (TH - 1) * STR + K, IW = 31 * STR + K;
     const int nslot = IH * (STR == 2 ? 2 * ((IW + 1) / 2) : IW);                                    // stride 2: de-interleaved rows
-    const bool planar = ENERF_C2_PLANAR && !NCHW3 && CB >= 8;
-    const size_t shmem = (size_t)(planar ? (nslot + 15) / 16 * 16 : nslot) * CB * sizeof(float);
+    const size_t shmem = (size_t)nslot * CB * sizeof(float);
     const unsigned grid = (unsigned)((long long)N * tiles_y * tiles_x);
     ENERF_LAUNCH((k_conv2d<CINP, RT, K, STR, TH, NCHW3, CHAIN>), grid, 256, shmem, st, L.w, L.scale, L.shift, in, out, up,
                  rgb_src, out_stride, L.cout, L.relu, N, Hi, Wi, Ho, Wo, Hc, Wc, tiles_y, tiles_x, L.chain_w, L.chain_shift);
@@ -384,119 +352,9 @@ static void launch_c2(const Conv2dDesc& L, const float* in, float* out, const fl
 // 10x34 haloed tile (22 column tiles, 1.33x halo recompute of a 1-k-step layer) straight into LDS — zero outside
 // the image, which is conv0.1's padding — and runs conv0.1 from there exactly like k_conv2d<8,...>.
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_conv0_fused(const float* __restrict__ w0, const float* __restrict__ scale0,
-                                                     const float* __restrict__ shift0, const float* __restrict__ w1,
-                                                     const float* __restrict__ scale1, const float* __restrict__ shift1,
-                                                     const float* __restrict__ img, float* __restrict__ out, int N, int H,
-                                                     int W, int tiles_y, int tiles_x) {
-    constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, NPX = IH * IW;      // conv0.1 input tile (10 x 34)
-    constexpr int PH = IH + 2, PW = IW + 2, NPP = PH * PW;                        // image patch (12 x 36)
-    constexpr int NT0 = (NPX + 15) / 16;                                          // column tiles of stage 1 (22)
-    constexpr int CTW = 4;
-    ENERF_DYN_SMEM(float, lds);
-    float* pat = lds;                   // [NPP][4]   image texels (4th channel 0)
-    float* til = lds + NPP * 4;         // [NPX][8]   conv0.0 output tile
-
-    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
-    const int bid = (int)xcd_contiguous(blockIdx.x, gridDim.x);
-    const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
-    const int oy0 = ty * TH, ox0 = tx * TW;
-
-    // weights of both layers (9 + 18 A operands per lane), requested before the staging traffic
-    float a0[9], a1[9][2];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        a0[t] = w0[t * 64 + lane];
-        a1[t][0] = w1[(t * 2 + 0) * 64 + lane];
-        a1[t][1] = w1[(t * 2 + 1) * 64 + lane];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {   // ---- image patch -> LDS: one thread per patch pixel, three coalesced plane reads, zero outside ----
-        constexpr int NIT = (NPP + 255) / 256;
-        float v0[NIT], v1[NIT], v2[NIT];
-        bool sk[NIT];
-        const float* base = img + (long long)n * 3 * H * W;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = threadIdx.x + it * 256, ic = i < NPP ? i : NPP - 1;
-            const int ly = ic / PW, lx = ic - ly * PW, gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
-            sk[it] = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const int off = sk[it] ? gy * W + gx : 0;
-            v0[it] = base[off]; v1[it] = base[H * W + off]; v2[it] = base[2 * H * W + off];
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = threadIdx.x + it * 256;
-            if (i < NPP)
-                *reinterpret_cast<float4*>(pat + i * 4) =
-                    sk[it] ? make_float4(v0[it], v1[it], v2[it], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    __syncthreads();
-
-    // ---- stage 1: conv0.0 + BN + ReLU on the haloed tile -> LDS (lane group g supplies input channel g) ----
-    {
-        float sc[4], sh[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { sc[r] = scale0[(4 * g + r) & 15]; sh[r] = shift0[(4 * g + r) & 15]; }
-#pragma unroll 1
-        for (int tile = wv; tile < NT0; tile += 4) {
-            const int p = tile * 16 + j, pc = p < NPX ? p : NPX - 1;
-            const int ly = pc / IW, lx = pc - ly * IW;
-            const float* pb = pat + (ly * PW + lx) * 4 + g;
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], pb[((t / 3) * PW + (t % 3)) * 4], acc, 0, 0, 0);
-            const int gy = oy0 - 1 + ly, gx = ox0 - 1 + lx;
-            const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            if (p < NPX && g < 2) {
-                float4 o;
-                o.x = inside ? relu1(acc[0] * sc[0] + sh[0]) : 0.f;
-                o.y = inside ? relu1(acc[1] * sc[1] + sh[1]) : 0.f;
-                o.z = inside ? relu1(acc[2] * sc[2] + sh[2]) : 0.f;
-                o.w = inside ? relu1(acc[3] * sc[3] + sh[3]) : 0.f;
-                *reinterpret_cast<float4*>(til + p * 8 + 4 * g) = o;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- stage 2: conv0.1 (8 -> 8) from the LDS tile ----
-    f32x4 acc[CTW];
-#pragma unroll
-    for (int c = 0; c < CTW; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int kh = t / 3, kw = t - kh * 3;
-        float bv[CTW][2];
-#pragma unroll
-        for (int c = 0; c < CTW; ++c) {
-            const int ct = wv * CTW + c, tr = ct >> 1, tc = ct & 1;
-            const float2 tq = *reinterpret_cast<const float2*>(til + ((tr + kh) * IW + tc * 16 + j + kw) * 8 + g * 2);
-            bv[c][0] = tq.x; bv[c][1] = tq.y;
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int c = 0; c < CTW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t][r], bv[c][r], acc[c], 0, 0, 0);
-    }
-    // ---- epilogue: BN + ReLU, channels-last store (cout = 8) ----
-    if (g < 2) {
-        const int ch0 = 4 * g;
-#pragma unroll
-        for (int c = 0; c < CTW; ++c) {
-            const int ct = wv * CTW + c, tr = ct >> 1, tc = ct & 1;
-            const int oy = oy0 + tr, ox = ox0 + tc * 16 + j;
-            if (oy >= H || ox >= W) continue;
-            const long long o = ((long long)n * H + oy) * W + ox;
-            *reinterpret_cast<float4*>(out + o * 8 + ch0) =
-                make_float4(relu1(acc[c][0] * scale1[ch0] + shift1[ch0]), relu1(acc[c][1] * scale1[ch0 + 1] + shift1[ch0 + 1]),
-                            relu1(acc[c][2] * scale1[ch0 + 2] + shift1[ch0 + 2]), relu1(acc[c][3] * scale1[ch0 + 3] + shift1[ch0 + 3]));
-        }
-    }
-}
-
+// (rounds 1-2 ran both layers on 16x16x4 MFMAs — k_conv0_fused — and rounds 3-4 on the batched 4x4x1 instruction with the weights
+// re-laid-out in LDS per block — k_conv0_fused_b4; both forms left the source in round 6: tools/patches/r06_pruned_conv2d_variants.diff)
+//
 // The same two layers on the batched 4x4x1 matrix instruction (see conv3d_b4.hip): both have Cout = 8, i.e. half of every
 // 16x16x4 tile multiplied zeros (and conv0.0's 3 input channels were padded to a 4-wide k-step).  LANE = PIXEL: a lane
 // feeds its own pixel's input value and receives its own pixel's four output channels; two instructions per input channel
@@ -505,146 +363,6 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const float* __restrict__ w
 // re-laid-out from the 16x16x4 operand images the library already packs (no new pack kernel): per (tap, quad, half) one
 // broadcast float4 per lane (row i = lane & 3).  198 + 288 16x16x4 MFMAs (15.5 k matrix cycles per block) become
 // 324 + 576 4x4x1 MFMAs (8.5 k).
-__global__ __launch_bounds__(256) void k_conv0_fused_b4(const float* __restrict__ w0, const float* __restrict__ scale0,
-                                                        const float* __restrict__ shift0, const float* __restrict__ w1,
-                                                        const float* __restrict__ scale1, const float* __restrict__ shift1,
-                                                        const float* __restrict__ img, float* __restrict__ out, int N, int H,
-                                                        int W, int tiles_y, int tiles_x) {
-    constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, NPX = IH * IW;      // conv0.1 input tile (10 x 34)
-    constexpr int PH = IH + 2, PW = IW + 2, NPP = PH * PW;                        // image patch (12 x 36)
-    ENERF_DYN_SMEM(float, lds);
-    float* pat = lds;                   // [NPP] float4 image texels (4th channel 0)
-    float* til = pat + NPP * 4;         // [2 quads][NPX] float4: conv0.0 output planes
-    float* wl0 = til + 2 * NPX * 4;     // [9 taps][2 halves][4 rows][4: c0 c1 c2 0]
-    float* wl1 = wl0 + 9 * 32;          // [9 taps][2 quads][2 halves][4 rows][4 channels of the quad]
-
-    const int tid = threadIdx.x, lane = tid & 63, li = tid & 3, wv = tid >> 6;
-    const int bid = (int)xcd_contiguous(blockIdx.x, gridDim.x);
-    const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
-    const int oy0 = ty * TH, ox0 = tx * TW;
-
-    // ---- weights: 16x16x4 operand images -> [row i][k] float4s (W0[o][c][t] = w0[t*64 + c*16 + o]; W1[o][2g+r][t] =
-    //      w1[(2t + r)*64 + g*16 + o], conv2d.hip k_conv2d_pack) ----
-    {   // (all loads first, then the LDS stores: as a plain loop this was load -> vmcnt(0) -> store, four serial L2 round trips)
-        constexpr int NWI = (9 * 32 + 9 * 64 + 255) / 256;
-        float wv[NWI];
-#pragma unroll
-        for (int it = 0; it < NWI; ++it) {
-            const int i = tid + it * 256, ic = i < 9 * 32 + 9 * 64 ? i : 9 * 32 + 9 * 64 - 1;
-            const float* src;
-            bool zero = false;
-            if (ic < 9 * 32) {
-                const int r = ic & 3, row = (ic >> 2) & 3, half = (ic >> 4) & 1, t = ic >> 5;
-                zero = r >= 3;
-                src = w0 + t * 64 + (r < 3 ? r : 0) * 16 + 4 * half + row;
-            } else {
-                const int k = ic - 9 * 32, r = k & 3, row = (k >> 2) & 3, half = (k >> 4) & 1, q = (k >> 5) & 1, t = k >> 6;
-                const int ch = 4 * q + r;
-                src = w1 + (t * 2 + (ch & 1)) * 64 + (ch >> 1) * 16 + 4 * half + row;
-            }
-            const float v = *src;
-            wv[it] = zero ? 0.f : v;
-        }
-#pragma unroll
-        for (int it = 0; it < NWI; ++it) {
-            const int i = tid + it * 256;
-            if (i < 9 * 32 + 9 * 64) wl0[i] = wv[it];              // wl1 follows wl0 contiguously
-        }
-    }
-    {   // ---- image patch -> LDS: one thread per patch pixel, three coalesced plane reads, zero outside ----
-        constexpr int NIT = (NPP + 255) / 256;
-        float v0[NIT], v1[NIT], v2[NIT];
-        bool sk[NIT];
-        const float* base = img + (long long)n * 3 * H * W;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256, ic = i < NPP ? i : NPP - 1;
-            const int ly = ic / PW, lx = ic - ly * PW, gy = oy0 - 2 + ly, gx = ox0 - 2 + lx;
-            sk[it] = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const int off = sk[it] ? gy * W + gx : 0;
-            v0[it] = base[off]; v1[it] = base[H * W + off]; v2[it] = base[2 * H * W + off];
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256;
-            if (i < NPP)
-                *reinterpret_cast<float4*>(pat + i * 4) =
-                    sk[it] ? make_float4(v0[it], v1[it], v2[it], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    __syncthreads();
-
-    // ---- stage 1: conv0.0 + BN + ReLU for the haloed tile, lane = haloed pixel (flat order) -> LDS planes ----
-#pragma unroll 1
-    for (int base = wv * 64; base < NPX; base += 256) {                    // wave-uniform
-        const int p = base + lane, pc = p < NPX ? p : NPX - 1;
-        const int ly = pc / IW, lx = pc - ly * IW;
-        const float* pb = pat + (ly * PW + lx) * 4;
-        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const float4 tex = *reinterpret_cast<const float4*>(pb + ((t / 3) * PW + (t % 3)) * 4);
-            const float4 A0 = *reinterpret_cast<const float4*>(wl0 + (t * 2 + 0) * 16 + li * 4);
-            const float4 A1 = *reinterpret_cast<const float4*>(wl0 + (t * 2 + 1) * 16 + li * 4);
-            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.x, tex.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.x, tex.x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.y, tex.y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.y, tex.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.z, tex.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.z, tex.z, acc1, 0, 0, 0);
-        }
-        const int gy = oy0 - 1 + ly, gx = ox0 - 1 + lx;
-        const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        if (p < NPX) {
-            float4 o0, o1;
-            o0.x = inside ? relu1(acc0[0] * scale0[0] + shift0[0]) : 0.f; o0.y = inside ? relu1(acc0[1] * scale0[1] + shift0[1]) : 0.f;
-            o0.z = inside ? relu1(acc0[2] * scale0[2] + shift0[2]) : 0.f; o0.w = inside ? relu1(acc0[3] * scale0[3] + shift0[3]) : 0.f;
-            o1.x = inside ? relu1(acc1[0] * scale0[4] + shift0[4]) : 0.f; o1.y = inside ? relu1(acc1[1] * scale0[5] + shift0[5]) : 0.f;
-            o1.z = inside ? relu1(acc1[2] * scale0[6] + shift0[6]) : 0.f; o1.w = inside ? relu1(acc1[3] * scale0[7] + shift0[7]) : 0.f;
-            *reinterpret_cast<float4*>(til + p * 4) = o0;
-            *reinterpret_cast<float4*>(til + (NPX + p) * 4) = o1;
-        }
-    }
-    __syncthreads();
-
-    // ---- stage 2: conv0.1 (8 -> 8), lane = output pixel; service group k of a wave = 16 consecutive pixels of one row ----
-    const int m = lane & 31;
-    const bool g1 = (m >= 4 && m < 12) || (m >= 16 && m < 20) || m >= 28;
-    const int pos = g1 ? (m < 12 ? m - 4 : m < 20 ? m - 8 : m - 16) : (m < 4 ? m : m < 16 ? m - 8 : m - 12);
-    const int kgrp = 2 * (lane >> 5) + (g1 ? 1 : 0);
-    const int row = 2 * wv + (kgrp >> 1), col = (kgrp & 1) * 16 + pos;
-    const float* tb = til + (row * IW + col) * 4;
-    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int off = ((t / 3) * IW + (t % 3)) * 4;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float4 bb = *reinterpret_cast<const float4*>(tb + q * NPX * 4 + off);
-            const float4 A0 = *reinterpret_cast<const float4*>(wl1 + ((t * 2 + q) * 2 + 0) * 16 + li * 4);
-            const float4 A1 = *reinterpret_cast<const float4*>(wl1 + ((t * 2 + q) * 2 + 1) * 16 + li * 4);
-            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.x, bb.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.x, bb.x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.y, bb.y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.y, bb.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.z, bb.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.z, bb.z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.w, bb.w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.w, bb.w, acc1, 0, 0, 0);
-        }
-    }
-    // ---- epilogue: BN + ReLU, channels-last store (cout = 8: 32 contiguous bytes per pixel) ----
-    const int oy = oy0 + row, ox = ox0 + col;
-    if (oy >= H || ox >= W) return;
-    const long long o = ((long long)n * H + oy) * W + ox;
-    *reinterpret_cast<float4*>(out + o * 8) =
-        make_float4(relu1(acc0[0] * scale1[0] + shift1[0]), relu1(acc0[1] * scale1[1] + shift1[1]),
-                    relu1(acc0[2] * scale1[2] + shift1[2]), relu1(acc0[3] * scale1[3] + shift1[3]));
-    *reinterpret_cast<float4*>(out + o * 8 + 4) =
-        make_float4(relu1(acc1[0] * scale1[4] + shift1[4]), relu1(acc1[1] * scale1[5] + shift1[5]),
-                    relu1(acc1[2] * scale1[6] + shift1[6]), relu1(acc1[3] * scale1[7] + shift1[7]));
-}
-
 // Round 5: the same two layers with their weights in REGISTERS (A-operand broadcast, common.h mfma4_bc): 54 + 144 weight columns =
 // 4 + 9 VGPRs, loaded with 13 coalesced loads from images packed once (k_conv2d_cb_pack).  The per-block re-layout of both
 // layers' weights into LDS (four gather loads + stores per thread, in front of the first barrier) and two of the three
@@ -771,34 +489,16 @@ __global__ __launch_bounds__(256) void k_conv0_fused_cb(const float* __restrict_
                     relu1(acc1[2] * scale1[6] + shift1[6]), relu1(acc1[3] * scale1[7] + shift1[7]));
 }
 
-#ifndef ENERF_CONV0_B4
-#define ENERF_CONV0_B4 1
-#endif
-#ifndef ENERF_CONV0_CB
-#define ENERF_CONV0_CB 1            // 1: k_conv0_fused_cb (weights in registers); 0: k_conv0_fused_b4
-#endif
 bool launch_conv0_fused(const Conv2dDesc& L0, const Conv2dDesc& L1, const float* w_cb0, const float* w_cb1, const float* img,
                         float* out, int N, int H, int W, hipStream_t st, const PrepJob* job) {
     const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
-    if (ENERF_CONV0_CB && ENERF_CONV0_B4 && w_cb0 != nullptr && w_cb1 != nullptr) {
-        const size_t shmem = (size_t)(12 * 36 * 4 + 2 * 10 * 34 * 4) * sizeof(float);
-        PrepJob none;
-        memset(&none, 0, sizeof(none));
-        const PrepJob& J = job != nullptr ? *job : none;
-        ENERF_LAUNCH(k_conv0_fused_cb, (unsigned)(N * tiles_y * tiles_x + J.nblocks), 256, shmem, st, w_cb0, L0.scale, L0.shift, w_cb1,
-                     L1.scale, L1.shift, img, out, N, H, W, tiles_y, tiles_x, J);
-        return job != nullptr;
-    }
-    if (ENERF_CONV0_B4) {
-        const size_t shmem = (size_t)(12 * 36 * 4 + 2 * 10 * 34 * 4 + 9 * 32 + 9 * 64) * sizeof(float);
-        ENERF_LAUNCH(k_conv0_fused_b4, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, L0.w, L0.scale, L0.shift, L1.w,
-                     L1.scale, L1.shift, img, out, N, H, W, tiles_y, tiles_x);
-        return false;
-    }
-    const size_t shmem = (size_t)(12 * 36 * 4 + 10 * 34 * 8) * sizeof(float);
-    ENERF_LAUNCH(k_conv0_fused, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, L0.w, L0.scale, L0.shift, L1.w, L1.scale,
-                 L1.shift, img, out, N, H, W, tiles_y, tiles_x);
-    return false;
+    const size_t shmem = (size_t)(12 * 36 * 4 + 2 * 10 * 34 * 4) * sizeof(float);
+    PrepJob none;
+    memset(&none, 0, sizeof(none));
+    const PrepJob& J = job != nullptr ? *job : none;
+    ENERF_LAUNCH(k_conv0_fused_cb, (unsigned)(N * tiles_y * tiles_x + J.nblocks), 256, shmem, st, w_cb0, L0.scale, L0.shift, w_cb1,
+                 L1.scale, L1.shift, img, out, N, H, W, tiles_y, tiles_x, J);
+    return job != nullptr;
 }
 
 // =====================================================================================================
@@ -810,398 +510,16 @@ bool launch_conv0_fused(const Conv2dDesc& L0, const Conv2dDesc& L1, const float*
 // and then runs the 3x3 32->8 convolution on the matrix cores exactly like k_conv2d (same packed weights,
 // same texel-mode epilogue).  HBM traffic per frame drops by ~290 MB and one launch disappears.
 // =====================================================================================================
-// PK (tap packing, as conv3d_pk8.hip): Cout = 8 uses half of the 16 MFMA rows, so each (kh, k-step) issues
-//   P: rows 0-7 = W[kw=0], rows 8-15 = W[kw=2]      Q: rows 0-7 = W[kw=1]
-// on the SAME B operand (the tile pixel at column position p); a product in column p belongs to output x = p+1
-// (kw=0), p (kw=1) or p-1 (kw=2), recombined after the K loop with two lane permutes per register.  A 16-column
-// tile then yields 14 outputs, the block tile is 8 x 28: 24 instead of 36 MFMAs per column tile and pass.
-template <bool PK>
-__global__ __launch_bounds__(256, 3) void k_smooth0_fused(   // 47 KB LDS -> 3 blocks/CU
-    const float* __restrict__ wpk, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, const float* __restrict__ c0,
-                                                       const float* __restrict__ f1pre, const float* __restrict__ lat_w,
-                                                       const float* __restrict__ lat_b, float* __restrict__ out,
-                                                       const float* __restrict__ rgb_src, int out_stride, int N, int H,
-                                                       int W, int tiles_y, int tiles_x) {
-    constexpr int TH = 8, TW = PK ? 28 : 32, K = 3, IH = TH + 2, IW = TW + 2, NPX = IH * IW;   // 10 x 34 (30) halo tile
-    constexpr int OW = PK ? 14 : 16;                                                    // outputs per column tile
-    constexpr int PH = 7, PW = 20, NPP = PH * PW;                                       // f1pre patch (half res)
-    constexpr int TS = 20;                                                              // tile row stride (16 ch + 4 pad)
-    constexpr int CTW = 4, KS = 8;
-    ENERF_DYN_SMEM(float, lds);
-    float* c0t = lds;                       // [NPX][8]
-    float* pat = c0t + NPX * 8;             // [NPP][16]   (channels of the current pass)
-    float* til = pat + NPP * 16;            // [NPX][TS]
-    float* lwt = til + NPX * TS;            // lat0 weight (32x8) + bias (32), staged once
-
-    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
-    const int bid = (int)xcd_contiguous(blockIdx.x, gridDim.x);
-    const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
-    const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 - 1, ix0 = ox0 - 1;
-    const int H1 = H / 2, W1 = W / 2;
-    const float sy = ac_scale(H1, H), sx = ac_scale(W1, W);
-    const int py0 = (int)(sy * (float)max(iy0, 0)), px0 = (int)(sx * (float)max(ix0, 0));   // patch origin (= lerp i0 of the first row/col)
-
-    for (int i = threadIdx.x; i < 288; i += 256) lwt[i] = i < 256 ? lat_w[i] : lat_b[i - 256];
-    // ---- c0 tile -> LDS (zero outside the image) ----
-    for (int i = threadIdx.x; i < NPX * 2; i += 256) {
-        const int px = i >> 1, q = i & 1, ly = px / IW, lx = px - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
-        const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const long long off = ok ? ((long long)n * H + gy) * W + gx : 0;
-        const float4 v = *reinterpret_cast<const float4*>(c0 + off * 8 + q * 4);
-        *reinterpret_cast<float4*>(c0t + i * 4) = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-
-    f32x4 acc[CTW], accP[PK ? CTW : 1];      // PK: acc = Q (kw=1), accP = P (kw=0 | kw=2)
-#pragma unroll
-    for (int c = 0; c < CTW; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < (PK ? CTW : 1); ++c) accP[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* wl = wpk + lane;            // PK: the P/Q image [((kh*8 + ks)*2 + pq)*64 + lane]
-
-#pragma unroll 1
-    for (int cb = 0; cb < 2; ++cb) {
-        // weights of the 3x3 conv for this pass, requested first (latency hides behind the tile build)
-        float aq[PK ? 6 : 9][4];              // PK: [kh*2 + pq][r]
-        if (PK) {
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    aq[kh * 2 + 0][r] = wl[((kh * KS + cb * 4 + r) * 2 + 0) * 64];
-                    aq[kh * 2 + 1][r] = wl[((kh * KS + cb * 4 + r) * 2 + 1) * 64];
-                }
-        } else {
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) aq[tap][r] = wl[((long long)tap * KS + cb * 4 + r) * 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (cb > 0) __syncthreads();          // previous pass done with pat/til
-        // ---- f1pre patch (16 channels of this pass) -> LDS ----
-        for (int i = threadIdx.x; i < NPP * 4; i += 256) {
-            const int pp = i >> 2, q = i & 3, pr = pp / PW, pc = pp - pr * PW;
-            const int gy = min(py0 + pr, H1 - 1), gx = min(px0 + pc, W1 - 1);
-            *reinterpret_cast<float4*>(pat + i * 4) =
-                *reinterpret_cast<const float4*>(f1pre + (((long long)n * H1 + gy) * W1 + gx) * 32 + cb * 16 + q * 4);
-        }
-        __syncthreads();
-        // ---- build the FPN-sum tile: item = 16 pixels x the pass's 16 channels, one per wave at a time ----
-        // lat0 (nn.Conv2d(8,32,1)) runs on the matrix cores: rows = the pass's 16 output channels, k = the 8 conv0 channels
-        // (two k-steps), columns = 16 tile pixels; lane (g, j) then holds channels 4g..4g+3 of pixel j — exactly the float4 it
-        // stores — and adds its own four bilinear blends.  (As 32 lane-local FMAs per (pixel, quad) item this was more
-        // than half of the build phase's VALU work, and the VALU does not overlap the MFMAs of the other waves.)
-        {
-            const float2 a_lat = *reinterpret_cast<const float2*>(lwt + (cb * 16 + j) * 8 + 2 * g);   // A: row j, k = channel 2g + r
-            const float4 bias4 = *reinterpret_cast<const float4*>(lwt + 256 + cb * 16 + 4 * g);
-            constexpr int NT16 = (NPX + 15) / 16;
-#pragma unroll 1
-            for (int t = wv; t < NT16; t += 4) {
-                const int px = t * 16 + j, pxc = px < NPX ? px : NPX - 1;
-                const int ly = pxc / IW, lx = pxc - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
-                const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
-                const float2 cv = *reinterpret_cast<const float2*>(c0t + pxc * 8 + 2 * g);           // B: k = channel 2g + r of pixel j
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat.x, cv.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat.y, cv.y, acc, 0, 0, 0);
-                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (inside) {
-                    const Lerp1 vy = ac_lerp(gy, sy, H1), vx = ac_lerp(gx, sx, W1);
-                    const float* p00 = pat + ((vy.i0 - py0) * PW + (vx.i0 - px0)) * 16 + g * 4;
-                    const float* p01 = pat + ((vy.i0 - py0) * PW + (vx.i1 - px0)) * 16 + g * 4;
-                    const float* p10 = pat + ((vy.i1 - py0) * PW + (vx.i0 - px0)) * 16 + g * 4;
-                    const float* p11 = pat + ((vy.i1 - py0) * PW + (vx.i1 - px0)) * 16 + g * 4;
-                    const float4 u00 = *reinterpret_cast<const float4*>(p00), u01 = *reinterpret_cast<const float4*>(p01);
-                    const float4 u10 = *reinterpret_cast<const float4*>(p10), u11 = *reinterpret_cast<const float4*>(p11);
-                    o.x = ac_blend(vy, vx, u00.x, u01.x, u10.x, u11.x) + (acc[0] + bias4.x);
-                    o.y = ac_blend(vy, vx, u00.y, u01.y, u10.y, u11.y) + (acc[1] + bias4.y);
-                    o.z = ac_blend(vy, vx, u00.z, u01.z, u10.z, u11.z) + (acc[2] + bias4.z);
-                    o.w = ac_blend(vy, vx, u00.w, u01.w, u10.w, u11.w) + (acc[3] + bias4.w);
-                }
-                if (px < NPX) *reinterpret_cast<float4*>(til + px * TS + g * 4) = o;
-            }
-        }
-        __syncthreads();
-        // ---- 3x3 conv, 16 input channels of this pass, on the matrix cores ----
-        if (PK) {
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                float bv[CTW][4];
-#pragma unroll
-                for (int c = 0; c < CTW; ++c) {
-                    const int ct = wv * CTW + c, tr = ct >> 1, tc = ct & 1;
-                    const float4 tq = *reinterpret_cast<const float4*>(til + ((tr + kh) * IW + tc * OW + j) * TS + g * 4);
-                    bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < CTW; ++c) {
-                        accP[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[kh * 2 + 0][r], bv[c][r], accP[c], 0, 0, 0);
-                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[kh * 2 + 1][r], bv[c][r], acc[c], 0, 0, 0);
-                    }
-            }
-        } else {
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int kh = tap / 3, kw = tap - kh * 3;
-                float bv[CTW][4];
-#pragma unroll
-                for (int c = 0; c < CTW; ++c) {
-                    const int ct = wv * CTW + c, tr = ct >> 1, tc = ct & 1;
-                    const float4 tq = *reinterpret_cast<const float4*>(til + ((tr + kh) * IW + tc * 16 + j + kw) * TS + g * 4);
-                    bv[c][0] = tq.x; bv[c][1] = tq.y; bv[c][2] = tq.z; bv[c][3] = tq.w;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < CTW; ++c)
-                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[tap][r], bv[c][r], acc[c], 0, 0, 0);
-            }
-        }
-    }
-
-    // ---- epilogue: bias, channels-last / texel store (cout = 8) ----
-#pragma unroll
-    for (int c = 0; c < CTW; ++c) {
-        float y[4];
-        if (PK) {     // out[x] = Q[x] + P.lo[x-1] + P.hi[x+1]: lanes (g, j-1) and (g+2, j+1); every lane takes part in the permutes
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                y[r] = acc[c][r] + __shfl(accP[c][r], lane - 1) + __shfl(accP[c][r], lane + 33);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) y[r] = acc[c][r];
-        }
-        const int ct = wv * CTW + c, tr = ct >> 1, tc = ct & 1;
-        const int oy = oy0 + tr, ox = PK ? ox0 + tc * OW + j - 1 : ox0 + tc * 16 + j;
-        if (oy >= H || ox >= W || (PK && (j < 1 || j > OW))) continue;
-        const long long o = ((long long)n * H + oy) * W + ox;
-        const int ch0 = 4 * g;
-        if (ch0 == 8 && rgb_src != nullptr) {
-            const float* sp = rgb_src + (long long)n * 3 * H * W + (long long)oy * W + ox;
-            *reinterpret_cast<float4*>(out + o * out_stride + 8) =
-                make_float4(sp[0] * 0.5f + 0.5f, sp[(long long)H * W] * 0.5f + 0.5f, sp[2LL * H * W] * 0.5f + 0.5f, 0.f);
-        }
-        if (ch0 >= 8) continue;
-        *reinterpret_cast<float4*>(out + o * out_stride + ch0) =
-            make_float4(y[0] * scale[ch0] + shift[ch0], y[1] * scale[ch0 + 1] + shift[ch0 + 1],
-                        y[2] * scale[ch0 + 2] + shift[ch0 + 2], y[3] * scale[ch0 + 3] + shift[ch0 + 3]);
-    }
-}
-
-// P/Q weight image of a 3x3 Cout=8 layer for the PK variant: packed[((kh*KS + ks)*2 + pq)*64 + lane], lane = (g, i):
-// P: i < 8 -> W[i][ci][kh][0], i >= 8 -> W[i-8][ci][kh][2];  Q: i < 8 -> W[i][ci][kh][1], else 0;  ci = 16(ks/4) + 4g + ks%4
-__global__ __launch_bounds__(256) void k_conv2d_pq_pack(const float* __restrict__ w, int cin, float* __restrict__ packed) {
-    const int KS = cin / 4, total = 3 * KS * 2 * 64;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int lane = i & 63, pq = (i >> 6) & 1, q = i >> 7, ks = q % KS, kh = q / KS;
-    const int g = lane >> 4, row = lane & 15, ci = (ks / 4) * 16 + 4 * g + (ks & 3);
-    float v = 0.f;
-    if (pq == 0) v = w[(((row & 7) * cin + ci) * 3 + kh) * 3 + (row < 8 ? 0 : 2)];
-    else if (row < 8) v = w[((row * cin + ci) * 3 + kh) * 3 + 1];
-    packed[i] = v;
-}
-void launch_conv2d_pq_pack(const float* w, int cin, float* packed, hipStream_t st) {
-    const int total = 3 * (cin / 4) * 2 * 64;
-    ENERF_LAUNCH_SIMPLE(k_conv2d_pq_pack, (unsigned)cdiv(total, 256), 256, 0, st, w, cin, packed);
-}
-
+// (rounds 1-2: k_smooth0_fused, the convolution on 16x16x4 MFMAs, plain or tap-packed; left the source in round 6 with its P/Q weight
+// image: tools/patches/r06_pruned_conv2d_variants.diff.  enerf_options_t.featnet_smooth0_plain now selects the two unfused launches.)
+//
 // The same fusion with the 3x3 32 -> 8 convolution on the batched 4x4x1 matrix instruction (conv3d_b4.hip's idea): lane =
 // output pixel, two instructions per input channel cover the 8 outputs, so nothing of the 16x16x4 tile's 16 rows is wasted
 // (the tap-packed variant above still wastes a third) and the tile is a full 8 x 32.  The FPN-sum tile lives in LDS as
 // [channel quad][pixel] float4 planes (the build phase's D layout stores straight into them), every ds_read_b128 service
 // group reads 16 consecutive pixels of a row, and the pass's weights are re-laid-out in LDS from the plain 16x16x4 operand
 // image (W[o][16cb + 4q + r][t] = w[((8t + 4cb + r)*64 + 16q + o], k_conv2d_pack) as broadcast float4s.
-__global__ __launch_bounds__(256, 3) void k_smooth0_b4(const float* __restrict__ w, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, const float* __restrict__ c0,
-                                                       const float* __restrict__ f1pre, const float* __restrict__ lat_w,
-                                                       const float* __restrict__ lat_b, float* __restrict__ out,
-                                                       const float* __restrict__ rgb_src, int out_stride, int N, int H,
-                                                       int W, int tiles_y, int tiles_x) {
-    constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, NPX = IH * IW;             // 10 x 34 halo tile
-    constexpr int PH = 7, PW = 20, NPP = PH * PW;                                       // f1pre patch (half res)
-    ENERF_DYN_SMEM(float, lds);
-    float* c0t = lds;                       // [NPX][8]
-    float* pat = c0t + NPX * 8;             // [NPP][16]   (channels of the current pass)
-    float* til = pat + NPP * 16;            // [4 quads][NPX] float4 planes (16 channels of the current pass)
-    float* lwt = til + 4 * NPX * 4;         // lat0 weight (32x8) + bias (32), staged once
-    float* wl = lwt + 288;                  // [9 taps][4 quads][2 halves][4 rows][4]: the pass's smooth0 weights
-    float* tabs = wl + 9 * 4 * 32;          // bilinear tables of the x2 align-corners upsample: 10 tile rows + 34 tile columns,
-                                            // {patch offset of i0, of i1 (floats; < 0: outside the image), l0, l1} each
-
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, j = lane & 15, wv = tid >> 6, li = tid & 3;
-    const int bid = (int)xcd_contiguous(blockIdx.x, gridDim.x);
-    const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
-    const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 - 1, ix0 = ox0 - 1;
-    const int H1 = H / 2, W1 = W / 2;
-    const float sy = ac_scale(H1, H), sx = ac_scale(W1, W);
-    const int py0 = (int)(sy * (float)max(iy0, 0)), px0 = (int)(sx * (float)max(ix0, 0));   // patch origin (= lerp i0 of the first row/col)
-
-    {   // ---- lat0 weights + the c0 tile -> LDS (zero outside the image).  ALL loads are issued before the first LDS store:
-        // written as `for (i = tid; ...) lds[i] = global[...]` hipcc emits load -> s_waitcnt vmcnt(0) -> store per iteration,
-        // i.e. one exposed L2/HBM round trip per iteration and thread (the staging loops of this kernel were ~12 us of
-        // serial latency per block) ----
-        constexpr int NC0 = (NPX * 2 + 255) / 256;
-        float4 cv[NC0];
-        bool ck[NC0];
-        const float lw0 = lat_w[tid], lw1 = tid < 32 ? lat_b[tid] : 0.f;
-#pragma unroll
-        for (int it = 0; it < NC0; ++it) {
-            const int i = tid + it * 256, ic = i < NPX * 2 ? i : NPX * 2 - 1;
-            const int px = ic >> 1, q = ic & 1, ly = px / IW, lx = px - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
-            ck[it] = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const long long off = ck[it] ? ((long long)n * H + gy) * W + gx : 0;
-            cv[it] = *reinterpret_cast<const float4*>(c0 + off * 8 + q * 4);
-        }
-        lwt[tid] = lw0;
-        if (tid < 32) lwt[256 + tid] = lw1;
-#pragma unroll
-        for (int it = 0; it < NC0; ++it) {
-            const int i = tid + it * 256;
-            if (i < NPX * 2) *reinterpret_cast<float4*>(c0t + i * 4) = ck[it] ? cv[it] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    if (tid < IH + IW) {
-        // The upsample's source rows / columns and weights depend on the tile row / column only: computed ONCE per block here
-        // (each build-loop iteration of each pass redid both ac_lerp's, the divisions and four pointer computations per lane —
-        // the build phase's VALU work equalled the convolution's matrix time, and the two do not overlap on a SIMD).
-        const bool isrow = tid < IH;
-        const int k = isrow ? tid : tid - IH, gq = (isrow ? iy0 : ix0) + k, lim = isrow ? H : W;
-        const Lerp1 v = ac_lerp(min(max(gq, 0), lim - 1), isrow ? sy : sx, isrow ? H1 : W1);
-        const int unit = isrow ? PW * 16 : 16, org = isrow ? py0 : px0;
-        const bool ok = gq >= 0 && gq < lim;
-        float4 e;
-        e.x = __int_as_float(ok ? (v.i0 - org) * unit : -1);
-        e.y = __int_as_float(ok ? (v.i1 - org) * unit : -1);
-        e.z = v.l0; e.w = v.l1;
-        *reinterpret_cast<float4*>(tabs + tid * 4) = e;
-    }
-    // stage-2 lane -> pixel map: service group k of a wave = 16 consecutive pixels of one tile row
-    const int m = lane & 31;
-    const bool g1 = (m >= 4 && m < 12) || (m >= 16 && m < 20) || m >= 28;
-    const int pos = g1 ? (m < 12 ? m - 4 : m < 20 ? m - 8 : m - 16) : (m < 4 ? m : m < 16 ? m - 8 : m - 12);
-    const int kgrp = 2 * (lane >> 5) + (g1 ? 1 : 0);
-    const int row = 2 * wv + (kgrp >> 1), col = (kgrp & 1) * 16 + pos;
-    const float* tb = til + (row * IW + col) * 4;
-    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // The passes' f1pre patches (16 channels each) and conv weights: loads first, LDS stores after the barrier that ends the
-    // previous pass.  (ext-vector registers: as float4 arrays hipcc kept the staged values in SCRATCH — 64 B per lane, 188 MB of
-    // scratch traffic per launch, found through WRITE_SIZE in the PMC pass.)
-    constexpr int NPF = (NPP * 4 + 255) / 256, NWF = (9 * 4 * 2 * 4 + 255) / 256;
-    auto load_pass = [&](int cb, f32x4 (&pv)[NPF], f32x4 (&wv4)[NWF]) {
-#pragma unroll
-        for (int it = 0; it < NPF; ++it) {
-            const int i = tid + it * 256, ic = i < NPP * 4 ? i : NPP * 4 - 1;
-            const int pp = ic >> 2, q = ic & 3, pr = pp / PW, pc = pp - pr * PW;
-            const int gy = min(py0 + pr, H1 - 1), gx = min(px0 + pc, W1 - 1);
-            pv[it] = *reinterpret_cast<const f32x4*>(f1pre + (((long long)n * H1 + gy) * W1 + gx) * 32 + cb * 16 + q * 4);
-        }
-        // weights: wl[((t*4 + q)*2 + half)*16 + rw*4 + r] = w[(t*8 + cb*4 + r)*64 + q*16 + 4*half + rw]: the source is contiguous
-        // in rw, so one float4 load per (t, q, half, r) and four scalar LDS stores
-#pragma unroll
-        for (int it = 0; it < NWF; ++it) {
-            const int i = tid + it * 256, ic = i < 288 ? i : 287;
-            const int r = ic & 3, half = (ic >> 2) & 1, q = (ic >> 3) & 3, t = ic >> 5;
-            wv4[it] = *reinterpret_cast<const f32x4*>(w + ((t * 8 + cb * 4 + r) * 64) + q * 16 + 4 * half);
-        }
-    };
-#ifndef ENERF_S0_HOIST
-#define ENERF_S0_HOIST 0             // 1: both passes' loads issued before the first pass (20 more live registers)
-#endif
-    f32x4 pvs[2][NPF], wvs[2][NWF];
-    if (ENERF_S0_HOIST) { load_pass(0, pvs[0], wvs[0]); load_pass(1, pvs[1], wvs[1]); }
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        if (!ENERF_S0_HOIST) load_pass(cb, pvs[cb], wvs[cb]);
-        f32x4 (&pv)[NPF] = pvs[cb];
-        f32x4 (&wv4)[NWF] = wvs[cb];
-        if (cb > 0) __syncthreads();          // previous pass done with pat / til / wl
-#pragma unroll
-        for (int it = 0; it < NPF; ++it) {
-            const int i = tid + it * 256;
-            if (i < NPP * 4) *reinterpret_cast<f32x4*>(pat + i * 4) = pv[it];
-        }
-#pragma unroll
-        for (int it = 0; it < NWF; ++it) {
-            const int i = tid + it * 256;
-            if (i < 288) {
-                const int r = i & 3, half = (i >> 2) & 1, q = (i >> 3) & 3, t = i >> 5;
-                float* d = wl + ((t * 4 + q) * 2 + half) * 16 + r;
-                d[0] = wv4[it][0]; d[4] = wv4[it][1]; d[8] = wv4[it][2]; d[12] = wv4[it][3];
-            }
-        }
-        __syncthreads();
-        // ---- build the FPN-sum tile (lat0 on the matrix cores, see k_smooth0_fused) into the quad planes ----
-        {
-            const float2 a_lat = *reinterpret_cast<const float2*>(lwt + (cb * 16 + j) * 8 + 2 * g);
-            const float4 bias4 = *reinterpret_cast<const float4*>(lwt + 256 + cb * 16 + 4 * g);
-            constexpr int NT16 = (NPX + 15) / 16;
-#pragma unroll 1
-            for (int t = wv; t < NT16; t += 4) {
-                const int px = t * 16 + j, pxc = px < NPX ? px : NPX - 1;
-                const int ly = (pxc * 241) >> 13, lx = pxc - ly * IW;                    // pxc / 34 for pxc < 340
-                const float4 rt = *reinterpret_cast<const float4*>(tabs + ly * 4);
-                const float4 ct = *reinterpret_cast<const float4*>(tabs + (IH + lx) * 4);
-                const int ro0 = __float_as_int(rt.x), ro1 = __float_as_int(rt.y), co0 = __float_as_int(ct.x), co1 = __float_as_int(ct.y);
-                const bool inside = (ro0 | co0) >= 0;
-                const float2 cv = *reinterpret_cast<const float2*>(c0t + pxc * 8 + 2 * g);
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat.x, cv.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat.y, cv.y, acc, 0, 0, 0);
-                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (inside) {
-                    Lerp1 vy, vx;
-                    vy.l0 = rt.z; vy.l1 = rt.w; vx.l0 = ct.z; vx.l1 = ct.w; vy.i0 = vy.i1 = vx.i0 = vx.i1 = 0;
-                    const float* pb = pat + g * 4;
-                    const float4 u00 = *reinterpret_cast<const float4*>(pb + ro0 + co0), u01 = *reinterpret_cast<const float4*>(pb + ro0 + co1);
-                    const float4 u10 = *reinterpret_cast<const float4*>(pb + ro1 + co0), u11 = *reinterpret_cast<const float4*>(pb + ro1 + co1);
-                    o.x = ac_blend(vy, vx, u00.x, u01.x, u10.x, u11.x) + (acc[0] + bias4.x);
-                    o.y = ac_blend(vy, vx, u00.y, u01.y, u10.y, u11.y) + (acc[1] + bias4.y);
-                    o.z = ac_blend(vy, vx, u00.z, u01.z, u10.z, u11.z) + (acc[2] + bias4.z);
-                    o.w = ac_blend(vy, vx, u00.w, u01.w, u10.w, u11.w) + (acc[3] + bias4.w);
-                }
-                if (px < NPX) *reinterpret_cast<float4*>(til + (g * NPX + px) * 4) = o;
-            }
-        }
-        __syncthreads();
-        // ---- 3x3 conv over the pass's 16 channels: 9 taps x 4 quads x 4 channels x 2 halves of 4x4x1 MFMAs ----
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int off = ((t / 3) * IW + (t % 3)) * 4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bb = *reinterpret_cast<const float4*>(tb + q * NPX * 4 + off);
-                const float4 A0 = *reinterpret_cast<const float4*>(wl + ((t * 4 + q) * 2 + 0) * 16 + li * 4);
-                const float4 A1 = *reinterpret_cast<const float4*>(wl + ((t * 4 + q) * 2 + 1) * 16 + li * 4);
-                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.x, bb.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.x, bb.x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.y, bb.y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.y, bb.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.z, bb.z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.z, bb.z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A0.w, bb.w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1.w, bb.w, acc1, 0, 0, 0);
-            }
-        }
-    }
-    // ---- epilogue: bias, channels-last / texel store (cout = 8): a pixel's 8 features (+ rgb texel) from its own lane ----
-    const int oy = oy0 + row, ox = ox0 + col;
-    if (oy >= H || ox >= W) return;
-    const long long o = ((long long)n * H + oy) * W + ox;
-    *reinterpret_cast<float4*>(out + o * out_stride) =
-        make_float4(acc0[0] * scale[0] + shift[0], acc0[1] * scale[1] + shift[1], acc0[2] * scale[2] + shift[2], acc0[3] * scale[3] + shift[3]);
-    *reinterpret_cast<float4*>(out + o * out_stride + 4) =
-        make_float4(acc1[0] * scale[4] + shift[4], acc1[1] * scale[5] + shift[5], acc1[2] * scale[6] + shift[6], acc1[3] * scale[7] + shift[7]);
-    if (rgb_src != nullptr) {
-        const float* sp = rgb_src + (long long)n * 3 * H * W + (long long)oy * W + ox;
-        *reinterpret_cast<float4*>(out + o * out_stride + 8) =
-            make_float4(sp[0] * 0.5f + 0.5f, sp[(long long)H * W] * 0.5f + 0.5f, sp[2LL * H * W] * 0.5f + 0.5f, 0.f);
-    }
-}
+// (k_smooth0_b4 — this form with the pass's weights re-laid-out in LDS — was rounds 3-4's kernel: tools/patches/r06_pruned_conv2d_variants.diff)
 
 // ---- round 5: the same fusion with the weights in REGISTERS (A-operand broadcast, common.h mfma4_bc) -------------------------
 // k_smooth0_b4's three co-resident blocks per CU spent half of the CU's LDS cycles (PMC r04: LDS busy 0.51, matrix pipe 0.38)
@@ -1334,14 +652,8 @@ __global__ __launch_bounds__(256, ENERF_S0_CB_BLOCKS) void k_smooth0_cb(
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat[cb].x, cvr[it].x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat[cb].y, cvr[it].y, acc, 0, 0, 0);
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#if defined(ENERF_ABL_S0) && (ENERF_ABL_S0 & 1)                          // timing ablation: no upsample blend (no patch reads)
-                if (inside) { o.x = acc[0] + bias4[cb].x; o.y = acc[1] + bias4[cb].y; o.z = acc[2] + bias4[cb].z; o.w = acc[3] + bias4[cb].w; }
-                if (false) {
-                    Lerp1 vy, vx;
-#else
                 if (inside) {
                     Lerp1 vy, vx;
-#endif
                     vy.l0 = rt.z; vy.l1 = rt.w; vx.l0 = ct.z; vx.l1 = ct.w; vy.i0 = vy.i1 = vx.i0 = vx.i1 = 0;
                     const float* pb = pat + g * 4;
                     const float4 u00 = *reinterpret_cast<const float4*>(pb + ro0 + co0), u01 = *reinterpret_cast<const float4*>(pb + ro0 + co1);
@@ -1365,11 +677,7 @@ __global__ __launch_bounds__(256, ENERF_S0_CB_BLOCKS) void k_smooth0_cb(
         float4 bq[2];
         bq[0] = *reinterpret_cast<const float4*>(tb);
 #pragma unroll
-#if defined(ENERF_ABL_S0) && (ENERF_ABL_S0 & 2)                                  // timing ablation: one tap of nine
-        for (int tq = 0; tq < 4; ++tq) {
-#else
         for (int tq = 0; tq < 36; ++tq) {
-#endif
             if (tq + 1 < 36) {
                 const int t1 = (tq + 1) >> 2, q1 = (tq + 1) & 3;
                 bq[(tq + 1) & 1] = *reinterpret_cast<const float4*>(tb + q1 * NPX * 4 + ((t1 / 3) * IW + (t1 % 3)) * 4);
@@ -1392,9 +700,6 @@ __global__ __launch_bounds__(256, ENERF_S0_CB_BLOCKS) void k_smooth0_cb(
     // ---- epilogue: bias, channels-last / texel store (cout = 8): a pixel's 8 features (+ rgb texel) from its own lane ----
     const int oy = oy0 + row, ox = ox0 + col;
     if (oy >= H || ox >= W) return;
-#if defined(ENERF_ABL_S0) && (ENERF_ABL_S0 & 4)                                  // timing ablation: no output stores
-    if (acc0[0] != 12345.678f) return;
-#endif
     const long long o = ((long long)n * H + oy) * W + ox;
     *reinterpret_cast<float4*>(out + o * out_stride) =
         make_float4(acc0[0] * scale[0] + shift[0], acc0[1] * scale[1] + shift[1], acc0[2] * scale[2] + shift[2], acc0[3] * scale[3] + shift[3]);
@@ -1418,218 +723,8 @@ __global__ __launch_bounds__(256, ENERF_S0_CB_BLOCKS) void k_smooth0_cb(
 // kernel consumes it).  One launch and the halo'd read-back of f1pre go away.  Structure = k_smooth0_cb's.
 // lat_w / sm_w: the layers' ordinary operand images (k_conv2d_pack): lat1 [ks 0..3][rt 0..1][64], smooth1 [tap][ks 0..7][64].
 // =====================================================================================================================
-// ---- round 5, second step: k_smooth0_cb as a PERSISTENT, tile-pipelined kernel ------------------------------------------------
-// Timing ablations of k_smooth0_cb (profiles/r05_smooth0_ablation.txt; zju): conv MFMAs 116-131 us (at the instruction's rate),
-// stores 24, blend 18 — and a 98 us "skeleton" that is left with all three removed: the per-block prologue (36 weight registers
-// re-loaded by each of 16,384 blocks' four waves, the lanes' conv0 values, the patch copy) and five barriers per tile with nothing
-// in flight across them.  Here a block walks SEVERAL tiles (grid = co-resident blocks; tile t -> block t mod grid): the weights, the
-// lat0 operands and the epilogue constants are loaded ONCE, and the next tile's inputs — its conv0 values (registers), its pass-0
-// patch (LDS-DMA into the patch buffer, which is free after pass 1's build) and its upsample tables (second table buffer) — are
-// requested right after the current tile's last build phase, so they land during its pass-1 MFMAs and stores.
-// Same arithmetic and order as k_smooth0_cb: bit-identical outputs.
-#ifndef ENERF_S0_CBP_BLOCKS
-#define ENERF_S0_CBP_BLOCKS 4        // (at 5 blocks per CU = 96 registers the tile loop's double set of inputs spills)
-#endif
-__global__ __launch_bounds__(256, ENERF_S0_CBP_BLOCKS) void k_smooth0_cbp(
-    const float* __restrict__ wcb, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ c0,
-    const float* __restrict__ f1pre, const float* __restrict__ lat_w, const float* __restrict__ lat_b, float* __restrict__ out,
-    const float* __restrict__ rgb_src, int out_stride, int N, int H, int W, int tiles_y, int tiles_x) {
-    constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, NPX = IH * IW;
-    constexpr int PH = 7, PW = 20, NPP = PH * PW;
-    constexpr int NPCH = (NPP * 4 + 63) / 64, NPK = (NPCH + 3) / 4;
-    constexpr int NT16 = (NPX + 15) / 16, NBI = (NT16 + 3) / 4;
-    ENERF_DYN_SMEM(float, lds);
-    float* pat = lds;                       // [NPCH * 64] float4: patch of the current pass (DMA destination)
-    float* til = pat + NPCH * 256;          // [4 quads][NPX] float4 planes
-    float* tabs2 = til + 4 * NPX * 4;       // two upsample-table buffers (tile parity)
-
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, j = lane & 15;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int H1 = H / 2, W1 = W / 2;
-    const float sy = ac_scale(H1, H), sx = ac_scale(W1, W);
-    const int ntiles = N * tiles_y * tiles_x;
-
-    // ---- once per block ----
-    float wr[2][18];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int r = 0; r < 18; ++r) wr[cb][r] = wcb[(cb * 18 + r) * 64 + lane];
-    float2 a_lat[2];
-    float4 bias4[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        a_lat[cb] = *reinterpret_cast<const float2*>(lat_w + (cb * 16 + j) * 8 + 2 * g);
-        bias4[cb] = *reinterpret_cast<const float4*>(lat_b + cb * 16 + 4 * g);
-    }
-    // stage-2 lane -> pixel map (as k_smooth0_cb)
-    const int m = lane & 31;
-    const bool g1 = (m >= 4 && m < 12) || (m >= 16 && m < 20) || m >= 28;
-    const int pos = g1 ? (m < 12 ? m - 4 : m < 20 ? m - 8 : m - 16) : (m < 4 ? m : m < 16 ? m - 8 : m - 12);
-    const int kgrp = 2 * (lane >> 5) + (g1 ? 1 : 0);
-    const int row = 2 * wv + (kgrp >> 1), col = (kgrp & 1) * 16 + pos;
-    const float* tb = til + (row * IW + col) * 4;
-
-    struct TilePos { int n, oy0, ox0; };
-    auto tile_pos = [&](int t) {
-        const int bid = (int)xcd_contiguous((unsigned)t, (unsigned)ntiles);     // the same tile order as the per-tile kernels
-        TilePos p;
-        const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y;
-        p.n = bid / (tiles_x * tiles_y);
-        p.oy0 = ty * TH; p.ox0 = tx * TW;
-        return p;
-    };
-    unsigned psrc[NPK];
-    // a tile's inputs: conv0 values -> registers, patch sources, pass-0 patch copy, upsample tables (buffer = tile parity)
-    auto request_tile = [&](const TilePos& pp_, float2 (&cv)[NBI], float* tabs) {
-        struct { int n, iy0, ix0, py0, px0; } p;
-        p.n = pp_.n; p.iy0 = pp_.oy0 - 1; p.ix0 = pp_.ox0 - 1;
-        p.py0 = (int)(sy * (float)max(p.iy0, 0)); p.px0 = (int)(sx * (float)max(p.ix0, 0));
-        int jq = j, gq_ = g, lq = lane;                              // opaque per call: see the tile loop
-        ENERF_OPAQUE_V(jq);
-        ENERF_OPAQUE_V(gq_);
-        ENERF_OPAQUE_V(lq);
-#pragma unroll
-        for (int it = 0; it < NBI; ++it) {
-            const int t = wv + 4 * it;
-            cv[it] = make_float2(0.f, 0.f);
-            if (t < NT16) {
-                const int px = t * 16 + jq, pxc = px < NPX ? px : NPX - 1;
-                const int ly = (pxc * 241) >> 13, lx = pxc - ly * IW, gy = p.iy0 + ly, gx = p.ix0 + lx;
-                const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-                const long long off = ok ? ((long long)p.n * H + gy) * W + gx : 0;
-                const float2 v = *reinterpret_cast<const float2*>(c0 + off * 8 + 2 * gq_);
-                cv[it] = ok ? v : make_float2(0.f, 0.f);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NPK; ++k) {
-            const int i = (wv + 4 * k) * 64 + lq, ic = i < NPP * 4 ? i : NPP * 4 - 1;
-            const int pp = ic >> 2, q = ic & 3, pr = pp / PW, pc = pp - pr * PW;
-            const int gy = min(p.py0 + pr, H1 - 1), gx = min(p.px0 + pc, W1 - 1);
-            psrc[k] = (unsigned)((((long long)p.n * H1 + gy) * W1 + gx) * 32 + q * 4);
-        }
-#pragma unroll
-        for (int k = 0; k < NPK; ++k)
-            if (wv + 4 * k < NPCH) glds16(f1pre + psrc[k], pat + (wv + 4 * k) * 256, lane);
-        if (tid < IH + IW) {
-            const bool isrow = tid < IH;
-            const int k = isrow ? tid : tid - IH, gq = (isrow ? p.iy0 : p.ix0) + k, lim = isrow ? H : W;
-            const Lerp1 v = ac_lerp(min(max(gq, 0), lim - 1), isrow ? sy : sx, isrow ? H1 : W1);
-            const int unit = isrow ? PW * 16 : 16, org = isrow ? p.py0 : p.px0;
-            const bool ok = gq >= 0 && gq < lim;
-            float4 e;
-            e.x = __int_as_float(ok ? (v.i0 - org) * unit : -1);
-            e.y = __int_as_float(ok ? (v.i1 - org) * unit : -1);
-            e.z = v.l0; e.w = v.l1;
-            *reinterpret_cast<float4*>(tabs + tid * 4) = e;
-        }
-    };
-
-    int t = blockIdx.x;
-    if (t >= ntiles) return;
-    TilePos P = tile_pos(t);
-    float2 cvr[NBI], cvn[NBI];
-    request_tile(P, cvr, tabs2);
-    int par = 0;
-#pragma unroll 1
-    for (; t < ntiles; t += gridDim.x) {
-        const float* tabs = tabs2 + par * (IH + IW) * 4;
-        const int tn = t + (int)gridDim.x;
-        TilePos Pn = P;
-        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-        // (the build items' pixel geometry does not depend on the tile: hipcc hoists all of it out of this loop — ~40 registers that
-        //  live across the whole kernel: 166 VGPRs — unless the lane coordinates are opaque per iteration)
-        int jv = j, gv = g;
-        ENERF_OPAQUE_V(jv);
-        ENERF_OPAQUE_V(gv);
-        glds_wait_all();                                              // this tile's pass-0 patch (and conv0 values) have landed
-        __syncthreads();                                              // ... everyone's; the tables are visible; the previous tile's conv is over
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-#pragma unroll
-            for (int it = 0; it < NBI; ++it) {
-                const int tt = wv + 4 * it;
-                if (tt < NT16) {
-                    const int px = tt * 16 + jv, pxc = px < NPX ? px : NPX - 1;
-                    const int ly = (pxc * 241) >> 13, lx = pxc - ly * IW;
-                    const float4 rt = *reinterpret_cast<const float4*>(tabs + ly * 4);
-                    const float4 ct = *reinterpret_cast<const float4*>(tabs + (IH + lx) * 4);
-                    const int ro0 = __float_as_int(rt.x), ro1 = __float_as_int(rt.y), co0 = __float_as_int(ct.x), co1 = __float_as_int(ct.y);
-                    const bool inside = (ro0 | co0) >= 0;
-                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat[cb].x, cvr[it].x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lat[cb].y, cvr[it].y, acc, 0, 0, 0);
-                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (inside) {
-                        Lerp1 vy, vx;
-                        vy.l0 = rt.z; vy.l1 = rt.w; vx.l0 = ct.z; vx.l1 = ct.w; vy.i0 = vy.i1 = vx.i0 = vx.i1 = 0;
-                        const float* pb = pat + gv * 4;
-                        const float4 u00 = *reinterpret_cast<const float4*>(pb + ro0 + co0), u01 = *reinterpret_cast<const float4*>(pb + ro0 + co1);
-                        const float4 u10 = *reinterpret_cast<const float4*>(pb + ro1 + co0), u11 = *reinterpret_cast<const float4*>(pb + ro1 + co1);
-                        o.x = ac_blend(vy, vx, u00.x, u01.x, u10.x, u11.x) + (acc[0] + bias4[cb].x);
-                        o.y = ac_blend(vy, vx, u00.y, u01.y, u10.y, u11.y) + (acc[1] + bias4[cb].y);
-                        o.z = ac_blend(vy, vx, u00.z, u01.z, u10.z, u11.z) + (acc[2] + bias4[cb].z);
-                        o.w = ac_blend(vy, vx, u00.w, u01.w, u10.w, u11.w) + (acc[3] + bias4[cb].w);
-                    }
-                    if (px < NPX) *reinterpret_cast<float4*>(til + (gv * NPX + px) * 4) = o;
-                }
-            }
-            __syncthreads();                                          // tile complete; nobody reads the patch any more
-            if (cb == 0) {                                            // pass 1's patch travels during pass 0's MFMAs
-#pragma unroll
-                for (int k = 0; k < NPK; ++k)
-                    if (wv + 4 * k < NPCH) glds16(f1pre + psrc[k] + 16, pat + (wv + 4 * k) * 256, lane);
-            } else if (tn < ntiles) {                                 // the NEXT tile's inputs travel during pass 1's MFMAs + the stores
-                Pn = tile_pos(tn);
-                request_tile(Pn, cvn, tabs2 + (par ^ 1) * (IH + IW) * 4);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            float4 bq[2];
-            bq[0] = *reinterpret_cast<const float4*>(tb);
-#pragma unroll
-            for (int tq = 0; tq < 36; ++tq) {
-                if (tq + 1 < 36) {
-                    const int t1 = (tq + 1) >> 2, q1 = (tq + 1) & 3;
-                    bq[(tq + 1) & 1] = *reinterpret_cast<const float4*>(tb + q1 * NPX * 4 + ((t1 / 3) * IW + (t1 % 3)) * 4);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const float4 bb = bq[tq & 1];
-                const float a = wr[cb][tq >> 1];
-                const int kb = (tq & 1) * 8;
-                acc0 = mfma4_bc(a, bb.x, acc0, kb + 0); acc1 = mfma4_bc(a, bb.x, acc1, kb + 1);
-                acc0 = mfma4_bc(a, bb.y, acc0, kb + 2); acc1 = mfma4_bc(a, bb.y, acc1, kb + 3);
-                acc0 = mfma4_bc(a, bb.z, acc0, kb + 4); acc1 = mfma4_bc(a, bb.z, acc1, kb + 5);
-                acc0 = mfma4_bc(a, bb.w, acc0, kb + 6); acc1 = mfma4_bc(a, bb.w, acc1, kb + 7);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (cb == 0) {
-                glds_wait_all();
-                __syncthreads();
-            }
-        }
-        // ---- epilogue of this tile ----
-        const int oy = P.oy0 + row, ox = P.ox0 + col;
-        if (oy < H && ox < W) {
-            const long long o = ((long long)P.n * H + oy) * W + ox;
-            *reinterpret_cast<float4*>(out + o * out_stride) =
-                make_float4(acc0[0] * scale[0] + shift[0], acc0[1] * scale[1] + shift[1], acc0[2] * scale[2] + shift[2], acc0[3] * scale[3] + shift[3]);
-            *reinterpret_cast<float4*>(out + o * out_stride + 4) =
-                make_float4(acc1[0] * scale[4] + shift[4], acc1[1] * scale[5] + shift[5], acc1[2] * scale[6] + shift[6], acc1[3] * scale[7] + shift[7]);
-            if (rgb_src != nullptr) {
-                const float* sp = rgb_src + (long long)P.n * 3 * H * W + (long long)oy * W + ox;
-                *reinterpret_cast<float4*>(out + o * out_stride + 8) =
-                    make_float4(sp[0] * 0.5f + 0.5f, sp[(long long)H * W] * 0.5f + 0.5f, sp[2LL * H * W] * 0.5f + 0.5f, 0.f);
-            }
-        }
-        // next tile: its conv0 values were loaded into cvn, its patch / tables are in flight or landed
-#pragma unroll
-        for (int it = 0; it < NBI; ++it) cvr[it] = cvn[it];
-        P = Pn;
-        par ^= 1;
-    }
-}
-
+// (k_smooth0_cbp — k_smooth0_cb as a persistent, tile-pipelined kernel — measured NOT faster alone (round 5, profiles/r05_smooth0_ablation.txt) and, with a
+// capped grid as a side-lane kernel, slower in the frame (round 6, profiles/r06_ab_smooth0_persistent_capped.txt): tools/patches/r06_pruned_conv2d_variants.diff)
 #ifndef ENERF_S1F_BLOCKS
 #define ENERF_S1F_BLOCKS 4
 #endif
@@ -1815,51 +910,13 @@ bool launch_smooth1_fused(const Conv2dDesc& Llat, const Conv2dDesc& Lsm, const f
     return true;
 }
 
-#ifndef ENERF_SMOOTH0_B4
-#define ENERF_SMOOTH0_B4 1
-#endif
-#ifndef ENERF_SMOOTH0_CB
-#define ENERF_SMOOTH0_CB 1           // 1: k_smooth0_cb (weights in registers through the A-operand broadcast); 0: k_smooth0_b4
-#endif
 void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1pre, const float* lat_w, const float* lat_b,
-                          const float* w_pq, const float* w_cb, float* out, int N, int H, int W, hipStream_t st) {
+                          const float* w_cb, float* out, int N, int H, int W, hipStream_t st) {
     const int out_stride = L.out_stride > 0 ? L.out_stride : 8;
-#ifndef ENERF_S0_PERSIST
-#define ENERF_S0_PERSIST 0           // 1: k_smooth0_cbp (persistent blocks, the next tile's inputs in flight: measured NOT faster, profiles/r05_smooth0_ablation.txt); 0: one tile per block
-#endif
-    if (ENERF_S0_PERSIST && ENERF_SMOOTH0_CB && ENERF_SMOOTH0_B4 && w_pq != nullptr && w_cb != nullptr) {
-        const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
-        const long long ntiles = (long long)N * tiles_y * tiles_x, resident = (long long)device_cu_count() * ENERF_S0_CBP_BLOCKS;
-        const size_t shmem = (size_t)(9 * 256 + 4 * 340 * 4 + 2 * 44 * 4) * sizeof(float);
-        ENERF_LAUNCH(k_smooth0_cbp, (unsigned)(ntiles < resident ? ntiles : resident), 256, shmem, st, w_cb, L.scale, L.shift, c0, f1pre,
-                     lat_w, lat_b, out, L.rgb_src, out_stride, N, H, W, tiles_y, tiles_x);
-        return;
-    }
-    if (ENERF_SMOOTH0_CB && ENERF_SMOOTH0_B4 && w_pq != nullptr && w_cb != nullptr) {   // round 5, first step: weights in registers
-        const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
-        const size_t shmem = (size_t)(9 * 256 + 4 * 340 * 4 + 44 * 4) * sizeof(float);
-        ENERF_LAUNCH(k_smooth0_cb, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, w_cb, L.scale, L.shift, c0, f1pre, lat_w,
-                     lat_b, out, L.rgb_src, out_stride, N, H, W, tiles_y, tiles_x);
-        return;
-    }
-    if (ENERF_SMOOTH0_B4 && w_pq != nullptr) {                         // round 3/4: batched-4x4 convolution, weights through LDS
-        const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
-        const size_t shmem = (size_t)(340 * 8 + 140 * 16 + 4 * 340 * 4 + 288 + 9 * 4 * 32 + 44 * 4) * sizeof(float);
-        ENERF_LAUNCH(k_smooth0_b4, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, L.w, L.scale, L.shift, c0, f1pre, lat_w,
-                     lat_b, out, L.rgb_src, out_stride, N, H, W, tiles_y, tiles_x);
-        return;
-    }
-    if (w_pq != nullptr) {                                             // tap-packed 8x28 tiles (nullptr: plain 8x32)
-        const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 28);
-        const size_t shmem = (size_t)(300 * 8 + 140 * 16 + 300 * 20 + 288) * sizeof(float);
-        ENERF_LAUNCH(k_smooth0_fused<true>, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, w_pq, L.scale, L.shift, c0,
-                     f1pre, lat_w, lat_b, out, L.rgb_src, out_stride, N, H, W, tiles_y, tiles_x);
-        return;
-    }
     const int tiles_y = cdiv(H, 8), tiles_x = cdiv(W, 32);
-    const size_t shmem = (size_t)(340 * 8 + 140 * 16 + 340 * 20 + 288) * sizeof(float);
-    ENERF_LAUNCH(k_smooth0_fused<false>, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, L.w, L.scale, L.shift, c0, f1pre,
-                 lat_w, lat_b, out, L.rgb_src, out_stride, N, H, W, tiles_y, tiles_x);
+    const size_t shmem = (size_t)(9 * 256 + 4 * 340 * 4 + 44 * 4) * sizeof(float);
+    ENERF_LAUNCH(k_smooth0_cb, (unsigned)(N * tiles_y * tiles_x), 256, shmem, st, w_cb, L.scale, L.shift, c0, f1pre, lat_w,
+                 lat_b, out, L.rgb_src, out_stride, N, H, W, tiles_y, tiles_x);
 }
 
 // The eleven FeatureNet layers use exactly these shapes (feature_net.py:7-22).
@@ -1869,12 +926,8 @@ int launch_conv2d(const Conv2dDesc& L, const float* in, float* out, const float*
     // 4-row tiles for the 3x3 layers whose 8-row tiling gives fewer than ~4 blocks per CU (quarter/half-resolution maps;
     // measured: smooth1 33.5 -> 30.0 us, conv2.1 18.0 -> 17.1, conv1.1 17.9 -> 17.2).
     const bool th4 = (long long)N * cdiv(Hi, 8) * cdiv(Wi, 32) < 1024;
-#ifndef ENERF_C2_TH2
-#define ENERF_C2_TH2 0               // 1: 2-row tiles for the quarter-resolution layers when 4-row tiles give < 2 blocks per CU (measured SLOWER: conv2.0 24.5 -> 29.1 us, conv2.1 16.7 -> 19.6, profiles/r05_ab_conv2d_planar.txt)
-#endif
-    // conv2.0 / conv2.1 at dtu: 61,440 output pixels = 480 four-row tiles for 256 CUs (< 2 waves per SIMD: a latency chain)
-    const bool th2_s2 = ENERF_C2_TH2 && (long long)N * cdiv((Hi + 1) / 2, 4) * cdiv((Wi + 1) / 2, 32) < 512;   // stride-2 layers: output extent
-    const bool th2 = ENERF_C2_TH2 && (long long)N * cdiv(Hi, 4) * cdiv(Wi, 32) < 512;
+    // (2-row tiles for conv2.0 / conv2.1 at dtu — 480 four-row tiles for 256 CUs — measured SLOWER: 24.5 -> 29.1 / 16.7 -> 19.6 us,
+    // profiles/r05_ab_conv2d_planar.txt)
     switch (key) {
         case 3 * 10000 + 8 * 100 + 31: launch_c2<4, 1, 3, 1, 8, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;     // conv0.0
         case 8 * 10000 + 8 * 100 + 31: launch_c2<8, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st); return 0;    // conv0.1
@@ -1884,12 +937,10 @@ int launch_conv2d(const Conv2dDesc& L, const float* in, float* out, const float*
             else launch_c2<16, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             return 0;
         case 16 * 10000 + 32 * 100 + 52:                                                                                   // conv2.0
-            if (th2_s2) launch_c2<16, 2, 5, 2, 2, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
-            else launch_c2<16, 2, 5, 2, 4, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
+            launch_c2<16, 2, 5, 2, 4, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             return 0;
         case 32 * 10000 + 32 * 100 + 31:                                                                                   // conv2.1 (+ toplayer)
-            if (L.chain_w != nullptr && th2) launch_c2<32, 2, 3, 1, 2, false, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
-            else if (L.chain_w != nullptr && th4) launch_c2<32, 2, 3, 1, 4, false, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
+            if (L.chain_w != nullptr && th4) launch_c2<32, 2, 3, 1, 4, false, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             else if (L.chain_w != nullptr) launch_c2<32, 2, 3, 1, 8, false, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             else launch_c2<32, 2, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             return 0;

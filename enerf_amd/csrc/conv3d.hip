@@ -290,36 +290,11 @@ __global__ __launch_bounds__(KIND == kConvT2 ? 512 : (SPLIT * 64 > 256 ? SPLIT *
         // the transposed layers (1-8 taps per parity class: the ring only adds redundant clamped loads) and no
         // better for the small stride-1 layers, which keep depth 2.  Depth is capped by registers.
         constexpr int REGS_PER_TAP = CT * NB * 4 + NA;
-#ifndef ENERF_C3_UPFRONT
-#define ENERF_C3_UPFRONT 0           // register budget of an up-front operand window for the tap-split layers; 0 (default): the two-deep ring
-#endif
-        if constexpr (SPLIT > 1 && ENERF_C3_UPFRONT > 0) {
-            // Round 5 ("request all tap operands of a wave up front"): built, measured, NOT the default
-            // (profiles/r05_ab_b4c_conv3d_upfront.txt).  A wave requests the operands of all of its 9 taps (budget 160: 9 of 9 for
-            // Cin <= 32, 5 of 9 for Cin = 64; budget 96: 6 / 3) before the first MFMA and refills a slot right after its tap has
-            // issued.  conv4 (32 -> 32) 11.0 -> 13.4 us (budget 160) / 11.8 (96), conv3 7.9 -> 8.1, conv5 8.2 -> 8.1 / 7.6, conv6
-            // 12.0 -> 11.8 / 11.4; zju conv4 12.5 -> 15.7 / 13.6.  The two-deep ring already covers the round trips with the other
-            // waves of the SIMD; what these layers pay is the ~90 vector-memory instructions a wave issues for 72 MFMAs (every
-            // wave re-reads its 18 KB of weights from L1/L2: the address path, not the latency), and 160 registers cost waves.
-            constexpr int NT = 27 / SPLIT;
-            constexpr int UPW = ENERF_C3_UPFRONT / REGS_PER_TAP;
-            constexpr int UP = UPW >= NT ? NT : (UPW < 2 ? 2 : UPW);
-            float4 bq[UP][CT][NB];
-            float aq[UP][NA];
-            const int tbeg = sp * NT;
-#pragma unroll
-            for (int k = 0; k < UP; ++k) issue(tbeg + k, bq[k], aq[k]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                compute(bq[t % UP], aq[t % UP]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (t + UP < NT) {
-                    issue(tbeg + t + UP, bq[t % UP], aq[t % UP]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        } else {
+        // (Round 5, VERDICT r04 #2 "request all tap operands of a wave up front": built as an operand window of 96 / 160 registers, measured, NOT
+        // kept — conv4 11.0 -> 13.4 / 11.8 us, conv3 7.9 -> 8.1, conv5 8.2 -> 8.1 / 7.6, conv6 12.0 -> 11.8 / 11.4: profiles/r05_ab_b4c_conv3d_upfront.txt,
+        // tools/patches/r06_pruned_knobs.diff.  Round 6 measured why (profiles/r06_ab_conv3d_wl.txt): these layers are bound by the BYTES their taps
+        // pull through L2 -> L1 (~8.5 TB/s), not by the round trips of the ring.)
+        {
         constexpr int PF = KIND != kConvS2 ? 2 : (REGS_PER_TAP <= 24 ? 4 : (REGS_PER_TAP <= 40 ? 3 : 2));
         float4 bq[PF][CT][NB];
         float aq[PF][NA];

@@ -282,12 +282,10 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_s1_b4g(const float* __restric
         w_off[k] = tap * NQ * 48 + e * 4;
     }
     auto issue = [&](int cq, float* buf) {
-#if !(defined(ENERF_ABL_B4G) && (ENERF_ABL_B4G & 2))            // ablation: no input staging (weights only)
 #pragma unroll
         for (int k = 0; k < MYCH; ++k)
             if (wv + 4 * k < NCH)                                  // wave-uniform
                 glds16(src_off[k] >= 0 ? inb + src_off[k] + cq * qstride : g_b4_zeros, buf + (wv + 4 * k) * 256, lane);
-#endif
 #pragma unroll
         for (int k = 0; k < MYW; ++k)
             if (wv + 4 * k < NWCH)
@@ -320,11 +318,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3d_s1_b4g(const float* __restric
         float4 aq[2][NS], bq[2][V];
         read_a(0, aq[0]);
         read_b(0, bq[0]);
-#if defined(ENERF_ABL_B4G) && (ENERF_ABL_B4G & 1)               // ablation (tools/build_variant.py): 9 of the 27 taps
-        constexpr int NTAP = 9;
-#else
         constexpr int NTAP = 27;
-#endif
 #pragma unroll
         for (int tap = 0; tap < NTAP; ++tap) {
             if (tap + 1 < NTAP) { read_a(tap + 1, aq[(tap + 1) & 1]); read_b(tap + 1, bq[(tap + 1) & 1]); }
@@ -535,24 +529,8 @@ static void launch_b4g(const Conv3dDesc& L, const float* in, float* out, float* 
     const int nbd = cdiv(D, BD), nbh = cdiv(H, 8), nbw = cdiv(W, 16);
     const unsigned grid = (unsigned)((long long)B * nbd * nbh * nbw);
     const long long cus_ = device_cu_count();
-#ifndef ENERF_B4_BD2
-#define ENERF_B4_BD2 0               // 1: half-depth boxes (2 x 8 x 16) on b4c for every layer; 2: only where they fit the chip in whole rounds of five
-#endif
-    if (BD == 4 && ENERF_B4_BD2 != 0) {
-        // Half-depth boxes: twice the blocks at 24.6 KB of LDS and 88 registers = FIVE co-resident blocks per CU.  dtu level 1 (1280
-        // boxes of depth 4 = 3 + 2 per CU) becomes 2560 = exactly two rounds of five; dtu level 0 (480 = under two per CU) becomes 960
-        // blocks resident at once.  The price: the depth halo (4 planes staged for 2, was 6 for 4).
-        constexpr int NVOX2 = 4 * 10 * 18, NCH2 = (NVOX2 + 63) / 64;
-        const int nbd2 = cdiv(D, 2);
-        const long long grid2 = (long long)B * nbd2 * nbh * nbw;
-        const bool whole = grid2 <= 5 * cus_ || grid2 % (5 * cus_) == 0 || cdivl(grid2, 5 * cus_) * 5 * 2 <= cdivl(grid, 3 * cus_) * 3 * 4 * 2 / 4;
-        if (ENERF_B4_BD2 == 1 || whole) {
-            const size_t shmem_2 = (size_t)2 * (NCH2 + (HEADS ? 1 : 0)) * 64 * 4 * sizeof(float);
-            ENERF_LAUNCH((k_conv3d_s1_b4c<CIN, 2, HEADS>), (unsigned)grid2, 256, shmem_2, st, L.w_b4, L.scale, L.shift, in, out, out2, L.relu,
-                         B, D, H, W, nbd2, nbh, nbw, L.in_planar);
-            return;
-        }
-    }
+    // (half-depth boxes — 2 x 8 x 16 on the register-weight kernel, five co-resident blocks per CU — measured in round 5 and not kept:
+    // tools/patches/r06_pruned_knobs.diff)
     const long long sr4 = cdivl(grid, 4 * cus_) * 4, sr3 = cdivl(grid, 3 * cus_) * 3;
     if (ENERF_B4_CB == 2 || (ENERF_B4_CB == 1 && sr4 <= sr3)) {
         const size_t shmem_c = (size_t)2 * (NCH + (HEADS ? 1 : 0)) * 64 * 4 * sizeof(float);

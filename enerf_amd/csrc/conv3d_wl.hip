@@ -19,9 +19,6 @@
 
 // timing ablations (tools/build_variant.py; outputs are garbage): bit 0 = no weight copy, 1 = no activation loads, 2 = no MFMAs,
 // 3 = no stores, 4 = no XCD-contiguous block order
-#ifndef ENERF_WL_ABL
-#define ENERF_WL_ABL 0
-#endif
 
 namespace enerf {
 
@@ -44,7 +41,7 @@ __global__ __launch_bounds__(CTB * 192) void k_conv3d_wl(const float* __restrict
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int sp = wv % 3, cl = wv / 3;                  // kw of this wave's taps, column tile inside the block
-    const int bid = (ENERF_WL_ABL & 16) ? (int)blockIdx.x : (int)xcd_contiguous(blockIdx.x, gridDim.x);
+    const int bid = (0 & 16) ? (int)blockIdx.x : (int)xcd_contiguous(blockIdx.x, gridDim.x);
     const int grp = bid / rt_total, rt = bid - grp * rt_total;
 
     const int n = B * Do * Ho * Wo;                      // output voxels in raster order (n < 2^31: launcher)
@@ -101,7 +98,7 @@ __global__ __launch_bounds__(CTB * 192) void k_conv3d_wl(const float* __restrict
         for (int i = wv; i < ninstr; i += NW) {
             const int row0 = 4 * i;
             const int kd = kdlo + row0 / (9 * KS);
-            if (((kdmask >> kd) & 1u) && !(ENERF_WL_ABL & 1)) glds16(wsrc + (long long)(kdlo * 9 * KS + row0) * rt_total * 64, wlds + row0 * 64, lane);
+            if (((kdmask >> kd) & 1u) && !(0 & 1)) glds16(wsrc + (long long)(kdlo * 9 * KS + row0) * rt_total * 64, wlds + row0 * 64, lane);
         }
     }
     // ---- every B operand of this wave's (up to) 9 taps: unconditional loads, padding lanes read zeros ----
@@ -114,7 +111,7 @@ __global__ __launch_bounds__(CTB * 192) void k_conv3d_wl(const float* __restrict
         for (int kh = 0; kh < 3; ++kh) {
             const unsigned sel = (1u << kd) | (8u << kh) | (64u << sp);
             const bool ok = (vmask & sel) == sel;
-            const float* p = (ok && !(ENERF_WL_ABL & 2)) ? in + (long long)(vbase + (kd * Hi + kh) * Wi + sp) * CIN + g * 4 : zeros;
+            const float* p = (ok && !(0 & 2)) ? in + (long long)(vbase + (kd * Hi + kh) * Wi + sp) * CIN + g * 4 : zeros;
 #pragma unroll
             for (int cb = 0; cb < NB; ++cb) bq[kd * 3 + kh][cb] = *reinterpret_cast<const float4*>(p + cb * 16);
         }
@@ -147,7 +144,7 @@ __global__ __launch_bounds__(CTB * 192) void k_conv3d_wl(const float* __restrict
             for (int ks = 0; ks < KS; ++ks) {
                 const float4 bv = bq[kd * 3 + kh][ks >> 2];
                 const float b = (ks & 3) == 0 ? bv.x : ((ks & 3) == 1 ? bv.y : ((ks & 3) == 2 ? bv.z : bv.w));
-                if (ENERF_WL_ABL & 4) acc[ks & 3] += aq[kh & 1][ks] * b;
+                if (0 & 4) acc[ks & 3] += aq[kh & 1][ks] * b;
                 else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[kh & 1][ks], b, acc, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -173,7 +170,7 @@ __global__ __launch_bounds__(CTB * 192) void k_conv3d_wl(const float* __restrict
                 if (relu) y[r] = relu1(y[r]);
             }
             const long long o = (long long)(tile * 16 + j);
-            if (!(ENERF_WL_ABL & 8) || y[0] == 12345.678f) *reinterpret_cast<float4*>(out + o * cout + c0) = make_float4(y[0], y[1], y[2], y[3]);
+            if (!(0 & 8) || y[0] == 12345.678f) *reinterpret_cast<float4*>(out + o * cout + c0) = make_float4(y[0], y[1], y[2], y[3]);
         }
     }
 }

@@ -139,14 +139,12 @@ int feature_net_stage_job(const float* packed, const float* src_inps, int n_img,
                           float* feat_l2, int l2_stride, void* workspace, size_t workspace_bytes, int stage,
                           const enerf_options_t* options, hipStream_t stream, const PrepJob* job, int* job_done);
 // smooth0(up2(f1pre) + lat0(c0)) fused (feature_net.py:32-35); L = smooth0's descriptor, lat_w/lat_b raw (32,8)/(32)
-// w_pq: the layer's P/Q tap-packed image (launch_conv2d_pq_pack) or nullptr for the plain 8x32 tiling
 // smooth1(up2(f2) + lat1(c1)) fused (feature_net.py:33-34, round 5): writes f1pre (N,H1,W1,32) and out (N,H1,W1,16); false: not applicable
 bool launch_smooth1_fused(const Conv2dDesc& Llat, const Conv2dDesc& Lsm, const float* c1, const float* f2, float* f1pre, float* out,
                           int N, int H1, int W1, hipStream_t st);
-// w_cb: the layer's broadcast-A image (launch_conv2d_cb_pack; round 5 default kernel) or nullptr
+// w_cb: the layer's broadcast-A image (launch_conv2d_cb_pack)
 void launch_smooth0_fused(const Conv2dDesc& L, const float* c0, const float* f1pre, const float* lat_w, const float* lat_b,
-                          const float* w_pq, const float* w_cb, float* out, int N, int H, int W, hipStream_t st);   // w_pq == nullptr: plain tiling
-void launch_conv2d_pq_pack(const float* w, int cin, float* packed, hipStream_t st);   // 3*(cin/4)*2*64 floats
+                          const float* w_cb, float* out, int N, int H, int W, hipStream_t st);
 // broadcast-A image (common.h mfma4_bc) of input channels ci0 .. ci0+cinp-1 of a 3x3, Cout = 8 layer: ceil(18*cinp/16)*64 floats
 void launch_conv2d_cb_pack(const float* w, int cin, int ci0, int cinp, float* packed, hipStream_t st);
 // texels from channels-last features at the render resolution + resized colours (general case)

@@ -275,17 +275,10 @@ void k_render_rays(RenderArgs a) {
     // Tile order (round 4, profiles/r04_ab_warp_variants_render_xcd_band.txt): XCD k (= block id % 8) renders the k-th eighth of
     // the tile list = an image row band, round-robin over ITS blocks, so the texels its gathers touch stay in its own L2:
     // FETCH_SIZE 241 -> 159 MB per launch at the same kernel time (190.2 vs 190.6 us).  (Round 3's variant — one contiguous run
-    // of tiles per BLOCK — measured ~3 % slower; ENERF_RENDER_XCD_BAND=0 is the plain round-robin order.)
-#ifndef ENERF_RENDER_XCD_BAND
-#define ENERF_RENDER_XCD_BAND 1
-#endif
-#if ENERF_RENDER_XCD_BAND
+    // of tiles per BLOCK — measured ~3 % slower; 1=0 is the plain round-robin order.)
     const long long nbands = gridDim.x < 8 ? gridDim.x : 8;                      // (small launches: fewer blocks than XCDs)
     const long long xcd_ = blockIdx.x % nbands, nb8 = ((long long)gridDim.x + nbands - 1 - xcd_) / nbands, bi_ = blockIdx.x / nbands;
     const long long t_hi = ntiles * (xcd_ + 1) / nbands;
-#ifndef ENERF_RENDER_BALANCE
-#define ENERF_RENDER_BALANCE 1
-#endif
 // The level-0 kernel (R = 9; lego: 2500 tiles for 2048 waves) gains even more ALONE from the balanced deal (266 -> 201 us = 0.50 of
 // the fp32-MFMA peak: a SIMD carries 3 tiles instead of 4).  In the frame it runs FORKED beside level 1; as one persistent block per CU
 // the balanced form held every CU to the end and delayed level 1 (lego 543.9 -> 535.3 frames/s, profiles/r05_ab_render_balance.txt).
@@ -294,7 +287,6 @@ void k_render_rays(RenderArgs a) {
 #ifndef ENERF_RENDER_BALANCE_R9
 #define ENERF_RENDER_BALANCE_R9 1
 #endif
-#if ENERF_RENDER_BALANCE
     // Round 5: the band's PARTIAL last round of tiles is dealt out evenly.  Round-robin, it went to the band's first blocks, 12
     // tiles each: at dtu (2560 tiles per band = 6 full rounds of 32 x 12 + 256) 21 of a band's 32 CUs rendered 84 tiles and 10
     // rendered 72 — the launch ends with the 84s, 5 % above the 80-tile average.  Now every block takes rem / nb8 of them
@@ -309,12 +301,6 @@ void k_render_rays(RenderArgs a) {
     for (long long it = 0; it < n_it; ++it) {
         const long long tile = (it < full || !kBal) ? t_lo + it * per_round + bi_ * WAVES + wave_in_block
                                                     : t_lo + full * per_round + my_rem_lo + wave_in_block;
-#else
-    for (long long tile = ntiles * xcd_ / nbands + bi_ * WAVES + wave_in_block; tile < t_hi; tile += nb8 * WAVES) {
-#endif
-#else
-    for (long long tile = (long long)blockIdx.x * WAVES + wave_in_block; tile < ntiles; tile += (long long)gridDim.x * WAVES) {
-#endif
         long long ray = tile * 16 + j;
         const bool rok = ray < nrays;
         const long long rc = rok ? ray : nrays - 1;
@@ -870,14 +856,8 @@ int launch_render_rays(const RenderArgs& a, hipStream_t st) {
     if (R == 9) {                                                                   // C = 32: one 8-wave block per CU
         const size_t shmem = render_shmem<9, 8>(a);
         if (shmem > 160 * 1024) return -2;
-#ifndef ENERF_R9_GRID_MULT
-#define ENERF_R9_GRID_MULT 1         // > 1: more blocks than CUs (each exits after fewer tiles: a forked level-0 render frees CUs sooner)
-#endif
-#ifndef ENERF_R9_TIGHT_GRID
-#define ENERF_R9_TIGHT_GRID 0        // 1 (with the balanced deal): only as many blocks as give every SIMD the same t = ceil(tiles / SIMDs) tiles
-#endif
-        unsigned grid = grid_for(8, ENERF_R9_GRID_MULT);
-        if (ENERF_R9_TIGHT_GRID && ENERF_RENDER_BALANCE_R9 && ntiles > 0) {
+        unsigned grid = grid_for(8, 1);
+        if (0 && ENERF_RENDER_BALANCE_R9 && ntiles > 0) {
             const long long t = cdivl(ntiles, 4LL * cus), tight = cdivl(ntiles, 4 * t);
             if (tight < (long long)grid) grid = (unsigned)tight;
         }

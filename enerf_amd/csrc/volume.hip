@@ -11,18 +11,8 @@
 // write D*h*w*C*4.  The 4-tap gathers re-read features from L2/MALL, not HBM.
 #include "kernels.h"
 
-#ifndef ENERF_VOL_PK
-#define ENERF_VOL_PK 0               // A/B: packed-fp32 blend + moments
-#endif
-#ifndef ENERF_VOL_BYTEOFF
-#define ENERF_VOL_BYTEOFF 0          // A/B (tools/build_variant.py): 32-bit byte offsets for the tap loads
-#endif
 
 namespace enerf {
-
-#ifndef ENERF_EMU
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-#endif
 
 // The CQ lanes of a voxel share its geometry, so they also share the work: lane q projects the voxel into
 // view s0+q (homography, perspective divide, bilinear taps: ~130 VALU with the IEEE divides the reference
@@ -33,16 +23,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // CONVERGENCE: group_bcast_i runs with bound_ctrl = true, i.e. an INACTIVE source lane yields 0 — all CQ lanes of a group must reach
 // every broadcast together.  They do: dead lanes (beyond the volume) shadow a live voxel instead of exiting (see `live` below), and
 // no broadcast sits under a lane-divergent branch.  (GPU check of the primitives: tools/micro/dpp_primitives.hip.)
-#ifndef ENERF_VOL_DPP
-#define ENERF_VOL_DPP 1
-#endif
-#if ENERF_VOL_DPP
 #define ENERF_VOL_BCAST_I(v, k) group_bcast_i<CQ>((v), (k))
 #define ENERF_VOL_BCAST_F(v, k) group_bcast_f<CQ>((v), (k))
-#else
-#define ENERF_VOL_BCAST_I(v, k) __shfl((v), lead + (k))
-#define ENERF_VOL_BCAST_F(v, k) __shfl((v), lead + (k))
-#endif
 template <int CQ>  // CQ = C/4 lanes per voxel
 __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict__ feat, const float* __restrict__ proj,
                                                         const float* __restrict__ dv, int B, int S, int Hs, int Ws,
@@ -86,9 +68,6 @@ __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict_
     const float inv_half_w = 1.f / (float)((Ws - 1) / 2.0), inv_half_h = 1.f / (float)((Hs - 1) / 2.0);
     const unsigned img = (unsigned)(Hs * Ws * C);      // floats per source view (launcher: B*S*img < 2^32)
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
-#if ENERF_VOL_PK && !defined(ENERF_EMU)
-    f32x2 s1a = {0.f, 0.f}, s1b = {0.f, 0.f}, s2a = {0.f, 0.f}, s2b = {0.f, 0.f};
-#endif
     for (int s0 = 0; s0 < S; s0 += CQ) {
         // ---- this lane's view ----
         const int sv = min(s0 + cq, S - 1);
@@ -114,57 +93,19 @@ __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict_
         const Taps2 t = gs_taps2<false>(gs_unnorm(gx, Ws), gs_unnorm(gy, Hs), Ws, Hs);
         const unsigned vb = (unsigned)(b * S + sv) * img;
         const int r0 = mul24(t.y0, Ws), r1 = mul24(t.y1, Ws);
-#if ENERF_VOL_BYTEOFF    /* 32-bit BYTE offsets: `scalar base + lane offset` loads, no 64-bit address add per tap (launcher: < 2^30 floats) */
-        const int my_o[4] = {(int)((vb + (unsigned)mul24(r0 + t.x0, C)) * 4u), (int)((vb + (unsigned)mul24(r0 + t.x1, C)) * 4u),
-                             (int)((vb + (unsigned)mul24(r1 + t.x0, C)) * 4u), (int)((vb + (unsigned)mul24(r1 + t.x1, C)) * 4u)};
-#else
         const int my_o[4] = {(int)(vb + (unsigned)mul24(r0 + t.x0, C)), (int)(vb + (unsigned)mul24(r0 + t.x1, C)),
                              (int)(vb + (unsigned)mul24(r1 + t.x0, C)), (int)(vb + (unsigned)mul24(r1 + t.x1, C))};
-#endif
         const float my_w[4] = {t.w00, t.w01, t.w10, t.w11};
         // ---- the group's views in turn ----
 #pragma unroll
         for (int k = 0; k < CQ; ++k) {
             if (s0 + k >= S) break;                                          // uniform
-#if ENERF_VOL_PK && !defined(ENERF_EMU)
-            // packed-fp32 form of the blend and the moments (v_pk_mul/fma/add_f32: two channels per instruction)
-            f32x2 ra = {0.f, 0.f}, rb = {0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const unsigned o = (unsigned)ENERF_VOL_BCAST_I(my_o[c], k) + (unsigned)(cq * (ENERF_VOL_BYTEOFF ? 16 : 4));
-                const float wgt = ENERF_VOL_BCAST_F(my_w[c], k);
-#if ENERF_VOL_BYTEOFF
-                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(feat) + o);
-#else
-                const float4 v = *reinterpret_cast<const float4*>(feat + o);
-#endif
-                const f32x2 va = {v.x, v.y}, vb2 = {v.z, v.w}, w2 = {wgt, wgt};
-                if (c == 0) { ra = va * w2; rb = vb2 * w2; }
-                else { ra = __builtin_elementwise_fma(va, w2, ra); rb = __builtin_elementwise_fma(vb2, w2, rb); }
-            }
-            s1a += ra; s1b += rb;
-            s2a = __builtin_elementwise_fma(ra, ra, s2a); s2b = __builtin_elementwise_fma(rb, rb, s2b);
-            continue;
-#endif
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-#if ENERF_VOL_BYTEOFF
-                const unsigned o = (unsigned)ENERF_VOL_BCAST_I(my_o[c], k) + (unsigned)(cq * 16);
-#else
                 const unsigned o = (unsigned)ENERF_VOL_BCAST_I(my_o[c], k) + (unsigned)(cq * 4);
-#endif
                 const float wgt = ENERF_VOL_BCAST_F(my_w[c], k);
-                // ENERF_ABL_VOL: compile-time ablations behind profiles/r03_volume_ablation.txt (never defined in the product build)
-#if defined(ENERF_ABL_VOL) && (ENERF_ABL_VOL & 1)      /* one tap's load stands in for all four (gather traffic / 4) */
-                const float4 v = *reinterpret_cast<const float4*>(feat + ((unsigned)ENERF_VOL_BCAST_I(my_o[0], k) + (unsigned)(cq * 4)));
-#elif defined(ENERF_ABL_VOL) && (ENERF_ABL_VOL & 2)    /* no gathers at all (a lane-dependent constant) */
-                const float4 v = make_float4(wgt, 1.f, 2.f, (float)o);
-#elif ENERF_VOL_BYTEOFF
-                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(feat) + o);
-#else
                 const float4 v = *reinterpret_cast<const float4*>(feat + o);
-#endif
                 if (c == 0) { r.x = v.x * wgt; r.y = v.y * wgt; r.z = v.z * wgt; r.w = v.w * wgt; }
                 else { r.x += v.x * wgt; r.y += v.y * wgt; r.z += v.z * wgt; r.w += v.w * wgt; }
             }
@@ -175,9 +116,6 @@ __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict_
     // utils.py:345 `div_(S)`: with a Python scalar divisor ATen's GPU kernel multiplies by the reciprocal
     // (BinaryDivTrueKernel: is_cpu_scalar -> MulFunctor(1/b)), so this is the reference's device arithmetic;
     // the CPU oracle divides, which differs by <= 1 ulp of the mean.
-#if ENERF_VOL_PK && !defined(ENERF_EMU)
-    s1 = make_float4(s1a.x, s1a.y, s1b.x, s1b.y); s2 = make_float4(s2a.x, s2a.y, s2b.x, s2b.y);
-#endif
     const float inv_s = 1.f / (float)S;
     float4 o;
     float m;
@@ -189,11 +127,7 @@ __global__ __launch_bounds__(256) void k_feature_volume(const float* __restrict_
     // channels-last voxel would give it 16 useful bytes of every 64-128-byte line, re-fetched once per pass)
     const unsigned nvp = (unsigned)(D * h * w);
     const long long oidx = planar ? ((long long)((unsigned)b * CQ + cq) * nvp + (vox - (unsigned)b * nvp)) * 4 : (long long)vox * C + cq * 4;
-#if defined(ENERF_ABL_VOL) && (ENERF_ABL_VOL & 4)      /* (almost) no output writes */
-    if (live && o.x == 12345.678f) *reinterpret_cast<float4*>(vol + oidx) = o;
-#else
     if (live) *reinterpret_cast<float4*>(vol + oidx) = o;
-#endif
 }
 
 // Two depth planes per wave (the default when D is even): the same pixel at two consecutive hypotheses — one set of projection

@@ -43,7 +43,8 @@ typedef struct {
     int conv3d_pk8;                  /* tap-packed Cout=8 kernel: 0 = where it is faster alone (Cin=16, big heads),
                                         1 = never, 2 = every Cout=8(+1) layer (fewest MFMAs: throughput mode) */
     int featnet_unfused;             /* 1: one launch per FeatureNet layer (no conv0/toplayer/lat0 fusions) */
-    int featnet_smooth0_plain;       /* 1: the 16x16x4-MFMA form of the fused smooth0 kernel instead of the batched-4x4 one */
+    int featnet_smooth0_plain;       /* 1: lat0 + smooth0 as the two plain 16x16x4-MFMA launches instead of the fused batched-4x4 kernel
+                                        (ABI >= 10; rounds 2-5: a fused 16x16x4 kernel) */
     int conv3d_b4;                   /* batched 4x4x1-MFMA kernel for the Cout=8(+1) stride-1 3-D layers (conv0, fused heads):
                                         0 = on (default; since ABI 5 the asynchronously staged kernel: global_load_lds, two LDS
                                         buffers, one channel quad per pass, cost volume / conv11 output handed over as

@@ -97,6 +97,30 @@ def _assert_as_close_to_fp64_as_the_reference(dist, noise=None, slack=3.0, what=
     return stats
 
 
+def _assert_stable_parameters_elementwise(named_grads, g32, g64, noise, sparse, tol=3e-4, what=""):
+    """VERDICT r05 #6c.  The fp64 arbitration above is a STATISTICAL bar; where the reference is demonstrably stable it is not
+    needed.  A parameter is 'stable' when the unmodified reference, re-run with its inputs moved by one ulp, stays within 1e-4 of
+    float64 in EVERY draw (tests/golden/train_*_noise.npz) and its pinned fp32 gradient does too.  For those — 30 of 114 at
+    512x640: every MLP layer of level 1, most of level 0's, the FeatureNet's lateral / smooth0 layers, the level-1 heads — our
+    gradient is compared ELEMENT-WISE with the reference's fp32 gradient: max|ours - ref| <= tol x max|ref| (3e-4: both sit within
+    1e-4 of float64, plus fp32 summation order).  Returns the names it covered."""
+    key, covered = ("rows" if sparse else "full"), []
+    for name, grad in named_grads:
+        k, nk = f"grad/{name}/{key}", f"noise/{name}"
+        if k not in g32.files or k not in g64.files or nk not in noise.files:
+            continue
+        r64, r32 = g64[k].astype(np.float64), g32[k].astype(np.float64)
+        scale = float(g64[f"grad/{name}/absmax"]) if sparse else float(np.abs(r64).max())
+        if scale < 1e-9 or float(noise[nk]) >= 1e-4 or float(np.abs(r32 - r64).max() / scale) >= 1e-4:
+            continue
+        f = grad.detach().reshape(-1).cpu().numpy().astype(np.float64)
+        f = f[::97] if sparse else f
+        err = float(np.abs(f - r32).max() / scale)
+        assert err <= tol, (what, name, err)
+        covered.append(name)
+    return covered
+
+
 def _train_batch(seed=7, H=32, W=64, S=3, planes=(8, 8)):
     cfg = EnerfConfig().with_cas(volume_planes=planes, render_if=(True, True))
     b = make_batch(H, W, S, cfg, seed=seed, textured=True)
@@ -906,8 +930,11 @@ def test_training_step_on_gpu_matches_reference_gradients():
         loss2 = _loss(net2(batch2), batch2)
         assert float(loss2) == pytest.approx(float(g2["loss"]), rel=1e-4)
         loss2.backward()
-        dist = _distance_to_fp64([(n, p.grad) for n, p in net2.named_parameters() if p.grad is not None], g2, g2_64)
+        named2 = [(n, p.grad) for n, p in net2.named_parameters() if p.grad is not None]
+        dist = _distance_to_fp64(named2, g2, g2_64)
         noise2 = np.load(os.path.join(GOLDEN, "train_small_noise.npz"))
+        stable2 = _assert_stable_parameters_elementwise(named2, g2, g2_64, noise2, sparse=False, what=f"128x160 hip_fnet={hip_fnet}")
+        print(f"128x160: {len(stable2)} stable parameters element-wise within 3e-4 of the reference's fp32 gradients")
         print("128x160 fp64 arbitration (ours, reference), FeatureNet on HIP =", hip_fnet,
               _assert_as_close_to_fp64_as_the_reference(dist, noise2, what=f"128x160 hip_fnet={hip_fnet}"))
     opt = torch.optim.Adam(net.parameters(), lr=5e-4)
@@ -994,9 +1021,13 @@ def test_full_size_training_step_is_as_close_to_fp64_as_the_reference():
         if n64 > 1e-9:
             assert abs(float(gr.double().norm()) - n64) <= 0.1 * n64, (n, float(gr.double().norm()), n64)
     dist = _distance_to_fp64(named, g32, g64, sparse=True)
+    noise = np.load(os.path.join(GOLDEN, "train_full_noise.npz"))
+    stable = _assert_stable_parameters_elementwise(named, g32, g64, noise, sparse=True, what="512x640")
+    assert len(stable) >= 28, stable                    # the parameters the reference's own 1-ulp draws leave within 1e-4 of float64
     print("512x640 outputs vs reference fp32:", {k: f"{v:.1e}" for k, v in worst.items()})
+    print(f"512x640: {len(stable)} stable parameters element-wise within 3e-4 of the reference's fp32 gradients")
     print("512x640 fp64 arbitration (ours, reference):",
-          _assert_as_close_to_fp64_as_the_reference(dist, np.load(os.path.join(GOLDEN, "train_full_noise.npz")), what="512x640"))
+          _assert_as_close_to_fp64_as_the_reference(dist, noise, what="512x640"))
 
 
 @pytest.mark.gpu
