@@ -75,13 +75,8 @@ void launch_conv2d_pack(const float* w, const float* bias, const float* bn_w, co
 // epilogue.  This layer's D registers (rows 16rt+4g+r of pixel j) are exactly the B operands of the next layer's
 // k-steps in the standard packed-weight order (ci = 16cb + 4g + r), so the chained layer is 8*RT more MFMAs per
 // column tile on values that never leave the registers; this layer's own output is not stored.
-// WG = 2 (round 6): EIGHT waves per block — wave group wv >> 2 owns half of the layer's 16-row output tiles over the same LDS tile.
-// For a layer with few blocks (conv2.0 at dtu: 480 four-row tiles for 256 CUs = two waves per SIMD, both in the same phase) that doubles
-// the waves that interleave LDS reads with MFMAs and halves the staging time per thread, at the same MFMA count and tile traffic.
-// WC = 2: eight waves as well, but the wave groups split the block's COLUMN tiles (conv2.1, whose chained 1x1 epilogue needs every row tile
-// of a pixel in one wave): half the MFMAs per wave at the price of every wave loading the pass's weights.
-template <int CINP, int RT, int K, int STR, int TH, bool NCHW3, bool CHAIN = false, int WG = 1, int WC = 1>
-__global__ __launch_bounds__(256 * WG * WC) void k_conv2d(const float* __restrict__ wpk, const float* __restrict__ scale,
+template <int CINP, int RT, int K, int STR, int TH, bool NCHW3, bool CHAIN = false>
+__global__ __launch_bounds__(256) void k_conv2d(const float* __restrict__ wpk, const float* __restrict__ scale,
                                                 const float* __restrict__ shift, const float* __restrict__ in,
                                                 float* __restrict__ out, const float* __restrict__ up,
                                                 const float* __restrict__ rgb_src, int out_stride, int cout,
@@ -91,7 +86,7 @@ __global__ __launch_bounds__(256 * WG * WC) void k_conv2d(const float* __restric
     constexpr int TW = 32, P = (K - 1) / 2;
     constexpr int CB = CINP >= 16 ? 16 : CINP, CPL = CB / 4, NCB = CINP / CB, KS = CINP / 4;
     constexpr int IH = (TH - 1) * STR + K, IW = (TW - 1) * STR + K;
-    constexpr int NT = TH * (TW / 16), CTW = NT / (4 * WC);      // column tiles per block / per wave
+    constexpr int NT = TH * (TW / 16), CTW = NT / 4;      // column tiles per block / per wave
     constexpr int QV = CB / 4 > 0 ? CB / 4 : 1;
     constexpr int NPX = IH * IW;
     // Stride-2 layers read every other tile pixel per lane: with the tile stored pixel-major, lane j sits 2 pixels
@@ -103,13 +98,8 @@ __global__ __launch_bounds__(256 * WG * WC) void k_conv2d(const float* __restric
     // (round 5 measured the tile as channel-quad PLANES — conflict-free ds_read_b128 / ds_write_b128 groups — with no change on any
     // layer: the bank conflicts PMC counts do not bound these kernels; profiles/r05_ab_conv2d_planar.txt, tools/patches/)
     ENERF_DYN_SMEM(float, lds);
-    static_assert(WG == 1 || (WG == 2 && RT % 2 == 0 && !CHAIN && !NCHW3), "wave groups split the row tiles");
-    static_assert(WC == 1 || (WC == 2 && WG == 1 && NT % 8 == 0 && !NCHW3), "wave groups split the column tiles");
-    constexpr int RTW = RT / WG, NTHR = 256 * WG * WC;        // row tiles per wave; threads per block
 
-    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-    const int wv = WC == 1 ? (int)((threadIdx.x >> 6) & 3) : (int)(threadIdx.x >> 6);         // column-tile owner index
-    const int wg = WG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));     // this wave's row-tile half
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wv = threadIdx.x >> 6;
     int bid = blockIdx.x;
     {   // XCD-contiguous block order (bijective), see conv3d.hip
         const int nblk = gridDim.x, q = nblk / 8, r = nblk % 8, xcd = bid % 8, kk = bid / 8;
@@ -121,13 +111,13 @@ __global__ __launch_bounds__(256 * WG * WC) void k_conv2d(const float* __restric
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * STR - P, ix0 = ox0 * STR - P;
 
-    f32x4 acc[CTW][RTW];
+    f32x4 acc[CTW][RT];
 #pragma unroll
     for (int c = 0; c < CTW; ++c)
 #pragma unroll
-        for (int rt = 0; rt < RTW; ++rt) acc[c][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* wl = wpk + lane + wg * RTW * 64;
-    constexpr int NAQ = K * CPL * RTW;
+        for (int rt = 0; rt < RT; ++rt) acc[c][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wl = wpk + lane;
+    constexpr int NAQ = K * CPL * RT;
     // PRE: the whole pass's weights are requested before the tile is staged and stay in registers (k <= 3 always; round 5: also the
     // 5x5 stride-2 layer with few channels, conv1.0: 50 registers — its per-row operand ring cost 11 of 79 us at zju sizes, timing
     // ablation profiles/r05_conv2d_ablation.txt).  conv2.0 (200 registers) keeps the two-row ring.
@@ -145,8 +135,8 @@ __global__ __launch_bounds__(256 * WG * WC) void k_conv2d(const float* __restric
 #pragma unroll
                 for (int r = 0; r < CPL; ++r)
 #pragma unroll
-                    for (int rt = 0; rt < RTW; ++rt)
-                        aq[(kw * CPL + r) * RTW + rt] = wt[((long long)(kw * KS + r) * RT + rt) * 64];
+                    for (int rt = 0; rt < RT; ++rt)
+                        aq[(kw * CPL + r) * RT + rt] = wt[((long long)(kw * KS + r) * RT + rt) * 64];
         };
         // k<=3: the whole pass's weights are requested BEFORE the tile is staged, so their L2 latency hides
         // behind the staging traffic; sched_barrier pins the loads here (hipcc otherwise sinks each load to
@@ -181,14 +171,14 @@ __global__ __launch_bounds__(256 * WG * WC) void k_conv2d(const float* __restric
             }
         } else {
             constexpr int NITEM = NPX * QV;
-            constexpr int NIT = (NITEM + NTHR - 1) / NTHR;
+            constexpr int NIT = (NITEM + 255) / 256;
             float4 sv[NIT];
             bool sk[NIT];
             int so[NIT];
             const float* base = in + (long long)n * Hi * Wi * CINP + cb * CB;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int i = threadIdx.x + it * NTHR, ic = i < NITEM ? i : NITEM - 1;
+                const int i = threadIdx.x + it * 256, ic = i < NITEM ? i : NITEM - 1;
                 const int px = ic / QV, q = ic - px * QV;
                 const int ly = px / IW, lx = px - ly * IW, gy = iy0 + ly, gx = ix0 + lx;
                 sk[it] = gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
@@ -198,7 +188,7 @@ __global__ __launch_bounds__(256 * WG * WC) void k_conv2d(const float* __restric
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int i = threadIdx.x + it * NTHR;
+                const int i = threadIdx.x + it * 256;
                 if (i < NITEM)
                     *reinterpret_cast<float4*>(lds + so[it]) = sk[it] ? sv[it] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -235,10 +225,10 @@ __global__ __launch_bounds__(256 * WG * WC) void k_conv2d(const float* __restric
 #pragma unroll
                 for (int r = 0; r < CPL; ++r)
 #pragma unroll
-                    for (int rt = 0; rt < RTW; ++rt)
+                    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                         for (int c = 0; c < CTW; ++c)
-                            acc[c][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[(kw * CPL + r) * RTW + rt], bq[kw & 1][c][r],
+                            acc[c][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[(kw * CPL + r) * RT + rt], bq[kw & 1][c][r],
                                                                               acc[c][rt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -303,8 +293,8 @@ __global__ __launch_bounds__(256 * WG * WC) void k_conv2d(const float* __restric
         if (oy >= Ho || ox >= Wo) continue;
         const long long o = ((long long)n * Ho + oy) * Wo + ox;
 #pragma unroll
-        for (int rt = 0; rt < RTW; ++rt) {
-            const int c0 = (wg * RTW + rt) * 16 + 4 * g;
+        for (int rt = 0; rt < RT; ++rt) {
+            const int c0 = rt * 16 + 4 * g;
             if (c0 == cout && rgb_src != nullptr) {
                 // texel mode (smooth0 -> render gather source): the first idle lane group appends
                 // [rgb*0.5+0.5 | 0] (unpreprocess utils.py:608 + cat network.py:34) behind the features
@@ -338,7 +328,7 @@ __global__ __launch_bounds__(256 * WG * WC) void k_conv2d(const float* __restric
     }
 }
 
-template <int CINP, int RT, int K, int STR, int TH, bool NCHW3, bool CHAIN = false, int WG = 1, int WC = 1>
+template <int CINP, int RT, int K, int STR, int TH, bool NCHW3, bool CHAIN = false>
 static void launch_c2(const Conv2dDesc& L, const float* in, float* out, const float* up, int N, int Hi, int Wi, int Hc,
                       int Wc, hipStream_t st) {
     const float* rgb_src = L.rgb_src;
@@ -350,7 +340,7 @@ static void launch_c2(const Conv2dDesc& L, const float* in, float* out, const fl
     const int nslot = IH * (STR == 2 ? 2 * ((IW + 1) / 2) : IW);                                    // stride 2: de-interleaved rows
     const size_t shmem = (size_t)nslot * CB * sizeof(float);
     const unsigned grid = (unsigned)((long long)N * tiles_y * tiles_x);
-    ENERF_LAUNCH((k_conv2d<CINP, RT, K, STR, TH, NCHW3, CHAIN, WG, WC>), grid, 256 * WG * WC, shmem, st, L.w, L.scale, L.shift, in, out, up,
+    ENERF_LAUNCH((k_conv2d<CINP, RT, K, STR, TH, NCHW3, CHAIN>), grid, 256, shmem, st, L.w, L.scale, L.shift, in, out, up,
                  rgb_src, out_stride, L.cout, L.relu, N, Hi, Wi, Ho, Wo, Hc, Wc, tiles_y, tiles_x, L.chain_w, L.chain_shift);
 }
 
@@ -947,21 +937,10 @@ int launch_conv2d(const Conv2dDesc& L, const float* in, float* out, const float*
             else launch_c2<16, 1, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             return 0;
         case 16 * 10000 + 32 * 100 + 52:                                                                                   // conv2.0
-#ifndef ENERF_C2_WG2
-#define ENERF_C2_WG2 1               // 0: four waves per block for conv2.0 whatever its block count (rounds 1 - 5)
-#endif
-            // fewer than four blocks per CU: eight waves per block (two row-tile halves over one LDS tile)
-            if (ENERF_C2_WG2 && (long long)N * cdiv((Hi + 1) / 2, 4) * cdiv((Wi + 1) / 2, 32) < 1024)
-                launch_c2<16, 2, 5, 2, 4, false, false, 2>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
-            else launch_c2<16, 2, 5, 2, 4, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
+            launch_c2<16, 2, 5, 2, 4, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             return 0;
         case 32 * 10000 + 32 * 100 + 31:                                                                                   // conv2.1 (+ toplayer)
-#ifndef ENERF_C2_WC2
-#define ENERF_C2_WC2 0               // 1: conv2.1 (+ toplayer) with eight waves per block (column tiles split) when it has < 4 blocks per CU
-#endif
-            if (ENERF_C2_WC2 && L.chain_w != nullptr && th4 && (long long)N * cdiv(Hi, 4) * cdiv(Wi, 32) < 1024)
-                launch_c2<32, 2, 3, 1, 4, false, true, 1, 2>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
-            else if (L.chain_w != nullptr && th4) launch_c2<32, 2, 3, 1, 4, false, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
+            if (L.chain_w != nullptr && th4) launch_c2<32, 2, 3, 1, 4, false, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             else if (L.chain_w != nullptr) launch_c2<32, 2, 3, 1, 8, false, true>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             else launch_c2<32, 2, 3, 1, 8, false>(L, in, out, up, N, Hi, Wi, Hc, Wc, st);
             return 0;
