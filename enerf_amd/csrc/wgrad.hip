@@ -872,26 +872,45 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(const float* __restrict__ A,
     // raw buffer loads (common.h): scalar base + 32-bit lane offset, rows past P / columns past C read 0 through an
     // out-of-range offset — no branch around a load, no 64-bit address per load (P * ld < 2^30: checked by the C entry)
     const BufRsrc ra = buf_rsrc(A, (unsigned)(P * lda * 4)), rb = buf_rsrc(Bt, (unsigned)(P * ldb * 4));
-    for (long long grp = (long long)blockIdx.x * 4 + wave; grp < ngroups; grp += (long long)gridDim.x * 4) {
-        const unsigned p = (unsigned)grp * 4u + (unsigned)g;
-        const bool pv = p < (unsigned)P;
-        const unsigned arow = p * (unsigned)lda * 4u, brow = p * (unsigned)ldb * 4u;
-        float av[TA], bv[TB];
+    // U row groups per iteration, ALL their loads requested before the first MFMA (round 6).  A wave moves (TA + TB) x 256 B per row
+    // group; with one group per iteration and eight waves per CU the 1 x 1 .. 2 x 2 shapes (view_fc, fc, global_fc: most of the MLP's
+    // layers) had 4 - 8 KB in flight per CU and streamed their operands at 1.7 - 2.5 TB/s (the 4 x 6 shape: 5.4).  The groups of a
+    // wave are still accumulated in ascending order: same sums, bit for bit.
+#ifndef ENERF_GW_UNROLL
+#define ENERF_GW_UNROLL 1            // 0 (A/B): one row group per iteration (round 5)
+#endif
+#ifndef ENERF_GW_INFLIGHT
+#define ENERF_GW_INFLIGHT 16         // operand registers requested per iteration (x 256 B per wave in flight)
+#endif
+    constexpr int UQ = ENERF_GW_INFLIGHT / (TA + TB);
+    constexpr int U = !ENERF_GW_UNROLL ? 1 : (UQ < 1 ? 1 : (UQ > 8 ? 8 : UQ));
+    const long long gstride = (long long)gridDim.x * 4;
+    for (long long grp = (long long)blockIdx.x * 4 + wave; grp < ngroups; grp += gstride * U) {
+        float av[U][TA], bv[U][TB];
 #pragma unroll
-        for (int ta = 0; ta < TA; ++ta) {
-            const int ca = ta * 16 + j;
-            av[ta] = buf_load_f32(ra, (pv && ca < Ca) ? arow + (unsigned)ca * 4u : 0xffffffffu);
+        for (int u = 0; u < U; ++u) {
+            const long long gu = grp + u * gstride;
+            const unsigned p = (unsigned)gu * 4u + (unsigned)g;
+            const bool pv = gu < ngroups && p < (unsigned)P;
+            const unsigned arow = p * (unsigned)lda * 4u, brow = p * (unsigned)ldb * 4u;
+#pragma unroll
+            for (int ta = 0; ta < TA; ++ta) {
+                const int ca = ta * 16 + j;
+                av[u][ta] = buf_load_f32(ra, (pv && ca < Ca) ? arow + (unsigned)ca * 4u : 0xffffffffu);
+            }
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                const int cb = tb * 16 + j;
+                bv[u][tb] = buf_load_f32(rb, (pv && cb < Cb) ? brow + (unsigned)cb * 4u : 0xffffffffu);
+                if (bias && cb == Cb) bv[u][tb] = pv ? 1.f : 0.f;        // virtual all-ones column -> bias gradient
+            }
         }
 #pragma unroll
-        for (int tb = 0; tb < TB; ++tb) {
-            const int cb = tb * 16 + j;
-            bv[tb] = buf_load_f32(rb, (pv && cb < Cb) ? brow + (unsigned)cb * 4u : 0xffffffffu);
-            if (bias && cb == Cb) bv[tb] = pv ? 1.f : 0.f;           // virtual all-ones column -> bias gradient
-        }
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int ta = 0; ta < TA; ++ta)
+            for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
-            for (int tb = 0; tb < TB; ++tb) acc[ta * TB + tb] = ENERF_MFMA_W(av[ta], bv[tb], acc[ta * TB + tb]);
+                for (int tb = 0; tb < TB; ++tb) acc[ta * TB + tb] = ENERF_MFMA_W(av[u][ta], bv[u][tb], acc[ta * TB + tb]);
     }
     for (int src = 1; src < 4; ++src) {                               // waves 1..3 hand their tiles to wave 0
         if (wave == src) {
@@ -942,7 +961,10 @@ static bool launch_gemm_wgrad_ta(int tb, unsigned grid, hipStream_t st, const fl
 static long long gemm_wgrad_blocks(long long P) {
     const long long groups = cdivl(P, 4);
     long long blocks = cdivl(groups, 4 * 16);                         // >= 16 row groups per wave
-    const long long cap = (long long)device_cu_count() * 2;
+#ifndef ENERF_GW_BLOCKS_PER_CU
+#define ENERF_GW_BLOCKS_PER_CU 4       // measured: 2 -> 4 blocks per CU 9.92 -> 9.82 ms per training step
+#endif
+    const long long cap = (long long)device_cu_count() * ENERF_GW_BLOCKS_PER_CU;
     if (blocks > cap) blocks = cap;
     return blocks < 1 ? 1 : blocks;
 }
