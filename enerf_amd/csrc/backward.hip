@@ -170,12 +170,77 @@ bool launch_feature_volume_bwd(const float* feat, const float* proj, const float
 
 // ---------------------------------------------------------------------------------------------------------------------
 // depth_regression backward: p = softmax_D(prob), v = depth_inv ? 1/max(dv,1e-6) : dv, mu = sum p v,
-// var = sum p (v - mu)^2, std = sqrt(max(var, 1e-10)).  One thread per pixel (D <= 64 in every config).
+// var = sum p (v - mu)^2, std = sqrt(max(var, 1e-10)).
+// Round 6: the forward kernel's mapping (geometry.hip k_depth_regression: a wave = 16 pixels x 4 depth slices, lane slice sl takes
+// planes sl, sl + 4, ...; every plane value loaded ONCE into registers, exp'd once, the slice sums combined with two lane swaps).
+// One thread per pixel walked the D <= 64 planes six times with dependent loads and an expf per visit, on 20 blocks for level 0's
+// 64 x 80 pixels: 71 us per launch, two launches per training step.
 // ---------------------------------------------------------------------------------------------------------------------
+template <int MK>
 __global__ __launch_bounds__(256) void k_depth_regression_bwd(const float* __restrict__ prob, const float* __restrict__ dv,
                                                               const float* __restrict__ g_depth, const float* __restrict__ g_std,
                                                               int B, int D, int h, int w, int depth_inv,
                                                               float* __restrict__ g_prob, float* __restrict__ g_dv) {
+    const int lane = threadIdx.x & 63, sl = lane >> 4;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long hw = (long long)h * w;
+    const long long i = wave * 16 + (lane & 15);
+    const bool ok = i < (long long)B * hw;
+    const long long ii = ok ? i : 0;                    // dead lanes shadow pixel 0 (they take part in the lane swaps)
+    const long long b = ii / hw, p = ii - b * hw;
+    const float* pr = prob + b * D * hw + p;
+    const float* dp = dv + b * D * hw + p;
+    float e[MK], v[MK], d[MK];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kk = 0; kk < MK; ++kk) {
+        const int k = sl + 4 * kk;
+        const bool in = k < D;
+        const long long o = (long long)(in ? k : 0) * hw;
+        const float x = pr[o];
+        d[kk] = dp[o];
+        e[kk] = in ? x : -INFINITY;
+        v[kk] = depth_inv ? 1.f / clamp_min(d[kk], 1e-6f) : d[kk];
+        m = fmaxf(m, e[kk]);
+    }
+    m = group_max4(m);
+    float se = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < MK; ++kk)
+        if (sl + 4 * kk < D) { e[kk] = expf(e[kk] - m); se += e[kk]; } else e[kk] = 0.f;
+    se = group_sum4(se);
+    float mu = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < MK; ++kk) { e[kk] = e[kk] / se; mu += e[kk] * v[kk]; }          // e = p_k from here on (0 beyond D)
+    mu = group_sum4(mu);
+    float var = 0.f, s1 = 0.f;                          // s1 = sum p (v - mu): d var / d mu = -2 s1
+#pragma unroll
+    for (int kk = 0; kk < MK; ++kk) { const float c = v[kk] - mu; var += e[kk] * c * c; s1 += e[kk] * c; }
+    var = group_sum4(var);
+    s1 = group_sum4(s1);
+    const float gvar = var >= 1e-10f ? g_std[ii] * 0.5f / sqrtf(var) : 0.f;        // clamp_min + sqrt
+    const float gmu = g_depth[ii] + gvar * (-2.f * s1);
+    float dot = 0.f;                                    // sum_j p_j dL/dp_j (softmax backward)
+#pragma unroll
+    for (int kk = 0; kk < MK; ++kk) { const float c = v[kk] - mu; dot += e[kk] * (gmu * v[kk] + gvar * c * c); }
+    dot = group_sum4(dot);
+    if (!ok) return;
+#pragma unroll
+    for (int kk = 0; kk < MK; ++kk) {
+        const int k = sl + 4 * kk;
+        if (k >= D) continue;
+        const float c = v[kk] - mu, pk = e[kk];
+        const float gp = gmu * v[kk] + gvar * c * c;
+        g_prob[b * D * hw + k * hw + p] = pk * (gp - dot);
+        const float gvk = gmu * pk + gvar * 2.f * pk * c;
+        g_dv[b * D * hw + k * hw + p] = depth_inv ? (d[kk] >= 1e-6f ? -gvk / (d[kk] * d[kk]) : 0.f) : gvk;
+    }
+}
+// one thread per pixel, any D (the round 1 - 5 kernel; kept for D > 64)
+__global__ __launch_bounds__(256) void k_depth_regression_bwd_serial(const float* __restrict__ prob, const float* __restrict__ dv,
+                                                                     const float* __restrict__ g_depth, const float* __restrict__ g_std,
+                                                                     int B, int D, int h, int w, int depth_inv,
+                                                                     float* __restrict__ g_prob, float* __restrict__ g_dv) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long hw = (long long)h * w;
     if (i >= (long long)B * hw) return;
@@ -191,16 +256,16 @@ __global__ __launch_bounds__(256) void k_depth_regression_bwd(const float* __res
         const float d = dp[k * hw], v = depth_inv ? 1.f / clamp_min(d, 1e-6f) : d;
         mu += (expf(pr[k * hw] - m) / se) * v;
     }
-    float var = 0.f, s1 = 0.f;                          // s1 = sum p (v - mu): d var / d mu = -2 s1
+    float var = 0.f, s1 = 0.f;
     for (int k = 0; k < D; ++k) {
         const float d = dp[k * hw], v = depth_inv ? 1.f / clamp_min(d, 1e-6f) : d;
         const float pk = expf(pr[k * hw] - m) / se;
         var += pk * (v - mu) * (v - mu);
         s1 += pk * (v - mu);
     }
-    const float gvar = var >= 1e-10f ? g_std[i] * 0.5f / sqrtf(var) : 0.f;         // clamp_min + sqrt
+    const float gvar = var >= 1e-10f ? g_std[i] * 0.5f / sqrtf(var) : 0.f;
     const float gmu = g_depth[i] + gvar * (-2.f * s1);
-    float dot = 0.f;                                    // sum_j p_j dL/dp_j (softmax backward)
+    float dot = 0.f;
     for (int k = 0; k < D; ++k) {
         const float d = dp[k * hw], v = depth_inv ? 1.f / clamp_min(d, 1e-6f) : d;
         const float pk = expf(pr[k * hw] - m) / se;
@@ -217,8 +282,14 @@ __global__ __launch_bounds__(256) void k_depth_regression_bwd(const float* __res
 }
 void launch_depth_regression_bwd(const float* prob, const float* dv, const float* g_depth, const float* g_std, int B, int D,
                                  int h, int w, int depth_inv, float* g_prob, float* g_dv, hipStream_t st) {
-    ENERF_LAUNCH_SIMPLE(k_depth_regression_bwd, (unsigned)cdivl((long long)B * h * w, 256), 256, 0, st, prob, dv, g_depth, g_std, B,
-                        D, h, w, depth_inv, g_prob, g_dv);
+    const unsigned grid4 = (unsigned)cdivl((long long)B * h * w, 64);               // 16 pixels per wave, 4 waves per block
+    if (D <= 16)
+        ENERF_LAUNCH(k_depth_regression_bwd<4>, grid4, 256, 0, st, prob, dv, g_depth, g_std, B, D, h, w, depth_inv, g_prob, g_dv);
+    else if (D <= 64)
+        ENERF_LAUNCH(k_depth_regression_bwd<16>, grid4, 256, 0, st, prob, dv, g_depth, g_std, B, D, h, w, depth_inv, g_prob, g_dv);
+    else
+        ENERF_LAUNCH_SIMPLE(k_depth_regression_bwd_serial, (unsigned)cdivl((long long)B * h * w, 256), 256, 0, st, prob, dv, g_depth, g_std,
+                            B, D, h, w, depth_inv, g_prob, g_dv);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
