@@ -158,25 +158,7 @@ def live_pmc(workloads, child_flags=None, kernel_prefix=None):
             subprocess.run([rocprof, "--pmc", *counters.split(), "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", *child],
                            cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            rows = sorted(csv.DictReader(open(files[0])), key=lambda r: int(r["Dispatch_Id"]))
-            seg, inside, last_dispatch = -1, False, None
-            for r in rows:
-                k = r["Kernel_Name"].replace("void enerf::", "").replace("enerf::", "")
-                if child_flags is None:
-                    if k.startswith(PMC_SENTINEL):
-                        if r["Dispatch_Id"] != last_dispatch:     # (one row per counter and dispatch)
-                            inside = not inside
-                            seg += 1 if inside else 0
-                            last_dispatch = r["Dispatch_Id"]
-                        continue
-                    if not inside or seg >= len(workloads):
-                        continue
-                    key = (workloads[seg], k)
-                else:
-                    if kernel_prefix is not None and not k.startswith(kernel_prefix):
-                        continue
-                    key = ("", k)
-                acc.setdefault(key, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            pmc_accumulate(csv.DictReader(open(files[0])), workloads if child_flags is None else None, kernel_prefix, acc)
         except Exception:
             return None
         finally:
@@ -192,6 +174,33 @@ def live_pmc(workloads, child_flags=None, kernel_prefix=None):
             e["mfma_busy_frac"] = round(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * m["GRBM_GUI_ACTIVE"] / 8.0), 4)
         out.setdefault(w, {})[k] = e
     return out or None
+
+
+def pmc_accumulate(rows, workloads, kernel_prefix, acc):
+    """One counter pass's rows (rocprofv3 counter_collection.csv: one row per dispatch and counter) -> acc[(workload, kernel)][counter]
+    += [values].  ``workloads`` (the --pmc-sequence child): the dispatch-ordered rows are cut at the sentinel launches — the rows between
+    the (2k+1)-th and (2k+2)-th sentinel dispatch belong to workloads[k]; everything else (network construction, warm-up frames) is
+    dropped.  ``workloads is None`` (the training child): every kernel whose name starts with ``kernel_prefix``, under workload ""."""
+    rows = sorted(rows, key=lambda r: int(r["Dispatch_Id"]))
+    seg, inside, last_dispatch = -1, False, None
+    for r in rows:
+        k = r["Kernel_Name"].replace("void enerf::", "").replace("enerf::", "")
+        if workloads is not None:
+            if k.startswith(PMC_SENTINEL):
+                if r["Dispatch_Id"] != last_dispatch:     # (one row per counter and dispatch)
+                    inside = not inside
+                    seg += 1 if inside else 0
+                    last_dispatch = r["Dispatch_Id"]
+                continue
+            if not inside or seg >= len(workloads):
+                continue
+            key = (workloads[seg], k)
+        else:
+            if kernel_prefix is not None and not k.startswith(kernel_prefix):
+                continue
+            key = ("", k)
+        acc.setdefault(key, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return acc
 
 
 def pmc_lookup(pmc, workload, kernel_prefix):

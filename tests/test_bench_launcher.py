@@ -68,3 +68,43 @@ def test_train_gpus2_dry_run_takes_the_flat_data_parallel_step():
     assert "one flat gradient all-reduce per step" in d["config"]["parallelism"]
     assert "DRY RUN" in d["config"]["step_launch"]
     assert d["final_loss"] == d["final_loss"] and 0 < d["final_loss"] < 10
+
+
+def test_pmc_rows_are_cut_at_the_sentinel_launches():
+    """bench.py's live PMC child renders dtu, lego and zju in ONE process per counter pass, bracketing the measured frames of each
+    workload with sentinel launches (`--pmc-sequence`); `pmc_accumulate` must attribute the dispatch-ordered counter rows to the
+    right workload — both lego and zju launch k_render_rays<3, 4, ...> and every workload launches k_smooth0_cb — and drop
+    everything outside the brackets (network construction, warm-up frames)."""
+    sys.argv = sys.argv[:1]
+    import bench
+    rows, did = [], [0]
+
+    def disp(name, val):
+        did[0] += 1
+        rows.append({"Dispatch_Id": str(did[0]), "Kernel_Name": name, "Counter_Name": "FETCH_SIZE", "Counter_Value": str(val)})
+    S = f"enerf::{bench.PMC_SENTINEL}(float const*, int, int, int, unsigned char*)"
+    for w, (render, base) in enumerate((("void enerf::k_render_rays<3, 3, 12, 3, false, true, 0>(x)", 100.0),
+                                        ("void enerf::k_render_rays<3, 4, 12, 3, false, true, 0>(x)", 200.0),
+                                        ("void enerf::k_render_rays<3, 4, 12, 3, false, true, 0>(x)", 300.0))):
+        disp("enerf::k_conv2d_pack(x)", 1.0)                         # construction: outside the brackets
+        for _ in range(2):                                           # warm-up frames: outside
+            disp("enerf::k_smooth0_cb(x)", 9999.0); disp(render, 9999.0)
+        disp(S, 0.0)
+        for f in range(3):
+            disp("enerf::k_smooth0_cb(x)", base + f); disp(render, 10 * base + f)
+        disp(S, 0.0)
+    rows.reverse()                                                   # the parser sorts by dispatch id itself
+    acc = bench.pmc_accumulate(rows, ["dtu", "lego", "zju"], None, {})
+    assert sorted({w for w, _ in acc}) == ["dtu", "lego", "zju"]
+    for w, base in (("dtu", 100.0), ("lego", 200.0), ("zju", 300.0)):
+        assert acc[(w, "k_smooth0_cb(x)")]["FETCH_SIZE"] == [base, base + 1, base + 2]
+        (rk,) = [k for (ww, k) in acc if ww == w and k.startswith("k_render_rays")]
+        assert acc[(w, rk)]["FETCH_SIZE"] == [10 * base, 10 * base + 1, 10 * base + 2]
+    assert not any(k.startswith("k_conv2d_pack") for _, k in acc)
+    # the training child: no sentinels, one kernel prefix, workload ""
+    acc2 = bench.pmc_accumulate([{"Dispatch_Id": "2", "Kernel_Name": "void enerf::k_mlp_bwd<3, 3>(a)", "Counter_Name": "WRITE_SIZE", "Counter_Value": "5"},
+                                 {"Dispatch_Id": "1", "Kernel_Name": "void enerf::k_mlp_fwd<3, 3>(a)", "Counter_Name": "WRITE_SIZE", "Counter_Value": "7"}],
+                                None, "k_mlp_bwd<3, 3>", {})
+    assert acc2 == {("", "k_mlp_bwd<3, 3>(a)"): {"WRITE_SIZE": [5.0]}}
+    assert bench.pmc_lookup({"lego": {"k_render_rays<3, 4, 12, 3, false, true, 0>(x)": {"hbm_bytes_per_launch": 1.0}}}, "lego", "k_render_rays<3, 4")
+    assert bench.pmc_lookup(None, "lego", "k") is None and bench.pmc_lookup({"dtu": {}}, "lego", "k") is None
