@@ -707,19 +707,32 @@ class NerfMlpFn(torch.autograd.Function):
         hv, G, q, gs, a_, vm, d_c, d_q, d_p2, d_s, d_h, d_agg, d_u, d_g, d_gsum, d_v = sv
         PS = P * S
         x2 = x.reshape(PS, XW)
-        gw = {}
-        # color.2 (1,64) / color.0 (64, 88+F+4) / sigma (1,64) / lr0 (64,24) / fc (16,32) / agg_w (1,32) / global_fc (32,3F) / view_fc (F,4)
-        gw["color.2.weight"], gw["color.2.bias"] = lib.gemm_wgrad(d_c.reshape(PS, 1), q.reshape(PS, 64), bias=True)
-        w_hv, gw["color.0.bias"] = lib.gemm_wgrad(d_p2, hv, bias=True)
-        gw["color.0.weight"] = lib.concat_channels(w_hv, lib.gemm_wgrad(d_q.reshape(PS, 64), x2), 88 + XW)
-        gw["sigma.0.weight"], gw["sigma.0.bias"] = lib.gemm_wgrad(d_s.reshape(P, 1), hv, Cb=64, bias=True)
-        gw["lr0.0.weight"], gw["lr0.0.bias"] = lib.gemm_wgrad(d_h, hv[:, 64:], bias=True)
-        gw["agg.fc.0.weight"], gw["agg.fc.0.bias"] = lib.gemm_wgrad(d_agg, G, bias=True)
-        gw["agg.agg_w_fc.0.weight"], gw["agg.agg_w_fc.0.bias"] = lib.gemm_wgrad(d_u.reshape(PS, 1), gs.reshape(PS, 32), bias=True)
-        w_vm, gw["agg.global_fc.0.bias"] = lib.gemm_wgrad(d_gsum, vm, bias=True)
-        gw["agg.global_fc.0.weight"] = lib.concat_channels(lib.gemm_wgrad(d_g.reshape(PS, 32), a_.reshape(PS, F)), w_vm, 3 * F)
+        # color.2 (1,64) / color.0 (64, 88+F+4) / sigma (1,64) / lr0 (64,24) / fc (16,32) / agg_w (1,32) / global_fc (32,3F) / view_fc (F,4):
+        # ten (eleven) position reductions over the saved rows as ONE grouped call = two launches (enerf_gemm_wgrad_group); color.0 and
+        # global_fc are assembled in place from their two column blocks
+        w_c0 = torch.empty((64, 88 + XW), dtype=torch.float32, device=x.device)
+        w_gl = torch.empty((32, 3 * F), dtype=torch.float32, device=x.device)
+        members = [
+            dict(a=d_c.reshape(PS, 1), b=q.reshape(PS, 64), bias=True),                 # color.2
+            dict(a=d_p2, b=hv, bias=True, into=(w_c0, 0)),                              # color.0, shared columns [h | vox | agg]
+            dict(a=d_q.reshape(PS, 64), b=x2, into=(w_c0, 88)),                         # color.0, per-view columns [x_s | dir_s]
+            dict(a=d_s.reshape(P, 1), b=hv, Cb=64, bias=True),                          # sigma
+            dict(a=d_h, b=hv[:, 64:], bias=True),                                       # lr0
+            dict(a=d_agg, b=G, bias=True),                                              # agg.fc
+            dict(a=d_u.reshape(PS, 1), b=gs.reshape(PS, 32), bias=True),                # agg.agg_w_fc
+            dict(a=d_g.reshape(PS, 32), b=a_.reshape(PS, F), into=(w_gl, 0)),           # agg.global_fc, a columns
+            dict(a=d_gsum, b=vm, bias=True, into=(w_gl, F)),                            # agg.global_fc, [var | mean] columns
+        ]
+        names = ["color.2", "color.0", None, "sigma.0", "lr0.0", "agg.fc.0", "agg.agg_w_fc.0", None, "agg.global_fc.0"]
         if m.viewdir_agg:
-            gw["agg.view_fc.0.weight"], gw["agg.view_fc.0.bias"] = lib.gemm_wgrad(d_v.reshape(PS, F), x2[:, F:], bias=True)
+            members.append(dict(a=d_v.reshape(PS, F), b=x2[:, F:], bias=True))          # agg.view_fc
+            names.append("agg.view_fc.0")
+        gw = {}
+        for name, (w_, b_) in zip(names, lib.gemm_wgrad_group(members)):
+            if name is not None:
+                gw[name + ".weight"] = w_
+                if b_ is not None:
+                    gw[name + ".bias"] = b_
         grads = [gw.get(n) for n, _ in m.named_parameters()]
         return (None, None, None, g_vox, g_x) + tuple(grads)
 

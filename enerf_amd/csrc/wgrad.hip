@@ -188,15 +188,9 @@ __global__ __launch_bounds__(SPLIT * PL * 64) void k_conv_wgrad(const float* __r
 // deterministic, and no pre-zeroing of dW.
 //   conv (gemm == 0): scratch[((pair*chunks + c)*nt + t)*256 + e], pair = (ta, tb), t = tap, dW[(a*Cb + b)*nt + t]
 //   gemm (gemm == 1): scratch[(c*nt + t)*256 + e], t = ta*tiles_b + tb, dW[a*Cb + b]
-__global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__ scratch, int chunks, int nt, int tiles_b, int Ca,
-                                                       int Cb, int bias, int gemm, float* __restrict__ dW,
-                                                       float* __restrict__ dbias) {
-    __shared__ float red[16][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
-    const int r = blockIdx.x & 3, item = blockIdx.x >> 2;
-    const int pair = gemm ? 0 : item / nt, t = gemm ? item : item - pair * nt;
-    const float* sp = scratch + (((long long)pair * chunks) * nt + t) * 256 + r * 64 + lane;
-    const long long cstride = (long long)nt * 256;
+// this thread's element summed over the chunks (wave w takes c = w, w + 16, ...; the 16 waves meet in LDS; the value is valid in wave 0)
+__device__ __forceinline__ float wgrad_reduce_sum(const float* __restrict__ sp, int chunks, long long cstride, float (*red)[64]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
     int c = w;
 #if ENERF_WGRAD_REDUCE_8
@@ -211,10 +205,23 @@ __global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__
     for (; c < chunks; c += 16) s0 += sp[c * cstride];
     red[w][lane] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
     __syncthreads();
-    if (w != 0) return;
     float v = 0.f;
+    if (w == 0) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v += red[k][lane];
+        for (int k = 0; k < 16; ++k) v += red[k][lane];
+    }
+    return v;
+}
+__global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__ scratch, int chunks, int nt, int tiles_b, int Ca,
+                                                       int Cb, int bias, int gemm, float* __restrict__ dW,
+                                                       float* __restrict__ dbias) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+    const int r = blockIdx.x & 3, item = blockIdx.x >> 2;
+    const int pair = gemm ? 0 : item / nt, t = gemm ? item : item - pair * nt;
+    const float* sp = scratch + (((long long)pair * chunks) * nt + t) * 256 + r * 64 + lane;
+    const float v = wgrad_reduce_sum(sp, chunks, (long long)nt * 256, red);
+    if (w != 0) return;
     const int ta = gemm ? t / tiles_b : pair / tiles_b, tb = gemm ? t - ta * tiles_b : pair - ta * tiles_b;
     const int a_ch = ta * 16 + 4 * g + r, b_ch = tb * 16 + j;          // D layout: rows 4g+r of column j
     if (a_ch >= Ca) return;
@@ -858,12 +865,13 @@ bool launch_conv_wgrad(const float* A, const float* Bt, int n, int Da, int Ha, i
 // of B tiles_a times (3 KB per row for the 64 x 88 layer).  Here one wave keeps ALL TA x TB tile accumulators and walks its
 // share of the rows once: TA + TB loads and TA*TB MFMAs per 4 rows, every row read exactly once (612 B for 64 x 89).
 // ---------------------------------------------------------------------------------------------------------------------
+// (the body: block `bid` of `nblk` — blockIdx.x / gridDim.x for the single GEMM, a slice of the grid in k_gemm_wgrad_group; `red`: NT x 256
+// floats of LDS; `ldw`: row stride of dW, Cb unless the gradient is a column block of a wider matrix)
 template <int TA, int TB>
-__global__ __launch_bounds__(256) void k_gemm_wgrad(const float* __restrict__ A, const float* __restrict__ Bt, int lda, int ldb,
-                                                    int Ca, int Cb, int bias, long long P, float* __restrict__ dW,
-                                                    float* __restrict__ dbias, float* __restrict__ scratch) {
+__device__ __forceinline__ void gemm_wgrad_body(const float* __restrict__ A, const float* __restrict__ Bt, int lda, int ldb, int Ca, int Cb,
+                                                int bias, long long P, float* __restrict__ dW, int ldw, float* __restrict__ dbias,
+                                                float* __restrict__ scratch, int bid, int nblk, float* __restrict__ red) {
     constexpr int NT = TA * TB;
-    __shared__ float red[NT][256];
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
     f32x4 acc[NT];
 #pragma unroll
@@ -884,8 +892,8 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(const float* __restrict__ A,
 #endif
     constexpr int UQ = ENERF_GW_INFLIGHT / (TA + TB);
     constexpr int U = !ENERF_GW_UNROLL ? 1 : (UQ < 1 ? 1 : (UQ > 8 ? 8 : UQ));
-    const long long gstride = (long long)gridDim.x * 4;
-    for (long long grp = (long long)blockIdx.x * 4 + wave; grp < ngroups; grp += gstride * U) {
+    const long long gstride = (long long)nblk * 4;
+    for (long long grp = (long long)bid * 4 + wave; grp < ngroups; grp += gstride * U) {
         float av[U][TA], bv[U][TB];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -917,20 +925,20 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(const float* __restrict__ A,
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[t][r * 64 + lane] = acc[t][r];
+                for (int r = 0; r < 4; ++r) red[t * 256 + r * 64 + lane] = acc[t][r];
         }
         __syncthreads();
         if (wave == 0) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[t][r] += red[t][r * 64 + lane];
+                for (int r = 0; r < 4; ++r) acc[t][r] += red[t * 256 + r * 64 + lane];
         }
         __syncthreads();
     }
     if (wave != 0) return;
     if (scratch != nullptr) {       // two-stage commit (k_wgrad_reduce, gemm mode)
-        float* sp = scratch + ((long long)blockIdx.x * NT) * 256 + lane;
+        float* sp = scratch + ((long long)bid * NT) * 256 + lane;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -946,9 +954,74 @@ __global__ __launch_bounds__(256) void k_gemm_wgrad(const float* __restrict__ A,
                 const float v = acc[ta * TB + tb][r];
                 const int a_ch = ta * 16 + 4 * g + r, b_ch = tb * 16 + j;
                 if (a_ch >= Ca || v == 0.f) continue;
-                if (b_ch < Cb) atomic_add_f32(dW + (long long)a_ch * Cb + b_ch, v);
+                if (b_ch < Cb) atomic_add_f32(dW + (long long)a_ch * ldw + b_ch, v);
                 else if (bias && b_ch == Cb) atomic_add_f32(dbias + a_ch, v);
             }
+}
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void k_gemm_wgrad(const float* __restrict__ A, const float* __restrict__ Bt, int lda, int ldb,
+                                                    int Ca, int Cb, int bias, long long P, float* __restrict__ dW,
+                                                    float* __restrict__ dbias, float* __restrict__ scratch) {
+    __shared__ float red[TA * TB * 256];
+    gemm_wgrad_body<TA, TB>(A, Bt, lda, ldb, Ca, Cb, bias, P, dW, Cb, dbias, scratch, (int)blockIdx.x, (int)gridDim.x, red);
+}
+
+// ---- the weight gradients of ONE MLP level in two to four launches (round 6) ----
+// NerfMlpFn's backward is ten to eleven of these GEMMs over the rows k_mlp_bwd saved (2.8 GB at level 1), each with its reduction: 21 + 21
+// launches per level whose small members (view_fc 11 x 5, agg_w 1 x 33, fc 16 x 33 ...) run 20 - 50 us each on a ramp and a tail.  Here
+// the grid is the concatenation of the GEMMs' grids (per register class) — every GEMM keeps its own block count, block -> row-group map and
+// scratch slice, so each gradient is bit-identical to its single launch — and one reduction kernel follows for all of them; a gradient that is a column
+// block of a wider matrix (color.0 = [shared | per-view] columns, global_fc = [a | var, mean]) is reduced straight into it (ldw).
+struct GemmDesc {
+    const float *A, *B;
+    float *dW, *dbias, *scratch;
+    long long P;
+    int lda, ldb, Ca, Cb, bias, ldw, ta, tb, blocks, block0, rblock0, pad;
+};
+constexpr int kGemmGroupMax = 16;
+struct GemmGroup {
+    GemmDesc d[kGemmGroupMax];
+    int n;
+};
+// CLS: the members' register class — one kernel for all shapes would give the 1 x 1 .. 2 x 3 shapes (52 - 68 registers, their loads
+// in flight are what they live on) the 212 registers and two waves per SIMD of the 4 x 6 shape.  0: <= 6 tiles, 1: <= 12, 2: the rest.
+__host__ __device__ constexpr int gemm_group_class(int nt) { return nt <= 6 ? 0 : (nt <= 12 ? 1 : 2); }
+template <int CLS>
+__global__ __launch_bounds__(256) void k_gemm_wgrad_group(GemmGroup G) {
+    __shared__ float red[(CLS == 0 ? 6 : (CLS == 1 ? 12 : 24)) * 256];
+    int i = 0;
+    while (i + 1 < G.n && (int)blockIdx.x >= G.d[i + 1].block0) ++i;
+    const GemmDesc& d = G.d[i];
+    const int bid = (int)blockIdx.x - d.block0;
+#define ENERF_GG(TA, TB)                                                                                                              \
+    case TA * 8 + TB:                                                                                                                 \
+        if constexpr (gemm_group_class(TA * TB) == CLS)                                                                               \
+            gemm_wgrad_body<TA, TB>(d.A, d.B, d.lda, d.ldb, d.Ca, d.Cb, d.bias, d.P, d.dW, d.ldw, d.dbias, d.scratch, bid, d.blocks, red); \
+        break;
+    switch (d.ta * 8 + d.tb) {
+        ENERF_GG(1, 1) ENERF_GG(1, 2) ENERF_GG(1, 3) ENERF_GG(1, 4) ENERF_GG(1, 5) ENERF_GG(1, 6)
+        ENERF_GG(2, 1) ENERF_GG(2, 2) ENERF_GG(2, 3) ENERF_GG(2, 4) ENERF_GG(2, 5) ENERF_GG(2, 6)
+        ENERF_GG(3, 1) ENERF_GG(3, 2) ENERF_GG(3, 3) ENERF_GG(3, 4) ENERF_GG(3, 5) ENERF_GG(3, 6)
+        ENERF_GG(4, 1) ENERF_GG(4, 2) ENERF_GG(4, 3) ENERF_GG(4, 4) ENERF_GG(4, 5) ENERF_GG(4, 6)
+        default: break;
+    }
+#undef ENERF_GG
+}
+// k_wgrad_reduce (gemm mode) for every member: block = (member, tile t, register r)
+__global__ __launch_bounds__(1024) void k_gemm_wgrad_group_reduce(GemmGroup G) {
+    __shared__ float red[16][64];
+    int i = 0;
+    while (i + 1 < G.n && (int)blockIdx.x >= G.d[i + 1].rblock0) ++i;
+    const GemmDesc& d = G.d[i];
+    const int lb = (int)blockIdx.x - d.rblock0, lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+    const int r = lb & 3, t = lb >> 2, nt = d.ta * d.tb;
+    const float v = wgrad_reduce_sum(d.scratch + (long long)t * 256 + r * 64 + lane, d.blocks, (long long)nt * 256, red);
+    if (w != 0) return;
+    const int ta = t / d.tb, tb = t - ta * d.tb;
+    const int a_ch = ta * 16 + 4 * g + r, b_ch = tb * 16 + j;
+    if (a_ch >= d.Ca) return;
+    if (b_ch < d.Cb) d.dW[(long long)a_ch * d.ldw + b_ch] = v;
+    else if (d.bias && b_ch == d.Cb) d.dbias[a_ch] = v;
 }
 
 template <int TA>
@@ -992,10 +1065,75 @@ bool launch_gemm_wgrad(const float* A, int lda, int Ca, const float* Bt, int ldb
     return ok;
 }
 
+// host side of the group: per member its own block count and scratch slice (what launch_gemm_wgrad would use), then the two launches
+static size_t gemm_group_plan(const enerf_gemm_wgrad_desc_t* u, int n, GemmGroup* G) {
+    size_t floats = 0;
+    int block0 = 0, rblock0 = 0;
+    for (int i = 0; i < n; ++i) {
+        const int bias = u[i].grad_bias != nullptr, ta = cdiv(u[i].Ca, 16), tb = cdiv(u[i].Cb + bias, 16);
+        const int blocks = (int)gemm_wgrad_blocks(u[i].P);
+        if (G != nullptr) {
+            GemmDesc& d = G->d[i];
+            d.A = u[i].a; d.B = u[i].b; d.dW = u[i].grad_w; d.dbias = u[i].grad_bias; d.scratch = nullptr;
+            d.P = u[i].P; d.lda = u[i].lda; d.ldb = u[i].ldb; d.Ca = u[i].Ca; d.Cb = u[i].Cb; d.bias = bias;
+            d.ldw = u[i].ldw > 0 ? u[i].ldw : u[i].Cb; d.ta = ta; d.tb = tb; d.blocks = blocks; d.block0 = block0; d.rblock0 = rblock0;
+            d.pad = (int)(floats / 256);                          // scratch offset in 256-float tiles (resolved by the caller)
+        }
+        floats += (size_t)blocks * ta * tb * 256;
+        block0 += blocks;
+        rblock0 += ta * tb * 4;
+    }
+    if (G != nullptr) { G->n = n; G->d[0].pad = 0; }
+    return floats * sizeof(float);
+}
+
 }  // namespace enerf
 
 using namespace enerf;
 extern "C" {
+size_t enerf_gemm_wgrad_group_workspace_bytes(const enerf_gemm_wgrad_desc_t* descs, int n) {
+    if (descs == nullptr || n < 1 || n > kGemmGroupMax) return 0;
+    for (int i = 0; i < n; ++i)
+        if (descs[i].P <= 0 || descs[i].Ca < 1 || descs[i].Cb < 1) return 0;
+    return gemm_group_plan(descs, n, nullptr);
+}
+int enerf_gemm_wgrad_group(const enerf_gemm_wgrad_desc_t* descs, int n, void* workspace, size_t workspace_bytes, enerf_stream_t stream) {
+    REQUIRE(descs && n >= 1 && n <= kGemmGroupMax, "gemm_wgrad_group: 1..%d members", kGemmGroupMax);
+    for (int i = 0; i < n; ++i) {
+        const enerf_gemm_wgrad_desc_t& u = descs[i];
+        REQUIRE(u.a && u.b && u.grad_w && u.Ca > 0 && u.Cb > 0 && u.lda >= u.Ca && u.ldb >= u.Cb && (u.ldw == 0 || u.ldw >= u.Cb),
+                "gemm_wgrad_group: member %d: bad arguments", i);
+        REQUIRE(u.P > 0 && u.P < (1LL << 31), "gemm_wgrad_group: member %d: P out of range", i);
+        REQUIRE(u.P * u.lda < (1LL << 30) && u.P * u.ldb < (1LL << 30),
+                "gemm_wgrad_group: member %d: a matrix of 4 GiB or more (32-bit byte offsets inside the kernel)", i);
+        REQUIRE(cdiv(u.Ca, 16) <= 4 && cdiv(u.Cb + (u.grad_bias != nullptr), 16) <= 6,
+                "gemm_wgrad_group: member %d: more than 4 x 6 tiles (%d x %d columns): use enerf_gemm_wgrad", i, u.Ca, u.Cb);
+    }
+    GemmGroup G;
+    const size_t need = gemm_group_plan(descs, n, &G);
+    REQUIRE(workspace != nullptr && workspace_bytes >= need, "gemm_wgrad_group: workspace of %zu bytes, need %zu (enerf_gemm_wgrad_group_workspace_bytes)",
+            workspace_bytes, need);
+    for (int i = 0; i < n; ++i) { G.d[i].scratch = (float*)workspace + (size_t)G.d[i].pad * 256; G.d[i].pad = 0; }
+    const GemmDesc& last = G.d[n - 1];
+    for (int cls = 0; cls < 3; ++cls) {                     // the members of one register class: one launch
+        GemmGroup Gc;
+        Gc.n = 0;
+        int blocks = 0;
+        for (int i = 0; i < n; ++i)
+            if (gemm_group_class(G.d[i].ta * G.d[i].tb) == cls) {
+                Gc.d[Gc.n] = G.d[i];
+                Gc.d[Gc.n].block0 = blocks;
+                blocks += G.d[i].blocks;
+                ++Gc.n;
+            }
+        if (Gc.n == 0) continue;
+        if (cls == 0) ENERF_LAUNCH(k_gemm_wgrad_group<0>, (unsigned)blocks, 256, 0, (hipStream_t)stream, Gc);
+        else if (cls == 1) ENERF_LAUNCH(k_gemm_wgrad_group<1>, (unsigned)blocks, 256, 0, (hipStream_t)stream, Gc);
+        else ENERF_LAUNCH(k_gemm_wgrad_group<2>, (unsigned)blocks, 256, 0, (hipStream_t)stream, Gc);
+    }
+    ENERF_LAUNCH(k_gemm_wgrad_group_reduce, (unsigned)(last.rblock0 + last.ta * last.tb * 4), 1024, 0, (hipStream_t)stream, G);
+    return check_launch("gemm_wgrad_group");
+}
 // scratch for the two-stage (atomic-free, deterministic) commit of the weight gradients; without it the entries fall back to
 // fp32 atomics onto grad_w (correct, several times slower: see k_wgrad_reduce)
 size_t enerf_conv_wgrad_workspace_bytes(long long positions_a, int Ca, int Cb, int kd, int kh, int kw) {

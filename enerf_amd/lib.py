@@ -14,7 +14,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libenerf_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _f = C.c_void_p     # device float*
 _i = C.c_int
@@ -73,6 +73,11 @@ class GatherArgs(C.Structure):
     _fields_ = ([(n, _f) for n in ("xyz", "dn", "uv", "tex", "vol", "cam", "tcen", "x", "vox", "g_x", "g_vox", "g_tex",
                                    "g_vol", "g_xyz", "g_dn")]
                 + [("P", _ll)] + [(n, _i) for n in ("B", "S", "F", "Hr", "Wr", "D", "h", "w", "ray_w", "n_samples")])
+
+
+class GemmWgradDesc(C.Structure):
+    _fields_ = [("a", _f), ("lda", _i), ("Ca", _i), ("b", _f), ("ldb", _i), ("Cb", _i), ("P", _ll), ("grad_w", _f), ("ldw", _i),
+                ("grad_bias", _f)]
 
 
 class RenderArgs(C.Structure):
@@ -164,6 +169,8 @@ _SIGNATURES = {
     "enerf_gemm_wgrad_workspace_bytes": (C.c_size_t, [_ll, _i, _i, _i]),
     "enerf_nerf_mlp_bwd": (_i, [C.POINTER(MlpBwdArgs), _f]),
     "enerf_gemm_wgrad": (_i, [_f, _i, _i, _f, _i, _i, _ll, _f, _f, C.c_void_p, C.c_size_t, _f]),
+    "enerf_gemm_wgrad_group_workspace_bytes": (C.c_size_t, [C.POINTER(GemmWgradDesc), _i]),
+    "enerf_gemm_wgrad_group": (_i, [C.POINTER(GemmWgradDesc), _i, C.c_void_p, C.c_size_t, _f]),
     "enerf_nerf_mlp_fwd": (_i, [_f, _f, _f, _ll, _i, _i, _f, _f]),
     "enerf_gather_fwd": (_i, [C.POINTER(GatherArgs), _f]),
     "enerf_gather_bwd": (_i, [C.POINTER(GatherArgs), _f]),
@@ -622,6 +629,35 @@ class EnerfLib:
         self._check(self.dll.enerf_gemm_wgrad(a.data_ptr(), a.stride(0), Ca, b.data_ptr(), b.stride(0), Cb, P, _ptr(gw),
                                               _ptr(gb), ws.data_ptr(), ws.numel(), self.stream_of(a)), "gemm_wgrad")
         return (gw, gb) if bias else gw
+
+    def gemm_wgrad_group(self, members):
+        """Several ``gemm_wgrad`` calls as TWO launches (enerf_gemm_wgrad_group; every gradient bit-identical to its single call).
+        ``members``: dicts with ``a``, ``b`` (2-D row-major, possibly column slices), optional ``Cb`` (leading columns of b used),
+        ``bias`` (also the column sums of a) and ``into = (matrix (Ca, W), first column)`` — the gradient is a column block of a
+        wider weight matrix and is written in place.  Returns one (grad_w or the ``into`` matrix, grad_bias or None) per member."""
+        n = len(members)
+        descs, out = (GemmWgradDesc * n)(), []
+        for d, m in zip(descs, members):
+            a, b = m["a"], m["b"]
+            if a.stride(1) != 1 or b.stride(1) != 1 or a.shape[0] != b.shape[0]:
+                raise EnerfError("gemm_wgrad_group: rows must be contiguous and of equal count")
+            Ca, Cb = a.shape[1], m.get("Cb") or b.shape[1]
+            gb = torch.empty((Ca,), dtype=torch.float32, device=a.device) if m.get("bias") else None
+            if m.get("into") is not None:
+                mat, c0 = m["into"]
+                if mat.shape[0] != Ca or not mat.is_contiguous() or c0 + Cb > mat.shape[1]:
+                    raise EnerfError("gemm_wgrad_group: `into` matrix does not hold the column block")
+                gw, ptr, ldw = mat, mat.data_ptr() + 4 * c0, mat.shape[1]
+            else:
+                gw = torch.empty((Ca, Cb), dtype=torch.float32, device=a.device)
+                ptr, ldw = gw.data_ptr(), Cb
+            d.a, d.lda, d.Ca, d.b, d.ldb, d.Cb, d.P = a.data_ptr(), a.stride(0), Ca, b.data_ptr(), b.stride(0), Cb, a.shape[0]
+            d.grad_w, d.ldw, d.grad_bias = ptr, ldw, _ptr(gb)
+            out.append((gw, gb))
+        a0 = members[0]["a"]
+        ws = self._scratch(self.dll.enerf_gemm_wgrad_group_workspace_bytes(descs, n), a0.device)
+        self._check(self.dll.enerf_gemm_wgrad_group(descs, n, ws.data_ptr(), ws.numel(), self.stream_of(a0)), "gemm_wgrad_group")
+        return out
 
     def nerf_mlp_fwd(self, vox, x, packed, S, F):
         raw = torch.empty((vox.shape[0], 4), dtype=torch.float32, device=vox.device)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ENERF_ABI_VERSION 10
+#define ENERF_ABI_VERSION 11
 #define ENERF_OK 0
 #define ENERF_EINVAL (-1)   /* bad argument / unsupported shape */
 #define ENERF_ELAUNCH (-2)  /* HIP launch error */
@@ -455,6 +455,22 @@ size_t enerf_gemm_wgrad_workspace_bytes(long long P, int Ca, int Cb, int with_bi
 int enerf_gemm_wgrad(const float* a, int lda, int Ca, const float* b, int ldb, int Cb, long long P, float* grad_w,
                      float* grad_bias /* nullable: (Ca) = sum_p a[p][:] from the same pass */, void* workspace,
                      size_t workspace_bytes, enerf_stream_t stream);
+/* ABI v11: several of those GEMMs in two to four launches (the members' grids concatenated per register class, then one reduction kernel
+ * for all): the weight
+ * gradients of one Agg + NeRF MLP (nerf.py:29-89) are ten to eleven position reductions over the rows enerf_nerf_mlp_bwd saved.  Every
+ * member keeps the block count, row map and summation order of its single enerf_gemm_wgrad call: bit-identical gradients.  ldw: row
+ * stride of grad_w in floats (0 = Cb) — a gradient that is a column block of a wider weight matrix (color.0 = [shared | per-view]
+ * columns, nerf.py:64-66) is written in place.  At most 16 members of at most 4 x 6 tiles (64 x 95 columns); the workspace
+ * (enerf_gemm_wgrad_group_workspace_bytes) is required. */
+typedef struct {
+    const float* a; int lda, Ca;
+    const float* b; int ldb, Cb;
+    long long P;
+    float* grad_w; int ldw;
+    float* grad_bias;                       /* nullable */
+} enerf_gemm_wgrad_desc_t;
+size_t enerf_gemm_wgrad_group_workspace_bytes(const enerf_gemm_wgrad_desc_t* descs, int n);
+int enerf_gemm_wgrad_group(const enerf_gemm_wgrad_desc_t* descs, int n, void* workspace, size_t workspace_bytes, enerf_stream_t stream);
 int enerf_build_feature_volume_bwd(const float* feat, const float* proj, const float* depth_values, const float* grad_vol, int B,
                                    int S, int C, int Hs, int Ws, int D, int h, int w, float* grad_feat, float* grad_depth_values,
                                    enerf_stream_t stream);

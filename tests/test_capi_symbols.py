@@ -28,7 +28,7 @@ def test_hip_library_builds_and_exports_all_symbols():
     assert set(_declared()) <= exported, set(_declared()) - exported
     lib = EnerfLib(LIB_PATH)                              # dlopen + ABI version; no compute calls here
     from enerf_amd.lib import ABI_VERSION
-    assert lib.dll.enerf_abi_version() == ABI_VERSION == 10
+    assert lib.dll.enerf_abi_version() == ABI_VERSION == 11
     assert lib.dll.enerf_nerf_packed_floats(11) > 0 and lib.dll.enerf_cost_reg_packed_floats(16, 1) > 0
 
 

@@ -433,6 +433,29 @@ def _check_conv_wgrad(lib, dev):
     lib._check(lib.dll.enerf_gemm_wgrad(am.data_ptr(), 40, 40, bm.data_ptr(), 24, 24, 1000, g2.data_ptr(), None, None, 0,
                                         lib.stream_of(am)), "gemm_wgrad")
     assert float((g2 - g1).abs().max()) <= 1e-5 * float(g1.abs().max())
+    # ABI v11: the grouped call (what NerfMlpFn's backward issues: all of one MLP's weight gradients in two to four launches) gives
+    # every member the bits of its single call — shapes of all three register classes, column slices, a gradient written as a
+    # column block of a wider matrix, with and without the bias column, ragged row counts
+    P = 1003
+    hv, d64, d1, d32, xs = rnd(P, 88), rnd(P, 64), rnd(P, 1), rnd(P, 32), rnd(P, 15)
+    wide = torch.full((64, 88 + 15), 7.0, device=dev)
+    members = [dict(a=d1, b=d64, bias=True), dict(a=d64, b=hv, bias=True, into=(wide, 0)), dict(a=d64, b=xs, into=(wide, 88)),
+               dict(a=d1, b=hv, Cb=64, bias=True), dict(a=d64, b=hv[:, 64:], bias=True), dict(a=d32[:, :16], b=d32, bias=True),
+               dict(a=d32, b=xs[:, :11]), dict(a=d32, b=hv[:, :71], bias=True), dict(a=xs[:, :11], b=xs[:, 11:], bias=True)]
+    got = lib.gemm_wgrad_group(members)
+    for m, (gw_, gb_) in zip(members, got):
+        single = lib.gemm_wgrad(m["a"], m["b"], Cb=m.get("Cb"), bias=bool(m.get("bias")))
+        sw, sb = single if m.get("bias") else (single, None)
+        if m.get("into") is not None:
+            c0 = m["into"][1]
+            assert gw_ is wide and torch.equal(wide[:, c0:c0 + sw.shape[1]], sw)
+        else:
+            assert torch.equal(gw_, sw)
+        assert (gb_ is None) == (sb is None) and (sb is None or torch.equal(gb_, sb))
+    with pytest.raises(Exception, match="4 x 6 tiles"):
+        lib.gemm_wgrad_group([dict(a=rnd(10, 80), b=rnd(10, 8))])
+    with pytest.raises(Exception, match="1..16 members"):
+        lib.gemm_wgrad_group([dict(a=d1, b=d64)] * 17)
 
 
 def _check_feature_net_train(lib, dev, H=32, W=64, n=3, tol=2e-4):
