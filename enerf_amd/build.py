@@ -10,7 +10,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
-SOURCES = ["geometry.hip", "volume.hip", "conv3d.hip", "conv3d_pk8.hip", "conv3d_b4.hip", "conv3d_s2.hip", "conv3d_t2.hip", "conv3d_wl.hip", "conv2d.hip", "render.hip", "io.hip", "frame.hip", "backward.hip", "wgrad.hip", "train.hip", "train_glue.hip", "mlp_train.hip", "gather.hip", "capi.hip"]
+SOURCES = ["geometry.hip", "volume.hip", "conv3d.hip", "conv3d_pk8.hip", "conv3d_b4.hip", "conv3d_s2.hip", "conv3d_t2.hip", "conv3d_wl.hip", "conv2d.hip", "render.hip", "io.hip", "frame.hip", "backward.hip", "wgrad.hip", "train.hip", "train_glue.hip", "mlp_train.hip", "gather.hip", "selftest.hip", "capi.hip"]
 LIB = os.path.join(PKG, "libenerf_hip.so")
 STAMP = os.path.join(PKG, "csrc", ".build_stamp")
 ARCH = "gfx950"

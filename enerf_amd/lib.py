@@ -169,6 +169,8 @@ _SIGNATURES = {
     "enerf_gemm_wgrad_workspace_bytes": (C.c_size_t, [_ll, _i, _i, _i]),
     "enerf_nerf_mlp_bwd": (_i, [C.POINTER(MlpBwdArgs), _f]),
     "enerf_gemm_wgrad": (_i, [_f, _i, _i, _f, _i, _i, _ll, _f, _f, C.c_void_p, C.c_size_t, _f]),
+    "enerf_selftest_checks": (_i, []),
+    "enerf_selftest_primitives": (_i, [_f, _i, _f, _i, C.c_void_p, _f]),
     "enerf_gemm_wgrad_group_workspace_bytes": (C.c_size_t, [C.POINTER(GemmWgradDesc), _i]),
     "enerf_gemm_wgrad_group": (_i, [C.POINTER(GemmWgradDesc), _i, C.c_void_p, C.c_size_t, _f]),
     "enerf_nerf_mlp_fwd": (_i, [_f, _f, _f, _ll, _i, _i, _f, _f]),
@@ -629,6 +631,22 @@ class EnerfLib:
         self._check(self.dll.enerf_gemm_wgrad(a.data_ptr(), a.stride(0), Ca, b.data_ptr(), b.stride(0), Cb, P, _ptr(gw),
                                               _ptr(gb), ws.data_ptr(), ws.numel(), self.stream_of(a)), "gemm_wgrad")
         return (gw, gb) if bias else gw
+
+    SELFTEST_NAMES = ("xor16", "xor32", "group_sum4", "group_max4", "row_sum16", "add_xor8", "group_bcast<2>", "group_bcast<4>",
+                      "group_bcast<8>", "glds16 + raw barrier", "raw buffer loads", "mfma 16x16x4 layout", "mfma 4x4x1 broadcast-A",
+                      "mfma 4x4x1", "relu1 (med3)", "mul24", "lds / global fp32 atomics", "rcp / sqrt / exp", "wave_sync", "xcd_contiguous")
+
+    def selftest_primitives(self, device, blocks: int = 24):
+        """{check name: lanes that disagree with the memory-only specification} (enerf_selftest_primitives): all zero on a sound build."""
+        n = self.dll.enerf_selftest_checks()
+        assert n == len(self.SELFTEST_NAMES)
+        g = torch.Generator().manual_seed(5)
+        table = torch.randn(4096, generator=g).to(device)
+        scratch = torch.empty(blocks * 16, dtype=torch.float32, device=device)
+        bad = torch.empty(n, dtype=torch.int32, device=device)
+        self._check(self.dll.enerf_selftest_primitives(_ptr(table), table.numel(), _ptr(scratch), blocks, bad.data_ptr(),
+                                                       self.stream_of(table)), "selftest_primitives")
+        return dict(zip(self.SELFTEST_NAMES, (int(v) for v in bad.cpu())))
 
     def gemm_wgrad_group(self, members):
         """Several ``gemm_wgrad`` calls as TWO launches (enerf_gemm_wgrad_group; every gradient bit-identical to its single call).

@@ -33,6 +33,16 @@ typedef void* enerf_stream_t; /* hipStream_t */
 int enerf_abi_version(void);
 const char* enerf_last_error(void);
 
+/* ABI v11: self-test of the gfx950-only primitives the kernels are written on (LDS-DMA copies, raw buffer loads, DPP / permlane lane
+ * exchanges, the two matrix instructions' operand layouts incl. the broadcast-A form, med3 ReLU, 24-bit multiplies, LDS / global
+ * fp32 atomics, hardware rcp / sqrt / exp, wave-level LDS ordering, the XCD block map): each check computes the primitive and the
+ * same quantity from values staged through memory with plain indexed reads, and counts disagreeing lanes into
+ * mismatches[enerf_selftest_checks()] (device, zeroed here).  No reference function: it ties the intrinsic build to the lane
+ * emulator's twins of the same helpers (csrc/common.h), on which the CPU test suite runs the kernel sources.
+ * table: >= 1024 arbitrary device floats (a multiple of 4); scratch: blocks * 16 device floats. */
+int enerf_selftest_checks(void);
+int enerf_selftest_primitives(const float* table, int table_floats, float* scratch, int blocks, unsigned* mismatches, enerf_stream_t stream);
+
 /* ---- kernel-variant choices, passed EXPLICITLY per call (ABI >= 3; no environment variables are read).
  * Every entry point that has more than one kernel variant takes a `const enerf_options_t*`; NULL (or a
  * zero-filled struct) selects the defaults, which are the single-frame-latency choices measured on MI355X.

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "enerf_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
-SOURCES = ["geometry.hip", "volume.hip", "conv3d.hip", "conv3d_pk8.hip", "conv3d_b4.hip", "conv3d_s2.hip", "conv3d_t2.hip", "conv3d_wl.hip", "conv2d.hip", "render.hip", "io.hip", "frame.hip", "backward.hip", "wgrad.hip", "train.hip", "train_glue.hip", "mlp_train.hip", "gather.hip", "capi.hip"]
+SOURCES = ["geometry.hip", "volume.hip", "conv3d.hip", "conv3d_pk8.hip", "conv3d_b4.hip", "conv3d_s2.hip", "conv3d_t2.hip", "conv3d_wl.hip", "conv2d.hip", "render.hip", "io.hip", "frame.hip", "backward.hip", "wgrad.hip", "train.hip", "train_glue.hip", "mlp_train.hip", "gather.hip", "selftest.hip", "capi.hip"]
 
 
 def _digest() -> str:
@@ -18,6 +18,7 @@ def _digest() -> str:
     for f in srcs + ["../../tests/emu/hip_emu.h", "../../include/enerf_hip.h"]:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
+    h.update(" ".join(SOURCES).encode())
     return h.hexdigest()[:16]
 
 

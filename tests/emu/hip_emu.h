@@ -320,6 +320,9 @@ inline float atomicAdd(float* p, float v) {            // blocks run on several 
     return of;
 }
 
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+
 inline int atomicMin(int* p, int v) {
     int old = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
