@@ -289,10 +289,10 @@ class _BatchNormTrain:
         lib, bn = self.lib, self.bn
         C_ = z.shape[-1]
         self.fused = not self._synced(bn) and lib.bn_stats_fit(z)
-        if self.fused:       # no statistics exchange: partial sums, then their reduction + the coefficients in ONE launch (ABI v8)
-            self.mean_invstd, ss, n = lib.bn_train_stats(z, bn)
-            self.z, self.n, self.scale, self.shift = z, n, ss[0], ss[1]
-            return lib.channel_affine(z, self.scale, self.shift, residual=residual, relu=self.relu)
+        if self.fused:       # no statistics exchange: partial sums, then the affine pass with their reduction + the coefficients in its
+            y, self.mean_invstd, self.ss, n = lib.bn_train_apply(z, bn, residual, self.relu)      # prologue (ABI v11; large layers: three launches)
+            self.z, self.n, self.scale, self.shift = z, n, self.ss[0], self.ss[1]
+            return y
         sums, n = lib.channel_sums_raw(z, z), z.numel() // C_
         if self._synced(bn):
             import torch.distributed as dist
@@ -308,8 +308,7 @@ class _BatchNormTrain:
         lib, bn, z = self.lib, self.bn, self.z
         mask = dict(z_mask=z, mask_scale=self.scale, mask_shift=self.shift) if self.relu else {}
         if self.fused:
-            dgb, k23 = lib.bn_train_bwd_stats(g, z, self.mean_invstd, self.scale, **mask)
-            dz = lib.channel_affine(g, self.scale, k23[1], b=z, q=k23[0], **mask)
+            dz, dgb = lib.bn_train_bwd_apply(g, z, self.mean_invstd, self.ss, self.relu)
             return dz, dgb[0], dgb[1]
         local = lib.channel_sums_raw(g, z, **mask)                                   # sum gm, sum gm*z over this rank
         glob = local

@@ -213,6 +213,107 @@ __global__ __launch_bounds__(1024) void k_bn_finish_bwd_coeffs(const double* __r
     if (c < C) bn_bwd_channel(c, C, tot[c], tot[C + c], tot[c], tot[C + c], n, mean_invstd, scale, dgamma_dbeta, k2k3);
 }
 
+// ---- round 6: the coefficient launch folded into the AFFINE kernel's prologue (small / mid layers) ----
+// Forward and backward of a BatchNorm were three launches each (partial sums; their reduction + the C-sized coefficients in one
+// 1024-thread block; the affine pass), and for the 13 of 23 layers below ~8 MB all three sit at the 5 - 8 us floor of a graph node.
+// Here every block of the affine kernel first redoes the reduction of the nb partial rows and the coefficient arithmetic itself —
+// nb x 2C doubles from L2, a few KB — with 256 threads standing in for finish_rows' 1024 (same additions in the same order: the
+// coefficients are bit-identical to k_bn_finish_*'s), keeps them in LDS, and block 0 alone stores what later kernels read (mean / invstd,
+// scale / shift, the running statistics, d gamma / d beta).  The launcher uses it when nb * C <= 2048 (<= 32 KB of rows) and caps the
+// grid at 512 blocks, so the redone reductions move <= 16 MB through L2 per layer; larger layers keep the three launches.
+__device__ __forceinline__ void finish_rows256(const double* __restrict__ partials, int nb, int C2, double* red /* [1024] */, double* tot /* [128] */) {
+    const int nr = 1024 / C2;
+    for (int vt = threadIdx.x; vt < 1024; vt += 256) {       // virtual thread vt of finish_rows
+        const int c = vt % C2, r0 = vt / C2;
+        double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        int blk = r0;
+        for (; blk + 3 * nr < nb; blk += 4 * nr) {
+            const double v0 = partials[(long long)blk * C2 + c], v1 = partials[(long long)(blk + nr) * C2 + c];
+            const double v2 = partials[(long long)(blk + 2 * nr) * C2 + c], v3 = partials[(long long)(blk + 3 * nr) * C2 + c];
+            t0 += v0; t1 += v1; t2 += v2; t3 += v3;
+        }
+        for (; blk < nb; blk += nr) t0 += partials[(long long)blk * C2 + c];
+        red[vt] = (t0 + t1) + (t2 + t3);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < C2) {
+        const int c = threadIdx.x;
+        double t = 0;
+        for (int q = 0; q < nr; ++q) t += red[q * C2 + c];
+        tot[c] = t;
+    }
+    __syncthreads();
+}
+// the affine pass of k_channel_affine with the coefficients in LDS, grid-stride (same expression per element: same bits)
+__device__ __forceinline__ void affine_pass(const float* __restrict__ a, const float* __restrict__ b, const float* pp, const float* qq, const float* rr,
+                                            const float* __restrict__ zm, const float* ms, const float* mh, const float* __restrict__ residual,
+                                            int relu, long long n4, int CQ, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const int c0 = (int)(i % CQ) * 4;
+        const float4 av = *reinterpret_cast<const float4*>(a + i * 4);
+        float x[4] = {av.x, av.y, av.z, av.w};
+        if (zm != nullptr) {
+            const float4 zv = *reinterpret_cast<const float4*>(zm + i * 4);
+            const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+            for (int k = 0; k < 4; ++k) x[k] = (zz[k] * ms[c0 + k] + mh[c0 + k] > 0.f) ? x[k] : 0.f;
+        }
+        float y[4];
+        for (int k = 0; k < 4; ++k) y[k] = x[k] * pp[c0 + k] + rr[c0 + k];
+        if (b != nullptr) {
+            const float4 bv = *reinterpret_cast<const float4*>(b + i * 4);
+            const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+            for (int k = 0; k < 4; ++k) y[k] += bb[k] * qq[c0 + k];
+        }
+        if (relu) for (int k = 0; k < 4; ++k) y[k] = fmaxf(y[k], 0.f);
+        if (residual != nullptr) {
+            const float4 rv = *reinterpret_cast<const float4*>(residual + i * 4);
+            y[0] += rv.x; y[1] += rv.y; y[2] += rv.z; y[3] += rv.w;
+        }
+        *reinterpret_cast<float4*>(out + i * 4) = make_float4(y[0], y[1], y[2], y[3]);
+    }
+}
+__global__ __launch_bounds__(256) void k_bn_affine_fwd(const float* __restrict__ z, const double* __restrict__ partials, int nb, double n,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, double eps, double momentum,
+                                                       float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
+                                                       int nbt_increment, int C, double* __restrict__ sums_out, double* __restrict__ mean_invstd,
+                                                       float* __restrict__ scale_shift, const float* __restrict__ residual, int relu, long long n4,
+                                                       float* __restrict__ out) {
+    __shared__ double red[1024], tot[128];
+    __shared__ double mi[128];
+    __shared__ float ss[128];
+    const long long tracked = (blockIdx.x == 0 && nbt != nullptr) ? *nbt + nbt_increment : 1;       // (only block 0 touches the running statistics)
+    finish_rows256(partials, nb, 2 * C, red, tot);
+    const int c = threadIdx.x;
+    const bool first = blockIdx.x == 0;
+    if (first && c == 0 && nbt != nullptr && nbt_increment) *nbt = tracked;
+    if (first && c < 2 * C && sums_out != nullptr) sums_out[c] = tot[c];
+    if (c < C) {       // bn_fwd_channel's arithmetic into LDS; block 0 also stores it (and updates the running statistics)
+        if (first) {
+            bn_fwd_channel(c, C, tot[c], tot[C + c], n, tracked, gamma, beta, eps, momentum, running_mean, running_var, mean_invstd, scale_shift);
+            ss[c] = scale_shift[c]; ss[C + c] = scale_shift[C + c];
+        } else {
+            bn_fwd_channel(c, C, tot[c], tot[C + c], n, 1, gamma, beta, eps, momentum, nullptr, nullptr, mi, ss);
+        }
+    }
+    __syncthreads();
+    affine_pass(z, nullptr, ss, nullptr, ss + C, nullptr, nullptr, nullptr, residual, relu, n4, C / 4, out);
+}
+__global__ __launch_bounds__(256) void k_bn_affine_bwd(const float* __restrict__ g, const float* __restrict__ z, const double* __restrict__ partials,
+                                                       int nb, double n, const double* __restrict__ mean_invstd, const float* __restrict__ scale_shift,
+                                                       int relu_mask, int C, float* __restrict__ dgamma_dbeta, long long n4, float* __restrict__ out) {
+    __shared__ double red[1024], tot[128];
+    __shared__ float dgb[128], k23[128], ss[128];
+    finish_rows256(partials, nb, 2 * C, red, tot);
+    const int c = threadIdx.x;
+    if (c < C) {
+        bn_bwd_channel(c, C, tot[c], tot[C + c], tot[c], tot[C + c], n, mean_invstd, scale_shift, blockIdx.x == 0 ? dgamma_dbeta : dgb, k23);
+        ss[c] = scale_shift[c]; ss[C + c] = scale_shift[C + c];
+    }
+    __syncthreads();
+    // d z = g m scale + z k2 + k3,  m = (z scale + shift > 0) under a ReLU
+    affine_pass(g, z, ss, k23, k23 + C, relu_mask ? z : nullptr, ss, ss + C, nullptr, 0, n4, C / 4, out);
+}
+
 __global__ void k_bn_train_coeffs(const double* __restrict__ sums, const double* __restrict__ count_dev, double count_host,
                                   const float* __restrict__ gamma, const float* __restrict__ beta, double eps, double momentum,
                                   float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -457,6 +558,62 @@ int enerf_bn_train_bwd_stats(const float* g, const float* z, const float* z_mask
     ENERF_LAUNCH(k_bn_finish_bwd_coeffs, 1, 1024, 0, (hipStream_t)stream, partials, (int)blocks, (double)n, mean_invstd, scale, C, dgamma_dbeta,
                  k2k3);
     return check_launch("bn_train_bwd_stats");
+}
+// the affine launch of the fused forms: at most 512 blocks (each redoes the row reduction)
+static unsigned bn_affine_blocks(long long n4) {
+    const long long b = cdivl(n4, 256);
+    return (unsigned)(b > 512 ? 512 : b);
+}
+static bool bn_fold_fits(long long blocks, int C) { return blocks * C <= 2048; }
+int enerf_bn_train_apply(const float* z, long long n, int C, void* workspace, size_t workspace_bytes, const float* gamma, const float* beta,
+                         double eps, double momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
+                         int increment_num_batches_tracked, double* mean_invstd, float* scale_shift, const float* residual, int relu,
+                         float* out, enerf_stream_t stream) {
+    REQUIRE(z && gamma && beta && mean_invstd && scale_shift && out && workspace && n > 0 && C >= 4 && C <= 64 && C % 4 == 0 && (256 % (C / 4)) == 0,
+            "bn_train_apply: bad arguments (C in 4..64, power-of-two quads)");
+    REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_apply: running_mean and running_var come together");
+    const long long blocks = channel_sums_blocks(n, C);
+    REQUIRE(workspace_bytes >= (size_t)blocks * 2 * C * sizeof(double), "bn_train_apply: workspace of %zu bytes, need %zu", workspace_bytes,
+            (size_t)blocks * 2 * C * sizeof(double));
+    double* partials = (double*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const long long n4 = n * (C / 4);
+    ENERF_LAUNCH((k_channel_sums<true, false>), (unsigned)blocks, 256, 0, st, z, z, nullptr, nullptr, nullptr, n, C, (double*)nullptr, partials);
+    if (bn_fold_fits(blocks, C)) {
+        ENERF_LAUNCH(k_bn_affine_fwd, bn_affine_blocks(n4), 256, 0, st, z, partials, (int)blocks, (double)n, gamma, beta, eps, momentum, running_mean,
+                     running_var, num_batches_tracked, increment_num_batches_tracked, C, (double*)nullptr, mean_invstd, scale_shift, residual, relu, n4, out);
+    } else {
+        ENERF_LAUNCH(k_bn_finish_coeffs, 1, 1024, 0, st, partials, (int)blocks, (double)n, gamma, beta, eps, momentum, running_mean, running_var,
+                     num_batches_tracked, increment_num_batches_tracked, C, (double*)nullptr, mean_invstd, scale_shift);
+        ENERF_LAUNCH_SIMPLE(k_channel_affine, (unsigned)cdivl(n4, 256), 256, 0, st, z, nullptr, scale_shift, nullptr, scale_shift + C, nullptr, nullptr,
+                            nullptr, residual, relu, n4, C / 4, out);
+    }
+    return check_launch("bn_train_apply");
+}
+int enerf_bn_train_bwd_apply(const float* g, const float* z, int relu, long long n, int C, void* workspace, size_t workspace_bytes,
+                             const double* mean_invstd, const float* scale_shift, float* dgamma_dbeta, float* grad_z, enerf_stream_t stream) {
+    REQUIRE(g && z && mean_invstd && scale_shift && dgamma_dbeta && grad_z && workspace && n > 0 && C >= 4 && C <= 64 && C % 4 == 0 &&
+                (256 % (C / 4)) == 0, "bn_train_bwd_apply: bad arguments (C in 4..64, power-of-two quads)");
+    const long long blocks = channel_sums_blocks(n, C);
+    REQUIRE(workspace_bytes >= (size_t)(blocks * 2 * C) * sizeof(double) + (size_t)2 * C * sizeof(float),
+            "bn_train_bwd_apply: workspace of %zu bytes, need %zu", workspace_bytes, (size_t)(blocks * 2 * C) * sizeof(double) + (size_t)2 * C * sizeof(float));
+    double* partials = (double*)workspace;
+    float* k2k3 = (float*)(partials + blocks * 2 * C);
+    hipStream_t st = (hipStream_t)stream;
+    const long long n4 = n * (C / 4);
+    const float *scale = scale_shift, *shift = scale_shift + C;
+    if (relu) ENERF_LAUNCH((k_channel_sums<false, true>), (unsigned)blocks, 256, 0, st, g, z, z, scale, shift, n, C, (double*)nullptr, partials);
+    else ENERF_LAUNCH((k_channel_sums<false, false>), (unsigned)blocks, 256, 0, st, g, z, (const float*)nullptr, (const float*)nullptr,
+                      (const float*)nullptr, n, C, (double*)nullptr, partials);
+    if (bn_fold_fits(blocks, C)) {
+        ENERF_LAUNCH(k_bn_affine_bwd, bn_affine_blocks(n4), 256, 0, st, g, z, partials, (int)blocks, (double)n, mean_invstd, scale_shift, relu, C,
+                     dgamma_dbeta, n4, grad_z);
+    } else {
+        ENERF_LAUNCH(k_bn_finish_bwd_coeffs, 1, 1024, 0, st, partials, (int)blocks, (double)n, mean_invstd, scale, C, dgamma_dbeta, k2k3);
+        ENERF_LAUNCH_SIMPLE(k_channel_affine, (unsigned)cdivl(n4, 256), 256, 0, st, g, z, scale, k2k3, k2k3 + C, relu ? z : nullptr, scale, shift,
+                            nullptr, 0, n4, C / 4, grad_z);
+    }
+    return check_launch("bn_train_bwd_apply");
 }
 int enerf_channel_affine(const float* a, const float* b, const float* p, const float* q, const float* r, const float* z_mask,
                          const float* mask_scale, const float* mask_shift, const float* residual, int relu, long long n, int C,

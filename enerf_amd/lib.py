@@ -169,6 +169,8 @@ _SIGNATURES = {
     "enerf_gemm_wgrad_workspace_bytes": (C.c_size_t, [_ll, _i, _i, _i]),
     "enerf_nerf_mlp_bwd": (_i, [C.POINTER(MlpBwdArgs), _f]),
     "enerf_gemm_wgrad": (_i, [_f, _i, _i, _f, _i, _i, _ll, _f, _f, C.c_void_p, C.c_size_t, _f]),
+    "enerf_bn_train_apply": (_i, [_f, _ll, _i, C.c_void_p, C.c_size_t, _f, _f, C.c_double, C.c_double, _f, _f, C.c_void_p, _i, C.c_void_p, _f, _f, _i, _f, _f]),
+    "enerf_bn_train_bwd_apply": (_i, [_f, _f, _i, _ll, _i, C.c_void_p, C.c_size_t, C.c_void_p, _f, _f, _f, _f]),
     "enerf_selftest_checks": (_i, []),
     "enerf_selftest_primitives": (_i, [_f, _i, _f, _i, C.c_void_p, _f]),
     "enerf_gemm_wgrad_group_workspace_bytes": (C.c_size_t, [C.POINTER(GemmWgradDesc), _i]),
@@ -599,6 +601,36 @@ class EnerfLib:
                                                       mean_invstd.data_ptr(), _ptr(scale), _ptr(dgb), _ptr(k23), self.stream_of(z)),
                     "bn_train_bwd_stats")
         return dgb, k23
+
+    def bn_train_apply(self, z, bn, residual=None, relu=False):
+        """ABI v11: training-mode BatchNorm of z (..., C) (+ ReLU) (+ residual) in two launches for small / mid layers, three otherwise
+        (enerf_bn_train_apply) -> (out, mean_invstd (2,C) fp64, scale_shift (2,C) fp32, positions); updates the running statistics."""
+        Cc = z.shape[-1]
+        n = z.numel() // Cc
+        nb = self.dll.enerf_channel_sums_workspace_bytes(n, Cc)
+        ws = self._scratch(nb, z.device)
+        mi = torch.empty((2, Cc), dtype=torch.float64, device=z.device)
+        ss = torch.empty((2, Cc), dtype=torch.float32, device=z.device)
+        out = torch.empty_like(z)
+        track = bn.track_running_stats and bn.running_mean is not None
+        self._check(self.dll.enerf_bn_train_apply(_ptr(z), n, Cc, ws.data_ptr(), nb, _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
+                                                  float(bn.eps), -1.0 if bn.momentum is None else float(bn.momentum),
+                                                  _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
+                                                  bn.num_batches_tracked.data_ptr() if track else None, 1, mi.data_ptr(), _ptr(ss),
+                                                  _ptr(residual), int(relu), _ptr(out), self.stream_of(z)), "bn_train_apply")
+        return out, mi, ss, n
+
+    def bn_train_bwd_apply(self, g, z, mean_invstd, scale_shift, relu):
+        """ABI v11: (grad_z, dgamma_dbeta (2,C)) of the BatchNorm (+ ReLU) whose forward was bn_train_apply (enerf_bn_train_bwd_apply)."""
+        Cc = z.shape[-1]
+        n = z.numel() // Cc
+        nb = self.dll.enerf_channel_sums_workspace_bytes(n, Cc) + 2 * Cc * 4
+        ws = self._scratch(nb, z.device)
+        dgb = torch.empty((2, Cc), dtype=torch.float32, device=z.device)
+        dz = torch.empty_like(z)
+        self._check(self.dll.enerf_bn_train_bwd_apply(_ptr(g), _ptr(z), int(relu), n, Cc, ws.data_ptr(), nb, mean_invstd.data_ptr(),
+                                                      _ptr(scale_shift), _ptr(dgb), _ptr(dz), self.stream_of(z)), "bn_train_bwd_apply")
+        return dz, dgb
 
     def bn_train_bwd_coeffs(self, local, glob, count, mean_invstd, scale):
         Cc = local.shape[1]

@@ -414,6 +414,18 @@ int enerf_bn_train_stats(const float* z, long long n, int C, void* workspace, si
 int enerf_bn_train_bwd_stats(const float* g, const float* z, const float* z_mask, const float* mask_scale, const float* mask_shift,
                              long long n, int C, void* workspace, size_t workspace_bytes, const double* mean_invstd,
                              const float* scale, float* dgamma_dbeta, float* k2k3, enerf_stream_t stream);
+/* ABI v11: a whole BatchNorm direction in TWO launches where the layer is small enough (partial rows x channels <= 2048: the layers below
+ * ~8 MB, 13 of the 23 of a dtu_pretrain step), three otherwise: the affine kernel's blocks redo the row reduction and the coefficient
+ * arithmetic of enerf_bn_train[_bwd]_stats in their prologue (same additions, same order: identical coefficients) instead of a
+ * one-block launch in between.  forward: out = [relu](z * scale + shift) [+ residual], plus everything enerf_bn_train_stats leaves
+ * (mean_invstd, scale_shift, running statistics).  backward: grad_z = g m scale + z k2 + k3 with m the ReLU mask (relu != 0), plus
+ * dgamma_dbeta.  workspace: enerf_channel_sums_workspace_bytes(n, C) (+ 2 C floats for the backward). */
+int enerf_bn_train_apply(const float* z, long long n, int C, void* workspace, size_t workspace_bytes, const float* gamma, const float* beta,
+                         double eps, double momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
+                         int increment_num_batches_tracked, double* mean_invstd, float* scale_shift, const float* residual /* nullable */,
+                         int relu, float* out, enerf_stream_t stream);
+int enerf_bn_train_bwd_apply(const float* g, const float* z, int relu, long long n, int C, void* workspace, size_t workspace_bytes,
+                             const double* mean_invstd, const float* scale_shift, float* dgamma_dbeta, float* grad_z, enerf_stream_t stream);
 int enerf_channel_affine(const float* a, const float* b, const float* p, const float* q, const float* r, const float* z_mask,
                          const float* mask_scale, const float* mask_shift, const float* residual, int relu, long long n, int C,
                          float* out, enerf_stream_t stream);

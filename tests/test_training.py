@@ -546,6 +546,46 @@ def test_batchnorm_train_kernels_match_torch_modules_emulated():
                 assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == it + 1
 
 
+def _check_bn_two_launch_form(lib, dev):
+    """enerf_bn_train_apply / enerf_bn_train_bwd_apply (ABI v11: the coefficient launch folded into the affine kernel's prologue for
+    small / mid layers) against the three-launch entries they replace — outputs, coefficients, running statistics and gradients
+    bit for bit, on layers on both sides of the fold's size limit (partial rows x C <= 2048) and with ragged tails."""
+    import copy
+    torch.manual_seed(11)
+    for C_, n, relu, res in ((64, 1280, True, True), (32, 10240, True, False), (16, 81920, False, True), (8, 60, True, True),
+                             (8, 300000, True, False), (32, 61440, False, False), (16, 777, True, True)):
+        bn = torch.nn.BatchNorm1d(C_, momentum=0.1).train().to(dev)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
+        bn2 = copy.deepcopy(bn)
+        z, g = (torch.randn(n, C_) * 2 + 1).to(dev), torch.randn(n, C_).to(dev)
+        r = torch.randn(n, C_).to(dev) if res else None
+        y, mi, ss, cnt = lib.bn_train_apply(z, bn, r, relu)
+        mi2, ss2, cnt2 = lib.bn_train_stats(z, bn2)
+        y2 = lib.channel_affine(z, ss2[0], ss2[1], residual=r, relu=relu)
+        what = (C_, n, relu, res)
+        assert cnt == cnt2 and torch.equal(mi, mi2) and torch.equal(ss, ss2) and torch.equal(y, y2), what
+        assert torch.equal(bn.running_mean, bn2.running_mean) and torch.equal(bn.running_var, bn2.running_var), what
+        assert int(bn.num_batches_tracked) == int(bn2.num_batches_tracked) == 1
+        dz, dgb = lib.bn_train_bwd_apply(g, z, mi, ss, relu)
+        mask = dict(z_mask=z, mask_scale=ss2[0], mask_shift=ss2[1]) if relu else {}
+        dgb2, k23 = lib.bn_train_bwd_stats(g, z, mi2, ss2[0], **mask)
+        dz2 = lib.channel_affine(g, ss2[0], k23[1], b=z, q=k23[0], **mask)
+        assert torch.equal(dgb, dgb2) and torch.equal(dz, dz2), what
+
+
+def test_batchnorm_two_launch_form_equals_the_three_launch_form_emulated():
+    from emu_lib import emu_lib
+    _check_bn_two_launch_form(emu_lib(), "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_batchnorm_two_launch_form_equals_the_three_launch_form_on_gpu():
+    from enerf_amd.lib import get_lib
+    _check_bn_two_launch_form(get_lib(), "cuda:0")
+
+
 def test_up2_adjoint_emulated_sizes():
     """enerf_up2_adjoint against autograd through F.interpolate at even, odd and non-square coarse sizes, with and without the
     summed-in second gradient; and the guards of the entry."""
