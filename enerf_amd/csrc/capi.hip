@@ -18,6 +18,12 @@ void zero_async(void* p, size_t bytes, hipStream_t st) {
     if (blocks > 4096) blocks = 4096;
     ENERF_LAUNCH_SIMPLE(k_zero, (unsigned)blocks, 256, 0, st, (unsigned*)p, n);
 }
+// two accumulators in one launch when the caller allocated them back to back (the Python binding does)
+void zero_async2(void* p, size_t bytes_p, void* q, size_t bytes_q, hipStream_t st) {
+    if ((char*)p + bytes_p == (char*)q && bytes_p % 4 == 0) { zero_async(p, bytes_p + bytes_q, st); return; }
+    zero_async(p, bytes_p, st);
+    zero_async(q, bytes_q, st);
+}
 int device_cu_count() {
 #ifdef ENERF_EMU
     return 256;

@@ -662,8 +662,7 @@ int enerf_gather_bwd(const enerf_gather_args_t* u, enerf_stream_t stream) {
     if (rc != ENERF_OK) return rc;
     REQUIRE(u->g_x && u->g_vox && u->g_tex && u->g_vol && u->g_xyz && u->g_dn, "gather_bwd: null gradient buffer");
     hipStream_t st = (hipStream_t)stream;
-    zero_async(a.g_tex, (size_t)a.B * a.S * a.Hr * a.Wr * a.F * sizeof(float), st);
-    zero_async(a.g_vol, (size_t)a.B * a.D * a.h * a.w * 8 * sizeof(float), st);
+    zero_async2(a.g_tex, (size_t)a.B * a.S * a.Hr * a.Wr * a.F * sizeof(float), a.g_vol, (size_t)a.B * a.D * a.h * a.w * 8 * sizeof(float), st);
     if (u->P == 0) return ENERF_OK;
     const long long total = (long long)a.B * a.P * a.S;
     a.ray_w = u->ray_w; a.n_samples = u->n_samples;

@@ -20,6 +20,7 @@ int device_cu_count();
 // Zero `bytes` (a multiple of 4) on the stream with a fill KERNEL: a hipMemsetAsync becomes a memset node when the stream is
 // being captured, and those did not replay reliably inside a whole-training-step hipGraph on this stack.
 void zero_async(void* p, size_t bytes, hipStream_t st);
+void zero_async2(void* p, size_t bytes_p, void* q, size_t bytes_q, hipStream_t st);
 
 // ---- geometry.hip -------------------------------------------------------------------------------
 void launch_channels_last(const float* src, float* dst, int n, int C, long long P, int Cpad, hipStream_t st);

@@ -457,8 +457,7 @@ int enerf_ray_samples_bwd(const float* rays8, const float* depth, const float* s
     REQUIRE(rays8 && depth && std && near_far && grad_xyz && grad_dn && grad_depth && grad_std && B > 0 && N > 0 && n_samples > 0,
             "ray_samples_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    zero_async(grad_depth, (size_t)B * h * w * sizeof(float), st);
-    zero_async(grad_std, (size_t)B * h * w * sizeof(float), st);
+    zero_async2(grad_depth, (size_t)B * h * w * sizeof(float), grad_std, (size_t)B * h * w * sizeof(float), st);
     ENERF_LAUNCH_SIMPLE(k_ray_samples_bwd, (unsigned)cdivl((long long)B * N, 256), 256, 0, st, rays8, depth, std, near_far, grad_xyz, grad_dn,
                         B, N, n_samples, h, w, Hr, Wr, depth_inv, grad_depth, grad_std);
     return check_launch("ray_samples_bwd");

@@ -755,7 +755,14 @@ class EnerfLib:
         a = self._gather_args(xyz, dn, uv, tex_cl, vol_cl, cam, tcen)
         a.n_samples, a.ray_w = int(n_samples), int(ray_w)
         E = lambda ref: torch.empty_like(ref)
-        g_tex, g_vol, g_xyz, g_dn = E(tex_cl), E(vol_cl), E(xyz), E(dn)
+        g_xyz, g_dn = E(xyz), E(dn)
+        # the two scatter targets back to back: the library zeroes them with one launch (gather.hip zero_async2)
+        # (when the first keeps the second 256-byte aligned; otherwise two allocations, two launches)
+        if tex_cl.numel() % 64 == 0:
+            acc = torch.empty((tex_cl.numel() + vol_cl.numel(),), dtype=torch.float32, device=xyz.device)
+            g_tex, g_vol = acc[:tex_cl.numel()].view(tex_cl.shape), acc[tex_cl.numel():].view(vol_cl.shape)
+        else:
+            g_tex, g_vol = E(tex_cl), E(vol_cl)
         a.g_x, a.g_vox, a.g_tex, a.g_vol, a.g_xyz, a.g_dn = (_ptr(g_x), _ptr(g_vox), _ptr(g_tex), _ptr(g_vol), _ptr(g_xyz),
                                                             _ptr(g_dn))
         self._check(self.dll.enerf_gather_bwd(C.byref(a), self.stream_of(xyz)), "gather_bwd")
