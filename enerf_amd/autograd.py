@@ -340,19 +340,20 @@ class _Block:
         z = lib.conv3d_layer(self.pk_fwd, self.cin, self.cout, self.kind, x)
         return self.norm.forward(z, residual)
 
-    def backward(self, g):
-        """g = gradient w.r.t. the block's output (the skip branch's share is the same tensor).  Returns
-        (grad_input, grad_weight, grad_bn_weight, grad_bn_bias)."""
+    def backward(self, g, add=None):
+        """g = gradient w.r.t. the block's output (the skip branch's share is the same tensor); ``add``: a tensor of the input's
+        shape added to the input gradient in the convolution's epilogue (the skip branch's gradient of the block's input).
+        Returns (grad_input (+ add), grad_weight, grad_bn_weight, grad_bn_bias)."""
         lib = self.lib
         dz, dgamma, dbeta = self.norm.backward(g)
         if self.kind == _S1:                                                         # dgrad: flipped, channel-transposed weights
-            gx = lib.conv3d_layer(self.pk_bwd, self.cout, self.cin, _S1, dz)
+            gx = lib.conv3d_layer(self.pk_bwd, self.cout, self.cin, _S1, dz, residual=add)
             gw = lib.conv_wgrad_cl(dz, self.x, 1)
         elif self.kind == _S2:                                                       # dgrad of a stride-2 conv = transposed conv on w
-            gx = lib.conv3d_layer(self.pk_bwd, self.cout, self.cin, _T2, dz)
+            gx = lib.conv3d_layer(self.pk_bwd, self.cout, self.cin, _T2, dz, residual=add)
             gw = lib.conv_wgrad_cl(dz, self.x, 2)
         else:                                                                        # dgrad of a transposed conv = stride-2 conv on w
-            gx = lib.conv3d_layer(self.pk_bwd, self.cout, self.cin, _S2, dz)
+            gx = lib.conv3d_layer(self.pk_bwd, self.cout, self.cin, _S2, dz, residual=add)
             gw = lib.conv_wgrad_cl(self.x, dz, 2)
         return gx, gw, dgamma, dbeta
 
@@ -396,28 +397,29 @@ class CostRegTrainFn(torch.autograd.Function):
         lib, m, blk, y = ctx.lib, ctx.m, ctx.blk, ctx.y
         B, D, h, w, _ = y.shape
         g16 = lib.concat_channels(_c(g_feat.permute(0, 2, 3, 4, 1)), _c(g_prob).unsqueeze(-1), 16)
+        with lib.wgrad_reduce_batch(g16):            # the eleven weight gradients' second stages: one launch at the end of the pass
+            return CostRegTrainFn._backward(ctx, g16)
+
+    @staticmethod
+    def _backward(ctx, g16):
+        lib, m, blk, y = ctx.lib, ctx.m, ctx.blk, ctx.y
         g = lib.conv3d_layer(ctx.heads_bwd, 16, 8, _S1, g16)                         # d y11
         gw16 = lib.conv_wgrad_cl(g16, y, 1)
         grads = {"feat": gw16[:8], "depth": gw16[8:9]}
 
-        def back(i, gi):
-            gx, gw, dg, db = blk[i].backward(gi)
+        def back(i, gi, add=None):
+            gx, gw, dg, db = blk[i].backward(gi, add)
             grads[i] = (gw, dg, db)
             return gx
         g_c0 = g
         g = back(11, g)                                           # -> d y9 ; skip share of y11 goes to c0
         g_c2 = g
         g = back(9, g)                                            # -> d y7
-        if m.full:
-            g_c4 = g
-            g = back(5, back(6, back(7, g)))
-            g_c4 = lib.add(g_c4, g)
-        else:
-            g_c4 = g
-        g = back(3, back(4, g_c4))
-        g_c2 = lib.add(g_c2, g)
-        g = back(1, back(2, g_c2))
-        g_c0 = lib.add(g_c0, g)
+        # a skip tensor's gradient = the skip share + what comes back through the stride-2 block below it: the sum rides in the
+        # epilogue of that block's input-gradient convolution (residual operand), not in a launch of its own
+        g_c4 = back(5, back(6, back(7, g)), add=g) if m.full else g
+        g_c2 = back(3, back(4, g_c4), add=g_c2)
+        g_c0 = back(1, back(2, g_c2), add=g_c0)
         g_x = back(0, g_c0)
         out = []
         for i in ctx.order:
@@ -535,6 +537,11 @@ class FeatureNetTrainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_f2, g_s1, g_s0):
+        with ctx.lib.wgrad_reduce_batch(g_s0):       # the eleven weight gradients' second stages: one launch at the end of the pass
+            return FeatureNetTrainFn._backward(ctx, g_f2, g_s1, g_s0)
+
+    @staticmethod
+    def _backward(ctx, g_f2, g_s1, g_s0):
         conv, norm, lib = ctx.conv, ctx.norm, ctx.lib
         grads = {}
         cl = lambda g: g.permute(0, 2, 3, 1).contiguous()       # (a no-op when the gradient arrives as a channels-last view)

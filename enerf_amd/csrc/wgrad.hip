@@ -212,12 +212,10 @@ __device__ __forceinline__ float wgrad_reduce_sum(const float* __restrict__ sp, 
     }
     return v;
 }
-__global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__ scratch, int chunks, int nt, int tiles_b, int Ca,
-                                                       int Cb, int bias, int gemm, float* __restrict__ dW,
-                                                       float* __restrict__ dbias) {
-    __shared__ float red[16][64];
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ scratch, int chunks, int nt, int tiles_b, int Ca, int Cb, int bias,
+                                                  int gemm, float* __restrict__ dW, float* __restrict__ dbias, int bid, float (*red)[64]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
-    const int r = blockIdx.x & 3, item = blockIdx.x >> 2;
+    const int r = bid & 3, item = bid >> 2;
     const int pair = gemm ? 0 : item / nt, t = gemm ? item : item - pair * nt;
     const float* sp = scratch + (((long long)pair * chunks) * nt + t) * 256 + r * 64 + lane;
     const float v = wgrad_reduce_sum(sp, chunks, (long long)nt * 256, red);
@@ -228,9 +226,102 @@ __global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__
     if (b_ch < Cb) dW[gemm ? (long long)a_ch * Cb + b_ch : ((long long)a_ch * Cb + b_ch) * nt + t] = v;
     else if (bias && b_ch == Cb && (gemm || nt == 1)) dbias[a_ch] = v;
 }
+__global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__ scratch, int chunks, int nt, int tiles_b, int Ca,
+                                                       int Cb, int bias, int gemm, float* __restrict__ dW,
+                                                       float* __restrict__ dbias) {
+    __shared__ float red[16][64];
+    wgrad_reduce_body(scratch, chunks, nt, tiles_b, Ca, Cb, bias, gemm, dW, dbias, (int)blockIdx.x, red);
+}
+// out[.] = sum over the rows c < chunks of part[c * n_out + i], fixed order: 16 waves take rows c = w, w + 16, ... (four loads in
+// flight), then wave 0 adds the 16 partial sums.  by = segment: its rows start at part + by * chunks * n_out and element i
+// goes to out[(i / inner) * ostride + by * inner + i % inner] (channel halves of a wider layer; one segment, inner = n_out: out[i]).
+__device__ __forceinline__ void colsum_body(const float* __restrict__ part, int chunks, int n_out, int inner, int ostride, float* __restrict__ out,
+                                            int bx, int by, float (*red)[64]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = bx * 64 + lane;
+    const bool live = i < n_out;
+    const float* sp = part + (long long)by * chunks * n_out + (live ? i : 0);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = w;
+    for (; c + 48 < chunks; c += 64) {
+        s0 += sp[(long long)c * n_out]; s1 += sp[(long long)(c + 16) * n_out];
+        s2 += sp[(long long)(c + 32) * n_out]; s3 += sp[(long long)(c + 48) * n_out];
+    }
+    for (; c < chunks; c += 16) s0 += sp[(long long)c * n_out];
+    red[w][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w != 0 || !live) return;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[k][lane];
+    const int o = i / inner;
+    out[(long long)o * ostride + by * inner + (i - o * inner)] = v;
+}
+__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ part, int chunks, int n_out, int inner, int ostride,
+                                                 float* __restrict__ out) {
+    __shared__ float red[16][64];
+    colsum_body(part, chunks, n_out, inner, ostride, out, (int)blockIdx.x, (int)blockIdx.y, red);
+}
+
+// ---- deferred second stages (round 6) ----
+// Every weight gradient of a network's backward pass ends with one of the two small kernels above (k_wgrad_reduce / k_colsum: 30 launches
+// of ~5 us per training step) and nothing reads a weight gradient before the pass is over.  Between enerf_wgrad_reduce_begin() and
+// enerf_wgrad_reduce_flush(stream) on the calling thread the second stages are RECORDED instead of launched (the caller keeps the
+// workspaces alive) and the flush runs them all as one kernel: block -> (recorded reduction, its own block id); same code, same bits.
+struct ReduceDesc {
+    const float* scratch;
+    float *dW, *dbias;
+    int kind;                          // 0: wgrad_reduce_body, 1: colsum_body
+    int a0, a1, a2, a3, a4, a5, a6;    // kind 0: chunks, nt, tiles_b, Ca, Cb, bias, gemm;  kind 1: chunks, n_out, inner, ostride, grid x
+    int blocks, block0;
+};
+constexpr int kReduceBatchMax = 24;
+struct ReduceBatch {
+    ReduceDesc d[kReduceBatchMax];
+    int n;
+};
+__global__ __launch_bounds__(1024) void k_wgrad_reduce_batch(ReduceBatch G) {
+    __shared__ float red[16][64];
+    int i = 0;
+    while (i + 1 < G.n && (int)blockIdx.x >= G.d[i + 1].block0) ++i;
+    const ReduceDesc& d = G.d[i];
+    const int lb = (int)blockIdx.x - d.block0;
+    if (d.kind == 0) wgrad_reduce_body(d.scratch, d.a0, d.a1, d.a2, d.a3, d.a4, d.a5, d.a6, d.dW, d.dbias, lb, red);
+    else colsum_body(d.scratch, d.a0, d.a1, d.a2, d.a3, d.dW, lb % d.a4, lb / d.a4, red);
+}
+static thread_local bool g_reduce_deferring = false;
+static thread_local int g_reduce_pending = 0;
+static thread_local ReduceDesc g_reduce_list[4 * kReduceBatchMax];
+static bool reduce_defer(const ReduceDesc& d) {
+    if (!g_reduce_deferring || g_reduce_pending >= 4 * kReduceBatchMax) return false;
+    g_reduce_list[g_reduce_pending++] = d;
+    return true;
+}
 static void launch_wgrad_reduce(const float* scratch, int pairs, int chunks, int nt, int tiles_b, int Ca, int Cb, int bias, int gemm,
                                 float* dW, float* dbias, hipStream_t st) {
+    const ReduceDesc d = {scratch, dW, dbias, 0, chunks, nt, tiles_b, Ca, Cb, bias, gemm, pairs * nt * 4, 0};
+    if (reduce_defer(d)) return;
     ENERF_LAUNCH(k_wgrad_reduce, (unsigned)(pairs * nt * 4), 1024, 0, st, scratch, chunks, nt, tiles_b, Ca, Cb, bias, gemm, dW, dbias);
+}
+static void launch_colsum(const float* part, int chunks, int n_out, int inner, int ostride, float* out, int gx, int gy, hipStream_t st) {
+    const ReduceDesc d = {part, out, nullptr, 1, chunks, n_out, inner, ostride, gx, 0, 0, gx * gy, 0};
+    if (reduce_defer(d)) return;
+    ENERF_LAUNCH(k_colsum, dim3((unsigned)gx, (unsigned)gy), 1024, 0, st, part, chunks, n_out, inner, ostride, out);
+}
+static void reduce_flush(hipStream_t st) {
+    for (int first = 0; first < g_reduce_pending; first += kReduceBatchMax) {
+        ReduceBatch G;
+        G.n = g_reduce_pending - first < kReduceBatchMax ? g_reduce_pending - first : kReduceBatchMax;
+        int blocks = 0;
+        for (int i = 0; i < G.n; ++i) {
+            G.d[i] = g_reduce_list[first + i];
+            G.d[i].block0 = blocks;
+            blocks += G.d[i].blocks;
+        }
+        ENERF_LAUNCH(k_wgrad_reduce_batch, (unsigned)blocks, 1024, 0, st, G);
+    }
+    g_reduce_pending = 0;
+    g_reduce_deferring = false;
 }
 
 template <int KD, int KH, int KW, int SPLIT, int PL>
@@ -578,33 +669,6 @@ __global__ __launch_bounds__(256) void k_wgrad2d_3x3_p16(const float* __restrict
             __syncthreads();
         }
 }
-// out[.] = sum over the rows c < chunks of part[c * n_out + i], fixed order: 16 waves take rows c = w, w + 16, ... (four loads in
-// flight), then wave 0 adds the 16 partial sums.  blockIdx.y = segment: its rows start at part + y * chunks * n_out and element i
-// goes to out[(i / inner) * ostride + y * inner + i % inner] (channel halves of a wider layer; one segment, inner = n_out: out[i]).
-__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ part, int chunks, int n_out, int inner, int ostride,
-                                                 float* __restrict__ out) {
-    __shared__ float red[16][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + lane;
-    const bool live = i < n_out;
-    const float* sp = part + (long long)blockIdx.y * chunks * n_out + (live ? i : 0);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int c = w;
-    for (; c + 48 < chunks; c += 64) {
-        s0 += sp[(long long)c * n_out]; s1 += sp[(long long)(c + 16) * n_out];
-        s2 += sp[(long long)(c + 32) * n_out]; s3 += sp[(long long)(c + 48) * n_out];
-    }
-    for (; c < chunks; c += 16) s0 += sp[(long long)c * n_out];
-    red[w][lane] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (w != 0 || !live) return;
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v += red[k][lane];
-    const int o = i / inner;
-    out[(long long)o * ostride + (int)blockIdx.y * inner + (i - o * inner)] = v;
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // The same for the 3x3x3 stride-1 layers of the cost-regularisation networks with <= 8 channels on one side: conv0 (32 / 16 -> 8:
 // A = d y has 8 channels) and the fused heads (8 -> 16: B = y has 8 channels — run with the roles SWAPPED, A' = y, B' = d heads:
@@ -756,7 +820,7 @@ static bool launch_wgrad2d(const float* A, const float* Bt, int n, int H, int W,
 #define ENERF_W2P(NA, NB) ENERF_LAUNCH((k_wgrad2d_3x3_p16<NA, NB>), (unsigned)blocks, 256, 0, st, A, Bt, n, H, W, lda, ldb, ty16, tiles_x, abytes, bbytes, scratch)
         if (Ca == 32) ENERF_W2P(2, 2); else if (Cb == 32) ENERF_W2P(1, 2); else ENERF_W2P(1, 1);
 #undef ENERF_W2P
-        ENERF_LAUNCH(k_colsum, (unsigned)cdiv(Ca * Cb * 9, 64), 1024, 0, st, scratch, blocks, Ca * Cb * 9, Ca * Cb * 9, 0, dW);
+        launch_colsum(scratch, blocks, Ca * Cb * 9, Ca * Cb * 9, 0, dW, cdiv(Ca * Cb * 9, 64), 1, st);
         return true;
     }
     const bool a4 = (Ca == 4 || Ca == 8) && lda % 4 == 0 && ((uintptr_t)A & 15) == 0;
@@ -768,7 +832,7 @@ static bool launch_wgrad2d(const float* A, const float* Bt, int n, int H, int W,
     else if (a4) { if (b4) ENERF_W2(true, true, 1); else ENERF_W2(true, false, 1); }
     else { if (b4) ENERF_W2(false, true, 1); else ENERF_W2(false, false, 1); }
 #undef ENERF_W2
-    ENERF_LAUNCH(k_colsum, (unsigned)cdiv(Ca * Cb * 9, 64), 1024, 0, st, scratch, blocks, Ca * Cb * 9, Ca * Cb * 9, 0, dW);
+    launch_colsum(scratch, blocks, Ca * Cb * 9, Ca * Cb * 9, 0, dW, cdiv(Ca * Cb * 9, 64), 1, st);
     return true;
 }
 #ifndef ENERF_WGRAD3D_TILE
@@ -807,8 +871,7 @@ static bool launch_wgrad3d(const float* A, const float* Bt, int n, int D, int H,
     else { if (a4) ENERF_W3(true, 1); else ENERF_W3(false, 1); }
 #undef ENERF_W3
     const int n_row = Cak * Cbk * 27;
-    ENERF_LAUNCH(k_colsum, dim3((unsigned)cdiv(n_row, 64), (unsigned)cols), 1024, 0, st, scratch, blocks, n_row, swapped ? n_row : Cbk * 27,
-                 Cbt * 27, dW);
+    launch_colsum(scratch, blocks, n_row, swapped ? n_row : Cbk * 27, Cbt * 27, dW, cdiv(n_row, 64), cols, st);
     return true;
 }
 
@@ -1091,6 +1154,17 @@ static size_t gemm_group_plan(const enerf_gemm_wgrad_desc_t* u, int n, GemmGroup
 
 using namespace enerf;
 extern "C" {
+int enerf_wgrad_reduce_begin(void) {
+    REQUIRE(!g_reduce_deferring, "wgrad_reduce_begin: already deferring on this thread (missing enerf_wgrad_reduce_flush)");
+    g_reduce_deferring = true;
+    g_reduce_pending = 0;
+    return ENERF_OK;
+}
+int enerf_wgrad_reduce_flush(enerf_stream_t stream) {
+    REQUIRE(g_reduce_deferring, "wgrad_reduce_flush: no enerf_wgrad_reduce_begin on this thread");
+    reduce_flush((hipStream_t)stream);
+    return check_launch("wgrad_reduce_flush");
+}
 size_t enerf_gemm_wgrad_group_workspace_bytes(const enerf_gemm_wgrad_desc_t* descs, int n) {
     if (descs == nullptr || n < 1 || n > kGemmGroupMax) return 0;
     for (int i = 0; i < n; ++i)

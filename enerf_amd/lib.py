@@ -6,6 +6,7 @@ fallback: if the shared library is missing or a call fails, an exception is rais
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from typing import Optional
@@ -171,6 +172,8 @@ _SIGNATURES = {
     "enerf_gemm_wgrad": (_i, [_f, _i, _i, _f, _i, _i, _ll, _f, _f, C.c_void_p, C.c_size_t, _f]),
     "enerf_bn_train_apply": (_i, [_f, _ll, _i, C.c_void_p, C.c_size_t, _f, _f, C.c_double, C.c_double, _f, _f, C.c_void_p, _i, C.c_void_p, _f, _f, _i, _f, _f]),
     "enerf_bn_train_bwd_apply": (_i, [_f, _f, _i, _ll, _i, C.c_void_p, C.c_size_t, C.c_void_p, _f, _f, _f, _f]),
+    "enerf_wgrad_reduce_begin": (_i, []),
+    "enerf_wgrad_reduce_flush": (_i, [_f]),
     "enerf_selftest_checks": (_i, []),
     "enerf_selftest_primitives": (_i, [_f, _i, _f, _i, C.c_void_p, _f]),
     "enerf_gemm_wgrad_group_workspace_bytes": (C.c_size_t, [C.POINTER(GemmWgradDesc), _i]),
@@ -261,10 +264,32 @@ class EnerfLib:
     def stream_of(t: torch.Tensor):
         return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else None
 
-    @staticmethod
-    def _scratch(nbytes: int, device):
+    _deferred_scratch = None           # a list while wgrad_reduce_batch() is open: the partial sums must outlive their wrapper calls
+
+    def _scratch(self, nbytes: int, device):
         """Per-call scratch from torch's caching allocator (stream-ordered, graph-capture safe)."""
-        return torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=device)
+        t = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=device)
+        if self._deferred_scratch is not None:
+            self._deferred_scratch.append(t)
+        return t
+
+    @contextlib.contextmanager
+    def wgrad_reduce_batch(self, ref):
+        """ABI v11: inside the block the second stage of every enerf_conv_wgrad / enerf_gemm_wgrad call (the reduction of the blocks'
+        partial sums into grad_w) is recorded instead of launched, and ONE kernel runs them all on leaving it (on ``ref``'s stream):
+        the gradients returned inside the block are complete only after it.  Same arithmetic, same bits."""
+        if os.environ.get("ENERF_WGRAD_DEFER", "1") == "0":       # A/B only (tools/gpu_r06_defer_ab.sh): immediate second stages
+            yield
+            return
+        self._check(self.dll.enerf_wgrad_reduce_begin(), "wgrad_reduce_begin")
+        self._deferred_scratch = []
+        try:
+            yield
+        finally:
+            try:
+                self._check(self.dll.enerf_wgrad_reduce_flush(self.stream_of(ref)), "wgrad_reduce_flush")
+            finally:
+                self._deferred_scratch = None
 
     def _check(self, rc: int, what: str):
         if rc != 0:

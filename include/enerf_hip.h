@@ -484,6 +484,13 @@ int enerf_gemm_wgrad(const float* a, int lda, int Ca, const float* b, int ldb, i
  * stride of grad_w in floats (0 = Cb) — a gradient that is a column block of a wider weight matrix (color.0 = [shared | per-view]
  * columns, nerf.py:64-66) is written in place.  At most 16 members of at most 4 x 6 tiles (64 x 95 columns); the workspace
  * (enerf_gemm_wgrad_group_workspace_bytes) is required. */
+/* ABI v11: deferred second stages.  Every enerf_conv_wgrad / enerf_gemm_wgrad with a workspace is two launches: the blocks' partial sums,
+ * then a small reduction into grad_w (30 of those per dtu_pretrain step).  Between enerf_wgrad_reduce_begin() and
+ * enerf_wgrad_reduce_flush(stream) ON THE CALLING THREAD the reductions are recorded instead of launched and the flush runs them as one
+ * kernel (same code per gradient: same bits); the caller keeps every workspace and grad_w alive and unread until the flush.  At most 96
+ * recorded reductions (further ones are launched at once). */
+int enerf_wgrad_reduce_begin(void);
+int enerf_wgrad_reduce_flush(enerf_stream_t stream);
 typedef struct {
     const float* a; int lda, Ca;
     const float* b; int ldb, Cb;

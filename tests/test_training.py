@@ -452,6 +452,24 @@ def _check_conv_wgrad(lib, dev):
         else:
             assert torch.equal(gw_, sw)
         assert (gb_ is None) == (sb is None) and (sb is None or torch.equal(gb_, sb))
+    # ABI v11: deferred second stages — the reductions of a whole backward pass recorded and run as ONE kernel on leaving the block:
+    # every gradient (the k_wgrad_reduce and the k_colsum kinds, 3-D, 2-D, GEMM, with a bias column) gets the bits of its immediate call
+    i1, i2, i3, i4 = (rnd(1, 8, 32, 40, 8), rnd(1, 8, 32, 40, 16)), (rnd(1, 4, 8, 10, 32), rnd(1, 8, 16, 20, 16)), \
+        (rnd(2, 16, 20, 8), rnd(2, 16, 20, 8)), (rnd(2, 8, 10, 16), rnd(2, 16, 20, 8))
+    calls = [lambda: lib.conv_wgrad_cl(a_cl, b_cl, 1), lambda: lib.conv_wgrad_cl(i1[0], i1[1], 1), lambda: lib.conv_wgrad_cl(i2[0], i2[1], 2),
+             lambda: lib.conv_wgrad_cl2d(i3[0], i3[1], 3, 1), lambda: lib.conv_wgrad_cl2d(i4[0], i4[1], 5, 2), lambda: lib.gemm_wgrad(am, bm),
+             lambda: lib.gemm_wgrad(am, bm, bias=True)]          # (every output of a recorded call must stay alive until the flush)
+    now = [c() for c in calls]
+    with lib.wgrad_reduce_batch(a_cl):
+        later = [c() for c in calls]
+        with pytest.raises(Exception, match="already deferring"):
+            with lib.wgrad_reduce_batch(a_cl):
+                pass
+    for k, (x0, x1) in enumerate(zip(now[:6], later[:6])):
+        assert torch.equal(x0, x1), k
+    assert torch.equal(now[6][0], later[6][0]) and torch.equal(now[6][1], later[6][1])
+    assert lib._deferred_scratch is None
+    assert torch.equal(lib.conv_wgrad_cl(a_cl, b_cl, 1), two[0])          # and the library is back to immediate second stages
     with pytest.raises(Exception, match="4 x 6 tiles"):
         lib.gemm_wgrad_group([dict(a=rnd(10, 80), b=rnd(10, 8))])
     with pytest.raises(Exception, match="1..16 members"):
