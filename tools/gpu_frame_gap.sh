@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 TAG=${1:-r03_gap}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/pg -o p -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-stages > $O/bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/pg -o p -- python $R/bench.py --workload ${WL:-dtu} --no-secondary --steps 100 --warmup 10 --no-cpu-baseline --no-stages > $O/bench.log 2>&1
 F=$(find /tmp/pg -name "*kernel_trace.csv" | head -1)
 python - <<PY
 import csv
