@@ -9,6 +9,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -264,13 +265,23 @@ class EnerfLib:
     def stream_of(t: torch.Tensor):
         return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else None
 
-    _deferred_scratch = None           # a list while wgrad_reduce_batch() is open: the partial sums must outlive their wrapper calls
+    _tls = threading.local()           # .keep: a list while wgrad_reduce_batch() is open ON THIS THREAD (the C side records per thread too):
+                                       # the partial sums must outlive their wrapper calls
+
+    @property
+    def _deferred_scratch(self):
+        return getattr(self._tls, "keep", None)
+
+    @_deferred_scratch.setter
+    def _deferred_scratch(self, value):
+        self._tls.keep = value
 
     def _scratch(self, nbytes: int, device):
         """Per-call scratch from torch's caching allocator (stream-ordered, graph-capture safe)."""
         t = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=device)
-        if self._deferred_scratch is not None:
-            self._deferred_scratch.append(t)
+        keep = self._deferred_scratch
+        if keep is not None:
+            keep.append(t)
         return t
 
     @contextlib.contextmanager
