@@ -214,8 +214,9 @@ static bool dispatch_wl(const Conv3dDesc& L, const float* in, float* out, int B,
     for (int c = CIN == 64 ? 2 : 4; c > 1; c >>= 1)      // Cin = 64: 144 B-operand registers, 12 waves would spill
         if (cdivl(tiles, c) * rt_total >= min_blocks) { ctb = c; break; }
     (void)wbytes;
+    if constexpr (CIN != 64)                              // (never instantiated for Cin = 64: that kernel spills 56 registers)
+        if (ctb == 4) return launch_wl<CIN, KIND, 4>(L, in, out, B, Di, Hi, Wi, Do, Ho, Wo, kdlo, nkd, st);
     switch (ctb) {
-        case 4: return launch_wl<CIN, KIND, 4>(L, in, out, B, Di, Hi, Wi, Do, Ho, Wo, kdlo, nkd, st);
         case 2: return launch_wl<CIN, KIND, 2>(L, in, out, B, Di, Hi, Wi, Do, Ho, Wo, kdlo, nkd, st);
         default: return launch_wl<CIN, KIND, 1>(L, in, out, B, Di, Hi, Wi, Do, Ho, Wo, kdlo, nkd, st);
     }
