@@ -709,7 +709,9 @@ class NerfMlpFn(torch.autograd.Function):
         F = XW - 4
         packed = ctx.packed
         bimg, offs = mlp_backward_images(m, S, lib)
-        g_vox, g_x, sv = lib.nerf_mlp_bwd(vox.contiguous(), x.contiguous(), g_raw.contiguous(), packed, bimg, offs, S, F)
+        inkernel = F == 11 and P > 0            # the per-view colour branch's weight gradients accumulated inside the kernel (mlp_train.hip WG)
+        res = lib.nerf_mlp_bwd(vox.contiguous(), x.contiguous(), g_raw.contiguous(), packed, bimg, offs, S, F, partials=inkernel)
+        g_vox, g_x, sv = res[:3]
         hv, G, q, gs, a_, vm, d_c, d_q, d_p2, d_s, d_h, d_agg, d_u, d_g, d_gsum, d_v = sv
         PS = P * S
         x2 = x.reshape(PS, XW)
@@ -718,10 +720,16 @@ class NerfMlpFn(torch.autograd.Function):
         # global_fc are assembled in place from their two column blocks
         w_c0 = torch.empty((64, 88 + XW), dtype=torch.float32, device=x.device)
         w_gl = torch.empty((32, 3 * F), dtype=torch.float32, device=x.device)
+        if inkernel:       # color.2 and color.0's per-view columns arrive as per-wave partial sums (q, d_q, d_c were never written)
+            m_c2 = None
+            m_c0v = dict(partials=res[3], Ca=64, Cb=XW, into=(w_c0, 88))
+        else:
+            m_c2 = dict(a=d_c.reshape(PS, 1), b=q.reshape(PS, 64), bias=True)
+            m_c0v = dict(a=d_q.reshape(PS, 64), b=x2, into=(w_c0, 88))
         members = [
-            dict(a=d_c.reshape(PS, 1), b=q.reshape(PS, 64), bias=True),                 # color.2
+            m_c2,                                                                       # color.2
             dict(a=d_p2, b=hv, bias=True, into=(w_c0, 0)),                              # color.0, shared columns [h | vox | agg]
-            dict(a=d_q.reshape(PS, 64), b=x2, into=(w_c0, 88)),                         # color.0, per-view columns [x_s | dir_s]
+            m_c0v,                                                                      # color.0, per-view columns [x_s | dir_s]
             dict(a=d_s.reshape(P, 1), b=hv, Cb=64, bias=True),                          # sigma
             dict(a=d_h, b=hv[:, 64:], bias=True),                                       # lr0
             dict(a=d_agg, b=G, bias=True),                                              # agg.fc
@@ -734,6 +742,10 @@ class NerfMlpFn(torch.autograd.Function):
             members.append(dict(a=d_v.reshape(PS, F), b=x2[:, F:], bias=True))          # agg.view_fc
             names.append("agg.view_fc.0")
         gw = {}
+        if inkernel:
+            c2 = lib.colsum(res[4])
+            gw["color.2.weight"], gw["color.2.bias"] = c2[:64].view(1, 64), c2[64:65]
+            members, names = members[1:], names[1:]
         for name, (w_, b_) in zip(names, lib.gemm_wgrad_group(members)):
             if name is not None:
                 gw[name + ".weight"] = w_

@@ -27,6 +27,7 @@ struct MlpBwdArgs {
     long long P;
     int F, n_bimg;                       // floats of the backward images (staged in LDS behind the forward image)
     int o_b1, o_b2, o_b3, o_b4, o_b5, o_b6v, o_b6m, o_b7;                  // float offsets of the backward images
+    float *wg_q, *wg_c2;                 // WG: per-wave partial weight gradients ([wave][4][256] and [wave][80], see below)
 };
 
 // A/B switches (tools/build_variant.py): backward images from LDS (default) or from global memory as until round 3; the
@@ -37,7 +38,17 @@ struct MlpBwdArgs {
 #ifndef ENERF_MLPB_NOSTORE
 #define ENERF_MLPB_NOSTORE 0
 #endif
-template <int R, int S>
+// WG (round 6): the weight gradients of the PER-VIEW colour branch are accumulated inside the kernel instead of through
+// saved rows.  q = relu(P2 + W_v [x_s | dir_s]) and its pre-activation gradient d_q are the two widest per-(point, view) tensors the
+// kernel used to write (2 x 64 of its 967 floats per point at S = 3: 40 % of the 2.8 GB) for two consumers only:
+//   color.0's per-view columns  dW[c][i] = sum_{p,s} d_q[p,s,c] [x_s | dir_s][p,s,i]   (64 x (F + 4))
+//   color.2                     dW[c]    = sum_{p,s} d_c[p,s] q[p,s,c]  (+ bias sum d_c)
+// The first is a 16-point product on the matrix cores per view: d_q (D layout: unit rows, point columns) and [x_s | dir_s] (slot layout) are
+// transposed through a per-wave LDS tile (point-major rows, conflict-free pitches) into A / B operands with k = point — 16 MFMAs per view
+// into four accumulator tiles that live in registers for the whole kernel (R = 3 runs at 354 of 512 registers).  The second is 16 fused
+// multiply-adds per view into per-lane partial sums, reduced over the 16 point lanes once at the end.  Every wave ends with one row of
+// partials ([wave][4 tiles][256] and [wave][64 + 1 | pad to 80]); enerf_gemm_wgrad_group / enerf_colsum reduce them over the waves.
+template <int R, int S, bool WG = false>
 __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
     constexpr int TR = (R + 3) / 4;             // slot tiles of the F channels
     constexpr int TX = (R + 1 + 3) / 4;         // slot tiles of [channels | direction code]
@@ -65,6 +76,20 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
 #endif
     const long long ntiles = cdivl(a.P, 16);
     const int waves = blockDim.x >> 6;
+    // WG: this wave's transpose tiles behind the images: d_q as [point][80] (64 units; pitch 80: the four point rows of a k-block sit 16
+    // banks apart) and [x_s | dir_s] as [point][16] (column 15 = 0)
+    constexpr int kTq = 16 * 80, kTx = 16 * 16;
+    float* tq = nullptr;
+    float* tx = nullptr;
+    f32x4 wq[4], wc2[4];
+    float bc2 = 0.f;
+    if (WG) {
+        tq = wl + L.total + (ENERF_MLPB_LDS_BIMG ? a.n_bimg : 0) + (threadIdx.x >> 6) * (kTq + kTx);
+        tx = tq + kTq;
+        tx[j * 16 + 12 + g] = 0.f;                          // (columns 12..14 are rewritten per view; 15 stays 0)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { wq[v] = f32x4{0.f, 0.f, 0.f, 0.f}; wc2[v] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
     for (long long tile = (long long)blockIdx.x * waves + (threadIdx.x >> 6); tile < ntiles; tile += (long long)gridDim.x * waves) {
         const long long pr = tile * 16 + j;
         const bool ok = pr < a.P;
@@ -279,12 +304,33 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gq[v][r] = cc[v][r] > 0.f ? c2w[v][r] * gcpre[s] : 0.f;
                 dP2[v] += gq[v];
-                if (sv) {
+                if (WG) {                                   // color.2: d_c q into the per-lane partial sums
+                    const f32x4 qv = relu4(cc[v]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) wc2[v][r] += qv[r] * gcpre[s];
+                } else if (sv) {
                     *reinterpret_cast<f32x4*>(a.sv_q + (p * S + s) * 64 + 16 * v + 4 * g) = relu4(cc[v]);
                     *reinterpret_cast<f32x4*>(a.d_qpre + (p * S + s) * 64 + 16 * v + 4 * g) = gq[v];
                 }
             }
-            if (sv && g == 0) a.d_cpre[p * S + s] = gcpre[s];
+            if (WG) {
+                bc2 += gcpre[s];
+                // color.0's per-view columns: d_q and [x_s | dir_s] to point-major LDS rows, then k = point on the matrix cores
+#pragma unroll
+                for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(tq + j * 80 + 16 * v + 4 * g) = gq[v];
+#pragma unroll
+                for (int r = 0; r < R; ++r) if (g * R + r < F) tx[j * 16 + g * R + r] = x[s][r];
+                tx[j * 16 + F + g] = dsel[s];
+                wave_sync();
+                float bx[4];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) bx[kb] = tx[(4 * kb + g) * 16 + j];
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) wq[v] = ENERF_MFMA(tq[(4 * kb + g) * 80 + 16 * v + j], bx[kb], wq[v]);
+                wave_sync();
+            } else if (sv && g == 0) a.d_cpre[p * S + s] = gcpre[s];
             // B1: d [x_s | dir_s] = W_v^T gq
 #pragma unroll
             for (int t = 0; t < TX; ++t) {
@@ -423,6 +469,19 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
             }
         }
         if (ok) { a.g_vox[p * 8 + 2 * g] = dvox[0]; a.g_vox[p * 8 + 2 * g + 1] = dvox[1]; }
+    }
+    if (WG) {       // this wave's row of partial weight gradients (every wave writes one, also the waves that had no tile)
+        const long long gwv = (long long)blockIdx.x * waves + (threadIdx.x >> 6);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a.wg_q[(gwv * 4 + v) * 256 + r * 64 + lane] = wq[v][r];
+                const float t = row_sum16(wc2[v][r]);                          // over the 16 points of the row
+                if (j == 0) a.wg_c2[gwv * 80 + 16 * v + 4 * g + r] = t;
+            }
+        const float tb = row_sum16(bc2);                                      // (the same value in all four rows)
+        if (lane < 16) a.wg_c2[gwv * 80 + 64 + lane] = lane == 0 ? tb : 0.f;
     }
 }
 
@@ -617,19 +676,30 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const float* __restrict__ voxp,
 }  // namespace enerf
 
 using namespace enerf;
-extern "C" int enerf_nerf_mlp_bwd(const enerf_mlp_bwd_args_t* u, enerf_stream_t stream) {
+static long long mlp_bwd_blocks(long long P) {
+    long long blocks = cdivl(cdivl(P, 16), 4);
+#ifndef ENERF_MLPB_RESIDENT
+#define ENERF_MLPB_RESIDENT 2
+#endif
+    const long long resident = (long long)device_cu_count() * ENERF_MLPB_RESIDENT;
+    return blocks > resident ? resident : (blocks < 1 ? 1 : blocks);
+}
+static int mlp_bwd_launch(const enerf_mlp_bwd_args_t* u, float* wg_q, float* wg_c2, enerf_stream_t stream) {
+    const bool wg = wg_q != nullptr;
     REQUIRE(u, "nerf_mlp_bwd: null args");
     REQUIRE(u->F == 11 || u->F == 35, "nerf_mlp_bwd: F=%d unsupported (11 or 35)", u->F);
     REQUIRE(u->S >= 2 && u->S <= 4 && u->P >= 0, "nerf_mlp_bwd: bad shape");
+    if (wg) REQUIRE(u->F == 11 && wg_c2 != nullptr && u->P > 0, "nerf_mlp_bwd_partials: F = 11 only (the F = 35 kernel has neither the registers nor the LDS), P > 0");
     if (u->P == 0) return ENERF_OK;
     REQUIRE(u->vox && u->x && u->g_raw && u->packed && u->bimg && u->g_vox && u->g_x, "nerf_mlp_bwd: null pointer");
-    for (int i = 0; i < 16; ++i) REQUIRE(u->save[i], "nerf_mlp_bwd: save buffer %d missing", i);
+    for (int i = 0; i < 16; ++i) REQUIRE(u->save[i] || (wg && (i == 2 || i == 6 || i == 7)), "nerf_mlp_bwd: save buffer %d missing", i);
     MlpBwdArgs a;
     a.vox = u->vox; a.x = u->x; a.g_raw = u->g_raw; a.packed = u->packed; a.bimg = u->bimg; a.g_vox = u->g_vox; a.g_x = u->g_x;
     a.sv_hv = u->save[0]; a.sv_G = u->save[1]; a.sv_q = u->save[2]; a.sv_g = u->save[3]; a.sv_a = u->save[4]; a.sv_vm = u->save[5];
     a.d_cpre = u->save[6]; a.d_qpre = u->save[7]; a.d_p2 = u->save[8]; a.d_spre = u->save[9]; a.d_hpre = u->save[10];
     a.d_aggpre = u->save[11]; a.d_upre = u->save[12]; a.d_gpre = u->save[13]; a.d_gsum = u->save[14]; a.d_vpre = u->save[15];
     a.P = u->P; a.F = u->F;
+    a.wg_q = wg_q; a.wg_c2 = wg_c2;
     {
         const int Rr = (u->F + 3) / 4, TXr = (Rr + 1 + 3) / 4;
         a.n_bimg = u->image_offsets[7] + TXr * Rr * 64;      // b7 is the last image (autograd.py:mlp_backward_images)
@@ -637,23 +707,26 @@ extern "C" int enerf_nerf_mlp_bwd(const enerf_mlp_bwd_args_t* u, enerf_stream_t 
     a.o_b1 = u->image_offsets[0]; a.o_b2 = u->image_offsets[1]; a.o_b3 = u->image_offsets[2]; a.o_b4 = u->image_offsets[3];
     a.o_b5 = u->image_offsets[4]; a.o_b6v = u->image_offsets[5]; a.o_b6m = u->image_offsets[6]; a.o_b7 = u->image_offsets[7];
     REQUIRE(a.n_bimg % 4 == 0 && nerf_layout(u->F).total % 4 == 0, "nerf_mlp_bwd: image sizes not float4-aligned");
-    const size_t shmem = ((size_t)nerf_layout(u->F).total + (ENERF_MLPB_LDS_BIMG ? a.n_bimg : 0)) * sizeof(float);
+    const size_t shmem = ((size_t)nerf_layout(u->F).total + (ENERF_MLPB_LDS_BIMG ? a.n_bimg : 0) + (wg ? 4 * (16 * 80 + 16 * 16) : 0)) * sizeof(float);
     REQUIRE(shmem <= 160 * 1024, "nerf_mlp_bwd: images do not fit LDS");
-    const long long ntiles = cdivl(u->P, 16);
-    long long blocks = cdivl(ntiles, 4);
-#ifndef ENERF_MLPB_RESIDENT
-#define ENERF_MLPB_RESIDENT 2
-#endif
-    const long long resident = (long long)device_cu_count() * ENERF_MLPB_RESIDENT;
-    if (blocks > resident) blocks = resident;
-    const unsigned grid = (unsigned)blocks;
+    const unsigned grid = (unsigned)mlp_bwd_blocks(u->P);
     hipStream_t st = (hipStream_t)stream;
     const int R = (u->F + 3) / 4;
 #define ENERF_MLPB(RR, SS) ENERF_LAUNCH((k_mlp_bwd<RR, SS>), grid, 256, shmem, st, a)
-    if (R == 3) { if (u->S == 2) ENERF_MLPB(3, 2); else if (u->S == 3) ENERF_MLPB(3, 3); else ENERF_MLPB(3, 4); }
+#define ENERF_MLPB_WG(SS) ENERF_LAUNCH((k_mlp_bwd<3, SS, true>), grid, 256, shmem, st, a)
+    if (wg) { if (u->S == 2) ENERF_MLPB_WG(2); else if (u->S == 3) ENERF_MLPB_WG(3); else ENERF_MLPB_WG(4); }
+    else if (R == 3) { if (u->S == 2) ENERF_MLPB(3, 2); else if (u->S == 3) ENERF_MLPB(3, 3); else ENERF_MLPB(3, 4); }
     else { if (u->S == 2) ENERF_MLPB(9, 2); else if (u->S == 3) ENERF_MLPB(9, 3); else ENERF_MLPB(9, 4); }
 #undef ENERF_MLPB
+#undef ENERF_MLPB_WG
     return check_launch("nerf_mlp_bwd");
+}
+extern "C" int enerf_nerf_mlp_bwd(const enerf_mlp_bwd_args_t* u, enerf_stream_t stream) { return mlp_bwd_launch(u, nullptr, nullptr, stream); }
+// partial rows (waves) the kernel writes for P points: the chunk count of the reductions that follow
+extern "C" long long enerf_nerf_mlp_bwd_chunks(long long P) { return P > 0 ? mlp_bwd_blocks(P) * 4 : 0; }
+extern "C" int enerf_nerf_mlp_bwd_partials(const enerf_mlp_bwd_args_t* u, float* wg_q, float* wg_c2, enerf_stream_t stream) {
+    REQUIRE(wg_q && wg_c2, "nerf_mlp_bwd_partials: null partial buffers");
+    return mlp_bwd_launch(u, wg_q, wg_c2, stream);
 }
 
 extern "C" int enerf_nerf_mlp_fwd(const float* vox, const float* x, const float* packed, long long P, int S, int F, float* raw,

@@ -1134,19 +1134,20 @@ static size_t gemm_group_plan(const enerf_gemm_wgrad_desc_t* u, int n, GemmGroup
     int block0 = 0, rblock0 = 0;
     for (int i = 0; i < n; ++i) {
         const int bias = u[i].grad_bias != nullptr, ta = cdiv(u[i].Ca, 16), tb = cdiv(u[i].Cb + bias, 16);
-        const int blocks = (int)gemm_wgrad_blocks(u[i].P);
+        const bool pre = u[i].partials != nullptr;               // first stage done elsewhere: reduce only, no scratch of ours
+        const int blocks = pre ? u[i].partial_chunks : (int)gemm_wgrad_blocks(u[i].P);
         if (G != nullptr) {
             GemmDesc& d = G->d[i];
             d.A = u[i].a; d.B = u[i].b; d.dW = u[i].grad_w; d.dbias = u[i].grad_bias; d.scratch = nullptr;
             d.P = u[i].P; d.lda = u[i].lda; d.ldb = u[i].ldb; d.Ca = u[i].Ca; d.Cb = u[i].Cb; d.bias = bias;
             d.ldw = u[i].ldw > 0 ? u[i].ldw : u[i].Cb; d.ta = ta; d.tb = tb; d.blocks = blocks; d.block0 = block0; d.rblock0 = rblock0;
-            d.pad = (int)(floats / 256);                          // scratch offset in 256-float tiles (resolved by the caller)
+            d.pad = pre ? -1 : (int)(floats / 256);               // scratch offset in 256-float tiles (resolved by the caller); -1: partials
         }
-        floats += (size_t)blocks * ta * tb * 256;
+        if (!pre) floats += (size_t)blocks * ta * tb * 256;
         block0 += blocks;
         rblock0 += ta * tb * 4;
     }
-    if (G != nullptr) { G->n = n; G->d[0].pad = 0; }
+    if (G != nullptr) G->n = n;
     return floats * sizeof(float);
 }
 
@@ -1165,36 +1166,50 @@ int enerf_wgrad_reduce_flush(enerf_stream_t stream) {
     reduce_flush((hipStream_t)stream);
     return check_launch("wgrad_reduce_flush");
 }
+int enerf_colsum(const float* part, int chunks, int n, float* out, enerf_stream_t stream) {
+    REQUIRE(part && out && chunks > 0 && n > 0, "colsum: bad arguments");
+    launch_colsum(part, chunks, n, n, 0, out, cdiv(n, 64), 1, (hipStream_t)stream);
+    return check_launch("colsum");
+}
 size_t enerf_gemm_wgrad_group_workspace_bytes(const enerf_gemm_wgrad_desc_t* descs, int n) {
     if (descs == nullptr || n < 1 || n > kGemmGroupMax) return 0;
     for (int i = 0; i < n; ++i)
-        if (descs[i].P <= 0 || descs[i].Ca < 1 || descs[i].Cb < 1) return 0;
+        if ((descs[i].partials == nullptr && descs[i].P <= 0) || descs[i].Ca < 1 || descs[i].Cb < 1) return 0;
     return gemm_group_plan(descs, n, nullptr);
 }
 int enerf_gemm_wgrad_group(const enerf_gemm_wgrad_desc_t* descs, int n, void* workspace, size_t workspace_bytes, enerf_stream_t stream) {
     REQUIRE(descs && n >= 1 && n <= kGemmGroupMax, "gemm_wgrad_group: 1..%d members", kGemmGroupMax);
     for (int i = 0; i < n; ++i) {
         const enerf_gemm_wgrad_desc_t& u = descs[i];
-        REQUIRE(u.a && u.b && u.grad_w && u.Ca > 0 && u.Cb > 0 && u.lda >= u.Ca && u.ldb >= u.Cb && (u.ldw == 0 || u.ldw >= u.Cb),
-                "gemm_wgrad_group: member %d: bad arguments", i);
-        REQUIRE(u.P > 0 && u.P < (1LL << 31), "gemm_wgrad_group: member %d: P out of range", i);
-        REQUIRE(u.P * u.lda < (1LL << 30) && u.P * u.ldb < (1LL << 30),
-                "gemm_wgrad_group: member %d: a matrix of 4 GiB or more (32-bit byte offsets inside the kernel)", i);
+        if (u.partials != nullptr) {
+            REQUIRE(u.grad_w && u.Ca > 0 && u.Cb > 0 && u.partial_chunks > 0 && (u.ldw == 0 || u.ldw >= u.Cb),
+                    "gemm_wgrad_group: member %d (partials): bad arguments", i);
+        } else {
+            REQUIRE(u.a && u.b && u.grad_w && u.Ca > 0 && u.Cb > 0 && u.lda >= u.Ca && u.ldb >= u.Cb && (u.ldw == 0 || u.ldw >= u.Cb),
+                    "gemm_wgrad_group: member %d: bad arguments", i);
+            REQUIRE(u.P > 0 && u.P < (1LL << 31), "gemm_wgrad_group: member %d: P out of range", i);
+            REQUIRE(u.P * u.lda < (1LL << 30) && u.P * u.ldb < (1LL << 30),
+                    "gemm_wgrad_group: member %d: a matrix of 4 GiB or more (32-bit byte offsets inside the kernel)", i);
+        }
         REQUIRE(cdiv(u.Ca, 16) <= 4 && cdiv(u.Cb + (u.grad_bias != nullptr), 16) <= 6,
                 "gemm_wgrad_group: member %d: more than 4 x 6 tiles (%d x %d columns): use enerf_gemm_wgrad", i, u.Ca, u.Cb);
     }
     GemmGroup G;
     const size_t need = gemm_group_plan(descs, n, &G);
-    REQUIRE(workspace != nullptr && workspace_bytes >= need, "gemm_wgrad_group: workspace of %zu bytes, need %zu (enerf_gemm_wgrad_group_workspace_bytes)",
+    REQUIRE((workspace != nullptr || need == 0) && workspace_bytes >= need, "gemm_wgrad_group: workspace of %zu bytes, need %zu (enerf_gemm_wgrad_group_workspace_bytes)",
             workspace_bytes, need);
-    for (int i = 0; i < n; ++i) { G.d[i].scratch = (float*)workspace + (size_t)G.d[i].pad * 256; G.d[i].pad = 0; }
+    for (int i = 0; i < n; ++i) {       // pad: 1 = no first-stage blocks of ours (the member brought its partial rows)
+        const bool pre = G.d[i].pad < 0;
+        G.d[i].scratch = pre ? const_cast<float*>(descs[i].partials) : (float*)workspace + (size_t)G.d[i].pad * 256;
+        G.d[i].pad = pre ? 1 : 0;
+    }
     const GemmDesc& last = G.d[n - 1];
     for (int cls = 0; cls < 3; ++cls) {                     // the members of one register class: one launch
         GemmGroup Gc;
         Gc.n = 0;
         int blocks = 0;
         for (int i = 0; i < n; ++i)
-            if (gemm_group_class(G.d[i].ta * G.d[i].tb) == cls) {
+            if (G.d[i].pad == 0 && gemm_group_class(G.d[i].ta * G.d[i].tb) == cls) {
                 Gc.d[Gc.n] = G.d[i];
                 Gc.d[Gc.n].block0 = blocks;
                 blocks += G.d[i].blocks;

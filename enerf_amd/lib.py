@@ -79,7 +79,7 @@ class GatherArgs(C.Structure):
 
 class GemmWgradDesc(C.Structure):
     _fields_ = [("a", _f), ("lda", _i), ("Ca", _i), ("b", _f), ("ldb", _i), ("Cb", _i), ("P", _ll), ("grad_w", _f), ("ldw", _i),
-                ("grad_bias", _f)]
+                ("grad_bias", _f), ("partials", _f), ("partial_chunks", _i)]
 
 
 class RenderArgs(C.Structure):
@@ -170,6 +170,9 @@ _SIGNATURES = {
     "enerf_conv_wgrad": (_i, [_f, _f] + [_i] * 16 + [_f, C.c_void_p, C.c_size_t, _f]),
     "enerf_gemm_wgrad_workspace_bytes": (C.c_size_t, [_ll, _i, _i, _i]),
     "enerf_nerf_mlp_bwd": (_i, [C.POINTER(MlpBwdArgs), _f]),
+    "enerf_nerf_mlp_bwd_chunks": (_ll, [_ll]),
+    "enerf_nerf_mlp_bwd_partials": (_i, [C.POINTER(MlpBwdArgs), _f, _f, _f]),
+    "enerf_colsum": (_i, [_f, _i, _i, _f, _f]),
     "enerf_gemm_wgrad": (_i, [_f, _i, _i, _f, _i, _i, _ll, _f, _f, C.c_void_p, C.c_size_t, _f]),
     "enerf_bn_train_apply": (_i, [_f, _ll, _i, C.c_void_p, C.c_size_t, _f, _f, C.c_double, C.c_double, _f, _f, C.c_void_p, _i, C.c_void_p, _f, _f, _i, _f, _f]),
     "enerf_bn_train_bwd_apply": (_i, [_f, _f, _i, _ll, _i, C.c_void_p, C.c_size_t, C.c_void_p, _f, _f, _f, _f]),
@@ -724,6 +727,15 @@ class EnerfLib:
         n = len(members)
         descs, out = (GemmWgradDesc * n)(), []
         for d, m in zip(descs, members):
+            if m.get("partials") is not None:                  # first stage done elsewhere (nerf_mlp_bwd(partials=True)): reduce only
+                part, (mat, c0) = m["partials"], m["into"]
+                Ca, Cb = m["Ca"], m["Cb"]
+                if part.shape[1] * 16 * 16 < ((Ca + 15) // 16) * ((Cb + 15) // 16) * 256 or not part.is_contiguous() or not mat.is_contiguous():
+                    raise EnerfError("gemm_wgrad_group: partial rows do not hold the member's tiles")
+                d.Ca, d.Cb, d.grad_w, d.ldw = Ca, Cb, mat.data_ptr() + 4 * c0, mat.shape[1]
+                d.partials, d.partial_chunks = part.data_ptr(), part.shape[0]
+                out.append((mat, None))
+                continue
             a, b = m["a"], m["b"]
             if a.stride(1) != 1 or b.stride(1) != 1 or a.shape[0] != b.shape[0]:
                 raise EnerfError("gemm_wgrad_group: rows must be contiguous and of equal count")
@@ -740,7 +752,7 @@ class EnerfLib:
             d.a, d.lda, d.Ca, d.b, d.ldb, d.Cb, d.P = a.data_ptr(), a.stride(0), Ca, b.data_ptr(), b.stride(0), Cb, a.shape[0]
             d.grad_w, d.ldw, d.grad_bias = ptr, ldw, _ptr(gb)
             out.append((gw, gb))
-        a0 = members[0]["a"]
+        a0 = next(m["a"] for m in members if m.get("partials") is None)
         ws = self._scratch(self.dll.enerf_gemm_wgrad_group_workspace_bytes(descs, n), a0.device)
         self._check(self.dll.enerf_gemm_wgrad_group(descs, n, ws.data_ptr(), ws.numel(), self.stream_of(a0)), "gemm_wgrad_group")
         return out
@@ -751,21 +763,37 @@ class EnerfLib:
                                                 self.stream_of(vox)), "nerf_mlp_fwd")
         return raw
 
-    def nerf_mlp_bwd(self, vox, x, g_raw, packed, bimg, offsets, S, F):
-        """Fused MLP backward (enerf_nerf_mlp_bwd) -> (g_vox, g_x, saves: list of 16 tensors)."""
+    def nerf_mlp_bwd(self, vox, x, g_raw, packed, bimg, offsets, S, F, partials=False):
+        """Fused MLP backward (enerf_nerf_mlp_bwd) -> (g_vox, g_x, saves: list of 16 tensors).  ``partials`` (F = 11): the weight
+        gradients of the per-view colour branch are accumulated in the kernel (enerf_nerf_mlp_bwd_partials): saves 2, 6, 7 (q, d_cpre,
+        d_qpre) are None and two more results follow — wg_q (chunks, 4, 256) and wg_c2 (chunks, 80), one row of partial sums per wave."""
         P, dev = vox.shape[0], vox.device
         E = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         g_vox, g_x = E(P, 8), E(P, S, F + 4)
-        saves = [E(P, 88), E(P, 32), E(P, S, 64), E(P, S, 32), E(P, S, F), E(P, 2 * F),
-                 E(P, S), E(P, S, 64), E(P, 64), E(P), E(P, 64), E(P, 16), E(P, S), E(P, S, 32), E(P, 32), E(P, S, F)]
+        skip = (2, 6, 7) if partials else ()
+        shapes = [(P, 88), (P, 32), (P, S, 64), (P, S, 32), (P, S, F), (P, 2 * F),
+                  (P, S), (P, S, 64), (P, 64), (P,), (P, 64), (P, 16), (P, S), (P, S, 32), (P, 32), (P, S, F)]
+        saves = [None if i in skip else E(*sh) for i, sh in enumerate(shapes)]
         a = MlpBwdArgs(_ptr(vox), _ptr(x), _ptr(g_raw), _ptr(packed), _ptr(bimg), _ptr(g_vox), _ptr(g_x))
         for i, t in enumerate(saves):
-            a.save[i] = t.data_ptr()
+            a.save[i] = _ptr(t)
         a.P, a.F, a.S = P, F, S
         for i, o in enumerate(offsets):
             a.image_offsets[i] = int(o)
-        self._check(self.dll.enerf_nerf_mlp_bwd(C.byref(a), self.stream_of(vox)), "nerf_mlp_bwd")
-        return g_vox, g_x, saves
+        if not partials:
+            self._check(self.dll.enerf_nerf_mlp_bwd(C.byref(a), self.stream_of(vox)), "nerf_mlp_bwd")
+            return g_vox, g_x, saves
+        chunks = int(self.dll.enerf_nerf_mlp_bwd_chunks(P))
+        wg_q, wg_c2 = E(chunks, 4, 256), E(chunks, 80)
+        self._check(self.dll.enerf_nerf_mlp_bwd_partials(C.byref(a), _ptr(wg_q), _ptr(wg_c2), self.stream_of(vox)), "nerf_mlp_bwd_partials")
+        return g_vox, g_x, saves, wg_q, wg_c2
+
+    def colsum(self, part):
+        """out[i] = sum_c part[c, i] in a fixed order (enerf_colsum): the second stage of per-wave partial sums."""
+        chunks, n = part.shape
+        out = torch.empty((n,), dtype=torch.float32, device=part.device)
+        self._check(self.dll.enerf_colsum(_ptr(part), chunks, n, _ptr(out), self.stream_of(part)), "colsum")
+        return out
 
     def _gather_args(self, xyz, dn, uv, tex_cl, vol_cl, cam, tcen):
         B, P = xyz.shape[0], xyz.shape[1]

@@ -446,6 +446,15 @@ typedef struct {
     int image_offsets[8];
 } enerf_mlp_bwd_args_t;
 int enerf_nerf_mlp_bwd(const enerf_mlp_bwd_args_t* args, enerf_stream_t stream);
+/* ABI v11, F = 11: the same backward with the weight gradients of the per-view colour branch accumulated INSIDE the kernel — color.0's
+ * per-view columns (nerf.py:64-66: 64 x (F + 4), a 16-point product on the matrix cores per view) and color.2 (+ bias) — so that q, d_qpre
+ * and d_cpre (save[2], save[7], save[6]: 40 % of the saved bytes; may be NULL here) are never written.  Every wave writes one row of
+ * partial sums: wg_q[chunks][4][256] (four 16 x 16 tiles, the layout enerf_gemm_wgrad_group reduces: a member with `partials`) and
+ * wg_c2[chunks][80] = [color.2 weight 64 | bias | 0 ...] (enerf_colsum); chunks = enerf_nerf_mlp_bwd_chunks(P). */
+long long enerf_nerf_mlp_bwd_chunks(long long P);
+int enerf_nerf_mlp_bwd_partials(const enerf_mlp_bwd_args_t* args, float* wg_q, float* wg_c2, enerf_stream_t stream);
+/* out[i] = sum over the chunks c of part[c * n + i] (fixed order): the second stage of a per-wave partial-sum layout. */
+int enerf_colsum(const float* part, int chunks, int n, float* out, enerf_stream_t stream);
 /* forward of the same MLP on materialised inputs (training): raw (P,4) = [rgb, sigma]; nothing else is written. */
 int enerf_nerf_mlp_fwd(const float* vox, const float* x, const float* packed, long long P, int S, int F, float* raw,
                        enerf_stream_t stream);
@@ -497,6 +506,8 @@ typedef struct {
     long long P;
     float* grad_w; int ldw;
     float* grad_bias;                       /* nullable */
+    const float* partials;                  /* nullable.  non-NULL: the member's first stage already ran elsewhere (enerf_nerf_mlp_bwd_partials): */
+    int partial_chunks;                     /* partials[partial_chunks][ceil(Ca/16) * ceil(Cb/16)][256] are only reduced; a, b, P are ignored */
 } enerf_gemm_wgrad_desc_t;
 size_t enerf_gemm_wgrad_group_workspace_bytes(const enerf_gemm_wgrad_desc_t* descs, int n);
 int enerf_gemm_wgrad_group(const enerf_gemm_wgrad_desc_t* descs, int n, void* workspace, size_t workspace_bytes, enerf_stream_t stream);
