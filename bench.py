@@ -80,11 +80,14 @@ def render_mfma_tiles_per_16(S, R):
 def mlp_bwd_mfma_tiles_per_16(S, R):
     """16x16x4 fp32 MFMA tiles k_mlp_bwd issues per 16 points (mlp_train.hip): the forward recompute (= the render kernel's
     MLP), the colour layer's per-view half a second time, and the transposed-weight products b1..b7.  Equals the static
-    v_mfma count of the kernel's ISA (tools/isa_count.py: 482 at S=3,R=3; 940 at R=9)."""
+    v_mfma count of the kernel's ISA (tools/isa_count.py: 566 at S=3,R=3 with the in-kernel weight gradients, 482 without; 940 at R=9)."""
     TR, TX = (R + 3) // 4, (R + 4) // 4
     fwd = render_mfma_tiles_per_16(S, R)
     bwd = 4 * S * (R + 1) + 16 * S * TX + 96 + 32 + 8 + 16 * TR + 8 * S * TR + S * TX * R
-    return fwd + bwd
+    # round 6, R = 3 (F = 11): the per-view layers' weight gradients inside the kernel (k = point products): color.0's per-view columns
+    # 16 per view; with S <= 3 also global_fc's `a` columns 8 and view_fc 4 per view (autograd.NerfMlpFn: level 2, else 1)
+    wg = (28 * S if S <= 3 else 16 * S) if R == 3 else 0
+    return fwd + bwd + wg
 
 
 def render_dense_flop_per_sample(S, F):
@@ -490,9 +493,9 @@ def train_extras(args, net, batch, loss_fn, cfg, dev, ms_per_step):
     rec = {}
     orig = lib.nerf_mlp_bwd
 
-    def spy(vox, x, g_raw, packed, bimg, offsets, S, F):
-        rec[F] = (vox, x, g_raw, packed, bimg, offsets, S, F)
-        return orig(vox, x, g_raw, packed, bimg, offsets, S, F)
+    def spy(*a, **kw):                   # (vox, x, g_raw, packed, bimg, offsets, S, F, level=...)
+        rec[a[7]] = (a, kw)
+        return orig(*a, **kw)
     lib.nerf_mlp_bwd = spy
     try:
         for p_ in net.parameters():
@@ -506,14 +509,14 @@ def train_extras(args, net, batch, loss_fn, cfg, dev, ms_per_step):
     last = cfg.cas.num - 1
     F = cfg.cas.nerf_model_feat_ch[last] + 3
     if F in rec:
-        a = rec[F]
+        a, kw = rec[F]
         P, S, R = int(a[0].shape[0]), int(a[6]), (F + 3) // 4
         for _ in range(3):
-            orig(*a)
+            orig(*a, **kw)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
         ev[0].record()
         for i in range(10):
-            orig(*a)
+            orig(*a, **kw)
             ev[i + 1].record()
         torch.cuda.synchronize()
         t_ms = sum(ev[i].elapsed_time(ev[i + 1]) for i in range(10)) / 10
@@ -521,7 +524,8 @@ def train_extras(args, net, batch, loss_fn, cfg, dev, ms_per_step):
         flops = tiles * 2 * 16 * 16 * 4 * ((P + 15) // 16)
         ach = flops / (t_ms * 1e-3) / 1e12
         out["roofline"] = {
-            "kernel": f"k_mlp_bwd<{R},{S}> (level-{last} Agg + NeRF MLP: fused recompute-forward + backward, {P} points)",
+            "kernel": f"k_mlp_bwd<{R},{S}> (level-{last} Agg + NeRF MLP: fused recompute-forward + backward" +
+                      (" + the per-view layers' weight gradients" if R == 3 else "") + f", {P} points)",
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(t_ms, 4),
             "avg_launch_ms_source": "HIP events around 10 stand-alone launches on the bench's stream with the launch arguments "
@@ -529,12 +533,13 @@ def train_extras(args, net, batch, loss_fn, cfg, dev, ms_per_step):
             "algorithmic_flops_per_launch": flops, "mfma_tiles_per_16_points": tiles,
             "share_of_step": round(t_ms / ms_per_step, 4),
             "note": "issued fp32 16x16x4 MFMA work (static v_mfma count of the kernel = tiles per 16 points); one wave per SIMD at "
-                    "256 VGPRs + AGPR traffic is why the fraction is low (DESIGN.md)"}
+                    "256 VGPRs + AGPR traffic is why the fraction is low (DESIGN.md)",
+            "weight_gradients_in_kernel": kw.get("level", 0)}
         if not args.no_live_pmc and not args.emu:
             # HBM bytes of one launch, measured now: rocprofv3 --pmc passes over two EAGER steps of a child run (the same kernels
             # as the captured step; counters serialise the kernels either way)
             flags = ["--train", "--train-eager", "--steps", "2", "--warmup", "1"] + (["--no-perceptual"] if args.no_perceptual else [])
-            live = live_pmc([], kernel_prefix=f"k_mlp_bwd<{R}, {S}>", child_flags=flags)
+            live = live_pmc([], kernel_prefix=f"k_mlp_bwd<{R}, {S}", child_flags=flags)       # (<R, S> or <R, S, level>)
             live = next(iter(live[""].values())) if live and live.get("") else None
             if live is not None:
                 out["roofline"]["traffic"] = live["hbm_bytes_per_launch"]

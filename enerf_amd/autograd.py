@@ -709,43 +709,55 @@ class NerfMlpFn(torch.autograd.Function):
         F = XW - 4
         packed = ctx.packed
         bimg, offs = mlp_backward_images(m, S, lib)
-        inkernel = F == 11 and P > 0            # the per-view colour branch's weight gradients accumulated inside the kernel (mlp_train.hip WG)
-        res = lib.nerf_mlp_bwd(vox.contiguous(), x.contiguous(), g_raw.contiguous(), packed, bimg, offs, S, F, partials=inkernel)
+        # F = 11: the weight gradients of the per-(point, view) layers accumulated inside the kernel (mlp_train.hip WG; the aggregation branch
+        # too when the kernel has the registers: S <= 3), the per-point layers through the saved rows
+        level = (2 if S <= 3 else 1) if (F == 11 and P > 0) else 0
+        res = lib.nerf_mlp_bwd(vox.contiguous(), x.contiguous(), g_raw.contiguous(), packed, bimg, offs, S, F, level=level)
         g_vox, g_x, sv = res[:3]
+        part = res[3] if level else None
         hv, G, q, gs, a_, vm, d_c, d_q, d_p2, d_s, d_h, d_agg, d_u, d_g, d_gsum, d_v = sv
         PS = P * S
         x2 = x.reshape(PS, XW)
         # color.2 (1,64) / color.0 (64, 88+F+4) / sigma (1,64) / lr0 (64,24) / fc (16,32) / agg_w (1,32) / global_fc (32,3F) / view_fc (F,4):
-        # ten (eleven) position reductions over the saved rows as ONE grouped call = two launches (enerf_gemm_wgrad_group); color.0 and
-        # global_fc are assembled in place from their two column blocks
+        # position reductions over the saved rows (or over the kernel's per-wave partial sums) as ONE grouped call (enerf_gemm_wgrad_group);
+        # color.0 and global_fc are assembled in place from their two column blocks
         w_c0 = torch.empty((64, 88 + XW), dtype=torch.float32, device=x.device)
         w_gl = torch.empty((32, 3 * F), dtype=torch.float32, device=x.device)
-        if inkernel:       # color.2 and color.0's per-view columns arrive as per-wave partial sums (q, d_q, d_c were never written)
-            m_c2 = None
-            m_c0v = dict(partials=res[3], Ca=64, Cb=XW, into=(w_c0, 88))
+        gw, members, names = {}, [], []
+
+        def member(name, **kw):
+            members.append(kw)
+            names.append(name)
+        if level == 0:
+            member("color.2", a=d_c.reshape(PS, 1), b=q.reshape(PS, 64), bias=True)
+        member("color.0", a=d_p2, b=hv, bias=True, into=(w_c0, 0))                               # shared columns [h | vox | agg]
+        if level == 0:
+            member(None, a=d_q.reshape(PS, 64), b=x2, into=(w_c0, 88))                           # per-view columns [x_s | dir_s]
         else:
-            m_c2 = dict(a=d_c.reshape(PS, 1), b=q.reshape(PS, 64), bias=True)
-            m_c0v = dict(a=d_q.reshape(PS, 64), b=x2, into=(w_c0, 88))
-        members = [
-            m_c2,                                                                       # color.2
-            dict(a=d_p2, b=hv, bias=True, into=(w_c0, 0)),                              # color.0, shared columns [h | vox | agg]
-            m_c0v,                                                                      # color.0, per-view columns [x_s | dir_s]
-            dict(a=d_s.reshape(P, 1), b=hv, Cb=64, bias=True),                          # sigma
-            dict(a=d_h, b=hv[:, 64:], bias=True),                                       # lr0
-            dict(a=d_agg, b=G, bias=True),                                              # agg.fc
-            dict(a=d_u.reshape(PS, 1), b=gs.reshape(PS, 32), bias=True),                # agg.agg_w_fc
-            dict(a=d_g.reshape(PS, 32), b=a_.reshape(PS, F), into=(w_gl, 0)),           # agg.global_fc, a columns
-            dict(a=d_gsum, b=vm, bias=True, into=(w_gl, F)),                            # agg.global_fc, [var | mean] columns
-        ]
-        names = ["color.2", "color.0", None, "sigma.0", "lr0.0", "agg.fc.0", "agg.agg_w_fc.0", None, "agg.global_fc.0"]
+            member(None, partials=part["q"], Ca=64, Cb=XW, into=(w_c0, 88))
+        member("sigma.0", a=d_s.reshape(P, 1), b=hv, Cb=64, bias=True)
+        member("lr0.0", a=d_h, b=hv[:, 64:], bias=True)
+        member("agg.fc.0", a=d_agg, b=G, bias=True)
+        if level < 2:
+            member("agg.agg_w_fc.0", a=d_u.reshape(PS, 1), b=gs.reshape(PS, 32), bias=True)
+            member(None, a=d_g.reshape(PS, 32), b=a_.reshape(PS, F), into=(w_gl, 0))             # global_fc, a columns
+        else:
+            member(None, partials=part["g"], Ca=32, Cb=F, into=(w_gl, 0))
+        member("agg.global_fc.0", a=d_gsum, b=vm, bias=True, into=(w_gl, F))                     # global_fc, [var | mean] columns
         if m.viewdir_agg:
-            members.append(dict(a=d_v.reshape(PS, F), b=x2[:, F:], bias=True))          # agg.view_fc
-            names.append("agg.view_fc.0")
-        gw = {}
-        if inkernel:
-            c2 = lib.colsum(res[4])
-            gw["color.2.weight"], gw["color.2.bias"] = c2[:64].view(1, 64), c2[64:65]
-            members, names = members[1:], names[1:]
+            if level < 2:
+                member("agg.view_fc.0", a=d_v.reshape(PS, F), b=x2[:, F:], bias=True)
+            else:
+                w_vf = torch.empty((F, 4), dtype=torch.float32, device=x.device)
+                member(None, partials=part["v"], Ca=F, Cb=4, into=(w_vf, 0))
+                gw["agg.view_fc.0.weight"] = w_vf
+        if level:
+            rows = lib.colsum(part["rows"])          # [color.2 w 64 | b | 0 x 15 | agg_w w 32 | b | view_fc b F | 0 ...]
+            gw["color.2.weight"], gw["color.2.bias"] = rows[:64].view(1, 64), rows[64:65]
+            if level == 2:
+                gw["agg.agg_w_fc.0.weight"], gw["agg.agg_w_fc.0.bias"] = rows[80:112].view(1, 32), rows[112:113]
+                if m.viewdir_agg:
+                    gw["agg.view_fc.0.bias"] = rows[113:113 + F]
         for name, (w_, b_) in zip(names, lib.gemm_wgrad_group(members)):
             if name is not None:
                 gw[name + ".weight"] = w_

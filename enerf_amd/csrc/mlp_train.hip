@@ -27,7 +27,7 @@ struct MlpBwdArgs {
     long long P;
     int F, n_bimg;                       // floats of the backward images (staged in LDS behind the forward image)
     int o_b1, o_b2, o_b3, o_b4, o_b5, o_b6v, o_b6m, o_b7;                  // float offsets of the backward images
-    float *wg_q, *wg_c2;                 // WG: per-wave partial weight gradients ([wave][4][256] and [wave][80], see below)
+    float *wg_q, *wg_g, *wg_v, *wg_rows; // WG: per-wave partial weight gradients ([wave][4 | 2 | 1][256] tiles and [wave][128] rows, see below)
 };
 
 // A/B switches (tools/build_variant.py): backward images from LDS (default) or from global memory as until round 3; the
@@ -46,9 +46,14 @@ struct MlpBwdArgs {
 // The first is a 16-point product on the matrix cores per view: d_q (D layout: unit rows, point columns) and [x_s | dir_s] (slot layout) are
 // transposed through a per-wave LDS tile (point-major rows, conflict-free pitches) into A / B operands with k = point — 16 MFMAs per view
 // into four accumulator tiles that live in registers for the whole kernel (R = 3 runs at 354 of 512 registers).  The second is 16 fused
-// multiply-adds per view into per-lane partial sums, reduced over the 16 point lanes once at the end.  Every wave ends with one row of
-// partials ([wave][4 tiles][256] and [wave][64 + 1 | pad to 80]); enerf_gemm_wgrad_group / enerf_colsum reduce them over the waves.
-template <int R, int S, bool WG = false>
+// multiply-adds per view into per-lane partial sums, reduced over the 16 point lanes once at the end.
+// WG = 2 adds the per-view AGGREGATION branch the same way (g = relu(global_fc ...), d_g, a, d_u, d_v: another 27 % of the saved floats):
+//   global_fc's `a` columns  dW[o][i] = sum d_g[p,s,o] a[p,s,i]  (32 x F: 8 MFMAs per view),  agg_w_fc  dW[o] = sum d_u g[o] (+ bias),
+//   view_fc  dW[o][i] = sum d_v[p,s,o] dir[p,s,i]  (F x 4: 4 MFMAs per view, + bias sum d_v).
+// Every wave ends with one row of partials: tiles wg_q[wave][4][256], wg_g[wave][2][256], wg_v[wave][256] (the layout a
+// enerf_gemm_wgrad_group member with `partials` reduces) and wg_rows[wave][128] = [color.2 w 64 | b | 0 x 15 | agg_w w 32 | b | view_fc b 11 |
+// 0 x 4] (enerf_colsum).
+template <int R, int S, int WG = 0>
 __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
     constexpr int TR = (R + 3) / 4;             // slot tiles of the F channels
     constexpr int TX = (R + 1 + 3) / 4;         // slot tiles of [channels | direction code]
@@ -78,17 +83,23 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
     const int waves = blockDim.x >> 6;
     // WG: this wave's transpose tiles behind the images: d_q as [point][80] (64 units; pitch 80: the four point rows of a k-block sit 16
     // banks apart) and [x_s | dir_s] as [point][16] (column 15 = 0)
-    constexpr int kTq = 16 * 80, kTx = 16 * 16;
-    float* tq = nullptr;
-    float* tx = nullptr;
-    f32x4 wq[4], wc2[4];
-    float bc2 = 0.f;
+    constexpr int kTq = 16 * 80, kTx = 16 * 16, kWaveLds = kTq + 4 * kTx;
+    float *tq = nullptr, *tx = nullptr, *ta = nullptr, *tv = nullptr, *td = nullptr;
+    f32x4 wq[4], wc2[4], wga[2], wag[2], wvf = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bc2 = 0.f, bag = 0.f, bv[R];
     if (WG) {
-        tq = wl + L.total + (ENERF_MLPB_LDS_BIMG ? a.n_bimg : 0) + (threadIdx.x >> 6) * (kTq + kTx);
-        tx = tq + kTq;
+        tq = wl + L.total + (ENERF_MLPB_LDS_BIMG ? a.n_bimg : 0) + (threadIdx.x >> 6) * kWaveLds;
+        tx = tq + kTq; ta = tx + kTx; tv = ta + kTx; td = tv + kTx;
         tx[j * 16 + 12 + g] = 0.f;                          // (columns 12..14 are rewritten per view; 15 stays 0)
 #pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) { ta[j * 16 + 4 * q4 + g] = 0.f; tv[j * 16 + 4 * q4 + g] = 0.f; td[j * 16 + 4 * q4 + g] = 0.f; }   // columns >= F / 4 stay 0
+#pragma unroll
         for (int v = 0; v < 4; ++v) { wq[v] = f32x4{0.f, 0.f, 0.f, 0.f}; wc2[v] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { wga[u] = f32x4{0.f, 0.f, 0.f, 0.f}; wag[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int r = 0; r < R; ++r) bv[r] = 0.f;
+        wave_sync();
     }
     for (long long tile = (long long)blockIdx.x * waves + (threadIdx.x >> 6); tile < ntiles; tile += (long long)gridDim.x * waves) {
         const long long pr = tile * 16 + j;
@@ -250,12 +261,14 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
             *reinterpret_cast<f32x4*>(a.sv_hv + p * 88 + 72 + 4 * g) = agg;
 #pragma unroll
             for (int u = 0; u < 2; ++u) *reinterpret_cast<f32x4*>(a.sv_G + p * 32 + 16 * u + 4 * g) = G[u];
+            if (WG < 2) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
+                for (int s = 0; s < S; ++s) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) *reinterpret_cast<f32x4*>(a.sv_g + (p * S + s) * 32 + 16 * u + 4 * g) = gf[s][u];
+                    for (int u = 0; u < 2; ++u) *reinterpret_cast<f32x4*>(a.sv_g + (p * S + s) * 32 + 16 * u + 4 * g) = gf[s][u];
 #pragma unroll
-                for (int r = 0; r < R; ++r) if (g * R + r < F) a.sv_a[(p * S + s) * F + g * R + r] = av[s][r];
+                    for (int r = 0; r < R; ++r) if (g * R + r < F) a.sv_a[(p * S + s) * F + g * R + r] = av[s][r];
+                }
             }
 #pragma unroll
             for (int r = 0; r < R; ++r)
@@ -405,14 +418,34 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
         for (int s = 0; s < S; ++s) {
             const float du = aw[s] * (daw[s] - dot2);
             const float dup = (ok && upre[s] > 0.f) ? du : 0.f;
-            if (sv && g == 0) a.d_upre[p * S + s] = dup;
+            if (WG < 2 && sv && g == 0) a.d_upre[p * S + s] = dup;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const f32x4 wv = u == 0 ? aggw0 : aggw1;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dgp[s][u][r] = gf[s][u][r] > 0.f ? aw[s] * dG[u][r] + wv[r] * dup : 0.f;
                 dgsum[u] += dgp[s][u];
-                if (sv) *reinterpret_cast<f32x4*>(a.d_gpre + (p * S + s) * 32 + 16 * u + 4 * g) = dgp[s][u];
+                if (WG < 2 && sv) *reinterpret_cast<f32x4*>(a.d_gpre + (p * S + s) * 32 + 16 * u + 4 * g) = dgp[s][u];
+            }
+            if (WG >= 2) {      // agg_w_fc: d_u g into per-lane partial sums; global_fc's `a` columns: d_g (x) a on the matrix cores, k = point
+                bag += dup;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) wag[u][r] += gf[s][u][r] * dup;
+                    *reinterpret_cast<f32x4*>(tq + j * 80 + 16 * u + 4 * g) = dgp[s][u];
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) if (g * R + r < F) ta[j * 16 + g * R + r] = av[s][r];
+                wave_sync();
+                float ba[4];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) ba[kb] = ta[(4 * kb + g) * 16 + j];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) wga[u] = ENERF_MFMA(tq[(4 * kb + g) * 80 + 16 * u + j], ba[kb], wga[u]);
+                wave_sync();
             }
         }
         if (sv) {
@@ -451,10 +484,19 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
                                 dvar[r >> 2][r & 3] * (2.f / (float)(S - 1)) * (av[s][r] - mean[r]);
                 dx2[r >> 2][r & 3] += d;                                     // a_s = x_s + relu(view_fc(dir_s))
                 dvp[r] = vmask[s][r] ? d : 0.f;
-                if (sv && g * R + r < F) a.d_vpre[(p * S + s) * F + g * R + r] = dvp[r];
+                if (WG < 2 && sv && g * R + r < F) a.d_vpre[(p * S + s) * F + g * R + r] = dvp[r];
                 // the rgb channels also feed the colour blend directly: col = sum_s cw_s rgb_s
                 const int c = g * R + r - (F - 3);
                 if (c >= 0 && c < 3) dx2[r >> 2][r & 3] += cl[s] * gcol[c];
+            }
+            if (WG >= 2) {      // view_fc: d_v (x) dir_s on the matrix cores (k = point), its bias as per-lane partial sums
+#pragma unroll
+                for (int r = 0; r < R; ++r) { bv[r] += dvp[r]; if (g * R + r < F) tv[j * 16 + g * R + r] = dvp[r]; }
+                td[j * 16 + g] = dsel[s];
+                wave_sync();
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) wvf = ENERF_MFMA(tv[(4 * kb + g) * 16 + j], td[(4 * kb + g) * 16 + j], wvf);
+                wave_sync();
             }
             // B7: d dir_s += W_view^T dvp  (k-steps over the view_fc outputs in slot layout)
 #pragma unroll
@@ -478,10 +520,30 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
             for (int r = 0; r < 4; ++r) {
                 a.wg_q[(gwv * 4 + v) * 256 + r * 64 + lane] = wq[v][r];
                 const float t = row_sum16(wc2[v][r]);                          // over the 16 points of the row
-                if (j == 0) a.wg_c2[gwv * 80 + 16 * v + 4 * g + r] = t;
+                if (j == 0) a.wg_rows[gwv * 128 + 16 * v + 4 * g + r] = t;
             }
         const float tb = row_sum16(bc2);                                      // (the same value in all four rows)
-        if (lane < 16) a.wg_c2[gwv * 80 + 64 + lane] = lane == 0 ? tb : 0.f;
+        if (lane < 16) a.wg_rows[gwv * 128 + 64 + lane] = lane == 0 ? tb : 0.f;
+        if (WG >= 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a.wg_g[(gwv * 2 + u) * 256 + r * 64 + lane] = wga[u][r];
+                    const float t = row_sum16(wag[u][r]);
+                    if (j == 0) a.wg_rows[gwv * 128 + 80 + 16 * u + 4 * g + r] = t;
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.wg_v[gwv * 256 + r * 64 + lane] = wvf[r];
+            const float tg = row_sum16(bag);
+            if (lane < 16) a.wg_rows[gwv * 128 + 112 + lane] = lane == 0 ? tg : 0.f;   // [112] agg_w bias; [113..127] zeroed, then view_fc's bias:
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float t = row_sum16(bv[r]);
+                if (j == 0 && g * R + r < F) a.wg_rows[gwv * 128 + 113 + g * R + r] = t;
+            }
+        } else if (lane < 48) a.wg_rows[gwv * 128 + 80 + lane] = 0.f;
     }
 }
 
@@ -684,22 +746,25 @@ static long long mlp_bwd_blocks(long long P) {
     const long long resident = (long long)device_cu_count() * ENERF_MLPB_RESIDENT;
     return blocks > resident ? resident : (blocks < 1 ? 1 : blocks);
 }
-static int mlp_bwd_launch(const enerf_mlp_bwd_args_t* u, float* wg_q, float* wg_c2, enerf_stream_t stream) {
-    const bool wg = wg_q != nullptr;
+static int mlp_bwd_launch(const enerf_mlp_bwd_args_t* u, int level, float* wg_q, float* wg_g, float* wg_v, float* wg_rows, enerf_stream_t stream) {
+    const bool wg = level > 0;
     REQUIRE(u, "nerf_mlp_bwd: null args");
     REQUIRE(u->F == 11 || u->F == 35, "nerf_mlp_bwd: F=%d unsupported (11 or 35)", u->F);
     REQUIRE(u->S >= 2 && u->S <= 4 && u->P >= 0, "nerf_mlp_bwd: bad shape");
-    if (wg) REQUIRE(u->F == 11 && wg_c2 != nullptr && u->P > 0, "nerf_mlp_bwd_partials: F = 11 only (the F = 35 kernel has neither the registers nor the LDS), P > 0");
+    if (wg) REQUIRE(u->F == 11 && wg_q && wg_rows && u->P > 0 && (level == 1 || (level == 2 && wg_g && wg_v && u->S <= 3)),
+                    "nerf_mlp_bwd_partials: F = 11 only (the F = 35 kernel has neither the registers nor the LDS), P > 0, level 1 or 2 (2: S <= 3)");
     if (u->P == 0) return ENERF_OK;
     REQUIRE(u->vox && u->x && u->g_raw && u->packed && u->bimg && u->g_vox && u->g_x, "nerf_mlp_bwd: null pointer");
-    for (int i = 0; i < 16; ++i) REQUIRE(u->save[i] || (wg && (i == 2 || i == 6 || i == 7)), "nerf_mlp_bwd: save buffer %d missing", i);
+    for (int i = 0; i < 16; ++i)
+        REQUIRE(u->save[i] || (wg && (i == 2 || i == 6 || i == 7)) || (level == 2 && (i == 3 || i == 4 || i == 12 || i == 13 || i == 15)),
+                "nerf_mlp_bwd: save buffer %d missing", i);
     MlpBwdArgs a;
     a.vox = u->vox; a.x = u->x; a.g_raw = u->g_raw; a.packed = u->packed; a.bimg = u->bimg; a.g_vox = u->g_vox; a.g_x = u->g_x;
     a.sv_hv = u->save[0]; a.sv_G = u->save[1]; a.sv_q = u->save[2]; a.sv_g = u->save[3]; a.sv_a = u->save[4]; a.sv_vm = u->save[5];
     a.d_cpre = u->save[6]; a.d_qpre = u->save[7]; a.d_p2 = u->save[8]; a.d_spre = u->save[9]; a.d_hpre = u->save[10];
     a.d_aggpre = u->save[11]; a.d_upre = u->save[12]; a.d_gpre = u->save[13]; a.d_gsum = u->save[14]; a.d_vpre = u->save[15];
     a.P = u->P; a.F = u->F;
-    a.wg_q = wg_q; a.wg_c2 = wg_c2;
+    a.wg_q = wg_q; a.wg_g = wg_g; a.wg_v = wg_v; a.wg_rows = wg_rows;
     {
         const int Rr = (u->F + 3) / 4, TXr = (Rr + 1 + 3) / 4;
         a.n_bimg = u->image_offsets[7] + TXr * Rr * 64;      // b7 is the last image (autograd.py:mlp_backward_images)
@@ -707,26 +772,28 @@ static int mlp_bwd_launch(const enerf_mlp_bwd_args_t* u, float* wg_q, float* wg_
     a.o_b1 = u->image_offsets[0]; a.o_b2 = u->image_offsets[1]; a.o_b3 = u->image_offsets[2]; a.o_b4 = u->image_offsets[3];
     a.o_b5 = u->image_offsets[4]; a.o_b6v = u->image_offsets[5]; a.o_b6m = u->image_offsets[6]; a.o_b7 = u->image_offsets[7];
     REQUIRE(a.n_bimg % 4 == 0 && nerf_layout(u->F).total % 4 == 0, "nerf_mlp_bwd: image sizes not float4-aligned");
-    const size_t shmem = ((size_t)nerf_layout(u->F).total + (ENERF_MLPB_LDS_BIMG ? a.n_bimg : 0) + (wg ? 4 * (16 * 80 + 16 * 16) : 0)) * sizeof(float);
+    const size_t shmem = ((size_t)nerf_layout(u->F).total + (ENERF_MLPB_LDS_BIMG ? a.n_bimg : 0) + (wg ? 4 * (16 * 80 + 4 * 16 * 16) : 0)) * sizeof(float);
     REQUIRE(shmem <= 160 * 1024, "nerf_mlp_bwd: images do not fit LDS");
     const unsigned grid = (unsigned)mlp_bwd_blocks(u->P);
     hipStream_t st = (hipStream_t)stream;
     const int R = (u->F + 3) / 4;
 #define ENERF_MLPB(RR, SS) ENERF_LAUNCH((k_mlp_bwd<RR, SS>), grid, 256, shmem, st, a)
-#define ENERF_MLPB_WG(SS) ENERF_LAUNCH((k_mlp_bwd<3, SS, true>), grid, 256, shmem, st, a)
-    if (wg) { if (u->S == 2) ENERF_MLPB_WG(2); else if (u->S == 3) ENERF_MLPB_WG(3); else ENERF_MLPB_WG(4); }
+#define ENERF_MLPB_WG(SS, LV) ENERF_LAUNCH((k_mlp_bwd<3, SS, LV>), grid, 256, shmem, st, a)
+    if (level == 2) { if (u->S == 2) ENERF_MLPB_WG(2, 2); else ENERF_MLPB_WG(3, 2); }
+    else if (level == 1) { if (u->S == 2) ENERF_MLPB_WG(2, 1); else if (u->S == 3) ENERF_MLPB_WG(3, 1); else ENERF_MLPB_WG(4, 1); }
     else if (R == 3) { if (u->S == 2) ENERF_MLPB(3, 2); else if (u->S == 3) ENERF_MLPB(3, 3); else ENERF_MLPB(3, 4); }
     else { if (u->S == 2) ENERF_MLPB(9, 2); else if (u->S == 3) ENERF_MLPB(9, 3); else ENERF_MLPB(9, 4); }
 #undef ENERF_MLPB
 #undef ENERF_MLPB_WG
     return check_launch("nerf_mlp_bwd");
 }
-extern "C" int enerf_nerf_mlp_bwd(const enerf_mlp_bwd_args_t* u, enerf_stream_t stream) { return mlp_bwd_launch(u, nullptr, nullptr, stream); }
+extern "C" int enerf_nerf_mlp_bwd(const enerf_mlp_bwd_args_t* u, enerf_stream_t stream) { return mlp_bwd_launch(u, 0, nullptr, nullptr, nullptr, nullptr, stream); }
 // partial rows (waves) the kernel writes for P points: the chunk count of the reductions that follow
 extern "C" long long enerf_nerf_mlp_bwd_chunks(long long P) { return P > 0 ? mlp_bwd_blocks(P) * 4 : 0; }
-extern "C" int enerf_nerf_mlp_bwd_partials(const enerf_mlp_bwd_args_t* u, float* wg_q, float* wg_c2, enerf_stream_t stream) {
-    REQUIRE(wg_q && wg_c2, "nerf_mlp_bwd_partials: null partial buffers");
-    return mlp_bwd_launch(u, wg_q, wg_c2, stream);
+extern "C" int enerf_nerf_mlp_bwd_partials(const enerf_mlp_bwd_args_t* u, int level, float* wg_q, float* wg_g, float* wg_v, float* wg_rows,
+                                           enerf_stream_t stream) {
+    REQUIRE(level == 1 || level == 2, "nerf_mlp_bwd_partials: level 1 (colour branch) or 2 (+ aggregation branch)");
+    return mlp_bwd_launch(u, level, wg_q, wg_g, wg_v, wg_rows, stream);
 }
 
 extern "C" int enerf_nerf_mlp_fwd(const float* vox, const float* x, const float* packed, long long P, int S, int F, float* raw,

@@ -171,7 +171,7 @@ _SIGNATURES = {
     "enerf_gemm_wgrad_workspace_bytes": (C.c_size_t, [_ll, _i, _i, _i]),
     "enerf_nerf_mlp_bwd": (_i, [C.POINTER(MlpBwdArgs), _f]),
     "enerf_nerf_mlp_bwd_chunks": (_ll, [_ll]),
-    "enerf_nerf_mlp_bwd_partials": (_i, [C.POINTER(MlpBwdArgs), _f, _f, _f]),
+    "enerf_nerf_mlp_bwd_partials": (_i, [C.POINTER(MlpBwdArgs), _i, _f, _f, _f, _f, _f]),
     "enerf_colsum": (_i, [_f, _i, _i, _f, _f]),
     "enerf_gemm_wgrad": (_i, [_f, _i, _i, _f, _i, _i, _ll, _f, _f, C.c_void_p, C.c_size_t, _f]),
     "enerf_bn_train_apply": (_i, [_f, _ll, _i, C.c_void_p, C.c_size_t, _f, _f, C.c_double, C.c_double, _f, _f, C.c_void_p, _i, C.c_void_p, _f, _f, _i, _f, _f]),
@@ -763,14 +763,15 @@ class EnerfLib:
                                                 self.stream_of(vox)), "nerf_mlp_fwd")
         return raw
 
-    def nerf_mlp_bwd(self, vox, x, g_raw, packed, bimg, offsets, S, F, partials=False):
-        """Fused MLP backward (enerf_nerf_mlp_bwd) -> (g_vox, g_x, saves: list of 16 tensors).  ``partials`` (F = 11): the weight
-        gradients of the per-view colour branch are accumulated in the kernel (enerf_nerf_mlp_bwd_partials): saves 2, 6, 7 (q, d_cpre,
-        d_qpre) are None and two more results follow — wg_q (chunks, 4, 256) and wg_c2 (chunks, 80), one row of partial sums per wave."""
+    def nerf_mlp_bwd(self, vox, x, g_raw, packed, bimg, offsets, S, F, level=0):
+        """Fused MLP backward (enerf_nerf_mlp_bwd) -> (g_vox, g_x, saves: list of 16 tensors).  ``level`` 1 / 2 (F = 11; 2: S <= 3): the
+        weight gradients of the per-view colour (and aggregation) branch are accumulated in the kernel (enerf_nerf_mlp_bwd_partials): the
+        saves they replace are None and a dict of per-wave partial sums follows — "q" (chunks, 4, 256), "rows" (chunks, 128) and, level 2,
+        "g" (chunks, 2, 256), "v" (chunks, 1, 256)."""
         P, dev = vox.shape[0], vox.device
         E = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         g_vox, g_x = E(P, 8), E(P, S, F + 4)
-        skip = (2, 6, 7) if partials else ()
+        skip = () if level == 0 else ((2, 6, 7) if level == 1 else (2, 6, 7, 3, 4, 12, 13, 15))
         shapes = [(P, 88), (P, 32), (P, S, 64), (P, S, 32), (P, S, F), (P, 2 * F),
                   (P, S), (P, S, 64), (P, 64), (P,), (P, 64), (P, 16), (P, S), (P, S, 32), (P, 32), (P, S, F)]
         saves = [None if i in skip else E(*sh) for i, sh in enumerate(shapes)]
@@ -780,13 +781,16 @@ class EnerfLib:
         a.P, a.F, a.S = P, F, S
         for i, o in enumerate(offsets):
             a.image_offsets[i] = int(o)
-        if not partials:
+        if level == 0:
             self._check(self.dll.enerf_nerf_mlp_bwd(C.byref(a), self.stream_of(vox)), "nerf_mlp_bwd")
             return g_vox, g_x, saves
         chunks = int(self.dll.enerf_nerf_mlp_bwd_chunks(P))
-        wg_q, wg_c2 = E(chunks, 4, 256), E(chunks, 80)
-        self._check(self.dll.enerf_nerf_mlp_bwd_partials(C.byref(a), _ptr(wg_q), _ptr(wg_c2), self.stream_of(vox)), "nerf_mlp_bwd_partials")
-        return g_vox, g_x, saves, wg_q, wg_c2
+        part = {"q": E(chunks, 4, 256), "rows": E(chunks, 128)}
+        if level == 2:
+            part["g"], part["v"] = E(chunks, 2, 256), E(chunks, 1, 256)
+        self._check(self.dll.enerf_nerf_mlp_bwd_partials(C.byref(a), level, _ptr(part["q"]), _ptr(part.get("g")), _ptr(part.get("v")),
+                                                         _ptr(part["rows"]), self.stream_of(vox)), "nerf_mlp_bwd_partials")
+        return g_vox, g_x, saves, part
 
     def colsum(self, part):
         """out[i] = sum_c part[c, i] in a fixed order (enerf_colsum): the second stage of per-wave partial sums."""

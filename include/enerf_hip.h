@@ -446,13 +446,18 @@ typedef struct {
     int image_offsets[8];
 } enerf_mlp_bwd_args_t;
 int enerf_nerf_mlp_bwd(const enerf_mlp_bwd_args_t* args, enerf_stream_t stream);
-/* ABI v11, F = 11: the same backward with the weight gradients of the per-view colour branch accumulated INSIDE the kernel — color.0's
- * per-view columns (nerf.py:64-66: 64 x (F + 4), a 16-point product on the matrix cores per view) and color.2 (+ bias) — so that q, d_qpre
- * and d_cpre (save[2], save[7], save[6]: 40 % of the saved bytes; may be NULL here) are never written.  Every wave writes one row of
- * partial sums: wg_q[chunks][4][256] (four 16 x 16 tiles, the layout enerf_gemm_wgrad_group reduces: a member with `partials`) and
- * wg_c2[chunks][80] = [color.2 weight 64 | bias | 0 ...] (enerf_colsum); chunks = enerf_nerf_mlp_bwd_chunks(P). */
+/* ABI v11, F = 11: the same backward with the weight gradients of the per-(point, view) layers accumulated INSIDE the kernel, in registers
+ * for its whole run, instead of through saved rows:
+ *   level 1: the colour branch — color.0's per-view columns (nerf.py:64-66: 64 x (F + 4), a 16-point product on the matrix cores per view) and
+ *            color.2 (+ bias); q, d_qpre, d_cpre (save[2], save[7], save[6]: 40 % of the saved bytes) are never written and may be NULL;
+ *   level 2 (S <= 3): also the aggregation branch — global_fc's `a` columns (32 x F), agg_w_fc (+ bias), view_fc (+ bias) (nerf.py:29-52);
+ *            g, a, d_upre, d_gpre, d_vpre (save[3], save[4], save[12], save[13], save[15]: another 27 %) may be NULL too.
+ * Every wave writes one row of partial sums: tiles wg_q[chunks][4][256], wg_g[chunks][2][256], wg_v[chunks][256] (what a member with
+ * `partials` of enerf_gemm_wgrad_group reduces: 64 x (F + 4), 32 x F, F x 4) and wg_rows[chunks][128] = [color.2 weight 64 | bias | 0 x 15 |
+ * agg_w_fc weight 32 | bias | view_fc bias F | 0 ...] (enerf_colsum); chunks = enerf_nerf_mlp_bwd_chunks(P).  wg_g / wg_v: level 2 only. */
 long long enerf_nerf_mlp_bwd_chunks(long long P);
-int enerf_nerf_mlp_bwd_partials(const enerf_mlp_bwd_args_t* args, float* wg_q, float* wg_c2, enerf_stream_t stream);
+int enerf_nerf_mlp_bwd_partials(const enerf_mlp_bwd_args_t* args, int level, float* wg_q, float* wg_g, float* wg_v, float* wg_rows,
+                                enerf_stream_t stream);
 /* out[i] = sum over the chunks c of part[c * n + i] (fixed order): the second stage of a per-wave partial-sum layout. */
 int enerf_colsum(const float* part, int chunks, int n, float* out, enerf_stream_t stream);
 /* forward of the same MLP on materialised inputs (training): raw (P,4) = [rgb, sigma]; nothing else is written. */

@@ -10,7 +10,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the last replay: the last 430-ish kernels; find the last k_mlp_bwd<3, 3> and take a window of one step before the end
 names = [r["Kernel_Name"] for r in rows]
-idx = [i for i, n in enumerate(names) if "k_mlp_bwd<3, 3>" in n]
+idx = [i for i, n in enumerate(names) if "k_mlp_bwd<3, 3" in n]
 a, b = idx[-2], idx[-1]
 step = rows[a:b]
 t0 = int(step[0]["Start_Timestamp"])
