@@ -126,8 +126,12 @@ __global__ __launch_bounds__(256) void k_gather_fwd(GatherArgs a) {
 // load instruction); the 64 points are then fetched one per pass with lane = (tap, channel): 4 taps x 16 channels (64 lanes, the
 // four taps' weighted values summed across the lane groups by register permutes) for the texel, 8 taps x 8 channels for the
 // volume — every load and store instruction touches whole texels.  No LDS, no barriers.
+#ifndef ENERF_GFW_U
+#define ENERF_GFW_U 4                  // points fetched per iteration of the pass loops (all their loads in flight)
+#endif
 template <int NCH>                      // channel rounds: ceil(F / 16)
 __global__ __launch_bounds__(256) void k_gather_fwd_w(GatherArgs a) {
+    constexpr int GU = ENERF_GFW_U;
     const int F = a.F, XW = F + 4, l64 = threadIdx.x & 63;
     const long long wave0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;     // first point (b * P + p) of the wave
     const long long total = (long long)a.B * a.P;
@@ -139,6 +143,9 @@ __global__ __launch_bounds__(256) void k_gather_fwd_w(GatherArgs a) {
     const float X = a.xyz[bp * 3], Y = a.xyz[bp * 3 + 1], Z = a.xyz[bp * 3 + 2];
     const int tap = l64 >> 4, chl = l64 & 15, vtap = l64 >> 3, vch = l64 & 7;
     const int npass = (int)(total - wave0 < 64 ? total - wave0 : 64);
+    // Both pass loops below fetch ENERF_GFW_U points per iteration, all their loads requested before the first is reduced (round 6: one point
+    // per iteration was a chain of L2 round trips — load, wait, reduce, store — 64 x (1 + S) times per wave: 300 us at level 1), with
+    // 32-bit element offsets (the launcher checks the tensors are below 2^32 elements).
     // ---- the volume sample (once per point) ----
     {
         const VoxGeom v = vox_geom(a.uv[bp * 2], a.uv[bp * 2 + 1], a.dn[bp], a.Wr, a.Hr, a.D, a.h, a.w);
@@ -147,24 +154,35 @@ __global__ __launch_bounds__(256) void k_gather_fwd_w(GatherArgs a) {
         const int r3 = __float_as_int(v.wx[0]), r4 = __float_as_int(v.wx[1]), r5 = __float_as_int(v.wy[0]), r6 = __float_as_int(v.wy[1]);
         const int r7 = __float_as_int(v.wz[0]), r8 = __float_as_int(v.wz[1]);
         const int cx = vtap & 1, cy = (vtap >> 1) & 1, cz = vtap >> 2;
-#pragma unroll 2
-        for (int j = 0; j < npass; ++j) {
-            const int w0 = __builtin_amdgcn_readlane(r0, j), w1 = __builtin_amdgcn_readlane(r1, j), w2 = __builtin_amdgcn_readlane(r2, j);
-            const int bj = __builtin_amdgcn_readlane(rb, j);
-            // (every lane executes every v_readlane — they are wave-level operations; the selects come after)
-            const int x3 = __builtin_amdgcn_readlane(r3, j), x4 = __builtin_amdgcn_readlane(r4, j), x5 = __builtin_amdgcn_readlane(r5, j);
-            const int x6 = __builtin_amdgcn_readlane(r6, j), x7 = __builtin_amdgcn_readlane(r7, j), x8 = __builtin_amdgcn_readlane(r8, j);
-            const float wx = __int_as_float(cx ? x4 : x3), wy = __int_as_float(cy ? x6 : x5), wz = __int_as_float(cz ? x8 : x7);
-            const int xo = cx ? (w0 >> 16) & 0xffff : w0 & 0xffff, yo = cy ? (w1 >> 16) & 0xffff : w1 & 0xffff;
-            const int zo = cz ? (w2 >> 8) & 0xff : w2 & 0xff, vld = w2 >> 16;
-            const bool on = ((vld >> cx) & 1) && ((vld >> (2 + cy)) & 1) && ((vld >> (4 + cz)) & 1);
-            const float val = a.vol[(((long long)bj * a.D + zo) * a.h + yo) * a.w * 8 + (long long)xo * 8 + vch];
-            float acc = on ? val * (wx * wy * wz) : 0.f;
-            acc = group_sum4(add_xor8(acc));                      // over the 8 taps: lane bits 3 | 4, 5
-            if (l64 < 8) a.vox[(wave0 + j) * 8 + vch] = acc;
+        float* vrow = a.vox + wave0 * 8 + vch;
+        for (int j0 = 0; j0 < npass; j0 += GU) {
+            float val[GU], wgt[GU];
+            bool onm[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int j = min(j0 + u, npass - 1);
+                const int w0 = __builtin_amdgcn_readlane(r0, j), w1 = __builtin_amdgcn_readlane(r1, j), w2 = __builtin_amdgcn_readlane(r2, j);
+                const int bj = __builtin_amdgcn_readlane(rb, j);
+                // (every lane executes every v_readlane — they are wave-level operations; the selects come after)
+                const int x3 = __builtin_amdgcn_readlane(r3, j), x4 = __builtin_amdgcn_readlane(r4, j), x5 = __builtin_amdgcn_readlane(r5, j);
+                const int x6 = __builtin_amdgcn_readlane(r6, j), x7 = __builtin_amdgcn_readlane(r7, j), x8 = __builtin_amdgcn_readlane(r8, j);
+                const float wx = __int_as_float(cx ? x4 : x3), wy = __int_as_float(cy ? x6 : x5), wz = __int_as_float(cz ? x8 : x7);
+                const int xo = cx ? (w0 >> 16) & 0xffff : w0 & 0xffff, yo = cy ? (w1 >> 16) & 0xffff : w1 & 0xffff;
+                const int zo = cz ? (w2 >> 8) & 0xff : w2 & 0xff, vld = w2 >> 16;
+                const bool on = ((vld >> cx) & 1) && ((vld >> (2 + cy)) & 1) && ((vld >> (4 + cz)) & 1);
+                val[u] = a.vol[(((unsigned)(bj * a.D + zo) * (unsigned)a.h + (unsigned)yo) * (unsigned)a.w + (unsigned)xo) * 8u + (unsigned)vch];
+                wgt[u] = wx * wy * wz; onm[u] = on;
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                if (j0 + u >= npass) break;                       // (wave-uniform)
+                const float acc = group_sum4(add_xor8(onm[u] ? val[u] * wgt[u] : 0.f));      // over the 8 taps: lane bits 3 | 4, 5
+                if (l64 < 8) vrow[(j0 + u) * 8] = acc;
+            }
         }
     }
     // ---- the texel of every view ----
+    const unsigned img_texels = (unsigned)(a.Hr * a.Wr);
     for (int s = 0; s < a.S; ++s) {
         const float* c = a.cam + ((long long)b * a.S + s) * 16;
         const ViewGeom q = view_geom(c, a.tcen + b * 4, X, Y, Z, a.Wr, a.Hr);
@@ -172,23 +190,34 @@ __global__ __launch_bounds__(256) void k_gather_fwd_w(GatherArgs a) {
             float* xo = a.x + (bp * a.S + s) * XW + F;
             xo[0] = q.dir[0]; xo[1] = q.dir[1]; xo[2] = q.dir[2]; xo[3] = q.dir[3];
         }
-        const int r0 = q.x0 | (q.x1 << 16), r1 = q.y0 | (q.y1 << 16), rb = b;
+        const int r0 = q.x0 | (q.x1 << 16), r1 = q.y0 | (q.y1 << 16), rb = (int)((unsigned)(b * a.S + s) * img_texels);   // first texel of the image
         const int r2 = __float_as_int(q.w00), r3 = __float_as_int(q.w01), r4 = __float_as_int(q.w10), r5 = __float_as_int(q.w11);
-#pragma unroll 2
-        for (int j = 0; j < npass; ++j) {
-            const int gxw = __builtin_amdgcn_readlane(r0, j), gyw = __builtin_amdgcn_readlane(r1, j), bj = __builtin_amdgcn_readlane(rb, j);
-            const int x2 = __builtin_amdgcn_readlane(r2, j), x3 = __builtin_amdgcn_readlane(r3, j);   // (all lanes, then select)
-            const int x4 = __builtin_amdgcn_readlane(r4, j), x5 = __builtin_amdgcn_readlane(r5, j);
-            const float w = __int_as_float((tap & 2) ? ((tap & 1) ? x5 : x4) : ((tap & 1) ? x3 : x2));
-            const int x = (tap & 1) ? (gxw >> 16) & 0xffff : gxw & 0xffff, y = (tap & 2) ? (gyw >> 16) & 0xffff : gyw & 0xffff;
-            const long long t = ((((long long)bj * a.S + s) * a.Hr + y) * a.Wr + x) * F;
-            float* xrow = a.x + ((wave0 + j) * a.S + s) * XW;
+        float* xbase = a.x + (wave0 * a.S + s) * XW;
+        const unsigned xstep = (unsigned)(a.S * XW);
+        for (int j0 = 0; j0 < npass; j0 += GU) {
+            float v[GU][NCH], w[GU];
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                const int ch = chl + 16 * k;
-                const float v = a.tex[t + min(ch, F - 1)];                 // clamped: always loads
-                const float acc = group_sum4(v * w);
-                if (l64 < 16 && ch < F) xrow[ch] = acc;
+            for (int u = 0; u < GU; ++u) {
+                const int j = min(j0 + u, npass - 1);
+                const int gxw = __builtin_amdgcn_readlane(r0, j), gyw = __builtin_amdgcn_readlane(r1, j), tj = __builtin_amdgcn_readlane(rb, j);
+                const int x2 = __builtin_amdgcn_readlane(r2, j), x3 = __builtin_amdgcn_readlane(r3, j);   // (all lanes, then select)
+                const int x4 = __builtin_amdgcn_readlane(r4, j), x5 = __builtin_amdgcn_readlane(r5, j);
+                w[u] = __int_as_float((tap & 2) ? ((tap & 1) ? x5 : x4) : ((tap & 1) ? x3 : x2));
+                const int x = (tap & 1) ? (gxw >> 16) & 0xffff : gxw & 0xffff, y = (tap & 2) ? (gyw >> 16) & 0xffff : gyw & 0xffff;
+                const unsigned t = ((unsigned)tj + (unsigned)y * (unsigned)a.Wr + (unsigned)x) * (unsigned)F;
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) v[u][k] = a.tex[t + (unsigned)min(chl + 16 * k, F - 1)];         // clamped: always loads
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                if (j0 + u >= npass) break;                       // (wave-uniform)
+                float* xrow = xbase + (unsigned)(j0 + u) * xstep;
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const int ch = chl + 16 * k;
+                    const float acc = group_sum4(v[u][k] * w[u]);
+                    if (l64 < 16 && ch < F) xrow[ch] = acc;
+                }
             }
         }
     }
@@ -647,7 +676,8 @@ int enerf_gather_fwd(const enerf_gather_args_t* u, enerf_stream_t stream) {
     if (u->P == 0) return ENERF_OK;
     const long long waves = cdivl((long long)a.B * a.P, 64);
     // k_gather_fwd_w packs the tap coordinates (x, y in 16 bits, z in 8): larger maps take the thread-per-(point, view) kernel
-    const bool packable = a.Wr < 65535 && a.Hr < 65535 && a.w < 65535 && a.h < 65535 && a.D < 256;
+    const bool packable = a.Wr < 65535 && a.Hr < 65535 && a.w < 65535 && a.h < 65535 && a.D < 256 &&
+                          (long long)a.B * a.S * a.Hr * a.Wr * a.F < (1LL << 32) && (long long)a.B * a.D * a.h * a.w * 8 < (1LL << 32);   // 32-bit offsets
     if (packable && a.F <= 16) ENERF_LAUNCH(k_gather_fwd_w<1>, (unsigned)cdivl(waves, 4), 256, 0, (hipStream_t)stream, a);
     else if (packable && a.F <= 48) ENERF_LAUNCH(k_gather_fwd_w<3>, (unsigned)cdivl(waves, 4), 256, 0, (hipStream_t)stream, a);
     else {
