@@ -101,23 +101,45 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
         for (int r = 0; r < R; ++r) bv[r] = 0.f;
         wave_sync();
     }
-    for (long long tile = (long long)blockIdx.x * waves + (threadIdx.x >> 6); tile < ntiles; tile += (long long)gridDim.x * waves) {
+    // The NEXT tile's inputs are requested at the top of a tile and used one iteration later (round 6): with one wave per SIMD nothing
+    // else hides the ~2 us the (vox, x, dir, d raw) loads of a tile take — 40 tiles per wave, a tenth of the kernel.  PF: R = 3 only
+    // (the F = 35 kernel has no registers for a second set of 36 inputs).
+    constexpr bool PF = R == 3;
+    struct Inputs { float vox[2], x[S][R], dsel[S]; float4 graw; };
+    auto load_inputs = [&](long long t, Inputs& I) {
+        const long long pr_ = t * 16 + j, p_ = pr_ < a.P ? pr_ : a.P - 1;
+        I.vox[0] = a.vox[p_ * 8 + 2 * g]; I.vox[1] = a.vox[p_ * 8 + 2 * g + 1];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float* xp = a.x + (p_ * S + s) * XW;
+#pragma unroll
+            for (int r = 0; r < R; ++r) I.x[s][r] = xp[min(g * R + r, F - 1)];    // clamped index: always loads (masked when used)
+            I.dsel[s] = xp[F + g];
+        }
+        I.graw = *reinterpret_cast<const float4*>(a.g_raw + p_ * 4);
+    };
+    const long long tile0 = (long long)blockIdx.x * waves + (threadIdx.x >> 6), tstride = (long long)gridDim.x * waves;
+    Inputs nxt;
+    if (PF && tile0 < ntiles) load_inputs(tile0, nxt);
+    for (long long tile = tile0; tile < ntiles; tile += tstride) {
         const long long pr = tile * 16 + j;
         const bool ok = pr < a.P;
         const bool sv = ok && !ENERF_MLPB_NOSTORE;          // write the per-layer saves
         const long long p = ok ? pr : a.P - 1;
         // ---------------- inputs ----------------
+        Inputs cur;
+        if (PF) {
+            cur = nxt;
+            load_inputs(tile + tstride < ntiles ? tile + tstride : tile, nxt);   // (the last tile re-requests itself: never used)
+            __builtin_amdgcn_sched_barrier(0);
+        } else load_inputs(tile, cur);
         float vox[2], x[S][R], dsel[S];
-        vox[0] = a.vox[p * 8 + 2 * g]; vox[1] = a.vox[p * 8 + 2 * g + 1];
+        vox[0] = cur.vox[0]; vox[1] = cur.vox[1];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const float* xp = a.x + (p * S + s) * XW;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {     // unconditional load from a clamped index, then a select: `c ? p[i] : 0` makes hipcc
-                const float v = xp[min(g * R + r, F - 1)];       // branch around the load and wait on it (S*R serial round trips)
-                x[s][r] = (g * R + r < F) ? v : 0.f;
-            }
-            dsel[s] = xp[F + g];
+            for (int r = 0; r < R; ++r) x[s][r] = (g * R + r < F) ? cur.x[s][r] : 0.f;
+            dsel[s] = cur.dsel[s];
         }
         // ---------------- forward recompute (the render kernel's MLP phase) ----------------
         float aview[TR];
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpBwdArgs a) {
                 if (g * R + r < F) { a.sv_vm[p * 2 * F + g * R + r] = var[r]; a.sv_vm[p * 2 * F + F + g * R + r] = mean[r]; }
         }
         // ---------------- backward ----------------
-        const float4 graw = *reinterpret_cast<const float4*>(a.g_raw + p * 4);
+        const float4 graw = cur.graw;
         const float gcol[3] = {graw.x, graw.y, graw.z};
         const float gsig = ok ? graw.w : 0.f;
         // col = sum_s cw_s rgb_s (rgb_s = channels F-3..F-1 of x_s): d cw_s, softmax over views, ReLU of the logit
@@ -566,22 +588,37 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const float* __restrict__ voxp,
     const float* wlane = wl + lane;
     const long long ntiles = cdivl(a.P, 16);
     const int waves = blockDim.x >> 6;
-    for (long long tile = (long long)blockIdx.x * waves + (threadIdx.x >> 6); tile < ntiles; tile += (long long)gridDim.x * waves) {
+    // (the next tile's inputs are requested one iteration ahead, as in k_mlp_bwd)
+    struct Inputs { float vox[2], x[S][R], dsel[S]; };
+    auto load_inputs = [&](long long t, Inputs& I) {
+        const long long pr_ = t * 16 + j, p_ = pr_ < a.P ? pr_ : a.P - 1;
+        I.vox[0] = a.vox[p_ * 8 + 2 * g]; I.vox[1] = a.vox[p_ * 8 + 2 * g + 1];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float* xp = a.x + (p_ * S + s) * XW;
+#pragma unroll
+            for (int r = 0; r < R; ++r) I.x[s][r] = xp[min(g * R + r, F - 1)];    // clamped index: always loads (masked when used)
+            I.dsel[s] = xp[F + g];
+        }
+    };
+    const long long tile0 = (long long)blockIdx.x * waves + (threadIdx.x >> 6), tstride = (long long)gridDim.x * waves;
+    Inputs nxt;
+    if (tile0 < ntiles) load_inputs(tile0, nxt);
+    for (long long tile = tile0; tile < ntiles; tile += tstride) {
         const long long pr = tile * 16 + j;
         const bool ok = pr < a.P;
         const long long p = ok ? pr : a.P - 1;
         // ---------------- inputs ----------------
+        const Inputs cur = nxt;
+        load_inputs(tile + tstride < ntiles ? tile + tstride : tile, nxt);       // (the last tile re-requests itself: never used)
+        __builtin_amdgcn_sched_barrier(0);
         float vox[2], x[S][R], dsel[S];
-        vox[0] = a.vox[p * 8 + 2 * g]; vox[1] = a.vox[p * 8 + 2 * g + 1];
+        vox[0] = cur.vox[0]; vox[1] = cur.vox[1];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const float* xp = a.x + (p * S + s) * XW;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {     // unconditional load from a clamped index, then a select: `c ? p[i] : 0` makes hipcc
-                const float v = xp[min(g * R + r, F - 1)];       // branch around the load and wait on it (S*R serial round trips)
-                x[s][r] = (g * R + r < F) ? v : 0.f;
-            }
-            dsel[s] = xp[F + g];
+            for (int r = 0; r < R; ++r) x[s][r] = (g * R + r < F) ? cur.x[s][r] : 0.f;
+            dsel[s] = cur.dsel[s];
         }
         // ---------------- forward recompute (the render kernel's MLP phase) ----------------
         float aview[TR];
