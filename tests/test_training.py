@@ -1278,8 +1278,8 @@ def _check_mlp_backward(lib, dev):
     g = torch.Generator().manual_seed(11)
     torch.manual_seed(11)                                   # NerfParams draws its kaiming init from the global generator
     # (F = 11: the per-view layers' weight gradients come from inside the kernel — S <= 3: colour + aggregation branch, S = 4: colour branch)
-    for F, S, P in ((11, 3, 37), (11, 4, 16), (11, 2, 70), (35, 2, 21), (35, 4, 33)):
-        m = NerfParams(F, True).to(dev)
+    for F, S, P, vda in ((11, 3, 37, True), (11, 4, 16, True), (11, 2, 70, True), (11, 3, 21, False), (35, 2, 21, True), (35, 4, 33, True)):
+        m = NerfParams(F, vda).to(dev)
         with torch.no_grad():
             for p in m.parameters():
                 if p.dim() == 1:
